@@ -1,0 +1,218 @@
+/*
+ * dtt_hip.h -- C ABI of libdtt_hip.so, the MI355X (gfx950) Detect-to-Track hot path.
+ *
+ * This is the drop-in boundary: every entry point below replaces one of the reference's
+ * `extern "C"` CUDA launchers (the layer its cffi shims bind).  The
+ * reference file:line each symbol replaces is cited next to it (paths relative to the
+ * reference's lib/model/).  Argument order follows the reference launcher; where the
+ * reference passed tensor strides that it never honoured (it asserts contiguity,
+ * correlation/functions/correlation.py:21-22) they are dropped, and where the reference
+ * allocated scratch inside the call (correlation_cuda.c:36-42, nms_cuda_kernel.cu:95-105)
+ * the caller now passes a workspace instead: the library never allocates, frees or
+ * synchronises.
+ *
+ * Conventions
+ *   - plain C types only; every pointer is a DEVICE pointer unless the name ends in _host
+ *   - all tensors are contiguous fp32 NCHW / row-major, indices int32
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); all work is
+ *     enqueued on it and the call returns without waiting
+ *   - return value: 1 = launched, 0 = failure (same convention as the reference launchers,
+ *     e.g. correlation_cuda_kernel.cu:362-368); on 0, dtt_last_error() describes why.
+ *     Unlike psroi_pooling_kernel.cu:99-103 / roi_align_kernel.cu:85-88 nothing calls exit().
+ */
+#ifndef DTT_HIP_H
+#define DTT_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------------------------------------------------------- misc */
+int dtt_abi_version(void);
+const char* dtt_last_error(void);
+
+/* ---------------------------------------------------------------- correlation
+ * Replaces Correlation_forward_cuda_kernel  (correlation/src/correlation_cuda_kernel.cu:296-369)
+ *      and Correlation_backward_cuda_kernel (correlation/src/correlation_cuda_kernel.cu:371-473),
+ * plus the output-shape rule of Correlation_forward_cuda (correlation/src/correlation_cuda.c:25-34).
+ * No NHWC repack (`channels_first`, .cu:10-32) and no zero-filled padded copies: zero padding is
+ * applied on the fly.  corr_type_multiply is accepted and ignored, as in the reference.
+ */
+/* writes nOutputChannels, outputHeight, outputWidth; returns 0 on invalid parameters */
+int dtt_correlation_output_shape(int ic, int ih, int iw, int pad_size, int kernel_size,
+                                 int max_displacement, int stride1, int stride2,
+                                 int* oc, int* oh, int* ow);
+size_t dtt_correlation_forward_workspace_bytes(int batch, int ic, int ih, int iw, int pad_size,
+                                               int kernel_size, int max_displacement,
+                                               int stride1, int stride2);
+/* output may be a channel slice of a larger (ob, out_batch_stride/(oh*ow), oh, ow) tensor:
+ * out_batch_stride is the element stride between batch items (oc*oh*ow when dense), so the three
+ * correlations can write straight into the tracking concat buffer (rfcn.py:166-174). */
+int dtt_correlation_forward(float* output, int ob, int oc, int oh, int ow, long out_batch_stride,
+                            const float* input1, int ic, int ih, int iw,
+                            const float* input2,
+                            void* workspace, size_t workspace_bytes,
+                            int pad_size, int kernel_size, int max_displacement,
+                            int stride1, int stride2, int corr_type_multiply,
+                            void* stream);
+/* kernel_size must be 1 (the only value D&T uses, rfcn.py:58-60).  gradInput1/2 are fully
+ * written (no pre-zeroing needed).  For stride1 > 1 this is the mathematically correct gradient;
+ * the reference indexes out of bounds there (correlation_cuda_kernel.cu:120-121, 212-213). */
+int dtt_correlation_backward(const float* gradOutput, int gob, int goc, int goh, int gow,
+                             const float* input1, int ic, int ih, int iw,
+                             const float* input2,
+                             float* gradInput1, float* gradInput2,
+                             int pad_size, int kernel_size, int max_displacement,
+                             int stride1, int stride2, int corr_type_multiply,
+                             void* stream);
+
+/* ---------------------------------------------------------------- PSRoI pooling
+ * Replaces PSROIPoolForwardLauncher  (psroi_pooling/src/psroi_pooling_kernel.cu:82-106)
+ *      and PSROIPoolBackwardLauncher (psroi_pooling/src/psroi_pooling_kernel.cu:172-194).
+ * batch_size is an extra argument (the reference forward never needed it).  mapping_channel may
+ * be NULL (the channel is a pure function of the output index).  The backward writes every
+ * element of bottom_diff (no pre-zeroing needed) and uses LDS atomics only.
+ */
+int dtt_psroi_pool_forward(const float* bottom_data, float spatial_scale, int batch_size,
+                           int num_rois, int height, int width, int channels,
+                           int pooled_height, int pooled_width, const float* bottom_rois,
+                           int group_size, int output_dim, float* top_data,
+                           int* mapping_channel, void* stream);
+int dtt_psroi_pool_backward(const float* top_diff, const int* mapping_channel, int batch_size,
+                            int num_rois, float spatial_scale, int channels, int height,
+                            int width, int pooled_width, int pooled_height, int output_dim,
+                            int group_size, float* bottom_diff, const float* bottom_rois,
+                            void* stream);
+/* Fused PSRoI pool + the 7x7 average vote that always follows it (rfcn.py:62-64,136-140,196):
+ * vote_out is (num_rois, output_dim); top_data may be NULL. */
+int dtt_psroi_pool_vote_forward(const float* bottom_data, float spatial_scale, int batch_size,
+                                int num_rois, int height, int width, int channels,
+                                int pooled_height, int pooled_width, const float* bottom_rois,
+                                int group_size, int output_dim, float* top_data,
+                                float* vote_out, void* stream);
+
+/* ---------------------------------------------------------------- NMS
+ * Replaces nms_cuda_compute (nms/src/nms_cuda_kernel.cu:87-161).  boxes: (boxes_num, boxes_dim>=4)
+ * rows [x1,y1,x2,y2,...] already sorted by descending score.  keep_out: int32[boxes_num],
+ * num_out: int32[1].  Device in -> device out, stream ordered: the greedy sweep
+ * (nms_cuda_kernel.cu:131-144) runs on the GPU, nothing is copied to the host.
+ * max_keep > 0 lets the sweep stop after max_keep survivors (the proposal layer keeps only the
+ * first post_nms_topN, proposal_layer.py:151-152); 0 = keep all (reference behaviour).
+ */
+size_t dtt_nms_workspace_bytes(int boxes_num);
+int dtt_nms(int* keep_out, int* num_out, const float* boxes, int boxes_num, int boxes_dim,
+            float nms_overlap_thresh, int max_keep, void* workspace, size_t workspace_bytes,
+            void* stream);
+
+/* ---------------------------------------------------------------- RoI Align
+ * Replaces ROIAlignForwardLaucher  (roi_align/src/roi_align_kernel.cu:73-91)
+ *      and ROIAlignBackwardLaucher (roi_align/src/roi_align_kernel.cu:145-162).
+ * pool_mode: 0 = raw aligned_height x aligned_width samples (RoIAlign, modules/roi_align.py:6-16);
+ *            1 = samples on (h+1)x(w+1) then 2x2/s1 average (RoIAlignAvg, :18-29), fused;
+ *            2 = same with max (RoIAlignMax, :31-42), fused.
+ * For modes 1/2 aligned_height/width are the OUTPUT sizes (e.g. 7).  bottom_diff must be zeroed
+ * by the caller (the backward accumulates with atomics, as the reference does).
+ */
+int dtt_roi_align_forward(const float* bottom_data, float spatial_scale, int num_rois, int height,
+                          int width, int channels, int aligned_height, int aligned_width,
+                          const float* bottom_rois, float* top_data, int pool_mode, void* stream);
+int dtt_roi_align_backward(const float* top_diff, float spatial_scale, int batch_size,
+                           int num_rois, int height, int width, int channels, int aligned_height,
+                           int aligned_width, const float* bottom_rois, float* bottom_diff,
+                           void* stream);
+
+/* ---------------------------------------------------------------- RoI (max) pooling
+ * Replaces ROIPoolForwardLaucher  (roi_pooling/src/roi_pooling_kernel.cu:95-126)
+ *      and ROIPoolBackwardLaucher (roi_pooling/src/roi_pooling_kernel.cu:205-234).
+ * bottom_diff must be zeroed by the caller: the backward scatters top_diff through argmax
+ * (equivalent to the reference's O(pixels x RoIs) gather).
+ */
+int dtt_roi_pool_forward(const float* bottom_data, float spatial_scale, int num_rois, int height,
+                         int width, int channels, int pooled_height, int pooled_width,
+                         const float* bottom_rois, float* top_data, int* argmax_data,
+                         void* stream);
+int dtt_roi_pool_backward(const float* top_diff, float spatial_scale, int batch_size, int num_rois,
+                          int height, int width, int channels, int pooled_height,
+                          int pooled_width, const float* bottom_rois, float* bottom_diff,
+                          const int* argmax_data, void* stream);
+
+/* ---------------------------------------------------------------- RoI crop (bilinear grid sampler)
+ * Replaces BilinearSamplerBHWD_updateOutput_cuda_kernel    (roi_crop/src/roi_crop_cuda_kernel.cu:201-255)
+ *      and BilinearSamplerBHWD_updateGradInput_cuda_kernel (roi_crop/src/roi_crop_cuda_kernel.cu:257-326).
+ * inputImages (ib, ic, ih, iw) NCHW; grids (ob, oh, ow, 2) holding (y, x) in [-1,1]; output
+ * (ob, ic, oh, ow); RoI b samples image b / (ob / ib).  Output is fully written (samples falling
+ * outside give 0).  gradInputImages must be zeroed by the caller; as in the reference the grid
+ * gradient is not produced (roi_crop_cuda_kernel.cu:154-192 computes and drops it).
+ */
+int dtt_roi_crop_forward(int oc, int ow, int oh, int ob, int ic, int ih, int iw, int ib,
+                         const float* inputImages, const float* grids, float* output,
+                         void* stream);
+int dtt_roi_crop_backward(int goc, int gow, int goh, int gob, int ic, int ih, int iw, int ib,
+                          const float* inputImages, const float* grids, float* gradInputImages,
+                          const float* gradOutput, void* stream);
+
+/* ---------------------------------------------------------------- RPN proposal layer
+ * Replaces _ProposalLayer.forward (rpn/proposal_layer.py:49-161) = anchors + bbox_transform_inv
+ * (rpn/bbox_transform.py:108-134) + clip_boxes (:156-173) + torch.sort + per-image nms loop.
+ * One call handles the whole batch on the device with no host round trip.
+ *   cls_prob (B, 2A, H, W)   fg probability of anchor a at channel A + a (proposal_layer.py:67)
+ *   bbox_pred (B, 4A, H, W)  delta of anchor a at channels 4a..4a+3 (proposal_layer.py:98-99)
+ *   im_info (B, 3) = [height, width, scale];  anchors (A, 4) base anchors (generate_anchors.py:45-56)
+ *   rois_out (B, post_nms_topN, 5): [batch index, x1, y1, x2, y2], zero padded (proposal_layer.py:157-159)
+ *   num_out  int32[B] number of valid rows per image (may be NULL)
+ * Ordering: scores descending, ties broken by lower anchor index first (torch.sort on CUDA 0.3 was
+ * unspecified; this is the declared order, SURVEY.md section 7 hard part 3).
+ * pre_nms_topN follows the reference guard (proposal_layer.py:138-139): it is applied only when
+ * 0 < pre_nms_topN < B*K*A.
+ */
+size_t dtt_proposal_workspace_bytes(int batch, int num_anchors, int height, int width,
+                                    int pre_nms_topN);
+int dtt_proposal_forward(const float* cls_prob, const float* bbox_pred, const float* im_info,
+                         const float* anchors, int batch, int num_anchors, int height, int width,
+                         int feat_stride, int pre_nms_topN, int post_nms_topN, float nms_thresh,
+                         float* rois_out, int* num_out, void* workspace, size_t workspace_bytes,
+                         void* stream);
+
+/* ---------------------------------------------------------------- RPN anchor-target layer
+ * Replaces _AnchorTargetLayer.forward (rpn/anchor_target_layer.py:48-191) with bbox_overlaps_batch
+ * (rpn/bbox_transform.py:208-254) and bbox_transform_batch (:36-75).  Two stream-ordered phases
+ * so that the random subsampling can consume numpy's RNG on the host exactly as the reference
+ * does (anchor_target_layer.py:124-141):
+ *   phase 1 (dtt_anchor_target_assign): per-anchor labels {1,0,-1} before subsampling, the arg-max
+ *     GT per anchor, and per-image fg / bg counts.
+ *   host: reads the 2B counts, draws the permutations, uploads `disable` lists (may be empty).
+ *   phase 2 (dtt_anchor_target_finish): applies the disables, encodes regression targets and the
+ *     uniform weights, and writes the four outputs in the reference layouts
+ *     (anchor_target_layer.py:168-189).
+ * gt_boxes (B, G, 5) [x1,y1,x2,y2,cls]; im_info (B,3) -- only row 0 is used for the inside test
+ * (anchor_target_layer.py:85-86, reproduced).
+ */
+int dtt_anchor_target_assign(const float* gt_boxes, const float* im_info, const float* anchors,
+                             int batch, int num_gt, int num_anchors, int height, int width,
+                             int feat_stride, float negative_overlap, float positive_overlap,
+                             int clobber_positives,
+                             int* labels /* (B, K*A) */, int* argmax_gt /* (B, K*A) */,
+                             int* counts /* (B, 2): fg, bg */, void* stream);
+int dtt_anchor_target_finish(const float* gt_boxes, const float* anchors,
+                             const int* labels_in /* (B, K*A), after host/device subsampling */,
+                             const int* argmax_gt, int batch, int num_gt, int num_anchors,
+                             int height, int width, int feat_stride, float inside_weight,
+                             float positive_weight /* <0: uniform 1/num_examples of LAST image */,
+                             float* labels_out /* (B,1,A*H,W) */, float* bbox_targets /* (B,4A,H,W) */,
+                             float* bbox_inside_weights, float* bbox_outside_weights,
+                             void* stream);
+/* sets labels[b, idx] = -1 for idx in disable[b_off[b] .. b_off[b+1]) */
+int dtt_anchor_target_disable(int* labels, const int* disable, const int* disable_offsets,
+                              int batch, int total_anchors, void* stream);
+
+/* ---------------------------------------------------------------- test-time detection post-processing
+ * Replaces the per-class loop of test_net.py:274-291 (threshold, sort, nms(cls_dets, TEST.NMS))
+ * for all classes of one image in one launch.  
+ */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DTT_HIP_H */

@@ -1,0 +1,684 @@
+/*
+ * dtt_oracle.c -- CPU restatement of the reference's CUDA ops.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library; the
+ * product (pytorch-detect-to-track_amd/) never links, imports or falls back to it.
+ *
+ * Every function follows one reference kernel line by line (paths relative to the reference's
+ * lib/model/).  The reference's CUDA sources cannot be compiled or run in this environment (no
+ * nvcc / CUDA device, TH/THC headers gone from torch>=1.0, torch.utils.ffi removed) and the
+ * reference ships no tests, golden vectors or known-answer files for any of these ops, so
+ *
+ *     ***  PARITY UNPINNED for the ops in this file  ***
+ *
+ * by anything the reference itself provides.  What pins them instead: independent second
+ * formulations in PyTorch (tests/test_oracle_*.py: shifted-product correlation, python-loop
+ * pooling, F.grid_sample for RoI crop / RoI align, O(N^2) greedy NMS) and float64 autograd for the
+ * backwards.  The RPN-side pieces that CAN be imported from the reference are pinned by golden
+ * fixtures (tests/golden/, oracle/rpn_oracle.py).
+ *
+ * Floating point: compile with -ffp-contract=off -fno-fast-math.  nvcc's default -fmad=true may have
+ * contracted some mul+add pairs in the reference build; no such contraction is assumed here (the
+ * declared semantics are IEEE-754 binary32 separate multiply and add), and the HIP kernels make
+ * the same choice, so indices / keep lists are bit-exact between the two.
+ *
+ * OpenMP only parallelises loops over independent outputs; per-output arithmetic order is the
+ * reference's.
+ */
+#include <math.h>
+#include <float.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdint.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define REF_THREADS_PER_BLOCK 32 /* correlation_cuda_kernel.cu:8 */
+
+int oracle_num_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+void oracle_set_num_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Correlation
+ * ---------------------------------------------------------------------------------------------- */
+
+/* correlation_cuda.c:19-34 (Correlation_forward_cuda): output shape */
+int oracle_correlation_output_shape(int ic, int ih, int iw, int pad_size, int kernel_size,
+                                    int max_displacement, int stride1, int stride2, int* oc,
+                                    int* oh, int* ow) {
+  (void)ic;
+  if (stride1 <= 0 || stride2 <= 0 || kernel_size <= 0) return 0;
+  int kernel_radius = (kernel_size - 1) / 2;
+  int border_radius = kernel_radius + max_displacement;
+  int paddedInputHeight = ih + 2 * pad_size;
+  int paddedInputWidth = iw + 2 * pad_size;
+  int nOutputChannels =
+      ((max_displacement / stride2) * 2 + 1) * ((max_displacement / stride2) * 2 + 1);
+  int outputHeight = (int)ceil((float)(paddedInputHeight - 2 * border_radius) / (float)stride1);
+  int outputWidth = (int)ceil((float)(paddedInputWidth - 2 * border_radius) / (float)stride1);
+  *oc = nOutputChannels;
+  *oh = outputHeight;
+  *ow = outputWidth;
+  return outputHeight > 0 && outputWidth > 0;
+}
+
+/* correlation_cuda_kernel.cu:10-32 (channels_first): NCHW -> zero padded NHWC */
+static float* corr_repack(const float* input, int B, int C, int H, int W, int pad) {
+  int pH = H + 2 * pad, pW = W + 2 * pad;
+  size_t n = (size_t)B * pH * pW * C;
+  float* r = (float*)calloc(n, sizeof(float)); /* correlation_cuda.c:40-41 fill(0) */
+  if (!r) return NULL;
+#pragma omp parallel for collapse(2)
+  for (int b = 0; b < B; ++b)
+    for (int y = 0; y < H; ++y)
+      for (int x = 0; x < W; ++x)
+        for (int c = 0; c < C; ++c)
+          r[(((size_t)b * pH + (y + pad)) * pW + (x + pad)) * C + c] =
+              input[(((size_t)b * C + c) * H + y) * W + x];
+  return r;
+}
+
+/* correlation_cuda_kernel.cu:34-106 (Correlation_forward), launched from :296-369.
+ * Reduction order reproduced: THREADS_PER_BLOCK strided partial sums (each over (j, i, ch) in loop
+ * order), then a serial sum of the 32 partials by thread 0, then one division by nelems. */
+int oracle_correlation_forward(float* output, const float* input1, const float* input2, int B,
+                               int C, int H, int W, int pad_size, int kernel_size,
+                               int max_displacement, int stride1, int stride2) {
+  int oc, oh, ow;
+  if (!oracle_correlation_output_shape(C, H, W, pad_size, kernel_size, max_displacement, stride1,
+                                       stride2, &oc, &oh, &ow))
+    return 0;
+  /* the reference reads rInput out of bounds when pad_size < border radius; refuse instead */
+  float* r1 = corr_repack(input1, B, C, H, W, pad_size);
+  float* r2 = corr_repack(input2, B, C, H, W, pad_size);
+  if (!r1 || !r2) { free(r1); free(r2); return 0; }
+  int pW = W + 2 * pad_size, pH = H + 2 * pad_size;
+  int kernel_rad = (kernel_size - 1) / 2;
+  int displacement_rad = max_displacement / stride2;
+  int displacement_size = 2 * displacement_rad + 1;
+  size_t pdimyxc = (size_t)pH * pW * C, pdimxc = (size_t)pW * C;
+  int pdimc = C;
+  float nelems = (float)(kernel_size * kernel_size * pdimc);
+  int ok = 1;
+#pragma omp parallel for collapse(3)
+  for (int n = 0; n < B; ++n)
+    for (int by = 0; by < oh; ++by)
+      for (int bx = 0; bx < ow; ++bx) {
+        int y1 = by * stride1 + max_displacement + kernel_rad;
+        int x1 = bx * stride1 + max_displacement + kernel_rad;
+        for (int tj = -displacement_rad; tj <= displacement_rad; ++tj)
+          for (int ti = -displacement_rad; ti <= displacement_rad; ++ti) {
+            float prod_sum[REF_THREADS_PER_BLOCK];
+            int x2 = x1 + ti * stride2;
+            int y2 = y1 + tj * stride2;
+            for (int c = 0; c < REF_THREADS_PER_BLOCK; ++c) {
+              float acc = 0.f;
+              for (int j = -kernel_rad; j <= kernel_rad; ++j)
+                for (int i = -kernel_rad; i <= kernel_rad; ++i) {
+                  int ya = y1 + j, xa = x1 + i, yb = y2 + j, xb = x2 + i;
+                  /* positions outside the padded buffer: the reference would read out of bounds;
+                   * treat as zero padding (only reachable when pad_size < max_displacement) */
+                  int in_a = ya >= 0 && ya < pH && xa >= 0 && xa < pW;
+                  int in_b = yb >= 0 && yb < pH && xb >= 0 && xb < pW;
+                  for (int ch = c; ch < pdimc; ch += REF_THREADS_PER_BLOCK) {
+                    float a = in_a ? r1[n * pdimyxc + ya * pdimxc + (size_t)xa * pdimc + ch] : 0.f;
+                    float b = in_b ? r2[n * pdimyxc + yb * pdimxc + (size_t)xb * pdimc + ch] : 0.f;
+                    float p = a * b;
+                    acc = acc + p;
+                  }
+                }
+              prod_sum[c] = acc;
+            }
+            float reduce_sum = 0.f;
+            for (int index = 0; index < REF_THREADS_PER_BLOCK; ++index) reduce_sum += prod_sum[index];
+            int tc = (tj + displacement_rad) * displacement_size + (ti + displacement_rad);
+            output[(((size_t)n * oc + tc) * oh + by) * ow + bx] = reduce_sum / nelems;
+          }
+      }
+  free(r1);
+  free(r2);
+  return ok;
+}
+
+/* correlation_cuda_kernel.cu:108-198 (Correlation_backward_input1) and :200-290 (.._input2),
+ * launched from :371-473, for kernel_size == 1.
+ *
+ * Deliberate deviation: the reference launches one block per INPUT pixel
+ * but computes y = blockIdx.x*stride1 + pad_size (.cu:120-121, 212-213), so for stride1 > 1 it
+ * visits only every stride1-th pixel and runs out of bounds for the rest.  Here every input pixel
+ * (y, x) is visited and contributes only when (y + pad - max_displacement [- j2]) is an exact,
+ * in-range multiple of stride1 -- the mathematically correct gradient of the forward above.  For
+ * stride1 == 1 this is the reference arithmetic unchanged, including the summation order
+ * (32 strided partials over output channels, serial sum, one division). */
+int oracle_correlation_backward(float* gradInput1, float* gradInput2, const float* gradOutput,
+                                const float* input1, const float* input2, int B, int C, int H,
+                                int W, int pad_size, int kernel_size, int max_displacement,
+                                int stride1, int stride2) {
+  if (kernel_size != 1) return 0;
+  int oc, oh, ow;
+  if (!oracle_correlation_output_shape(C, H, W, pad_size, kernel_size, max_displacement, stride1,
+                                       stride2, &oc, &oh, &ow))
+    return 0;
+  float* r1 = corr_repack(input1, B, C, H, W, pad_size);
+  float* r2 = corr_repack(input2, B, C, H, W, pad_size);
+  if (!r1 || !r2) { free(r1); free(r2); return 0; }
+  int pW = W + 2 * pad_size, pH = H + 2 * pad_size;
+  int displacement_rad = max_displacement / stride2;
+  int displacement_size = 2 * displacement_rad + 1;
+  size_t pdimyxc = (size_t)pH * pW * C, pdimxc = (size_t)pW * C;
+  float nelems = (float)(kernel_size * kernel_size * C);
+  size_t tdimcyx = (size_t)oc * oh * ow, tdimyx = (size_t)oh * ow;
+#pragma omp parallel for collapse(3)
+  for (int n = 0; n < B; ++n)
+    for (int yy = 0; yy < H; ++yy)
+      for (int xx = 0; xx < W; ++xx) {
+        int y = yy + pad_size, x = xx + pad_size; /* padded coordinates */
+        for (int c = 0; c < C; ++c) {
+          /* ---- input1 (.cu:108-198) ---- */
+          {
+            float prod_sum[REF_THREADS_PER_BLOCK];
+            int ry = y - max_displacement, rx = x - max_displacement;
+            int valid = ry >= 0 && rx >= 0 && ry % stride1 == 0 && rx % stride1 == 0;
+            int oy = valid ? ry / stride1 : 0, ox = valid ? rx / stride1 : 0;
+            if (valid && (oy >= oh || ox >= ow)) valid = 0;
+            for (int t = 0; t < REF_THREADS_PER_BLOCK; ++t) {
+              float acc = 0.f;
+              if (valid)
+                for (int tc = t; tc < oc; tc += REF_THREADS_PER_BLOCK) {
+                  int i2 = (tc % displacement_size - displacement_rad) * stride2;
+                  int j2 = (tc / displacement_size - displacement_rad) * stride2;
+                  int yb = y + j2, xb = x + i2;
+                  float val2 = (yb >= 0 && yb < pH && xb >= 0 && xb < pW)
+                                   ? r2[n * pdimyxc + yb * pdimxc + (size_t)xb * C + c]
+                                   : 0.f;
+                  float p = gradOutput[n * tdimcyx + tc * tdimyx + (size_t)oy * ow + ox] * val2;
+                  acc = acc + p;
+                }
+              prod_sum[t] = acc;
+            }
+            float reduce_sum = 0.f;
+            for (int idx = 0; idx < REF_THREADS_PER_BLOCK; ++idx) reduce_sum += prod_sum[idx];
+            gradInput1[(((size_t)n * C + c) * H + yy) * W + xx] = reduce_sum / nelems;
+          }
+          /* ---- input2 (.cu:200-290) ---- */
+          {
+            float prod_sum[REF_THREADS_PER_BLOCK];
+            for (int t = 0; t < REF_THREADS_PER_BLOCK; ++t) {
+              float acc = 0.f;
+              for (int tc = t; tc < oc; tc += REF_THREADS_PER_BLOCK) {
+                int i2 = (tc % displacement_size - displacement_rad) * stride2;
+                int j2 = (tc / displacement_size - displacement_rad) * stride2;
+                int ry = y - max_displacement - j2, rx = x - max_displacement - i2;
+                if (ry < 0 || rx < 0 || ry % stride1 != 0 || rx % stride1 != 0) continue;
+                int oy = ry / stride1, ox = rx / stride1;
+                if (oy >= oh || ox >= ow) continue;
+                int ya = y - j2, xa = x - i2;
+                float val1 = (ya >= 0 && ya < pH && xa >= 0 && xa < pW)
+                                 ? r1[n * pdimyxc + ya * pdimxc + (size_t)xa * C + c]
+                                 : 0.f;
+                float p = gradOutput[n * tdimcyx + tc * tdimyx + (size_t)oy * ow + ox] * val1;
+                acc = acc + p;
+              }
+              prod_sum[t] = acc;
+            }
+            float reduce_sum = 0.f;
+            for (int idx = 0; idx < REF_THREADS_PER_BLOCK; ++idx) reduce_sum += prod_sum[idx];
+            gradInput2[(((size_t)n * C + c) * H + yy) * W + xx] = reduce_sum / nelems;
+          }
+        }
+      }
+  free(r1);
+  free(r2);
+  return 1;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * PSRoI pooling
+ * ---------------------------------------------------------------------------------------------- */
+
+/* CUDA's round() on a float argument promoted to double: half away from zero
+ * (psroi_pooling_kernel.cu:32-38 `static_cast<float>(round(bottom_rois[1]))`). */
+static inline float ref_roundf(float v) { return (float)round((double)v); }
+
+typedef struct { int hstart, hend, wstart, wend, is_empty; } ps_bin_t;
+
+/* psroi_pooling_kernel.cu:29-59: RoI geometry of one bin.  `max(x, 0.1)` compares a float with the
+ * double literal 0.1 (result double, then narrowed to float); `round(.) + 1.` is double. */
+static inline ps_bin_t psroi_bin(const float* roi, float spatial_scale, int ph, int pw,
+                                 int pooled_height, int pooled_width, int height, int width) {
+  float roi_start_w = (float)round((double)roi[1]) * spatial_scale;
+  float roi_start_h = (float)round((double)roi[2]) * spatial_scale;
+  float roi_end_w = (float)(round((double)roi[3]) + 1.) * spatial_scale;
+  float roi_end_h = (float)(round((double)roi[4]) + 1.) * spatial_scale;
+  double dw = (double)(roi_end_w - roi_start_w), dh = (double)(roi_end_h - roi_start_h);
+  float roi_width = (float)(dw > 0.1 ? dw : 0.1);
+  float roi_height = (float)(dh > 0.1 ? dh : 0.1);
+  float bin_size_h = roi_height / (float)pooled_height;
+  float bin_size_w = roi_width / (float)pooled_width;
+  ps_bin_t b;
+  b.hstart = (int)floorf((float)ph * bin_size_h + roi_start_h);
+  b.wstart = (int)floorf((float)pw * bin_size_w + roi_start_w);
+  b.hend = (int)ceilf((float)(ph + 1) * bin_size_h + roi_start_h);
+  b.wend = (int)ceilf((float)(pw + 1) * bin_size_w + roi_start_w);
+  b.hstart = b.hstart < 0 ? 0 : (b.hstart > height ? height : b.hstart);
+  b.hend = b.hend < 0 ? 0 : (b.hend > height ? height : b.hend);
+  b.wstart = b.wstart < 0 ? 0 : (b.wstart > width ? width : b.wstart);
+  b.wend = b.wend < 0 ? 0 : (b.wend > width ? width : b.wend);
+  b.is_empty = (b.hend <= b.hstart) || (b.wend <= b.wstart);
+  return b;
+}
+
+/* psroi_pooling_kernel.cu:15-79 (PSROIPoolForward) */
+int oracle_psroi_pool_forward(const float* bottom_data, float spatial_scale, int num_rois,
+                              int height, int width, int channels, int pooled_height,
+                              int pooled_width, const float* bottom_rois, int group_size,
+                              int output_dim, float* top_data, int* mapping_channel) {
+  long nthreads = (long)num_rois * output_dim * pooled_height * pooled_width;
+#pragma omp parallel for
+  for (long index = 0; index < nthreads; ++index) {
+    int pw = index % pooled_width;
+    int ph = (index / pooled_width) % pooled_height;
+    int ctop = (index / pooled_width / pooled_height) % output_dim;
+    int n = index / pooled_width / pooled_height / output_dim;
+    const float* roi = bottom_rois + (size_t)n * 5;
+    int roi_batch_ind = (int)roi[0];
+    ps_bin_t b = psroi_bin(roi, spatial_scale, ph, pw, pooled_height, pooled_width, height, width);
+    int gw = pw, gh = ph;
+    int c = (ctop * group_size + gh) * group_size + gw;
+    const float* plane = bottom_data + ((size_t)roi_batch_ind * channels + c) * height * width;
+    float out_sum = 0;
+    for (int h = b.hstart; h < b.hend; ++h)
+      for (int w = b.wstart; w < b.wend; ++w) out_sum += plane[h * width + w];
+    float bin_area = (float)((b.hend - b.hstart) * (b.wend - b.wstart));
+    top_data[index] = b.is_empty ? 0.f : out_sum / bin_area;
+    if (mapping_channel) mapping_channel[index] = c;
+  }
+  return 1;
+}
+
+/* psroi_pooling_kernel.cu:109-170 (PSROIPoolBackward).  The reference scatters with atomicAdd in an
+ * unspecified order; the oracle accumulates in output-index order (double accumulator would hide
+ * nothing useful: compare with a tolerance). bottom_diff must be zeroed by the caller
+ * (functions/psroi_pool.py:40). */
+int oracle_psroi_pool_backward(const float* top_diff, const int* mapping_channel, int batch_size,
+                               int num_rois, float spatial_scale, int channels, int height,
+                               int width, int pooled_width, int pooled_height, int output_dim,
+                               int group_size, float* bottom_diff, const float* bottom_rois) {
+  (void)batch_size;
+  long nthreads = (long)num_rois * output_dim * pooled_height * pooled_width;
+  for (long index = 0; index < nthreads; ++index) {
+    int pw = index % pooled_width;
+    int ph = (index / pooled_width) % pooled_height;
+    int ctop = (index / pooled_width / pooled_height) % output_dim;
+    int n = index / pooled_width / pooled_height / output_dim;
+    const float* roi = bottom_rois + (size_t)n * 5;
+    int roi_batch_ind = (int)roi[0];
+    ps_bin_t b = psroi_bin(roi, spatial_scale, ph, pw, pooled_height, pooled_width, height, width);
+    int c = mapping_channel ? mapping_channel[index] : (ctop * group_size + ph) * group_size + pw;
+    float* offset_bottom_diff = bottom_diff + ((size_t)roi_batch_ind * channels + c) * height * width;
+    float bin_area = (float)((b.hend - b.hstart) * (b.wend - b.wstart));
+    float diff_val = b.is_empty ? 0.f : top_diff[index] / bin_area;
+    for (int h = b.hstart; h < b.hend; ++h)
+      for (int w = b.wstart; w < b.wend; ++w) offset_bottom_diff[h * width + w] += diff_val;
+  }
+  return 1;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * NMS
+ * ---------------------------------------------------------------------------------------------- */
+
+/* nms_cuda_kernel.cu:31-39 (devIoU) */
+static inline float dev_iou(const float* a, const float* b) {
+  float left = fmaxf(a[0], b[0]), right = fminf(a[2], b[2]);
+  float top = fmaxf(a[1], b[1]), bottom = fminf(a[3], b[3]);
+  float width = fmaxf(right - left + 1, 0.f), height = fmaxf(bottom - top + 1, 0.f);
+  float interS = width * height;
+  float Sa = (a[2] - a[0] + 1) * (a[3] - a[1] + 1);
+  float Sb = (b[2] - b[0] + 1) * (b[3] - b[1] + 1);
+  return interS / (Sa + Sb - interS);
+}
+
+/* nms_cuda_kernel.cu:41-85 (nms_kernel) + :117-144 (host greedy sweep).  mask_out (optional) is the
+ * full (boxes_num, col_blocks) uint64 matrix for mask-level parity checks. */
+int oracle_nms(int* keep_out, int* num_out, const float* boxes, int boxes_num, int boxes_dim,
+               float nms_overlap_thresh, uint64_t* mask_out) {
+  const int tpb = 64; /* threadsPerBlock = sizeof(unsigned long long) * 8, .cu:29 */
+  int col_blocks = boxes_num / tpb + (boxes_num % tpb > 0);
+  uint64_t* mask = mask_out;
+  if (!mask) mask = (uint64_t*)malloc((size_t)(boxes_num > 0 ? boxes_num : 1) * (col_blocks > 0 ? col_blocks : 1) * sizeof(uint64_t));
+  if (!mask) return 0;
+#pragma omp parallel for
+  for (int cur = 0; cur < boxes_num; ++cur) {
+    int row_start = cur / tpb, tid = cur % tpb;
+    const float* cur_box = boxes + (size_t)cur * boxes_dim;
+    for (int col_start = 0; col_start < col_blocks; ++col_start) {
+      int col_size = boxes_num - col_start * tpb;
+      if (col_size > tpb) col_size = tpb;
+      uint64_t t = 0;
+      int start = 0;
+      if (row_start == col_start) start = tid + 1;
+      for (int i = start; i < col_size; ++i)
+        if (dev_iou(cur_box, boxes + (size_t)(col_start * tpb + i) * boxes_dim) > nms_overlap_thresh)
+          t |= 1ULL << i;
+      mask[(size_t)cur * col_blocks + col_start] = t;
+    }
+  }
+  uint64_t* remv = (uint64_t*)calloc(col_blocks > 0 ? col_blocks : 1, sizeof(uint64_t));
+  int num_to_keep = 0;
+  for (int i = 0; i < boxes_num; ++i) {
+    int nblock = i / tpb, inblock = i % tpb;
+    if (!(remv[nblock] & (1ULL << inblock))) {
+      keep_out[num_to_keep++] = i;
+      const uint64_t* p = mask + (size_t)i * col_blocks;
+      for (int j = nblock; j < col_blocks; ++j) remv[j] |= p[j];
+    }
+  }
+  *num_out = num_to_keep;
+  free(remv);
+  if (!mask_out) free(mask);
+  return 1;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * RoI Align
+ * ---------------------------------------------------------------------------------------------- */
+
+/* roi_align_kernel.cu:15-70 (ROIAlignForward).  Literals such as `1.` / `0.` are double in the
+ * reference: `roi_end_w - roi_start_w + 1.` is evaluated in double and narrowed by fmaxf's float
+ * parameter; `(aligned_height - 1.)` is double so the division is a double division narrowed to
+ * float; the bilinear blend `bottom_data[..] * (1. - h_ratio) * (1. - w_ratio) + ...` is evaluated in
+ * double and narrowed on the store. */
+int oracle_roi_align_forward(const float* bottom_data, float spatial_scale, int num_rois,
+                             int height, int width, int channels, int aligned_height,
+                             int aligned_width, const float* bottom_rois, float* top_data) {
+  long nthreads = (long)num_rois * channels * aligned_height * aligned_width;
+#pragma omp parallel for
+  for (long index = 0; index < nthreads; ++index) {
+    int pw = index % aligned_width;
+    int ph = (index / aligned_width) % aligned_height;
+    int c = (index / aligned_width / aligned_height) % channels;
+    int n = index / aligned_width / aligned_height / channels;
+    float roi_batch_ind = bottom_rois[n * 5 + 0];
+    float roi_start_w = bottom_rois[n * 5 + 1] * spatial_scale;
+    float roi_start_h = bottom_rois[n * 5 + 2] * spatial_scale;
+    float roi_end_w = bottom_rois[n * 5 + 3] * spatial_scale;
+    float roi_end_h = bottom_rois[n * 5 + 4] * spatial_scale;
+    float roi_width = fmaxf((float)((double)(roi_end_w - roi_start_w) + 1.), 0.f);
+    float roi_height = fmaxf((float)((double)(roi_end_h - roi_start_h) + 1.), 0.f);
+    float bin_size_h = (float)((double)roi_height / (aligned_height - 1.));
+    float bin_size_w = (float)((double)roi_width / (aligned_width - 1.));
+    float h = (float)(ph)*bin_size_h + roi_start_h;
+    float w = (float)(pw)*bin_size_w + roi_start_w;
+    int hstart = (int)fminf(floorf(h), (float)(height - 2));
+    int wstart = (int)fminf(floorf(w), (float)(width - 2));
+    long img_start = (long)(roi_batch_ind * channels * height * width); /* float arithmetic, .cu:50 */
+    if (h < 0 || h >= height || w < 0 || w >= width) {
+      top_data[index] = 0.f;
+    } else {
+      float h_ratio = h - (float)(hstart);
+      float w_ratio = w - (float)(wstart);
+      long upleft = img_start + ((long)c * height + hstart) * width + wstart;
+      long upright = upleft + 1, downleft = upleft + width, downright = downleft + 1;
+      double v = (double)bottom_data[upleft] * (1. - h_ratio) * (1. - w_ratio) +
+                 (double)bottom_data[upright] * (1. - h_ratio) * w_ratio +
+                 (double)bottom_data[downleft] * h_ratio * (1. - w_ratio) +
+                 (double)bottom_data[downright] * h_ratio * w_ratio;
+      top_data[index] = (float)v;
+    }
+  }
+  return 1;
+}
+
+/* roi_align_kernel.cu:94-143 (ROIAlignBackward).  atomicAdd(float*, double) narrows the value to
+ * float before adding.  bottom_diff must be zeroed by the caller (functions/roi_align.py:38-39). */
+int oracle_roi_align_backward(const float* top_diff, float spatial_scale, int batch_size,
+                              int num_rois, int height, int width, int channels,
+                              int aligned_height, int aligned_width, const float* bottom_rois,
+                              float* bottom_diff) {
+  (void)batch_size;
+  long nthreads = (long)num_rois * channels * aligned_height * aligned_width;
+  for (long index = 0; index < nthreads; ++index) {
+    int pw = index % aligned_width;
+    int ph = (index / aligned_width) % aligned_height;
+    int c = (index / aligned_width / aligned_height) % channels;
+    int n = index / aligned_width / aligned_height / channels;
+    float roi_batch_ind = bottom_rois[n * 5 + 0];
+    float roi_start_w = bottom_rois[n * 5 + 1] * spatial_scale;
+    float roi_start_h = bottom_rois[n * 5 + 2] * spatial_scale;
+    float roi_end_w = bottom_rois[n * 5 + 3] * spatial_scale;
+    float roi_end_h = bottom_rois[n * 5 + 4] * spatial_scale;
+    float roi_width = fmaxf((float)((double)(roi_end_w - roi_start_w) + 1.), 0.f);
+    float roi_height = fmaxf((float)((double)(roi_end_h - roi_start_h) + 1.), 0.f);
+    float bin_size_h = (float)((double)roi_height / (aligned_height - 1.));
+    float bin_size_w = (float)((double)roi_width / (aligned_width - 1.));
+    float h = (float)(ph)*bin_size_h + roi_start_h;
+    float w = (float)(pw)*bin_size_w + roi_start_w;
+    int hstart = (int)fminf(floorf(h), (float)(height - 2));
+    int wstart = (int)fminf(floorf(w), (float)(width - 2));
+    long img_start = (long)(roi_batch_ind * channels * height * width);
+    if (!(h < 0 || h >= height || w < 0 || w >= width)) {
+      float h_ratio = h - (float)(hstart);
+      float w_ratio = w - (float)(wstart);
+      long upleft = img_start + ((long)c * height + hstart) * width + wstart;
+      long upright = upleft + 1, downleft = upleft + width, downright = downleft + 1;
+      double g = (double)top_diff[index];
+      bottom_diff[upleft] += (float)(g * (1. - h_ratio) * (1 - w_ratio));
+      bottom_diff[upright] += (float)(g * (1. - h_ratio) * w_ratio);
+      bottom_diff[downleft] += (float)(g * h_ratio * (1 - w_ratio));
+      bottom_diff[downright] += (float)(g * h_ratio * w_ratio);
+    }
+  }
+  return 1;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * RoI (max) pooling
+ * ---------------------------------------------------------------------------------------------- */
+
+/* roi_pooling_kernel.cu:24-93 (ROIPoolForward).  `round(float)` with an int destination: CUDA's
+ * round(float) overload -> roundf (half away from zero).  fmaxf/fminf on ints convert to float. */
+int oracle_roi_pool_forward(const float* bottom_data, float spatial_scale, int num_rois,
+                            int height, int width, int channels, int pooled_height,
+                            int pooled_width, const float* bottom_rois, float* top_data,
+                            int* argmax_data) {
+  long nthreads = (long)num_rois * channels * pooled_height * pooled_width;
+#pragma omp parallel for
+  for (long index = 0; index < nthreads; ++index) {
+    int pw = index % pooled_width;
+    int ph = (index / pooled_width) % pooled_height;
+    int c = (index / pooled_width / pooled_height) % channels;
+    int n = index / pooled_width / pooled_height / channels;
+    int roi_batch_ind = (int)bottom_rois[n * 5 + 0];
+    int roi_start_w = (int)roundf(bottom_rois[n * 5 + 1] * spatial_scale);
+    int roi_start_h = (int)roundf(bottom_rois[n * 5 + 2] * spatial_scale);
+    int roi_end_w = (int)roundf(bottom_rois[n * 5 + 3] * spatial_scale);
+    int roi_end_h = (int)roundf(bottom_rois[n * 5 + 4] * spatial_scale);
+    int roi_width = (int)fmaxf((float)(roi_end_w - roi_start_w + 1), 1.f);
+    int roi_height = (int)fmaxf((float)(roi_end_h - roi_start_h + 1), 1.f);
+    float bin_size_h = (float)(roi_height) / (float)(pooled_height);
+    float bin_size_w = (float)(roi_width) / (float)(pooled_width);
+    int hstart = (int)(floorf((float)(ph)*bin_size_h));
+    int wstart = (int)(floorf((float)(pw)*bin_size_w));
+    int hend = (int)(ceilf((float)(ph + 1) * bin_size_h));
+    int wend = (int)(ceilf((float)(pw + 1) * bin_size_w));
+    hstart = (int)fminf(fmaxf((float)(hstart + roi_start_h), 0.f), (float)height);
+    hend = (int)fminf(fmaxf((float)(hend + roi_start_h), 0.f), (float)height);
+    wstart = (int)fminf(fmaxf((float)(wstart + roi_start_w), 0.f), (float)width);
+    wend = (int)fminf(fmaxf((float)(wend + roi_start_w), 0.f), (float)width);
+    int is_empty = (hend <= hstart) || (wend <= wstart);
+    float maxval = is_empty ? 0 : -FLT_MAX;
+    int maxidx = -1;
+    int bottom_data_batch_offset = roi_batch_ind * channels * height * width;
+    int bottom_data_offset = bottom_data_batch_offset + c * height * width;
+    for (int h = hstart; h < hend; ++h)
+      for (int w = wstart; w < wend; ++w) {
+        int bottom_index = h * width + w;
+        if (bottom_data[bottom_data_offset + bottom_index] > maxval) {
+          maxval = bottom_data[bottom_data_offset + bottom_index];
+          maxidx = bottom_data_offset + bottom_index;
+        }
+      }
+    top_data[index] = maxval;
+    if (argmax_data) argmax_data[index] = maxidx;
+  }
+  return 1;
+}
+
+/* roi_pooling_kernel.cu:128-203 (ROIPoolBackward): gather formulation, reproduced literally. */
+int oracle_roi_pool_backward(const float* top_diff, float spatial_scale, int batch_size,
+                             int num_rois, int height, int width, int channels,
+                             int pooled_height, int pooled_width, const float* bottom_rois,
+                             float* bottom_diff, const int* argmax_data) {
+  long nthreads = (long)batch_size * channels * height * width;
+#pragma omp parallel for
+  for (long index = 0; index < nthreads; ++index) {
+    long n = index;
+    int w = n % width; n /= width;
+    int h = n % height; n /= height;
+    int c = n % channels; n /= channels;
+    float gradient = 0;
+    for (int roi_n = 0; roi_n < num_rois; ++roi_n) {
+      const float* offset_bottom_rois = bottom_rois + roi_n * 5;
+      int roi_batch_ind = (int)offset_bottom_rois[0];
+      if (n != roi_batch_ind) continue;
+      int roi_start_w = (int)roundf(offset_bottom_rois[1] * spatial_scale);
+      int roi_start_h = (int)roundf(offset_bottom_rois[2] * spatial_scale);
+      int roi_end_w = (int)roundf(offset_bottom_rois[3] * spatial_scale);
+      int roi_end_h = (int)roundf(offset_bottom_rois[4] * spatial_scale);
+      int in_roi = (w >= roi_start_w && w <= roi_end_w && h >= roi_start_h && h <= roi_end_h);
+      if (!in_roi) continue;
+      long offset = (long)roi_n * pooled_height * pooled_width * channels;
+      const float* offset_top_diff = top_diff + offset;
+      const int* offset_argmax_data = argmax_data + offset;
+      int roi_width = (int)fmaxf((float)(roi_end_w - roi_start_w + 1), 1.f);
+      int roi_height = (int)fmaxf((float)(roi_end_h - roi_start_h + 1), 1.f);
+      float bin_size_h = (float)(roi_height) / (float)(pooled_height);
+      float bin_size_w = (float)(roi_width) / (float)(pooled_width);
+      int phstart = (int)floorf((float)(h - roi_start_h) / bin_size_h);
+      int phend = (int)ceilf((float)(h - roi_start_h + 1) / bin_size_h);
+      int pwstart = (int)floorf((float)(w - roi_start_w) / bin_size_w);
+      int pwend = (int)ceilf((float)(w - roi_start_w + 1) / bin_size_w);
+      phstart = (int)fminf(fmaxf((float)phstart, 0.f), (float)pooled_height);
+      phend = (int)fminf(fmaxf((float)phend, 0.f), (float)pooled_height);
+      pwstart = (int)fminf(fmaxf((float)pwstart, 0.f), (float)pooled_width);
+      pwend = (int)fminf(fmaxf((float)pwend, 0.f), (float)pooled_width);
+      for (int ph = phstart; ph < phend; ++ph)
+        for (int pw = pwstart; pw < pwend; ++pw)
+          if (offset_argmax_data[(c * pooled_height + ph) * pooled_width + pw] == index)
+            gradient += offset_top_diff[(c * pooled_height + ph) * pooled_width + pw];
+    }
+    bottom_diff[index] = gradient;
+  }
+  return 1;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * RoI crop (bilinear grid sampler, BCHW data, (y, x) grids)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* roi_crop_cuda_kernel.cu:11-22 (getTopLeft) */
+static inline void get_top_left(float x, int width, int* point, float* weight) {
+  float xcoord = (x + 1) * (width - 1) / 2;
+  *point = (int)floorf(xcoord);
+  *weight = 1 - (xcoord - *point);
+}
+static inline int between(int v, int lo, int hi) { return v >= lo && v <= hi; }
+
+/* roi_crop_cuda_kernel.cu:47-109 (bilinearSamplingFromGrid) with the strides the shim passes for
+ * contiguous tensors (roi_crop_cuda.c:15-52).  The reference skips fully-outside samples and relies
+ * on a pre-zeroed output (functions/roi_crop.py:11); the oracle writes the 0 explicitly. */
+int oracle_roi_crop_forward(int oc, int ow, int oh, int ob, int ic, int ih, int iw, int ib,
+                            const float* inputImages, const float* grids, float* output) {
+  int roiPerImage = ob / ib;
+  long nthreads = (long)ob * oh * ow * oc;
+#pragma omp parallel for
+  for (long index = 0; index < nthreads; ++index) {
+    int xOut = index % ow;
+    int yOut = (index / ow) % oh;
+    int cOut = (index / ow / oh) % oc;
+    int b = index / ow / oh / oc;
+    int width = iw, height = ih;
+    int b_input = b / roiPerImage;
+    float yf = grids[(((size_t)b * oh + yOut) * ow + xOut) * 2 + 0];
+    float xf = grids[(((size_t)b * oh + yOut) * ow + xOut) * 2 + 1];
+    int yInTopLeft, xInTopLeft;
+    float yWeightTopLeft, xWeightTopLeft;
+    get_top_left(xf, iw, &xInTopLeft, &xWeightTopLeft);
+    get_top_left(yf, ih, &yInTopLeft, &yWeightTopLeft);
+    size_t outAddress = (((size_t)b * oc + cOut) * oh + yOut) * ow + xOut;
+    long inTopLeftAddress = (((long)b_input * ic + cOut) * ih + yInTopLeft) * iw + xInTopLeft;
+    long inTopRightAddress = inTopLeftAddress + 1;
+    long inBottomLeftAddress = inTopLeftAddress + iw;
+    long inBottomRightAddress = inBottomLeftAddress + 1;
+    float v = 0, inTopLeft = 0, inTopRight = 0, inBottomLeft = 0, inBottomRight = 0;
+    int topLeftIsIn = between(xInTopLeft, 0, width - 1) && between(yInTopLeft, 0, height - 1);
+    int topRightIsIn = between(xInTopLeft + 1, 0, width - 1) && between(yInTopLeft, 0, height - 1);
+    int bottomLeftIsIn = between(xInTopLeft, 0, width - 1) && between(yInTopLeft + 1, 0, height - 1);
+    int bottomRightIsIn = between(xInTopLeft + 1, 0, width - 1) && between(yInTopLeft + 1, 0, height - 1);
+    if (!topLeftIsIn && !topRightIsIn && !bottomLeftIsIn && !bottomRightIsIn) {
+      output[outAddress] = 0.f;
+      continue;
+    }
+    if (topLeftIsIn) inTopLeft = inputImages[inTopLeftAddress];
+    if (topRightIsIn) inTopRight = inputImages[inTopRightAddress];
+    if (bottomLeftIsIn) inBottomLeft = inputImages[inBottomLeftAddress];
+    if (bottomRightIsIn) inBottomRight = inputImages[inBottomRightAddress];
+    v = xWeightTopLeft * yWeightTopLeft * inTopLeft +
+        (1 - xWeightTopLeft) * yWeightTopLeft * inTopRight +
+        xWeightTopLeft * (1 - yWeightTopLeft) * inBottomLeft +
+        (1 - xWeightTopLeft) * (1 - yWeightTopLeft) * inBottomRight;
+    output[outAddress] = v;
+  }
+  return 1;
+}
+
+/* roi_crop_cuda_kernel.cu:111-194 (backwardBilinearSampling): image gradient only; the grid
+ * gradient is computed-and-dropped in the reference (.cu:154-192), i.e. stays zero.
+ * gradInputImages must be zeroed by the caller (functions/roi_crop.py:18). */
+int oracle_roi_crop_backward(int goc, int gow, int goh, int gob, int ic, int ih, int iw, int ib,
+                             const float* inputImages, const float* grids,
+                             float* gradInputImages, const float* gradOutput) {
+  (void)inputImages;
+  int roiPerImage = gob / ib;
+  long nthreads = (long)gob * goh * gow * goc;
+  for (long index = 0; index < nthreads; ++index) {
+    int xOut = index % gow;
+    int yOut = (index / gow) % goh;
+    int cOut = (index / gow / goh) % goc;
+    int b = index / gow / goh / goc;
+    int b_input = b / roiPerImage;
+    int width = iw, height = ih;
+    float yf = grids[(((size_t)b * goh + yOut) * gow + xOut) * 2 + 0];
+    float xf = grids[(((size_t)b * goh + yOut) * gow + xOut) * 2 + 1];
+    int yInTopLeft, xInTopLeft;
+    float yWeightTopLeft, xWeightTopLeft;
+    get_top_left(xf, iw, &xInTopLeft, &xWeightTopLeft);
+    get_top_left(yf, ih, &yInTopLeft, &yWeightTopLeft);
+    long tl = (((long)b_input * ic + cOut) * ih + yInTopLeft) * iw + xInTopLeft;
+    long tr = tl + 1, bl = tl + iw, br = bl + 1;
+    int topLeftIsIn = between(xInTopLeft, 0, width - 1) && between(yInTopLeft, 0, height - 1);
+    int topRightIsIn = between(xInTopLeft + 1, 0, width - 1) && between(yInTopLeft, 0, height - 1);
+    int bottomLeftIsIn = between(xInTopLeft, 0, width - 1) && between(yInTopLeft + 1, 0, height - 1);
+    int bottomRightIsIn = between(xInTopLeft + 1, 0, width - 1) && between(yInTopLeft + 1, 0, height - 1);
+    float g = gradOutput[(((size_t)b * goc + cOut) * goh + yOut) * gow + xOut];
+    if (topLeftIsIn) gradInputImages[tl] += xWeightTopLeft * yWeightTopLeft * g;
+    if (topRightIsIn) gradInputImages[tr] += (1 - xWeightTopLeft) * yWeightTopLeft * g;
+    if (bottomLeftIsIn) gradInputImages[bl] += xWeightTopLeft * (1 - yWeightTopLeft) * g;
+    if (bottomRightIsIn) gradInputImages[br] += (1 - xWeightTopLeft) * (1 - yWeightTopLeft) * g;
+  }
+  return 1;
+}
