@@ -177,40 +177,37 @@ int dtt_proposal_forward(const float* cls_prob, const float* bbox_pred, const fl
 
 /* ---------------------------------------------------------------- RPN anchor-target layer
  * Replaces _AnchorTargetLayer.forward (rpn/anchor_target_layer.py:48-191) with bbox_overlaps_batch
- * (rpn/bbox_transform.py:208-254) and bbox_transform_batch (:36-75).  Two stream-ordered phases
- * so that the random subsampling can consume numpy's RNG on the host exactly as the reference
- * does (anchor_target_layer.py:124-141):
- *   phase 1 (dtt_anchor_target_assign): per-anchor labels {1,0,-1} before subsampling, the arg-max
- *     GT per anchor, and per-image fg / bg counts.
- *   host: reads the 2B counts, draws the permutations, uploads `disable` lists (may be empty).
- *   phase 2 (dtt_anchor_target_finish): applies the disables, encodes regression targets and the
- *     uniform weights, and writes the four outputs in the reference layouts
- *     (anchor_target_layer.py:168-189).
- * gt_boxes (B, G, 5) [x1,y1,x2,y2,cls]; im_info (B,3) -- only row 0 is used for the inside test
- * (anchor_target_layer.py:85-86, reproduced).
+ * (rpn/bbox_transform.py:208-254) and bbox_transform_batch (:36-75).  Stream-ordered phases, so that
+ * the random subsampling can consume numpy's RNG on the host exactly as the reference does
+ * (anchor_target_layer.py:124-141):
+ *   dtt_anchor_target_assign : per-anchor labels {1,0,-1} before subsampling (-1 also for anchors
+ *     outside the image), the arg-max GT per anchor, and per-image [fg, bg] counts.
+ *   host: reads the 2B counts, draws the permutations, uploads the indices to disable.
+ *   dtt_anchor_target_disable: labels[b, disable[i]] = -1 for i in [offsets[b], offsets[b+1]).
+ *   dtt_anchor_target_finish : regression targets, weights, and the four outputs in the reference
+ *     layouts (anchor_target_layer.py:168-189): labels (B,1,A*H,W), targets / inside / outside
+ *     weights (B,4A,H,W).
+ * gt_boxes (B, G, 5) [x1,y1,x2,y2,cls].  im_h0 / im_w0 = long(im_info[0][0]), long(im_info[0][1]):
+ * the reference tests "inside the image" against image 0 only (anchor_target_layer.py:85-86,
+ * reproduced); passing them by value keeps the call free of device-to-host copies.
+ * positive_weight / negative_weight are the outside weights of fg / bg anchors
+ * (1/num_examples of the LAST image under the reference's uniform weighting, :153-156).
+ * gt_max_scratch: int32[B*G] scratch.
  */
-int dtt_anchor_target_assign(const float* gt_boxes, const float* im_info, const float* anchors,
+int dtt_anchor_target_assign(const float* gt_boxes, int im_h0, int im_w0, const float* anchors,
                              int batch, int num_gt, int num_anchors, int height, int width,
                              int feat_stride, float negative_overlap, float positive_overlap,
-                             int clobber_positives,
-                             int* labels /* (B, K*A) */, int* argmax_gt /* (B, K*A) */,
-                             int* counts /* (B, 2): fg, bg */, void* stream);
-int dtt_anchor_target_finish(const float* gt_boxes, const float* anchors,
-                             const int* labels_in /* (B, K*A), after host/device subsampling */,
-                             const int* argmax_gt, int batch, int num_gt, int num_anchors,
-                             int height, int width, int feat_stride, float inside_weight,
-                             float positive_weight /* <0: uniform 1/num_examples of LAST image */,
-                             float* labels_out /* (B,1,A*H,W) */, float* bbox_targets /* (B,4A,H,W) */,
-                             float* bbox_inside_weights, float* bbox_outside_weights,
-                             void* stream);
-/* sets labels[b, idx] = -1 for idx in disable[b_off[b] .. b_off[b+1]) */
+                             int clobber_positives, int* labels /* (B, K*A) */,
+                             int* argmax_gt /* (B, K*A) */, int* counts /* (B, 2) */,
+                             int* gt_max_scratch, void* stream);
 int dtt_anchor_target_disable(int* labels, const int* disable, const int* disable_offsets,
                               int batch, int total_anchors, void* stream);
-
-/* ---------------------------------------------------------------- test-time detection post-processing
- * Replaces the per-class loop of test_net.py:274-291 (threshold, sort, nms(cls_dets, TEST.NMS))
- * for all classes of one image in one launch.  
- */
+int dtt_anchor_target_finish(const float* gt_boxes, int im_h0, int im_w0, const float* anchors,
+                             const int* labels_in, const int* argmax_gt, int batch, int num_gt,
+                             int num_anchors, int height, int width, int feat_stride,
+                             float inside_weight, float positive_weight, float negative_weight,
+                             float* labels_out, float* bbox_targets, float* bbox_inside_weights,
+                             float* bbox_outside_weights, void* stream);
 
 #ifdef __cplusplus
 }

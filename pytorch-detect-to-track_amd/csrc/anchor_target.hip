@@ -1,0 +1,200 @@
+// RPN anchor-target layer for gfx950.
+//
+// Replaces _AnchorTargetLayer.forward (reference rpn/anchor_target_layer.py:48-191): numpy meshgrid + H2D,
+// a dense (B, N_inside, G) IoU tensor with ~10 temporaries (bbox_transform.py:208-254), Python per-image
+// loops.  Here each anchor is one thread that recomputes its <= G IoUs in registers (nothing dense is
+// materialised):
+//   at_gt_max   : per-GT maximum IoU over the inside anchors (atomicMax on the float bits)
+//   at_assign   : labels {1, 0, -1}, arg-max GT, per-image fg / bg counts
+//   (host draws numpy permutations exactly like the reference, anchor_target_layer.py:124-141)
+//   at_disable  : applies the host's disable lists
+//   at_finish   : regression targets (bbox_transform.py:36-75), weights and the four output layouts
+//                 (anchor_target_layer.py:168-189)
+// IoU / encode arithmetic is binary32 in the reference's operation order, FP contraction off; log is
+// correctly rounded via double (declared semantics, see oracle/rpn_oracle.py).
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+struct AtGeom {
+  int B, G, A, H, W, K, n, stride;
+  int im_h, im_w;  // long(im_info[0][0]), long(im_info[0][1])  (image 0 only, anchor_target_layer.py:85-86)
+};
+
+__device__ __forceinline__ void anchor_of(const float* __restrict__ base, const AtGeom& g, int t, float& x1, float& y1,
+                                          float& x2, float& y2) {
+  const int k = t / g.A, a = t - k * g.A;
+  const int h = k / g.W, w = k - h * g.W;
+  const float sx = (float)(w * g.stride), sy = (float)(h * g.stride);
+  x1 = base[a * 4 + 0] + sx; y1 = base[a * 4 + 1] + sy;
+  x2 = base[a * 4 + 2] + sx; y2 = base[a * 4 + 3] + sy;
+}
+
+__device__ __forceinline__ bool inside(const AtGeom& g, float x1, float y1, float x2, float y2) {
+  return x1 >= 0.f && y1 >= 0.f && x2 < (float)g.im_w && y2 < (float)g.im_h;
+}
+
+// bbox_transform.py:228-254 for one (anchor, gt) pair
+__device__ __forceinline__ float overlap(float ax1, float ay1, float ax2, float ay2, const float* __restrict__ gt) {
+  const float gx = gt[2] - gt[0] + 1.f, gy = gt[3] - gt[1] + 1.f;
+  const float g_area = gx * gy;
+  const float ax = ax2 - ax1 + 1.f, ay = ay2 - ay1 + 1.f;
+  const float a_area = ax * ay;
+  float iw = fminf(ax2, gt[2]) - fmaxf(ax1, gt[0]) + 1.f;
+  if (iw < 0.f) iw = 0.f;
+  float ih = fminf(ay2, gt[3]) - fmaxf(ay1, gt[1]) + 1.f;
+  if (ih < 0.f) ih = 0.f;
+  const float ua = a_area + g_area - (iw * ih);
+  float ov = iw * ih / ua;
+  if (gx == 1.f && gy == 1.f) ov = 0.f;
+  if (ax == 1.f && ay == 1.f) ov = -1.f;
+  return ov;
+}
+
+// gt_max bits initialised to -1.0f by the launcher (memset pattern via kernel below)
+__global__ void at_init(int* __restrict__ gt_max_bits, int n, int* __restrict__ counts, int ncounts) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) gt_max_bits[i] = (int)0xBF800000;  // -1.0f: below every IoU >= 0 as a signed int
+  if (i < ncounts) counts[i] = 0;
+}
+
+__global__ __launch_bounds__(kThreads) void at_gt_max(const float* __restrict__ gt_boxes, const float* __restrict__ base,
+                                                      AtGeom g, int* __restrict__ gt_max_bits) {
+  const int t = blockIdx.x * kThreads + threadIdx.x, b = blockIdx.y;
+  if (t >= g.n) return;
+  float x1, y1, x2, y2;
+  anchor_of(base, g, t, x1, y1, x2, y2);
+  if (!inside(g, x1, y1, x2, y2)) return;
+  for (int j = 0; j < g.G; ++j) {
+    const float ov = overlap(x1, y1, x2, y2, gt_boxes + ((long)b * g.G + j) * 5);
+    if (ov >= 0.f) atomicMax(&gt_max_bits[b * g.G + j], __float_as_int(ov + 0.f));
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void at_assign(const float* __restrict__ gt_boxes, const float* __restrict__ base,
+                                                      AtGeom g, const int* __restrict__ gt_max_bits, float neg_thr,
+                                                      float pos_thr, int clobber, int* __restrict__ labels,
+                                                      int* __restrict__ argmax_gt, int* __restrict__ counts) {
+  const int t = blockIdx.x * kThreads + threadIdx.x, b = blockIdx.y;
+  if (t >= g.n) return;
+  float x1, y1, x2, y2;
+  anchor_of(base, g, t, x1, y1, x2, y2);
+  int label = -1, amax = 0;
+  if (inside(g, x1, y1, x2, y2)) {
+    float best = -INFINITY;
+    bool is_gt_best = false;
+    for (int j = 0; j < g.G; ++j) {
+      const float ov = overlap(x1, y1, x2, y2, gt_boxes + ((long)b * g.G + j) * 5);
+      if (ov > best) { best = ov; amax = j; }  // first maximum, as torch.max(dim)
+      float gm = __int_as_float(gt_max_bits[b * g.G + j]);
+      if (gm == 0.f) gm = 1e-5f;                // anchor_target_layer.py:104
+      if (ov == gm) is_gt_best = true;          // anchor_target_layer.py:105
+    }
+    if (!clobber && best < neg_thr) label = 0;
+    if (is_gt_best) label = 1;
+    if (best >= pos_thr) label = 1;
+    if (clobber && best < neg_thr) label = 0;
+    if (label == 1) atomicAdd(&counts[b * 2 + 0], 1);
+    if (label == 0) atomicAdd(&counts[b * 2 + 1], 1);
+  }
+  labels[(long)b * g.n + t] = label;
+  argmax_gt[(long)b * g.n + t] = amax;
+}
+
+__global__ void at_disable(int* __restrict__ labels, const int* __restrict__ disable,
+                           const int* __restrict__ offsets, int total_anchors) {
+  const int b = blockIdx.y;
+  const int beg = offsets[b], end = offsets[b + 1];
+  for (int i = beg + blockIdx.x * blockDim.x + threadIdx.x; i < end; i += gridDim.x * blockDim.x)
+    labels[(long)b * total_anchors + disable[i]] = -1;
+}
+
+__global__ __launch_bounds__(kThreads) void at_finish(const float* __restrict__ gt_boxes, const float* __restrict__ base,
+                                                      AtGeom g, const int* __restrict__ labels,
+                                                      const int* __restrict__ argmax_gt, float inside_w, float pos_w,
+                                                      float neg_w, float* __restrict__ labels_out,
+                                                      float* __restrict__ targets, float* __restrict__ in_w,
+                                                      float* __restrict__ out_w) {
+  const int t = blockIdx.x * kThreads + threadIdx.x, b = blockIdx.y;
+  if (t >= g.n) return;
+  const int k = t / g.A, a = t - k * g.A;
+  float x1, y1, x2, y2;
+  anchor_of(base, g, t, x1, y1, x2, y2);
+  const int label = labels[(long)b * g.n + t];
+  float tx = 0.f, ty = 0.f, tw = 0.f, th = 0.f;
+  if (inside(g, x1, y1, x2, y2)) {
+    const float* gt = gt_boxes + ((long)b * g.G + argmax_gt[(long)b * g.n + t]) * 5;
+    const float ew = x2 - x1 + 1.0f, eh = y2 - y1 + 1.0f;
+    const float ecx = x1 + 0.5f * ew, ecy = y1 + 0.5f * eh;
+    const float gw = gt[2] - gt[0] + 1.0f, gh = gt[3] - gt[1] + 1.0f;
+    const float gcx = gt[0] + 0.5f * gw, gcy = gt[1] + 0.5f * gh;
+    tx = (gcx - ecx) / ew;
+    ty = (gcy - ecy) / eh;
+    tw = (float)log((double)(gw / ew));
+    th = (float)log((double)(gh / eh));
+  }
+  // labels: (B, K*A) -> view (B,H,W,A) -> permute (0,3,1,2) -> (B,1,A*H,W)   (anchor_target_layer.py:171-173)
+  labels_out[((long)b * g.A + a) * g.K + k] = (float)label;
+  const float iw = label == 1 ? inside_w : 0.f;
+  const float ow = label == 1 ? pos_w : (label == 0 ? neg_w : 0.f);
+  const long o = ((long)b * 4 * g.A + 4 * a) * g.K + k;
+  targets[o] = tx; targets[o + g.K] = ty; targets[o + 2L * g.K] = tw; targets[o + 3L * g.K] = th;
+  in_w[o] = iw; in_w[o + g.K] = iw; in_w[o + 2L * g.K] = iw; in_w[o + 3L * g.K] = iw;
+  out_w[o] = ow; out_w[o + g.K] = ow; out_w[o + 2L * g.K] = ow; out_w[o + 3L * g.K] = ow;
+}
+
+}  // namespace
+
+// Host-side geometry needs im_info[0]; it is passed by value to keep the call free of D2H copies.
+extern "C" int dtt_anchor_target_assign(const float* gt_boxes, int im_h0, int im_w0, const float* anchors,
+                                           int batch, int num_gt, int num_anchors, int height, int width,
+                                           int feat_stride, float negative_overlap, float positive_overlap,
+                                           int clobber_positives, int* labels, int* argmax_gt, int* counts,
+                                           int* gt_max_scratch, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  DTT_REQUIRE(gt_boxes && anchors && labels && argmax_gt && counts && gt_max_scratch, "anchor_target: null pointer");
+  DTT_REQUIRE(batch > 0 && num_gt > 0 && num_anchors > 0 && height > 0 && width > 0, "anchor_target: bad shape");
+  AtGeom g;
+  g.B = batch; g.G = num_gt; g.A = num_anchors; g.H = height; g.W = width; g.K = height * width;
+  g.n = g.K * g.A; g.stride = feat_stride; g.im_h = im_h0; g.im_w = im_w0;
+  const int ninit = batch * num_gt > batch * 2 ? batch * num_gt : batch * 2;
+  hipLaunchKernelGGL(at_init, dim3(dtt_cdiv(ninit, 256)), dim3(256), 0, stream, gt_max_scratch, batch * num_gt, counts,
+                     batch * 2);
+  dim3 grid(dtt_cdiv(g.n, kThreads), batch);
+  hipLaunchKernelGGL(at_gt_max, grid, dim3(kThreads), 0, stream, gt_boxes, anchors, g, gt_max_scratch);
+  hipLaunchKernelGGL(at_assign, grid, dim3(kThreads), 0, stream, gt_boxes, anchors, g, gt_max_scratch,
+                     negative_overlap, positive_overlap, clobber_positives, labels, argmax_gt, counts);
+  DTT_CHECK_LAUNCH("anchor_target assign");
+  return 1;
+}
+
+extern "C" int dtt_anchor_target_disable(int* labels, const int* disable, const int* disable_offsets, int batch,
+                                         int total_anchors, void* stream_) {
+  DTT_REQUIRE(labels && disable && disable_offsets && batch > 0, "anchor_target disable: null pointer");
+  hipLaunchKernelGGL(at_disable, dim3(8, batch), dim3(256), 0, static_cast<hipStream_t>(stream_), labels, disable,
+                     disable_offsets, total_anchors);
+  DTT_CHECK_LAUNCH("anchor_target disable");
+  return 1;
+}
+
+extern "C" int dtt_anchor_target_finish(const float* gt_boxes, int im_h0, int im_w0, const float* anchors,
+                                           const int* labels_in, const int* argmax_gt, int batch, int num_gt,
+                                           int num_anchors, int height, int width, int feat_stride,
+                                           float inside_weight, float positive_weight, float negative_weight,
+                                           float* labels_out, float* bbox_targets, float* bbox_inside_weights,
+                                           float* bbox_outside_weights, void* stream_) {
+  DTT_REQUIRE(gt_boxes && anchors && labels_in && argmax_gt && labels_out && bbox_targets && bbox_inside_weights &&
+                  bbox_outside_weights,
+              "anchor_target finish: null pointer");
+  AtGeom g;
+  g.B = batch; g.G = num_gt; g.A = num_anchors; g.H = height; g.W = width; g.K = height * width;
+  g.n = g.K * g.A; g.stride = feat_stride; g.im_h = im_h0; g.im_w = im_w0;
+  hipLaunchKernelGGL(at_finish, dim3(dtt_cdiv(g.n, kThreads), batch), dim3(kThreads), 0,
+                     static_cast<hipStream_t>(stream_), gt_boxes, anchors, g, labels_in, argmax_gt, inside_weight,
+                     positive_weight, negative_weight, labels_out, bbox_targets, bbox_inside_weights,
+                     bbox_outside_weights);
+  DTT_CHECK_LAUNCH("anchor_target finish");
+  return 1;
+}

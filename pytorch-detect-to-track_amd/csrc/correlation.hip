@@ -1,0 +1,408 @@
+// FlowNet-style cross-frame correlation for gfx950.
+//
+// Replaces channels_first + Correlation_forward / Correlation_backward_input{1,2} (reference
+// correlation/src/correlation_cuda_kernel.cu:10-106, 108-290).  The reference first repacks both feature
+// maps into zero-padded NHWC scratch (after zero-filling it), then runs one 32-thread block per output
+// pixel that walks all D^2 displacements serially, re-reading frame t from L2 D^2 times.
+//
+// Here, for kernel_size 1 and stride1 == stride2 (every D&T call site, rfcn.py:58-60), the op is a banded
+// matrix product:   out[p, q] = sum_c f1[c, p] * f2[c, q]   for |q - p| <= R on the stride lattice,
+// computed with exact-f32 MFMA (v_mfma_f32_16x16x4_f32 is bitwise an fmaf chain, so no precision is
+// traded).  One workgroup = one 8x8 tile of output pixels x one channel slice:
+//   * NCHW is read directly with W-contiguous loads; zero padding is applied by predication
+//     (no repack, no scratch fills);
+//   * per 16-channel chunk the 8x8 frame-t tile and the (8+2R)^2 frame-(t+tau) halo are staged in LDS
+//     as [c][row][col] with row / plane strides chosen so both MFMA operand reads are conflict free;
+//   * each of the 4 waves owns a 4x4 block of frame-t pixels (MFMA rows) and multiplies it against the
+//     (4+2R)^2 halo it needs, cut into 4x4 pixel blocks (MFMA columns): 72 % of the MFMA work lands
+//     inside the displacement window at R = 8;
+//   * accumulators stay in registers for the whole channel loop; partial sums of the channel slices go
+//     to a workspace in fragment order (coalesced) and a small reduce kernel sums the slices in a fixed
+//     order, divides by C and scatters into NCHW -- deterministic, no atomics.
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kKc = 16;       // channels per LDS chunk
+constexpr int kTile = 8;      // output tile edge (lattice pixels)
+constexpr int kThreads = 256; // 4 waves, one 4x4 M-block each
+constexpr int kPS1 = 68;      // frame-t plane stride (64 px, +4: second k pair lands on the other banks)
+
+struct FastGeom {
+  int C, H, W;          // input
+  int oc, oh, ow;       // output
+  int s;                // lattice step (= stride1 = stride2)
+  int origin;           // unpadded coordinate of lattice point 0 (= max_displacement - pad_size)
+  int R;                // displacement radius in lattice units
+  int D;                // 2R + 1
+  int tiles_x, tiles_y; // output tiles
+  int ksplit, c_per_split;
+};
+
+template <int NBR>
+struct Cfg {
+  static constexpr int HR = 4 + 4 * NBR;                       // halo rows = cols held in LDS
+  static constexpr int HRS = (HR % 32 == 8 || HR % 32 == 24) ? HR : HR + 8;  // row stride: 4 rows on 4 bank groups
+  static constexpr int PS2 = ((HR * HRS + 7) / 8) * 8 + 4;     // plane stride = 4 mod 8
+  static constexpr int NB = NBR * NBR;                         // N-blocks per wave
+  static constexpr int ELEMS = (HR * HR + kThreads - 1) / kThreads;
+  static constexpr size_t LDS = (size_t)kKc * (PS2 + kPS1) * sizeof(float);
+};
+
+// grid: (tiles, ksplit, batch).  ws layout: [ksplit][batch][tile][wave][nb][reg][lane].
+template <int NBR>
+__global__ __launch_bounds__(kThreads) void corr_fwd_mfma(const float* __restrict__ in1, const float* __restrict__ in2,
+                                                          float* __restrict__ ws, FastGeom g) {
+  using K = Cfg<NBR>;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* l2 = lds;                  // [kKc][PS2]
+  float* l1 = lds + kKc * K::PS2;   // [kKc][kPS1]
+
+  const int ntiles = g.tiles_x * g.tiles_y;
+  const int tile = dtt_xcd_remap(blockIdx.x, ntiles);
+  const int ks = blockIdx.y, n = blockIdx.z;
+  const int ty0 = (tile / g.tiles_x) * kTile, tx0 = (tile % g.tiles_x) * kTile;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int my = wave >> 1, mx = wave & 1;
+  const long plane = (long)g.H * g.W;
+  const int c_begin = ks * g.c_per_split;
+  const int c_end = min(g.C, c_begin + g.c_per_split);
+
+  // ---- per-thread staging descriptors (identical for every channel)
+  int goff2[K::ELEMS], loff2[K::ELEMS];
+#pragma unroll
+  for (int e = 0; e < K::ELEMS; ++e) {
+    const int idx = tid + e * kThreads;
+    const int hr = idx / K::HR, hc = idx - hr * K::HR;
+    const int gy = g.origin + (ty0 - g.R + hr) * g.s, gx = g.origin + (tx0 - g.R + hc) * g.s;
+    const bool ok = idx < K::HR * K::HR && gy >= 0 && gy < g.H && gx >= 0 && gx < g.W;
+    goff2[e] = ok ? gy * g.W + gx : -1;
+    loff2[e] = idx < K::HR * K::HR ? hr * K::HRS + hc : -1;
+  }
+  int goff1, loff1, ch1;
+  {
+    const int p = tid & 63;
+    ch1 = tid >> 6;  // 4 channels per pass
+    const int py = p >> 3, px = p & 7;
+    const int gy = g.origin + (ty0 + py) * g.s, gx = g.origin + (tx0 + px) * g.s;
+    const bool ok = gy >= 0 && gy < g.H && gx >= 0 && gx < g.W && (ty0 + py) < g.oh && (tx0 + px) < g.ow;
+    goff1 = ok ? gy * g.W + gx : -1;
+    loff1 = p;
+  }
+
+  // ---- MFMA operand addresses
+  const int kq_lane = lane >> 4;               // k index inside a quad
+  const int ij = lane & 15;
+  const int a_off = kq_lane * kPS1 + (my * 4 + (ij >> 2)) * kTile + mx * 4 + (ij & 3);
+  const int b_off = kq_lane * K::PS2 + (my * 4 + (ij >> 2)) * K::HRS + mx * 4 + (ij & 3);
+
+  f32x4 acc[K::NB];
+#pragma unroll
+  for (int i = 0; i < K::NB; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const float* p1 = in1 + (long)n * g.C * plane;
+  const float* p2 = in2 + (long)n * g.C * plane;
+
+  for (int c0 = c_begin; c0 < c_end; c0 += kKc) {
+    // stage frame t+tau halo and frame t tile for channels [c0, c0 + kKc)
+#pragma unroll 4
+    for (int cc = 0; cc < kKc; ++cc) {
+      const int c = c0 + cc;
+      const float* src = p2 + (long)c * plane;
+      const bool cok = c < c_end;
+#pragma unroll
+      for (int e = 0; e < K::ELEMS; ++e) {
+        if (loff2[e] >= 0) l2[cc * K::PS2 + loff2[e]] = (cok && goff2[e] >= 0) ? src[goff2[e]] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int cc = 0; cc < kKc; cc += 4) {
+      const int c = c0 + cc + ch1;
+      l1[(cc + ch1) * kPS1 + loff1] = (c < c_end && goff1 >= 0) ? p1[(long)c * plane + goff1] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kq = 0; kq < kKc / 4; ++kq) {
+      const float a = l1[kq * 4 * kPS1 + a_off];
+      const float* bp = l2 + kq * 4 * K::PS2 + b_off;
+#pragma unroll
+      for (int nby = 0; nby < NBR; ++nby)
+#pragma unroll
+        for (int nbx = 0; nbx < NBR; ++nbx) {
+          const float b = bp[nby * 4 * K::HRS + nbx * 4];
+          acc[nby * NBR + nbx] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[nby * NBR + nbx], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+  }
+
+  // ---- partial sums to the workspace, fragment order (each store instruction = 256 contiguous bytes)
+  float* w = ws + ((((long)ks * gridDim.z + n) * ntiles + tile) * 4 + wave) * (long)(K::NB * 256);
+#pragma unroll
+  for (int nb = 0; nb < K::NB; ++nb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) w[(nb * 4 + r) * 64 + lane] = acc[nb][r];
+}
+
+// grid: (tiles * 4 waves, batch).  Sums the channel slices in slice order, divides by nelems
+// (correlation_cuda_kernel.cu:100 `reduce_sum / nelems`) and scatters the in-window entries to NCHW.
+template <int NBR>
+__global__ __launch_bounds__(kThreads) void corr_fwd_reduce(const float* __restrict__ ws, float* __restrict__ out,
+                                                            long out_batch_stride, FastGeom g, float nelems) {
+  using K = Cfg<NBR>;
+  extern __shared__ __attribute__((aligned(16))) float frag[];  // [NB*4][64]
+  const int ntiles = g.tiles_x * g.tiles_y;
+  const int tile = blockIdx.x >> 2, wave = blockIdx.x & 3, n = blockIdx.y;
+  const int nbatch = gridDim.y;
+  const int tid = threadIdx.x;
+  constexpr int FR = K::NB * 256;
+  const long slice_stride = (long)nbatch * ntiles * 4 * FR;
+  const float* src = ws + (((long)n * ntiles + tile) * 4 + wave) * (long)FR;
+  for (int i = tid; i < FR; i += kThreads) {
+    float s = src[i];
+    for (int k = 1; k < g.ksplit; ++k) s += src[i + k * slice_stride];
+    frag[i] = s;
+  }
+  __syncthreads();
+  const int ty0 = (tile / g.tiles_x) * kTile + (wave >> 1) * 4, tx0 = (tile % g.tiles_x) * kTile + (wave & 1) * 4;
+  float* o = out + (long)n * out_batch_stride;
+  const int total = g.oc * 16;
+  for (int idx = tid; idx < total; idx += kThreads) {
+    const int tc = idx >> 4, p = idx & 15;
+    const int iy = p >> 2, ix = p & 3;
+    const int y = ty0 + iy, x = tx0 + ix;
+    if (y >= g.oh || x >= g.ow) continue;
+    const int tj = tc / g.D, ti = tc - tj * g.D;  // already offset by +R
+    const int hr = tj + iy, hc = ti + ix;         // halo row/col relative to this wave's halo origin
+    const int nb = (hr >> 2) * NBR + (hc >> 2);
+    const int lane = iy * 16 + (hr & 3) * 4 + (hc & 3);
+    o[((long)tc * g.oh + y) * g.ow + x] = frag[(nb * 4 + ix) * 64 + lane] / nelems;
+  }
+}
+
+// Generic forward (any kernel_size / strides): one wave per output pixel, lanes over channels, wave
+// reduction per displacement.  Slow path, kept for API completeness (correlation.py:5-13 defaults).
+__global__ __launch_bounds__(64) void corr_fwd_generic(const float* __restrict__ in1, const float* __restrict__ in2,
+                                                       float* __restrict__ out, long out_batch_stride, int C, int H,
+                                                       int W, int oc, int oh, int ow, int pad, int ksize, int maxd,
+                                                       int s1, int s2) {
+  const int n = blockIdx.z, by = blockIdx.y, bx = blockIdx.x, lane = threadIdx.x;
+  const int krad = (ksize - 1) / 2, drad = maxd / s2, dsize = 2 * drad + 1;
+  const int pH = H + 2 * pad, pW = W + 2 * pad;
+  const int y1 = by * s1 + maxd + krad, x1 = bx * s1 + maxd + krad;  // padded coordinates (.cu:48-49)
+  const long plane = (long)H * W;
+  const float* p1 = in1 + (long)n * C * plane;
+  const float* p2 = in2 + (long)n * C * plane;
+  const float nelems = (float)(ksize * ksize * C);
+  for (int tj = -drad; tj <= drad; ++tj)
+    for (int ti = -drad; ti <= drad; ++ti) {
+      const int x2 = x1 + ti * s2, y2 = y1 + tj * s2;
+      float acc = 0.f;
+      for (int j = -krad; j <= krad; ++j)
+        for (int i = -krad; i <= krad; ++i) {
+          const int ya = y1 + j, xa = x1 + i, yb = y2 + j, xb = x2 + i;
+          const bool pa = ya >= 0 && ya < pH && xa >= 0 && xa < pW, pb = yb >= 0 && yb < pH && xb >= 0 && xb < pW;
+          const int ua = ya - pad, va = xa - pad, ub = yb - pad, vb = xb - pad;
+          const bool ina = pa && ua >= 0 && ua < H && va >= 0 && va < W;
+          const bool inb = pb && ub >= 0 && ub < H && vb >= 0 && vb < W;
+          if (!(ina && inb)) continue;
+          for (int ch = lane; ch < C; ch += 64) acc += p1[ch * plane + ua * W + va] * p2[ch * plane + ub * W + vb];
+        }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+      if (lane == 0) {
+        const int tc = (tj + drad) * dsize + (ti + drad);
+        out[(long)n * out_batch_stride + ((long)tc * oh + by) * ow + bx] = acc / nelems;
+      }
+    }
+}
+
+// Backward, kernel_size 1.  One thread per input element; gradients are the mathematically exact
+// adjoint of the forward (the reference's stride1 > 1 indexing is out of bounds, see dtt_hip.h).
+//   gradInput1[n,c,y,x] = 1/C * sum_tc gradOut[n,tc,oy,ox] * in2pad[n,c,y+j2,x+i2],  (oy,ox) = ((y+pad-d)/s1, ..) exact
+//   gradInput2[n,c,y,x] = 1/C * sum_tc gradOut[n,tc,oy,ox] * in1pad[n,c,y-j2,x-i2],  (oy,ox) = ((y+pad-d-j2)/s1, ..) exact
+__global__ void corr_bwd_simple(const float* __restrict__ gout, const float* __restrict__ in1,
+                                const float* __restrict__ in2, float* __restrict__ g1, float* __restrict__ g2, int B,
+                                int C, int H, int W, int oc, int oh, int ow, int pad, int maxd, int s1, int s2) {
+  const long total = (long)B * C * H * W;
+  const int drad = maxd / s2, dsize = 2 * drad + 1;
+  const float nelems = (float)C;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int x = idx % W, y = (idx / W) % H, c = (idx / ((long)W * H)) % C, n = idx / ((long)W * H * C);
+    const float* go = gout + (long)n * oc * oh * ow;
+    const float* f1 = in1 + ((long)n * C + c) * H * W;
+    const float* f2 = in2 + ((long)n * C + c) * H * W;
+    const int yp = y + pad, xp = x + pad;
+    // ---- input1
+    float a1 = 0.f;
+    {
+      const int ry = yp - maxd, rx = xp - maxd;
+      if (ry >= 0 && rx >= 0 && ry % s1 == 0 && rx % s1 == 0 && ry / s1 < oh && rx / s1 < ow) {
+        const int oy = ry / s1, ox = rx / s1;
+        for (int tc = 0; tc < oc; ++tc) {
+          const int i2 = (tc % dsize - drad) * s2, j2 = (tc / dsize - drad) * s2;
+          const int yb = y + j2, xb = x + i2;
+          if (yb < 0 || yb >= H || xb < 0 || xb >= W) continue;
+          a1 += go[((long)tc * oh + oy) * ow + ox] * f2[yb * W + xb];
+        }
+      }
+    }
+    // ---- input2
+    float a2 = 0.f;
+    for (int tc = 0; tc < oc; ++tc) {
+      const int i2 = (tc % dsize - drad) * s2, j2 = (tc / dsize - drad) * s2;
+      const int ry = yp - maxd - j2, rx = xp - maxd - i2;
+      if (ry < 0 || rx < 0 || ry % s1 != 0 || rx % s1 != 0) continue;
+      const int oy = ry / s1, ox = rx / s1;
+      if (oy >= oh || ox >= ow) continue;
+      const int ya = y - j2, xa = x - i2;
+      if (ya < 0 || ya >= H || xa < 0 || xa >= W) continue;
+      a2 += go[((long)tc * oh + oy) * ow + ox] * f1[ya * W + xa];
+    }
+    g1[idx] = a1 / nelems;
+    g2[idx] = a2 / nelems;
+  }
+}
+
+bool fast_path(int ksize, int s1, int s2, int maxd, int* nbr) {
+  if (ksize != 1 || s1 != s2) return false;
+  const int R = maxd / s2;
+  if (R < 1 || R > 16) return false;
+  *nbr = R <= 4 ? 3 : (R <= 8 ? 5 : 9);
+  return true;
+}
+
+FastGeom make_geom(int batch, int C, int H, int W, int oc, int oh, int ow, int pad, int maxd, int s) {
+  FastGeom g;
+  g.C = C; g.H = H; g.W = W; g.oc = oc; g.oh = oh; g.ow = ow; g.s = s;
+  g.origin = maxd - pad;
+  g.R = maxd / s;
+  g.D = 2 * g.R + 1;
+  g.tiles_x = (ow + kTile - 1) / kTile;
+  g.tiles_y = (oh + kTile - 1) / kTile;
+  // enough workgroups to cover 256 CUs about 3x, slices a multiple of the 16-channel chunk
+  const int tiles = g.tiles_x * g.tiles_y * batch;
+  int ks = (768 + tiles - 1) / tiles;
+  const int max_ks = (C + kKc - 1) / kKc;
+  if (ks > max_ks) ks = max_ks;
+  if (ks < 1) ks = 1;
+  int cps = (C + ks - 1) / ks;
+  cps = ((cps + kKc - 1) / kKc) * kKc;
+  g.c_per_split = cps;
+  g.ksplit = (C + cps - 1) / cps;
+  return g;
+}
+
+template <int NBR>
+size_t ws_bytes(const FastGeom& g, int batch) {
+  return (size_t)g.ksplit * batch * g.tiles_x * g.tiles_y * 4 * Cfg<NBR>::NB * 256 * sizeof(float);
+}
+
+template <int NBR>
+int launch_fast(float* output, long out_batch_stride, const float* in1, const float* in2, void* workspace,
+                size_t workspace_bytes, const FastGeom& g, int batch, hipStream_t stream) {
+  using K = Cfg<NBR>;
+  const size_t need = ws_bytes<NBR>(g, batch);
+  DTT_REQUIRE(workspace && workspace_bytes >= need, "correlation forward: workspace too small (%zu < %zu)",
+              workspace_bytes, need);
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(corr_fwd_mfma<NBR>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(corr_fwd_reduce<NBR>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    DTT_REQUIRE(e == hipSuccess && e2 == hipSuccess, "correlation: cannot raise dynamic LDS limit");
+    attr = true;
+  }
+  const int ntiles = g.tiles_x * g.tiles_y;
+  hipLaunchKernelGGL(corr_fwd_mfma<NBR>, dim3(ntiles, g.ksplit, batch), dim3(kThreads), K::LDS, stream, in1, in2,
+                     static_cast<float*>(workspace), g);
+  DTT_CHECK_LAUNCH("corr_fwd_mfma");
+  hipLaunchKernelGGL(corr_fwd_reduce<NBR>, dim3(ntiles * 4, batch), dim3(kThreads), (size_t)K::NB * 256 * sizeof(float),
+                     stream, static_cast<const float*>(workspace), output, out_batch_stride, g, (float)g.C);
+  DTT_CHECK_LAUNCH("corr_fwd_reduce");
+  return 1;
+}
+
+}  // namespace
+
+// correlation_cuda.c:19-34
+extern "C" int dtt_correlation_output_shape(int ic, int ih, int iw, int pad_size, int kernel_size,
+                                            int max_displacement, int stride1, int stride2, int* oc, int* oh,
+                                            int* ow) {
+  DTT_REQUIRE(oc && oh && ow, "correlation: null output pointer");
+  DTT_REQUIRE(ic > 0 && ih > 0 && iw > 0, "correlation: bad input shape");
+  DTT_REQUIRE(stride1 > 0 && stride2 > 0 && kernel_size > 0 && (kernel_size & 1) && pad_size >= 0 &&
+                  max_displacement >= 0,
+              "correlation: bad parameters (kernel_size must be odd and > 0, strides > 0)");
+  const int kernel_radius = (kernel_size - 1) / 2;
+  const int border_radius = kernel_radius + max_displacement;
+  const int pH = ih + 2 * pad_size, pW = iw + 2 * pad_size;
+  const int r = max_displacement / stride2;
+  *oc = (2 * r + 1) * (2 * r + 1);
+  *oh = (int)ceilf((float)(pH - 2 * border_radius) / (float)stride1);
+  *ow = (int)ceilf((float)(pW - 2 * border_radius) / (float)stride1);
+  DTT_REQUIRE(*oh > 0 && *ow > 0, "correlation: empty output (%d x %d)", *oh, *ow);
+  return 1;
+}
+
+extern "C" size_t dtt_correlation_forward_workspace_bytes(int batch, int ic, int ih, int iw, int pad_size,
+                                                          int kernel_size, int max_displacement, int stride1,
+                                                          int stride2) {
+  int oc, oh, ow, nbr;
+  if (!dtt_correlation_output_shape(ic, ih, iw, pad_size, kernel_size, max_displacement, stride1, stride2, &oc, &oh, &ow))
+    return 0;
+  if (!fast_path(kernel_size, stride1, stride2, max_displacement, &nbr)) return 0;
+  const FastGeom g = make_geom(batch, ic, ih, iw, oc, oh, ow, pad_size, max_displacement, stride1);
+  return nbr == 3 ? ws_bytes<3>(g, batch) : (nbr == 5 ? ws_bytes<5>(g, batch) : ws_bytes<9>(g, batch));
+}
+
+extern "C" int dtt_correlation_forward(float* output, int ob, int oc, int oh, int ow, long out_batch_stride,
+                                       const float* input1, int ic, int ih, int iw, const float* input2,
+                                       void* workspace, size_t workspace_bytes, int pad_size, int kernel_size,
+                                       int max_displacement, int stride1, int stride2, int corr_type_multiply,
+                                       void* stream_) {
+  (void)corr_type_multiply;  // accepted and ignored, as in the reference kernels
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  DTT_REQUIRE(output && input1 && input2, "correlation forward: null pointer");
+  int eoc, eoh, eow;
+  if (!dtt_correlation_output_shape(ic, ih, iw, pad_size, kernel_size, max_displacement, stride1, stride2, &eoc, &eoh, &eow))
+    return 0;
+  DTT_REQUIRE(ob > 0 && oc == eoc && oh == eoh && ow == eow,
+              "correlation forward: output is (%d,%d,%d,%d), expected (B,%d,%d,%d)", ob, oc, oh, ow, eoc, eoh, eow);
+  DTT_REQUIRE(out_batch_stride >= (long)oc * oh * ow, "correlation forward: out_batch_stride too small");
+  int nbr;
+  if (fast_path(kernel_size, stride1, stride2, max_displacement, &nbr)) {
+    const FastGeom g = make_geom(ob, ic, ih, iw, oc, oh, ow, pad_size, max_displacement, stride1);
+    if (nbr == 3) return launch_fast<3>(output, out_batch_stride, input1, input2, workspace, workspace_bytes, g, ob, stream);
+    if (nbr == 5) return launch_fast<5>(output, out_batch_stride, input1, input2, workspace, workspace_bytes, g, ob, stream);
+    return launch_fast<9>(output, out_batch_stride, input1, input2, workspace, workspace_bytes, g, ob, stream);
+  }
+  hipLaunchKernelGGL(corr_fwd_generic, dim3(ow, oh, ob), dim3(64), 0, stream, input1, input2, output,
+                     out_batch_stride, ic, ih, iw, oc, oh, ow, pad_size, kernel_size, max_displacement, stride1, stride2);
+  DTT_CHECK_LAUNCH("corr_fwd_generic");
+  return 1;
+}
+
+extern "C" int dtt_correlation_backward(const float* gradOutput, int gob, int goc, int goh, int gow,
+                                        const float* input1, int ic, int ih, int iw, const float* input2,
+                                        float* gradInput1, float* gradInput2, int pad_size, int kernel_size,
+                                        int max_displacement, int stride1, int stride2, int corr_type_multiply,
+                                        void* stream_) {
+  (void)corr_type_multiply;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  DTT_REQUIRE(gradOutput && input1 && input2 && gradInput1 && gradInput2, "correlation backward: null pointer");
+  DTT_REQUIRE(kernel_size == 1, "correlation backward: only kernel_size == 1 is supported (got %d)", kernel_size);
+  int eoc, eoh, eow;
+  if (!dtt_correlation_output_shape(ic, ih, iw, pad_size, kernel_size, max_displacement, stride1, stride2, &eoc, &eoh, &eow))
+    return 0;
+  DTT_REQUIRE(gob > 0 && goc == eoc && goh == eoh && gow == eow, "correlation backward: gradOutput shape mismatch");
+  const long total = (long)gob * ic * ih * iw;
+  hipLaunchKernelGGL(corr_bwd_simple, dim3(min(dtt_cdiv(total, 256), 1 << 20)), dim3(256), 0, stream, gradOutput,
+                     input1, input2, gradInput1, gradInput2, gob, ic, ih, iw, goc, goh, gow, pad_size,
+                     max_displacement, stride1, stride2);
+  DTT_CHECK_LAUNCH("corr_bwd_simple");
+  return 1;
+}

@@ -1,0 +1,251 @@
+// NMS for gfx950: 64x64 IoU bitmask tiles (one wave64 per tile, one uint64 per row) + an on-device
+// greedy sweep, so nothing returns to the host.
+//
+// Replaces nms_kernel + nms_cuda_compute (reference nms/src/nms_cuda_kernel.cu:41-161).  The IoU
+// arithmetic (devIoU, .cu:31-39) is reproduced operation by operation with FP contraction off, so the
+// keep list is bit-exact with the oracle (oracle/dtt_oracle.c: oracle_nms).
+#include "common.h"
+#include "nms_internal.h"
+
+namespace {
+
+constexpr int kTile = 64;          // threadsPerBlock = sizeof(unsigned long long) * 8 (.cu:29)
+constexpr int kSuper = 1024;       // boxes per LDS-resident super-chunk of the sweep
+constexpr int kSuperWords = kSuper / kTile;  // 16
+constexpr int kRowStride = kSuperWords + 1;  // 17 words: conflict-free ds_read_b64 down a column
+constexpr int kSweepThreads = 1024;
+
+// devIoU (.cu:31-39): same operations, same order, no contraction (file built with -ffp-contract=off).
+__device__ __forceinline__ float dev_iou(const float a0, const float a1, const float a2, const float a3,
+                                         const float b0, const float b1, const float b2, const float b3) {
+  float left = fmaxf(a0, b0), right = fminf(a2, b2);
+  float top = fmaxf(a1, b1), bottom = fminf(a3, b3);
+  float width = fmaxf(right - left + 1, 0.f), height = fmaxf(bottom - top + 1, 0.f);
+  float interS = width * height;
+  float Sa = (a2 - a0 + 1) * (a3 - a1 + 1);
+  float Sb = (b2 - b0 + 1) * (b3 - b1 + 1);
+  return interS / (Sa + Sb - interS);
+}
+
+// grid (col_blocks, row_blocks, batch), block 64.  Only tiles with col >= row are produced: the sweep
+// never reads words left of a row's own block (nms_cuda_kernel.cu:139 starts at j = nblock).
+__global__ __launch_bounds__(kTile) void nms_mask_kernel(const float* __restrict__ boxes, int boxes_dim,
+                                                          long box_batch_stride, const int* __restrict__ n_per_image,
+                                                          int n_max, float thresh, unsigned long long* __restrict__ mask,
+                                                          long mask_batch_stride, int col_blocks) {
+  const int col_start = blockIdx.x, row_start = blockIdx.y, img = blockIdx.z;
+  if (col_start < row_start) return;
+  const int n_boxes = n_per_image ? n_per_image[img] : n_max;
+  if (row_start * kTile >= n_boxes || col_start * kTile >= n_boxes) return;
+  const float* b = boxes + img * box_batch_stride;
+  unsigned long long* m = mask + img * mask_batch_stride;
+  const int row_size = min(n_boxes - row_start * kTile, kTile);
+  const int col_size = min(n_boxes - col_start * kTile, kTile);
+  __shared__ float bb[kTile * 4];
+  const int t = threadIdx.x;
+  if (t < col_size) {
+    const float* p = b + (long)(kTile * col_start + t) * boxes_dim;
+    bb[t * 4 + 0] = p[0];
+    bb[t * 4 + 1] = p[1];
+    bb[t * 4 + 2] = p[2];
+    bb[t * 4 + 3] = p[3];
+  }
+  __syncthreads();
+  if (t < row_size) {
+    const int cur = kTile * row_start + t;
+    const float* p = b + (long)cur * boxes_dim;
+    const float a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3];
+    unsigned long long bits = 0;
+    const int start = (row_start == col_start) ? t + 1 : 0;
+    for (int i = start; i < col_size; ++i) {
+      if (dev_iou(a0, a1, a2, a3, bb[i * 4 + 0], bb[i * 4 + 1], bb[i * 4 + 2], bb[i * 4 + 3]) > thresh)
+        bits |= 1ULL << i;
+    }
+    m[(long)cur * col_blocks + col_start] = bits;
+  }
+}
+
+__device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
+  unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+  unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ unsigned long long readlane64(unsigned long long v, int lane) {
+  unsigned lo = __builtin_amdgcn_readlane((unsigned)v, lane);
+  unsigned hi = __builtin_amdgcn_readlane((unsigned)(v >> 32), lane);
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+// Greedy sweep (nms_cuda_kernel.cu:131-144) for one image per workgroup.
+//   for i ascending: if bit i of remv is clear -> keep i, remv |= mask[i][i/64 ...]
+// restructured so that global-memory latency is paid twice per 1024 boxes instead of once per box:
+//   A. the 1024 x 16-word diagonal super-block of the mask is staged in LDS with one bulk load;
+//   B. wave 0 walks its 16 chunks: per chunk one LDS column read gives every lane its box's
+//      diagonal word, the serial keep decision runs on scalars (ctz / readlane), kept lanes OR
+//      their row into the later local words with LDS atomics;
+//   C. all waves OR the kept rows' remaining words (later super-chunks) into remv, again in bulk.
+// Optionally writes the surviving boxes straight into the RoI tensor (proposal layer epilogue).
+__global__ __launch_bounds__(kSweepThreads) void nms_sweep_kernel(
+    const unsigned long long* __restrict__ mask, long mask_batch_stride, const int* __restrict__ n_per_image,
+    int n_max, int col_blocks, int max_keep, int* __restrict__ keep_out, long keep_batch_stride,
+    int* __restrict__ num_out, const float* __restrict__ boxes, int boxes_dim, long box_batch_stride,
+    float* __restrict__ rois_out, int rois_rows) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned long long* sb = reinterpret_cast<unsigned long long*>(smem);            // [kSuper][kRowStride]
+  unsigned long long* remv = sb + (size_t)kSuper * kRowStride;                      // [col_blocks]
+  int* kept_list = reinterpret_cast<int*>(remv + col_blocks);                       // [kSuper]
+  int* ctl = kept_list + kSuper;                                                    // [0]=nk, [1]=total, [2]=done
+
+  const int img = blockIdx.x;
+  const int n = n_per_image ? n_per_image[img] : n_max;
+  const unsigned long long* m = mask + img * mask_batch_stride;
+  int* keep = keep_out ? keep_out + img * keep_batch_stride : nullptr;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cb = (n + kTile - 1) / kTile;
+  const int limit = (max_keep > 0 && max_keep < n) ? max_keep : n;
+
+  for (int j = tid; j < col_blocks; j += kSweepThreads) remv[j] = 0;
+  if (tid == 0) { ctl[0] = 0; ctl[1] = 0; ctl[2] = 0; }
+  __syncthreads();
+
+  const int n_super = (n + kSuper - 1) / kSuper;
+  for (int sc = 0; sc < n_super; ++sc) {
+    const int base = sc * kSuper;
+    const int rows = min(kSuper, n - base);
+    const int w0 = sc * kSuperWords;
+    const int nw = min(kSuperWords, cb - w0);
+    // ---- A: stage the diagonal super-block
+    for (int idx = tid; idx < rows * nw; idx += kSweepThreads) {
+      const int r = idx / nw, j = idx - r * nw;
+      sb[r * kRowStride + j] = ((r >> 6) <= j) ? m[(long)(base + r) * col_blocks + w0 + j] : 0ULL;
+    }
+    __syncthreads();
+    // ---- B: serial part, wave 0 only
+    if (wave == 0) {
+      int total = __builtin_amdgcn_readfirstlane(ctl[1]);
+      int nk = 0;
+      bool done = false;
+      for (int c = 0; c < nw && !done; ++c) {
+        unsigned long long r = uniform64(remv[w0 + c]);
+        const int rows_c = min(kTile, rows - c * kTile);
+        const unsigned long long valid = rows_c == kTile ? ~0ULL : ((1ULL << rows_c) - 1ULL);
+        const unsigned long long d = (lane < rows_c) ? sb[(c * kTile + lane) * kRowStride + c] : 0ULL;
+        unsigned long long alive = ~r & valid;
+        unsigned long long kept = 0;
+        int room = limit - total;
+        while (alive != 0 && room > 0) {
+          const int i = __builtin_ctzll(alive);
+          kept |= 1ULL << i;
+          --room;
+          r |= readlane64(d, i);
+          const unsigned long long above = (i == 63) ? 0ULL : (~0ULL << (i + 1));
+          alive = ~r & valid & above;
+        }
+        const int nkept = __builtin_popcountll(kept);
+        const bool mine = (kept >> lane) & 1ULL;
+        if (mine) {
+          const int rank = __builtin_popcountll(kept & ((1ULL << lane) - 1ULL));
+          const int row = c * kTile + lane;
+          kept_list[nk + rank] = row;
+          if (keep) keep[total + rank] = base + row;
+          for (int j = c + 1; j < nw; ++j) {
+            const unsigned long long v = sb[row * kRowStride + j];
+            if (v) atomicOr(&remv[w0 + j], v);
+          }
+        }
+        nk += nkept;
+        total += nkept;
+        if (total >= limit) done = true;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // LDS atomics visible to next column read
+      }
+      if (lane == 0) { ctl[0] = nk; ctl[1] = total; ctl[2] = done ? 1 : 0; }
+    }
+    __syncthreads();
+    const int nk = ctl[0];
+    const bool done = ctl[2] != 0;
+    // ---- C: kept rows suppress boxes of the later super-chunks
+    const int wnext = w0 + nw;
+    const int nrem = cb - wnext;
+    if (!done && nrem > 0 && nk > 0) {
+      for (int idx = tid; idx < nk * nrem; idx += kSweepThreads) {
+        const int k = idx / nrem, j = wnext + (idx - k * nrem);
+        const unsigned long long v = m[(long)(base + kept_list[k]) * col_blocks + j];
+        if (v) atomicOr(&remv[j], v);
+      }
+    }
+    __syncthreads();
+    if (done) break;
+  }
+  const int total = ctl[1];
+  if (tid == 0 && num_out) num_out[img] = total;
+  // ---- optional epilogue: RoI rows [img, x1, y1, x2, y2], zero padded (proposal_layer.py:157-159)
+  if (rois_out) {
+    __syncthreads();
+    const float* b = boxes + img * box_batch_stride;
+    float* out = rois_out + (long)img * rois_rows * 5;
+    for (int r = tid; r < rois_rows; r += kSweepThreads) {
+      float x1 = 0.f, y1 = 0.f, x2 = 0.f, y2 = 0.f;
+      if (r < total) {
+        const float* p = b + (long)keep[r] * boxes_dim;
+        x1 = p[0]; y1 = p[1]; x2 = p[2]; y2 = p[3];
+      }
+      out[r * 5 + 0] = (float)img;
+      out[r * 5 + 1] = x1;
+      out[r * 5 + 2] = y1;
+      out[r * 5 + 3] = x2;
+      out[r * 5 + 4] = y2;
+    }
+  }
+}
+
+size_t sweep_lds_bytes(int col_blocks) {
+  return (size_t)kSuper * kRowStride * 8 + (size_t)col_blocks * 8 + (size_t)kSuper * 4 + 16;
+}
+
+}  // namespace
+
+size_t dtt_nms_mask_bytes(int boxes_num) {
+  const long cb = (boxes_num + kTile - 1) / kTile;
+  return (size_t)(boxes_num > 0 ? boxes_num : 1) * (size_t)(cb > 0 ? cb : 1) * sizeof(unsigned long long);
+}
+
+int dtt_nms_batched_launch(const float* boxes, int boxes_dim, long box_batch_stride, const int* n_per_image,
+                           int n_max, int batch, float thresh, int max_keep, unsigned long long* mask,
+                           long mask_batch_stride, int* keep_out, long keep_batch_stride, int* num_out,
+                           float* rois_out, int rois_rows, hipStream_t stream) {
+  const int cb = (n_max + kTile - 1) / kTile;
+  DTT_REQUIRE(n_max > 0 && batch > 0, "nms: empty problem (n=%d, batch=%d)", n_max, batch);
+  DTT_REQUIRE(boxes_dim >= 4, "nms: boxes_dim must be >= 4 (got %d)", boxes_dim);
+  const size_t lds = sweep_lds_bytes(cb);
+  DTT_REQUIRE(lds <= 160 * 1024, "nms: %d boxes exceed the LDS-resident sweep state (%zu B)", n_max, lds);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(nms_sweep_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) { dtt_set_error("nms: cannot raise dynamic LDS limit: %s", hipGetErrorString(e)); return 0; }
+    attr_set = true;
+  }
+  dim3 grid(cb, cb, batch);
+  hipLaunchKernelGGL(nms_mask_kernel, grid, dim3(kTile), 0, stream, boxes, boxes_dim, box_batch_stride,
+                     n_per_image, n_max, thresh, mask, mask_batch_stride, cb);
+  DTT_CHECK_LAUNCH("nms_mask_kernel");
+  hipLaunchKernelGGL(nms_sweep_kernel, dim3(batch), dim3(kSweepThreads), lds, stream, mask, mask_batch_stride,
+                     n_per_image, n_max, cb, max_keep, keep_out, keep_batch_stride, num_out, boxes, boxes_dim,
+                     box_batch_stride, rois_out, rois_rows);
+  DTT_CHECK_LAUNCH("nms_sweep_kernel");
+  return 1;
+}
+
+extern "C" size_t dtt_nms_workspace_bytes(int boxes_num) { return dtt_nms_mask_bytes(boxes_num); }
+
+extern "C" int dtt_nms(int* keep_out, int* num_out, const float* boxes, int boxes_num, int boxes_dim,
+                       float nms_overlap_thresh, int max_keep, void* workspace, size_t workspace_bytes,
+                       void* stream) {
+  DTT_REQUIRE(keep_out && num_out && boxes, "nms: null pointer");
+  DTT_REQUIRE(boxes_num > 0, "nms: boxes_num must be > 0 (the wrapper returns [] for empty input, nms_wrapper.py:13-14)");
+  DTT_REQUIRE(workspace && workspace_bytes >= dtt_nms_mask_bytes(boxes_num),
+              "nms: workspace too small (%zu < %zu)", workspace_bytes, dtt_nms_mask_bytes(boxes_num));
+  return dtt_nms_batched_launch(boxes, boxes_dim, 0, nullptr, boxes_num, 1, nms_overlap_thresh, max_keep,
+                                static_cast<unsigned long long*>(workspace), 0, keep_out, 0, num_out, nullptr, 0,
+                                static_cast<hipStream_t>(stream));
+}

@@ -1,0 +1,204 @@
+// RPN proposal layer for gfx950: one call for the whole batch, nothing leaves the device.
+//
+// Replaces _ProposalLayer.forward (reference rpn/proposal_layer.py:49-161): numpy meshgrid + H2D every
+// call, decode/clip of all K*A anchors, a full torch.sort of the B x K*A scores, then a Python loop of
+// per-image NMS round trips.  Here:
+//   1. proposal_select_sort (one 1024-thread workgroup per image): radix-select the pre_nms_topN best
+//      (score, index) keys straight from the NCHW score map, bitonic-sort just those in LDS, and decode +
+//      clip only the survivors (bbox_transform.py:108-134, 156-173).  Keys are (descending score,
+//      ascending anchor index), a total order, so the result is deterministic.
+//   2. the batched NMS of nms.hip (mask tiles + on-device sweep) whose epilogue writes the zero-padded
+//      (B, post_nms_topN, 5) RoI tensor (proposal_layer.py:151-159).
+#include "common.h"
+#include "nms_internal.h"
+
+namespace {
+
+constexpr int kThreads = 1024;
+constexpr int kMaxSort = 16384;  // LDS-resident bitonic sort capacity (128 KiB of 64-bit keys)
+
+__device__ __forceinline__ unsigned desc_key(float s) {
+  s = s + 0.0f;  // -0.0 -> +0.0 so that both zeros tie, as a float comparison would
+  unsigned u = __float_as_uint(s);
+  unsigned asc = u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+  return ~asc;  // smaller key = larger score
+}
+
+struct PropGeom {
+  int A, H, W, K, n;       // anchors per cell, map size, cells, K*A
+  int feat_stride;
+  int topn;                // boxes handed to NMS per image
+  int P;                   // power-of-two sort size >= topn
+};
+
+// LDS: buf[P] u64 | hist[256] | ctl[8]
+__global__ __launch_bounds__(kThreads) void proposal_select_sort(const float* __restrict__ cls_prob,
+                                                                 const float* __restrict__ bbox_pred,
+                                                                 const float* __restrict__ im_info,
+                                                                 const float* __restrict__ anchors, PropGeom g,
+                                                                 float* __restrict__ boxes_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned long long* buf = reinterpret_cast<unsigned long long*>(smem);
+  unsigned* hist = reinterpret_cast<unsigned*>(buf + g.P);
+  unsigned* ctl = hist + 256;  // [0..1] prefix (hi, lo), [2] remaining, [3] fill counter
+  const int b = blockIdx.x, tid = threadIdx.x;
+  // fg scores: channel A + a, cell k  ->  flattened anchor index t = k*A + a (proposal_layer.py:102-103)
+  const float* sc = cls_prob + ((long)b * 2 * g.A + g.A) * g.K;
+
+  auto key64_of = [&](int m) -> unsigned long long {  // m = memory order index a*K + k
+    const int a = m / g.K, k = m - a * g.K;
+    const unsigned t = (unsigned)(k * g.A + a);
+    return ((unsigned long long)desc_key(sc[m]) << 32) | t;
+  };
+
+  unsigned long long thr = ~0ULL;  // select key64 <= thr
+  if (g.topn < g.n) {
+    // ---- MSB-first radix select of the topn-th smallest 64-bit key, 8 bits per pass
+    if (tid == 0) { ctl[0] = 0; ctl[1] = 0; ctl[2] = (unsigned)g.topn; }
+    unsigned long long prefix = 0;
+    for (int pass = 0; pass < 8; ++pass) {
+      const int shift = 56 - 8 * pass;
+      if (tid < 256) hist[tid] = 0;
+      __syncthreads();
+      const unsigned long long himask = pass == 0 ? 0ULL : (~0ULL << (shift + 8));
+      for (int m = tid; m < g.n; m += kThreads) {
+        const unsigned long long k64 = key64_of(m);
+        if ((k64 & himask) == prefix) atomicAdd(&hist[(unsigned)(k64 >> shift) & 255u], 1u);
+      }
+      __syncthreads();
+      if (tid == 0) {
+        unsigned rem = ctl[2], cum = 0;
+        int d = 0;
+        for (; d < 256; ++d) {
+          if (cum + hist[d] >= rem) break;
+          cum += hist[d];
+        }
+        ctl[2] = rem - cum;
+        const unsigned long long np = prefix | ((unsigned long long)d << shift);
+        ctl[0] = (unsigned)(np >> 32);
+        ctl[1] = (unsigned)np;
+      }
+      __syncthreads();
+      prefix = ((unsigned long long)ctl[0] << 32) | ctl[1];
+      __syncthreads();
+    }
+    thr = prefix;  // keys are unique, so exactly topn keys are <= thr
+  }
+  // ---- compact the selected keys into LDS (any order), pad, sort
+  if (tid == 0) ctl[3] = 0;
+  __syncthreads();
+  for (int m = tid; m < g.n; m += kThreads) {
+    const unsigned long long k64 = key64_of(m);
+    if (k64 <= thr) buf[atomicAdd(&ctl[3], 1u)] = k64;
+  }
+  for (int i = g.topn + tid; i < g.P; i += kThreads) buf[i] = ~0ULL;
+  __syncthreads();
+  for (int k = 2; k <= g.P; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int p = tid; p < (g.P >> 1); p += kThreads) {
+        const int i = ((p & ~(j - 1)) << 1) | (p & (j - 1));
+        const int ixj = i | j;
+        const unsigned long long x = buf[i], y = buf[ixj];
+        const bool up = (i & k) == 0;
+        if ((x > y) == up) { buf[i] = y; buf[ixj] = x; }
+      }
+      __syncthreads();
+    }
+  }
+  // ---- decode + clip the sorted survivors (bbox_transform.py:108-134, 156-173)
+  const float im_h = im_info[b * 3 + 0], im_w = im_info[b * 3 + 1];
+  const float xmax = im_w - 1.0f, ymax = im_h - 1.0f;
+  const float* dl = bbox_pred + (long)b * 4 * g.A * g.K;
+  float4* out = reinterpret_cast<float4*>(boxes_out) + (long)b * g.topn;
+  for (int r = tid; r < g.topn; r += kThreads) {
+    const unsigned t = (unsigned)buf[r];
+    const int k = t / g.A, a = t - k * g.A;
+    const int h = k / g.W, w = k - h * g.W;
+    const float sx = (float)(w * g.feat_stride), sy = (float)(h * g.feat_stride);
+    const float x1 = anchors[a * 4 + 0] + sx, y1 = anchors[a * 4 + 1] + sy;
+    const float x2 = anchors[a * 4 + 2] + sx, y2 = anchors[a * 4 + 3] + sy;
+    const float dx = dl[(long)(4 * a + 0) * g.K + k], dy = dl[(long)(4 * a + 1) * g.K + k];
+    const float dw = dl[(long)(4 * a + 2) * g.K + k], dh = dl[(long)(4 * a + 3) * g.K + k];
+    const float widths = x2 - x1 + 1.0f, heights = y2 - y1 + 1.0f;
+    const float ctr_x = x1 + 0.5f * widths, ctr_y = y1 + 0.5f * heights;
+    const float pcx = dx * widths + ctr_x, pcy = dy * heights + ctr_y;
+    const float pw = (float)exp((double)dw) * widths;   // correctly rounded binary32 exp (declared semantics)
+    const float ph = (float)exp((double)dh) * heights;
+    float4 o;
+    o.x = fminf(fmaxf(pcx - 0.5f * pw, 0.f), xmax);
+    o.y = fminf(fmaxf(pcy - 0.5f * ph, 0.f), ymax);
+    o.z = fminf(fmaxf(pcx + 0.5f * pw, 0.f), xmax);
+    o.w = fminf(fmaxf(pcy + 0.5f * ph, 0.f), ymax);
+    out[r] = o;
+  }
+}
+
+int next_pow2(int v) {
+  int p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+int effective_topn(int batch, int n, int pre_nms_topN) {
+  // proposal_layer.py:138-139: the guard compares against numel of the whole batch
+  if (pre_nms_topN > 0 && (long)pre_nms_topN < (long)batch * n) return pre_nms_topN < n ? pre_nms_topN : n;
+  return n;
+}
+
+}  // namespace
+
+extern "C" size_t dtt_proposal_workspace_bytes(int batch, int num_anchors, int height, int width,
+                                               int pre_nms_topN) {
+  const int n = num_anchors * height * width;
+  const int topn = effective_topn(batch, n, pre_nms_topN);
+  size_t boxes = align_up((size_t)batch * topn * 4 * sizeof(float), 256);
+  size_t mask = align_up((size_t)batch * dtt_nms_mask_bytes(topn), 256);
+  size_t keep = align_up((size_t)batch * topn * sizeof(int), 256);
+  size_t num = 256;
+  return boxes + mask + keep + num;
+}
+
+extern "C" int dtt_proposal_forward(const float* cls_prob, const float* bbox_pred, const float* im_info,
+                                    const float* anchors, int batch, int num_anchors, int height, int width,
+                                    int feat_stride, int pre_nms_topN, int post_nms_topN, float nms_thresh,
+                                    float* rois_out, int* num_out, void* workspace, size_t workspace_bytes,
+                                    void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  DTT_REQUIRE(cls_prob && bbox_pred && im_info && anchors && rois_out, "proposal: null pointer");
+  DTT_REQUIRE(batch > 0 && num_anchors > 0 && height > 0 && width > 0 && feat_stride > 0, "proposal: bad shape");
+  DTT_REQUIRE(post_nms_topN > 0, "proposal: post_nms_topN must be > 0");
+  PropGeom g;
+  g.A = num_anchors; g.H = height; g.W = width; g.K = height * width; g.n = g.K * g.A;
+  g.feat_stride = feat_stride;
+  g.topn = effective_topn(batch, g.n, pre_nms_topN);
+  g.P = next_pow2(g.topn);
+  DTT_REQUIRE(g.P <= kMaxSort, "proposal: %d boxes per image exceed the %d-entry LDS sort", g.topn, kMaxSort);
+  const size_t need = dtt_proposal_workspace_bytes(batch, num_anchors, height, width, pre_nms_topN);
+  DTT_REQUIRE(workspace && workspace_bytes >= need, "proposal: workspace too small (%zu < %zu)", workspace_bytes, need);
+  unsigned char* w = static_cast<unsigned char*>(workspace);
+  float* boxes = reinterpret_cast<float*>(w);
+  w += align_up((size_t)batch * g.topn * 4 * sizeof(float), 256);
+  unsigned long long* mask = reinterpret_cast<unsigned long long*>(w);
+  const size_t mask_per_image = dtt_nms_mask_bytes(g.topn);
+  w += align_up((size_t)batch * mask_per_image, 256);
+  int* keep = reinterpret_cast<int*>(w);
+  w += align_up((size_t)batch * g.topn * sizeof(int), 256);
+  int* num_ws = reinterpret_cast<int*>(w);
+
+  const size_t lds = (size_t)g.P * 8 + 256 * 4 + 8 * 4;
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(proposal_select_sort),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    DTT_REQUIRE(e == hipSuccess, "proposal: cannot raise dynamic LDS limit: %s", hipGetErrorString(e));
+    attr = true;
+  }
+  hipLaunchKernelGGL(proposal_select_sort, dim3(batch), dim3(kThreads), lds, stream, cls_prob, bbox_pred, im_info,
+                     anchors, g, boxes);
+  DTT_CHECK_LAUNCH("proposal_select_sort");
+  return dtt_nms_batched_launch(boxes, 4, (long)g.topn * 4, nullptr, g.topn, batch, nms_thresh, post_nms_topN, mask,
+                                (long)(mask_per_image / sizeof(unsigned long long)), keep, g.topn,
+                                num_out ? num_out : num_ws, rois_out, post_nms_topN, stream);
+}

@@ -1,0 +1,254 @@
+// Position-sensitive RoI pooling for gfx950.
+//
+// Replaces PSROIPoolForward / PSROIPoolBackward (reference psroi_pooling/src/psroi_pooling_kernel.cu:15-79,
+// 109-170).  The reference maps one thread to one output bin, so neighbouring threads walk different
+// channels (stride H*W) and every RoI re-reads the score map.  Here the map is the stationary operand:
+// one workgroup owns one (image, channel) score plane = one (ctop, ph, pw) bin position, stages the
+// plane in LDS with coalesced loads (each plane is read from HBM exactly once), and its threads walk the
+// RoIs of that image, summing their bin out of LDS in the reference's (h, w) order.  The backward does
+// the transpose: bins are scattered into the LDS plane with ds_add_f32 and the finished plane is written
+// once, coalesced -- no global atomics, no pre-zeroed output.
+//
+// Bin-edge arithmetic follows the reference operation by operation (double where the reference's
+// literals promote to double, no FMA contraction), so bin boundaries match the oracle bit for bit.
+#include "common.h"
+
+namespace {
+
+struct Bin { int hstart, hend, wstart, wend; bool empty; };
+
+// psroi_pooling_kernel.cu:29-59
+__device__ __forceinline__ Bin psroi_bin(const float* __restrict__ roi, float spatial_scale, int ph, int pw,
+                                         int pooled_height, int pooled_width, int height, int width) {
+  const float roi_start_w = (float)round((double)roi[1]) * spatial_scale;
+  const float roi_start_h = (float)round((double)roi[2]) * spatial_scale;
+  const float roi_end_w = (float)(round((double)roi[3]) + 1.) * spatial_scale;
+  const float roi_end_h = (float)(round((double)roi[4]) + 1.) * spatial_scale;
+  const double dw = (double)(roi_end_w - roi_start_w), dh = (double)(roi_end_h - roi_start_h);
+  const float roi_width = (float)(dw > 0.1 ? dw : 0.1);  // max(float, 0.1): double compare, then narrowed
+  const float roi_height = (float)(dh > 0.1 ? dh : 0.1);
+  const float bin_size_h = roi_height / (float)pooled_height;
+  const float bin_size_w = roi_width / (float)pooled_width;
+  Bin b;
+  b.hstart = (int)floorf((float)ph * bin_size_h + roi_start_h);
+  b.wstart = (int)floorf((float)pw * bin_size_w + roi_start_w);
+  b.hend = (int)ceilf((float)(ph + 1) * bin_size_h + roi_start_h);
+  b.wend = (int)ceilf((float)(pw + 1) * bin_size_w + roi_start_w);
+  b.hstart = min(max(b.hstart, 0), height);
+  b.hend = min(max(b.hend, 0), height);
+  b.wstart = min(max(b.wstart, 0), width);
+  b.wend = min(max(b.wend, 0), width);
+  b.empty = (b.hend <= b.hstart) || (b.wend <= b.wstart);
+  return b;
+}
+
+constexpr int kThreads = 256;
+
+// grid (channels, batch).  LDS: height*width floats.
+__global__ __launch_bounds__(kThreads) void psroi_fwd_plane(
+    const float* __restrict__ bottom_data, float spatial_scale, int num_rois, int height, int width, int channels,
+    int pooled_height, int pooled_width, const float* __restrict__ bottom_rois, int group_size, int output_dim,
+    float* __restrict__ top_data, int* __restrict__ mapping_channel) {
+  extern __shared__ __attribute__((aligned(16))) float plane[];
+  const int c = blockIdx.x, b = blockIdx.y;
+  const int gw = c % group_size, gh = (c / group_size) % group_size, ctop = c / (group_size * group_size);
+  if (gw >= pooled_width || gh >= pooled_height || ctop >= output_dim) return;  // channel feeds no bin
+  const int hw = height * width;
+  const float* src = bottom_data + ((long)b * channels + c) * hw;
+  for (int i = threadIdx.x; i < hw; i += kThreads) plane[i] = src[i];
+  __syncthreads();
+  for (int n = threadIdx.x; n < num_rois; n += kThreads) {
+    const float* roi = bottom_rois + (long)n * 5;
+    if ((int)roi[0] != b) continue;
+    const Bin bin = psroi_bin(roi, spatial_scale, gh, gw, pooled_height, pooled_width, height, width);
+    float out_sum = 0;
+    for (int h = bin.hstart; h < bin.hend; ++h)
+      for (int w = bin.wstart; w < bin.wend; ++w) out_sum += plane[h * width + w];
+    const float bin_area = (float)((bin.hend - bin.hstart) * (bin.wend - bin.wstart));
+    const long index = (((long)n * output_dim + ctop) * pooled_height + gh) * pooled_width + gw;
+    top_data[index] = bin.empty ? 0.f : out_sum / bin_area;
+    if (mapping_channel) mapping_channel[index] = c;
+  }
+}
+
+// grid (channels, batch).  LDS: height*width floats.  Writes the whole bottom_diff plane.
+__global__ __launch_bounds__(kThreads) void psroi_bwd_plane(
+    const float* __restrict__ top_diff, float spatial_scale, int num_rois, int height, int width, int channels,
+    int pooled_height, int pooled_width, const float* __restrict__ bottom_rois, int group_size, int output_dim,
+    float* __restrict__ bottom_diff) {
+  extern __shared__ __attribute__((aligned(16))) float plane[];
+  const int c = blockIdx.x, b = blockIdx.y;
+  const int hw = height * width;
+  float* dst = bottom_diff + ((long)b * channels + c) * hw;
+  const int gw = c % group_size, gh = (c / group_size) % group_size, ctop = c / (group_size * group_size);
+  const bool used = !(gw >= pooled_width || gh >= pooled_height || ctop >= output_dim);
+  for (int i = threadIdx.x; i < hw; i += kThreads) plane[i] = 0.f;
+  __syncthreads();
+  if (used) {
+    for (int n = threadIdx.x; n < num_rois; n += kThreads) {
+      const float* roi = bottom_rois + (long)n * 5;
+      if ((int)roi[0] != b) continue;
+      const Bin bin = psroi_bin(roi, spatial_scale, gh, gw, pooled_height, pooled_width, height, width);
+      if (bin.empty) continue;
+      const float bin_area = (float)((bin.hend - bin.hstart) * (bin.wend - bin.wstart));
+      const long index = (((long)n * output_dim + ctop) * pooled_height + gh) * pooled_width + gw;
+      const float diff_val = top_diff[index] / bin_area;
+      for (int h = bin.hstart; h < bin.hend; ++h)
+        for (int w = bin.wstart; w < bin.wend; ++w) atomicAdd(&plane[h * width + w], diff_val);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < hw; i += kThreads) dst[i] = plane[i];
+}
+
+// Fallbacks for score planes that do not fit LDS or pooled size > group size: one thread per output bin,
+// reference-style (psroi_pooling_kernel.cu:15-79, 109-170).
+__global__ void psroi_fwd_generic(long nthreads, const float* __restrict__ bottom_data, float spatial_scale,
+                                  int height, int width, int channels, int pooled_height, int pooled_width,
+                                  int group_size, int output_dim, const float* __restrict__ bottom_rois,
+                                  float* __restrict__ top_data, int* __restrict__ mapping_channel) {
+  for (long index = (long)blockIdx.x * blockDim.x + threadIdx.x; index < nthreads; index += (long)blockDim.x * gridDim.x) {
+    const int pw = index % pooled_width;
+    const int ph = (index / pooled_width) % pooled_height;
+    const int ctop = (index / pooled_width / pooled_height) % output_dim;
+    const int n = index / pooled_width / pooled_height / output_dim;
+    const float* roi = bottom_rois + (long)n * 5;
+    const int roi_batch_ind = (int)roi[0];
+    const Bin bin = psroi_bin(roi, spatial_scale, ph, pw, pooled_height, pooled_width, height, width);
+    const int c = (ctop * group_size + ph) * group_size + pw;
+    const float* src = bottom_data + ((long)roi_batch_ind * channels + c) * height * width;
+    float out_sum = 0;
+    for (int h = bin.hstart; h < bin.hend; ++h)
+      for (int w = bin.wstart; w < bin.wend; ++w) out_sum += src[h * width + w];
+    const float bin_area = (float)((bin.hend - bin.hstart) * (bin.wend - bin.wstart));
+    top_data[index] = bin.empty ? 0.f : out_sum / bin_area;
+    if (mapping_channel) mapping_channel[index] = c;
+  }
+}
+
+__global__ void psroi_bwd_generic(long nthreads, const float* __restrict__ top_diff,
+                                  const int* __restrict__ mapping_channel, float spatial_scale, int height, int width,
+                                  int channels, int pooled_height, int pooled_width, int group_size, int output_dim,
+                                  float* __restrict__ bottom_diff, const float* __restrict__ bottom_rois) {
+  for (long index = (long)blockIdx.x * blockDim.x + threadIdx.x; index < nthreads; index += (long)blockDim.x * gridDim.x) {
+    const int pw = index % pooled_width;
+    const int ph = (index / pooled_width) % pooled_height;
+    const int ctop = (index / pooled_width / pooled_height) % output_dim;
+    const int n = index / pooled_width / pooled_height / output_dim;
+    const float* roi = bottom_rois + (long)n * 5;
+    const int roi_batch_ind = (int)roi[0];
+    const Bin bin = psroi_bin(roi, spatial_scale, ph, pw, pooled_height, pooled_width, height, width);
+    if (bin.empty) continue;
+    const int c = mapping_channel ? mapping_channel[index] : (ctop * group_size + ph) * group_size + pw;
+    float* dst = bottom_diff + ((long)roi_batch_ind * channels + c) * height * width;
+    const float bin_area = (float)((bin.hend - bin.hstart) * (bin.wend - bin.wstart));
+    const float diff_val = top_diff[index] / bin_area;
+    for (int h = bin.hstart; h < bin.hend; ++h)
+      for (int w = bin.wstart; w < bin.wend; ++w) atomicAdd(dst + h * width + w, diff_val);
+  }
+}
+
+// 7x7 vote = nn.AvgPool2d((7,7)) over the pooled bins (rfcn.py:62-64): one thread per (roi, ctop),
+// row-major sum then one division by the bin count.
+__global__ void psroi_vote(const float* __restrict__ top_data, long n_out, int bins, float* __restrict__ vote) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_out) return;
+  const float* p = top_data + i * bins;
+  float s = 0.f;
+  for (int k = 0; k < bins; ++k) s += p[k];
+  vote[i] = s / (float)bins;
+}
+
+bool plane_path_ok(int height, int width, int pooled_height, int pooled_width, int group_size) {
+  return (size_t)height * width * sizeof(float) <= 144 * 1024 && pooled_height <= group_size &&
+         pooled_width <= group_size;
+}
+
+int raise_lds(const void* fn, size_t bytes) {
+  if (bytes <= 64 * 1024) return 1;
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) { dtt_set_error("psroi: cannot raise dynamic LDS limit: %s", hipGetErrorString(e)); return 0; }
+  return 1;
+}
+
+int check_common(int batch_size, int num_rois, int height, int width, int channels, int pooled_height,
+                 int pooled_width, int group_size, int output_dim) {
+  DTT_REQUIRE(batch_size > 0 && height > 0 && width > 0 && channels > 0, "psroi: bad feature shape");
+  DTT_REQUIRE(num_rois >= 0, "psroi: negative num_rois");
+  DTT_REQUIRE(pooled_height > 0 && pooled_width > 0 && group_size > 0 && output_dim > 0, "psroi: bad pooling parameters");
+  DTT_REQUIRE((long)((long)(output_dim - 1) * group_size + (pooled_height - 1)) * group_size + (pooled_width - 1) < channels,
+              "psroi: output_dim*group_size^2 exceeds the %d input channels", channels);
+  return 1;
+}
+
+}  // namespace
+
+extern "C" int dtt_psroi_pool_forward(const float* bottom_data, float spatial_scale, int batch_size, int num_rois,
+                                      int height, int width, int channels, int pooled_height, int pooled_width,
+                                      const float* bottom_rois, int group_size, int output_dim, float* top_data,
+                                      int* mapping_channel, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (!check_common(batch_size, num_rois, height, width, channels, pooled_height, pooled_width, group_size, output_dim))
+    return 0;
+  if (num_rois == 0) return 1;
+  DTT_REQUIRE(bottom_data && bottom_rois && top_data, "psroi forward: null pointer");
+  if (plane_path_ok(height, width, pooled_height, pooled_width, group_size)) {
+    const size_t lds = (size_t)height * width * sizeof(float);
+    if (!raise_lds(reinterpret_cast<const void*>(psroi_fwd_plane), lds)) return 0;
+    hipLaunchKernelGGL(psroi_fwd_plane, dim3(channels, batch_size), dim3(kThreads), lds, stream, bottom_data,
+                       spatial_scale, num_rois, height, width, channels, pooled_height, pooled_width, bottom_rois,
+                       group_size, output_dim, top_data, mapping_channel);
+  } else {
+    const long n = (long)num_rois * output_dim * pooled_height * pooled_width;
+    hipLaunchKernelGGL(psroi_fwd_generic, dim3(min(dtt_cdiv(n, 256), 65535)), dim3(256), 0, stream, n, bottom_data,
+                       spatial_scale, height, width, channels, pooled_height, pooled_width, group_size, output_dim,
+                       bottom_rois, top_data, mapping_channel);
+  }
+  DTT_CHECK_LAUNCH("psroi forward");
+  return 1;
+}
+
+extern "C" int dtt_psroi_pool_vote_forward(const float* bottom_data, float spatial_scale, int batch_size,
+                                           int num_rois, int height, int width, int channels, int pooled_height,
+                                           int pooled_width, const float* bottom_rois, int group_size,
+                                           int output_dim, float* top_data, float* vote_out, void* stream_) {
+  DTT_REQUIRE(top_data && vote_out, "psroi vote: top_data scratch and vote_out are required");
+  if (!dtt_psroi_pool_forward(bottom_data, spatial_scale, batch_size, num_rois, height, width, channels,
+                              pooled_height, pooled_width, bottom_rois, group_size, output_dim, top_data, nullptr,
+                              stream_))
+    return 0;
+  const long n_out = (long)num_rois * output_dim;
+  if (n_out == 0) return 1;
+  hipLaunchKernelGGL(psroi_vote, dim3(dtt_cdiv(n_out, 256)), dim3(256), 0, static_cast<hipStream_t>(stream_),
+                     top_data, n_out, pooled_height * pooled_width, vote_out);
+  DTT_CHECK_LAUNCH("psroi vote");
+  return 1;
+}
+
+extern "C" int dtt_psroi_pool_backward(const float* top_diff, const int* mapping_channel, int batch_size,
+                                       int num_rois, float spatial_scale, int channels, int height, int width,
+                                       int pooled_width, int pooled_height, int output_dim, int group_size,
+                                       float* bottom_diff, const float* bottom_rois, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (!check_common(batch_size, num_rois, height, width, channels, pooled_height, pooled_width, group_size, output_dim))
+    return 0;
+  DTT_REQUIRE(bottom_diff, "psroi backward: null bottom_diff");
+  DTT_REQUIRE(num_rois == 0 || (top_diff && bottom_rois), "psroi backward: null pointer");
+  if (plane_path_ok(height, width, pooled_height, pooled_width, group_size)) {
+    const size_t lds = (size_t)height * width * sizeof(float);
+    if (!raise_lds(reinterpret_cast<const void*>(psroi_bwd_plane), lds)) return 0;
+    hipLaunchKernelGGL(psroi_bwd_plane, dim3(channels, batch_size), dim3(kThreads), lds, stream, top_diff,
+                       spatial_scale, num_rois, height, width, channels, pooled_height, pooled_width, bottom_rois,
+                       group_size, output_dim, bottom_diff);
+  } else {
+    hipError_t e = hipMemsetAsync(bottom_diff, 0, (size_t)batch_size * channels * height * width * sizeof(float), stream);
+    DTT_REQUIRE(e == hipSuccess, "psroi backward: memset failed: %s", hipGetErrorString(e));
+    const long n = (long)num_rois * output_dim * pooled_height * pooled_width;
+    if (n > 0)
+      hipLaunchKernelGGL(psroi_bwd_generic, dim3(min(dtt_cdiv(n, 256), 65535)), dim3(256), 0, stream, n, top_diff,
+                         mapping_channel, spatial_scale, height, width, channels, pooled_height, pooled_width,
+                         group_size, output_dim, bottom_diff, bottom_rois);
+  }
+  DTT_CHECK_LAUNCH("psroi backward");
+  return 1;
+}

@@ -1,0 +1,329 @@
+// RoI Align / RoI max-pool / RoI crop (bilinear grid sampler) for gfx950.
+//
+// Replaces ROIAlignForward/Backward (reference roi_align/src/roi_align_kernel.cu:15-70, 94-143),
+// ROIPoolForward/Backward (roi_pooling/src/roi_pooling_kernel.cu:24-93, 128-203) and
+// bilinearSamplingFromGrid / backwardBilinearSampling (roi_crop/src/roi_crop_cuda_kernel.cu:47-109, 111-194).
+// These ops are write-bound gathers (R*C*P*P outputs from an L2-resident map): one thread per output
+// element with the output index fastest so stores coalesce; RoI Align fuses the 2x2 stride-1 pooling
+// that RoIAlignAvg / RoIAlignMax run as a second launch (modules/roi_align.py:26-29, 39-42); RoI pool's
+// backward is a scatter through argmax instead of the reference's O(pixels x RoIs) gather.
+// Arithmetic follows the reference expression by expression (including its double-precision
+// sub-expressions) with FP contraction off.
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+// one bilinear tap of roi_align_kernel.cu:33-68 at sample (ph, pw) of an (ah x aw) grid
+__device__ __forceinline__ float align_sample(const float* __restrict__ bottom_data, const float* __restrict__ roi,
+                                              float spatial_scale, int c, int ph, int pw, int ah, int aw, int height,
+                                              int width, int channels) {
+  const float roi_batch_ind = roi[0];
+  const float roi_start_w = roi[1] * spatial_scale;
+  const float roi_start_h = roi[2] * spatial_scale;
+  const float roi_end_w = roi[3] * spatial_scale;
+  const float roi_end_h = roi[4] * spatial_scale;
+  const float roi_width = fmaxf((float)((double)(roi_end_w - roi_start_w) + 1.), 0.f);
+  const float roi_height = fmaxf((float)((double)(roi_end_h - roi_start_h) + 1.), 0.f);
+  const float bin_size_h = (float)((double)roi_height / (ah - 1.));
+  const float bin_size_w = (float)((double)roi_width / (aw - 1.));
+  const float h = (float)(ph)*bin_size_h + roi_start_h;
+  const float w = (float)(pw)*bin_size_w + roi_start_w;
+  if (h < 0 || h >= height || w < 0 || w >= width) return 0.f;
+  const int hstart = (int)fminf(floorf(h), (float)(height - 2));
+  const int wstart = (int)fminf(floorf(w), (float)(width - 2));
+  const long img_start = (long)(roi_batch_ind * channels * height * width);
+  const float h_ratio = h - (float)(hstart);
+  const float w_ratio = w - (float)(wstart);
+  const long upleft = img_start + ((long)c * height + hstart) * width + wstart;
+  const double v = (double)bottom_data[upleft] * (1. - h_ratio) * (1. - w_ratio) +
+                   (double)bottom_data[upleft + 1] * (1. - h_ratio) * w_ratio +
+                   (double)bottom_data[upleft + width] * h_ratio * (1. - w_ratio) +
+                   (double)bottom_data[upleft + width + 1] * h_ratio * w_ratio;
+  return (float)v;
+}
+
+// pool_mode 0: (oh, ow) == sample grid.  1 / 2: samples on (oh+1, ow+1), 2x2 stride-1 avg / max.
+__global__ __launch_bounds__(kThreads) void roi_align_fwd(long nthreads, const float* __restrict__ bottom_data,
+                                                          float spatial_scale, int height, int width, int channels,
+                                                          int oh, int ow, const float* __restrict__ bottom_rois,
+                                                          float* __restrict__ top_data, int pool_mode) {
+  for (long index = (long)blockIdx.x * kThreads + threadIdx.x; index < nthreads; index += (long)gridDim.x * kThreads) {
+    const int pw = index % ow;
+    const int ph = (index / ow) % oh;
+    const int c = (index / ow / oh) % channels;
+    const int n = index / ow / oh / channels;
+    const float* roi = bottom_rois + (long)n * 5;
+    float v;
+    if (pool_mode == 0) {
+      v = align_sample(bottom_data, roi, spatial_scale, c, ph, pw, oh, ow, height, width, channels);
+    } else {
+      const float s00 = align_sample(bottom_data, roi, spatial_scale, c, ph, pw, oh + 1, ow + 1, height, width, channels);
+      const float s01 = align_sample(bottom_data, roi, spatial_scale, c, ph, pw + 1, oh + 1, ow + 1, height, width, channels);
+      const float s10 = align_sample(bottom_data, roi, spatial_scale, c, ph + 1, pw, oh + 1, ow + 1, height, width, channels);
+      const float s11 = align_sample(bottom_data, roi, spatial_scale, c, ph + 1, pw + 1, oh + 1, ow + 1, height, width, channels);
+      v = pool_mode == 1 ? (((s00 + s01) + s10) + s11) / 4.f : fmaxf(fmaxf(s00, s01), fmaxf(s10, s11));
+    }
+    top_data[index] = v;
+  }
+}
+
+// roi_align_kernel.cu:94-143
+__global__ __launch_bounds__(kThreads) void roi_align_bwd(long nthreads, const float* __restrict__ top_diff,
+                                                          float spatial_scale, int height, int width, int channels,
+                                                          int ah, int aw, float* __restrict__ bottom_diff,
+                                                          const float* __restrict__ bottom_rois) {
+  for (long index = (long)blockIdx.x * kThreads + threadIdx.x; index < nthreads; index += (long)gridDim.x * kThreads) {
+    const int pw = index % aw;
+    const int ph = (index / aw) % ah;
+    const int c = (index / aw / ah) % channels;
+    const int n = index / aw / ah / channels;
+    const float* roi = bottom_rois + (long)n * 5;
+    const float roi_batch_ind = roi[0];
+    const float roi_start_w = roi[1] * spatial_scale;
+    const float roi_start_h = roi[2] * spatial_scale;
+    const float roi_end_w = roi[3] * spatial_scale;
+    const float roi_end_h = roi[4] * spatial_scale;
+    const float roi_width = fmaxf((float)((double)(roi_end_w - roi_start_w) + 1.), 0.f);
+    const float roi_height = fmaxf((float)((double)(roi_end_h - roi_start_h) + 1.), 0.f);
+    const float bin_size_h = (float)((double)roi_height / (ah - 1.));
+    const float bin_size_w = (float)((double)roi_width / (aw - 1.));
+    const float h = (float)(ph)*bin_size_h + roi_start_h;
+    const float w = (float)(pw)*bin_size_w + roi_start_w;
+    if (h < 0 || h >= height || w < 0 || w >= width) continue;
+    const int hstart = (int)fminf(floorf(h), (float)(height - 2));
+    const int wstart = (int)fminf(floorf(w), (float)(width - 2));
+    const long img_start = (long)(roi_batch_ind * channels * height * width);
+    const float h_ratio = h - (float)(hstart);
+    const float w_ratio = w - (float)(wstart);
+    const long upleft = img_start + ((long)c * height + hstart) * width + wstart;
+    const double g = (double)top_diff[index];
+    atomicAdd(bottom_diff + upleft, (float)(g * (1. - h_ratio) * (1 - w_ratio)));
+    atomicAdd(bottom_diff + upleft + 1, (float)(g * (1. - h_ratio) * w_ratio));
+    atomicAdd(bottom_diff + upleft + width, (float)(g * h_ratio * (1 - w_ratio)));
+    atomicAdd(bottom_diff + upleft + width + 1, (float)(g * h_ratio * w_ratio));
+  }
+}
+
+// roi_pooling_kernel.cu:24-93
+__global__ __launch_bounds__(kThreads) void roi_pool_fwd(long nthreads, const float* __restrict__ bottom_data,
+                                                         float spatial_scale, int height, int width, int channels,
+                                                         int pooled_height, int pooled_width,
+                                                         const float* __restrict__ bottom_rois,
+                                                         float* __restrict__ top_data, int* __restrict__ argmax_data) {
+  for (long index = (long)blockIdx.x * kThreads + threadIdx.x; index < nthreads; index += (long)gridDim.x * kThreads) {
+    const int pw = index % pooled_width;
+    const int ph = (index / pooled_width) % pooled_height;
+    const int c = (index / pooled_width / pooled_height) % channels;
+    const int n = index / pooled_width / pooled_height / channels;
+    const float* roi = bottom_rois + (long)n * 5;
+    const int roi_batch_ind = (int)roi[0];
+    const int roi_start_w = (int)roundf(roi[1] * spatial_scale);
+    const int roi_start_h = (int)roundf(roi[2] * spatial_scale);
+    const int roi_end_w = (int)roundf(roi[3] * spatial_scale);
+    const int roi_end_h = (int)roundf(roi[4] * spatial_scale);
+    const int roi_width = (int)fmaxf((float)(roi_end_w - roi_start_w + 1), 1.f);
+    const int roi_height = (int)fmaxf((float)(roi_end_h - roi_start_h + 1), 1.f);
+    const float bin_size_h = (float)(roi_height) / (float)(pooled_height);
+    const float bin_size_w = (float)(roi_width) / (float)(pooled_width);
+    int hstart = (int)(floorf((float)(ph)*bin_size_h));
+    int wstart = (int)(floorf((float)(pw)*bin_size_w));
+    int hend = (int)(ceilf((float)(ph + 1) * bin_size_h));
+    int wend = (int)(ceilf((float)(pw + 1) * bin_size_w));
+    hstart = (int)fminf(fmaxf((float)(hstart + roi_start_h), 0.f), (float)height);
+    hend = (int)fminf(fmaxf((float)(hend + roi_start_h), 0.f), (float)height);
+    wstart = (int)fminf(fmaxf((float)(wstart + roi_start_w), 0.f), (float)width);
+    wend = (int)fminf(fmaxf((float)(wend + roi_start_w), 0.f), (float)width);
+    const bool is_empty = (hend <= hstart) || (wend <= wstart);
+    float maxval = is_empty ? 0 : -3.402823466e+38F;
+    int maxidx = -1;
+    const int off = (roi_batch_ind * channels + c) * height * width;
+    for (int h = hstart; h < hend; ++h)
+      for (int w = wstart; w < wend; ++w) {
+        const int bottom_index = h * width + w;
+        const float v = bottom_data[off + bottom_index];
+        if (v > maxval) { maxval = v; maxidx = off + bottom_index; }
+      }
+    top_data[index] = maxval;
+    if (argmax_data) argmax_data[index] = maxidx;
+  }
+}
+
+// Scatter form of roi_pooling_kernel.cu:128-203: bottom_diff[argmax] += top_diff.  An element's argmax
+// can only be inside its own bin, which is exactly the set the reference's gather enumerates.
+__global__ __launch_bounds__(kThreads) void roi_pool_bwd(long nthreads, const float* __restrict__ top_diff,
+                                                         const int* __restrict__ argmax_data,
+                                                         float* __restrict__ bottom_diff) {
+  for (long index = (long)blockIdx.x * kThreads + threadIdx.x; index < nthreads; index += (long)gridDim.x * kThreads) {
+    const int a = argmax_data[index];
+    if (a >= 0) atomicAdd(bottom_diff + a, top_diff[index]);
+  }
+}
+
+// roi_crop_cuda_kernel.cu:11-22
+__device__ __forceinline__ void get_top_left(float x, int width, int& point, float& weight) {
+  const float xcoord = (x + 1) * (width - 1) / 2;
+  point = (int)floorf(xcoord);
+  weight = 1 - (xcoord - point);
+}
+__device__ __forceinline__ bool between(int v, int lo, int hi) { return v >= lo && v <= hi; }
+
+// roi_crop_cuda_kernel.cu:47-109 for contiguous BCHW images / (B, H, W, 2) (y, x) grids
+__global__ __launch_bounds__(kThreads) void roi_crop_fwd(long nthreads, const float* __restrict__ images,
+                                                         const float* __restrict__ grids, float* __restrict__ output,
+                                                         int ic, int ih, int iw, int oh, int ow, int roi_per_image) {
+  for (long index = (long)blockIdx.x * kThreads + threadIdx.x; index < nthreads; index += (long)gridDim.x * kThreads) {
+    const int xOut = index % ow;
+    const int yOut = (index / ow) % oh;
+    const int cOut = (index / ow / oh) % ic;
+    const int b = index / ow / oh / ic;
+    const int b_input = b / roi_per_image;
+    const float yf = grids[(((long)b * oh + yOut) * ow + xOut) * 2 + 0];
+    const float xf = grids[(((long)b * oh + yOut) * ow + xOut) * 2 + 1];
+    int yInTopLeft, xInTopLeft;
+    float yWeightTopLeft, xWeightTopLeft;
+    get_top_left(xf, iw, xInTopLeft, xWeightTopLeft);
+    get_top_left(yf, ih, yInTopLeft, yWeightTopLeft);
+    const long tl = (((long)b_input * ic + cOut) * ih + yInTopLeft) * iw + xInTopLeft;
+    const bool tlIn = between(xInTopLeft, 0, iw - 1) && between(yInTopLeft, 0, ih - 1);
+    const bool trIn = between(xInTopLeft + 1, 0, iw - 1) && between(yInTopLeft, 0, ih - 1);
+    const bool blIn = between(xInTopLeft, 0, iw - 1) && between(yInTopLeft + 1, 0, ih - 1);
+    const bool brIn = between(xInTopLeft + 1, 0, iw - 1) && between(yInTopLeft + 1, 0, ih - 1);
+    float v = 0.f;
+    if (tlIn || trIn || blIn || brIn) {
+      const float inTopLeft = tlIn ? images[tl] : 0.f;
+      const float inTopRight = trIn ? images[tl + 1] : 0.f;
+      const float inBottomLeft = blIn ? images[tl + iw] : 0.f;
+      const float inBottomRight = brIn ? images[tl + iw + 1] : 0.f;
+      v = xWeightTopLeft * yWeightTopLeft * inTopLeft + (1 - xWeightTopLeft) * yWeightTopLeft * inTopRight +
+          xWeightTopLeft * (1 - yWeightTopLeft) * inBottomLeft +
+          (1 - xWeightTopLeft) * (1 - yWeightTopLeft) * inBottomRight;
+    }
+    output[index] = v;
+  }
+}
+
+// roi_crop_cuda_kernel.cu:111-194 (image gradient only; the grid gradient is never written there)
+__global__ __launch_bounds__(kThreads) void roi_crop_bwd(long nthreads, const float* __restrict__ grids,
+                                                         float* __restrict__ grad_images,
+                                                         const float* __restrict__ grad_output, int ic, int ih,
+                                                         int iw, int oh, int ow, int roi_per_image) {
+  for (long index = (long)blockIdx.x * kThreads + threadIdx.x; index < nthreads; index += (long)gridDim.x * kThreads) {
+    const int xOut = index % ow;
+    const int yOut = (index / ow) % oh;
+    const int cOut = (index / ow / oh) % ic;
+    const int b = index / ow / oh / ic;
+    const int b_input = b / roi_per_image;
+    const float yf = grids[(((long)b * oh + yOut) * ow + xOut) * 2 + 0];
+    const float xf = grids[(((long)b * oh + yOut) * ow + xOut) * 2 + 1];
+    int yInTopLeft, xInTopLeft;
+    float yWeightTopLeft, xWeightTopLeft;
+    get_top_left(xf, iw, xInTopLeft, xWeightTopLeft);
+    get_top_left(yf, ih, yInTopLeft, yWeightTopLeft);
+    const long tl = (((long)b_input * ic + cOut) * ih + yInTopLeft) * iw + xInTopLeft;
+    const bool tlIn = between(xInTopLeft, 0, iw - 1) && between(yInTopLeft, 0, ih - 1);
+    const bool trIn = between(xInTopLeft + 1, 0, iw - 1) && between(yInTopLeft, 0, ih - 1);
+    const bool blIn = between(xInTopLeft, 0, iw - 1) && between(yInTopLeft + 1, 0, ih - 1);
+    const bool brIn = between(xInTopLeft + 1, 0, iw - 1) && between(yInTopLeft + 1, 0, ih - 1);
+    const float g = grad_output[index];
+    if (tlIn) atomicAdd(grad_images + tl, xWeightTopLeft * yWeightTopLeft * g);
+    if (trIn) atomicAdd(grad_images + tl + 1, (1 - xWeightTopLeft) * yWeightTopLeft * g);
+    if (blIn) atomicAdd(grad_images + tl + iw, xWeightTopLeft * (1 - yWeightTopLeft) * g);
+    if (brIn) atomicAdd(grad_images + tl + iw + 1, (1 - xWeightTopLeft) * (1 - yWeightTopLeft) * g);
+  }
+}
+
+inline int grid_for(long n) { return (int)((n + kThreads - 1) / kThreads > 262144 ? 262144 : (n + kThreads - 1) / kThreads); }
+
+}  // namespace
+
+extern "C" int dtt_roi_align_forward(const float* bottom_data, float spatial_scale, int num_rois, int height,
+                                     int width, int channels, int aligned_height, int aligned_width,
+                                     const float* bottom_rois, float* top_data, int pool_mode, void* stream) {
+  DTT_REQUIRE(num_rois >= 0 && height > 1 && width > 1 && channels > 0, "roi_align forward: bad shape");
+  DTT_REQUIRE(pool_mode >= 0 && pool_mode <= 2, "roi_align forward: pool_mode must be 0, 1 or 2");
+  DTT_REQUIRE(aligned_height > (pool_mode == 0 ? 1 : 0) && aligned_width > (pool_mode == 0 ? 1 : 0),
+              "roi_align forward: aligned size too small");
+  const long n = (long)num_rois * channels * aligned_height * aligned_width;
+  if (n == 0) return 1;
+  DTT_REQUIRE(bottom_data && bottom_rois && top_data, "roi_align forward: null pointer");
+  hipLaunchKernelGGL(roi_align_fwd, dim3(grid_for(n)), dim3(kThreads), 0, static_cast<hipStream_t>(stream), n,
+                     bottom_data, spatial_scale, height, width, channels, aligned_height, aligned_width, bottom_rois,
+                     top_data, pool_mode);
+  DTT_CHECK_LAUNCH("roi_align_fwd");
+  return 1;
+}
+
+extern "C" int dtt_roi_align_backward(const float* top_diff, float spatial_scale, int batch_size, int num_rois,
+                                      int height, int width, int channels, int aligned_height, int aligned_width,
+                                      const float* bottom_rois, float* bottom_diff, void* stream) {
+  (void)batch_size;
+  DTT_REQUIRE(num_rois >= 0 && height > 1 && width > 1 && channels > 0 && aligned_height > 1 && aligned_width > 1,
+              "roi_align backward: bad shape");
+  const long n = (long)num_rois * channels * aligned_height * aligned_width;
+  if (n == 0) return 1;
+  DTT_REQUIRE(top_diff && bottom_rois && bottom_diff, "roi_align backward: null pointer");
+  hipLaunchKernelGGL(roi_align_bwd, dim3(grid_for(n)), dim3(kThreads), 0, static_cast<hipStream_t>(stream), n,
+                     top_diff, spatial_scale, height, width, channels, aligned_height, aligned_width, bottom_diff,
+                     bottom_rois);
+  DTT_CHECK_LAUNCH("roi_align_bwd");
+  return 1;
+}
+
+extern "C" int dtt_roi_pool_forward(const float* bottom_data, float spatial_scale, int num_rois, int height,
+                                    int width, int channels, int pooled_height, int pooled_width,
+                                    const float* bottom_rois, float* top_data, int* argmax_data, void* stream) {
+  DTT_REQUIRE(num_rois >= 0 && height > 0 && width > 0 && channels > 0 && pooled_height > 0 && pooled_width > 0,
+              "roi_pool forward: bad shape");
+  const long n = (long)num_rois * channels * pooled_height * pooled_width;
+  if (n == 0) return 1;
+  DTT_REQUIRE(bottom_data && bottom_rois && top_data, "roi_pool forward: null pointer");
+  hipLaunchKernelGGL(roi_pool_fwd, dim3(grid_for(n)), dim3(kThreads), 0, static_cast<hipStream_t>(stream), n,
+                     bottom_data, spatial_scale, height, width, channels, pooled_height, pooled_width, bottom_rois,
+                     top_data, argmax_data);
+  DTT_CHECK_LAUNCH("roi_pool_fwd");
+  return 1;
+}
+
+extern "C" int dtt_roi_pool_backward(const float* top_diff, float spatial_scale, int batch_size, int num_rois,
+                                     int height, int width, int channels, int pooled_height, int pooled_width,
+                                     const float* bottom_rois, float* bottom_diff, const int* argmax_data,
+                                     void* stream) {
+  (void)spatial_scale; (void)batch_size; (void)height; (void)width; (void)bottom_rois;
+  const long n = (long)num_rois * channels * pooled_height * pooled_width;
+  if (n == 0) return 1;
+  DTT_REQUIRE(top_diff && bottom_diff && argmax_data, "roi_pool backward: null pointer");
+  hipLaunchKernelGGL(roi_pool_bwd, dim3(grid_for(n)), dim3(kThreads), 0, static_cast<hipStream_t>(stream), n,
+                     top_diff, argmax_data, bottom_diff);
+  DTT_CHECK_LAUNCH("roi_pool_bwd");
+  return 1;
+}
+
+extern "C" int dtt_roi_crop_forward(int oc, int ow, int oh, int ob, int ic, int ih, int iw, int ib,
+                                    const float* inputImages, const float* grids, float* output, void* stream) {
+  DTT_REQUIRE(oc == ic, "roi_crop forward: output channels (%d) != input channels (%d)", oc, ic);
+  DTT_REQUIRE(ib > 0 && ob >= 0 && ob % ib == 0, "roi_crop forward: %d RoIs not a multiple of %d images", ob, ib);
+  const long n = (long)ob * oc * oh * ow;
+  if (n == 0) return 1;
+  DTT_REQUIRE(inputImages && grids && output, "roi_crop forward: null pointer");
+  hipLaunchKernelGGL(roi_crop_fwd, dim3(grid_for(n)), dim3(kThreads), 0, static_cast<hipStream_t>(stream), n,
+                     inputImages, grids, output, ic, ih, iw, oh, ow, ob / ib);
+  DTT_CHECK_LAUNCH("roi_crop_fwd");
+  return 1;
+}
+
+extern "C" int dtt_roi_crop_backward(int goc, int gow, int goh, int gob, int ic, int ih, int iw, int ib,
+                                     const float* inputImages, const float* grids, float* gradInputImages,
+                                     const float* gradOutput, void* stream) {
+  (void)inputImages;
+  DTT_REQUIRE(goc == ic, "roi_crop backward: channel mismatch");
+  DTT_REQUIRE(ib > 0 && gob >= 0 && gob % ib == 0, "roi_crop backward: %d RoIs not a multiple of %d images", gob, ib);
+  const long n = (long)gob * goc * goh * gow;
+  if (n == 0) return 1;
+  DTT_REQUIRE(grids && gradInputImages && gradOutput, "roi_crop backward: null pointer");
+  hipLaunchKernelGGL(roi_crop_bwd, dim3(grid_for(n)), dim3(kThreads), 0, static_cast<hipStream_t>(stream), n, grids,
+                     gradInputImages, gradOutput, ic, ih, iw, goh, gow, gob / ib);
+  DTT_CHECK_LAUNCH("roi_crop_bwd");
+  return 1;
+}

@@ -1,0 +1,387 @@
+"""Operator layer of the D&T hot path: same class names, constructor arguments and forward signatures
+as the reference's op packages, backed by libdtt_hip.so through its C ABI.
+
+Reference surface mirrored here (paths relative to the reference's lib/model/):
+  Correlation          correlation/modules/correlation.py:5-19   (+ functions/correlation.py:18-50)
+  _PSRoIPooling        psroi_pooling/modules/psroi_pool.py:7-18   (+ functions/psroi_pool.py:18-45)
+  RoIAlign/Avg/Max     roi_align/modules/roi_align.py:6-42        (+ functions/roi_align.py:7-47)
+  _RoIPooling          roi_pooling/modules/roi_pool.py:5-14       (+ functions/roi_pool.py:6-38)
+  _RoICrop             roi_crop/modules/roi_crop.py:4-8           (+ functions/roi_crop.py:7-21)
+  nms                  nms/nms_wrapper.py:11-18                   (+ nms_gpu.py:6-11)
+
+The reference builds an old-style stateful autograd Function per call; these are static
+torch.autograd.Function subclasses.  All ops are GPU-only and raise if the library is missing.
+"""
+import ctypes
+
+import torch
+from torch import nn
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import _lib
+from ._lib import check, ptr, require_f32_contig, require_gpu, stream_ptr
+
+
+def _workspace(nbytes, device):
+    return torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=device)
+
+
+# ------------------------------------------------------------------------------------ correlation
+def correlation_output_shape(channels, height, width, pad_size, kernel_size, max_displacement, stride1, stride2):
+    """Output (channels, height, width) per correlation_cuda.c:25-34."""
+    oc, oh, ow = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    ok = _lib.lib().dtt_correlation_output_shape(channels, height, width, pad_size, kernel_size, max_displacement,
+                                                 stride1, stride2, ctypes.byref(oc), ctypes.byref(oh),
+                                                 ctypes.byref(ow))
+    check(ok, "correlation_output_shape")
+    return oc.value, oh.value, ow.value
+
+
+def correlation_forward_into(out, input1, input2, pad_size, kernel_size, max_displacement, stride1, stride2,
+                             corr_multiply=1):
+    """Write the correlation of two (B,C,H,W) maps into `out`, which may be a channel slice
+    (B, oc, oh, ow) of a larger contiguous tensor (used to fill the tracking concat buffer in place)."""
+    require_gpu(out, input1, input2)
+    require_f32_contig("input1", input1)
+    require_f32_contig("input2", input2)
+    if input1.shape != input2.shape:
+        raise ValueError("correlation: input shapes differ: %s vs %s" % (tuple(input1.shape), tuple(input2.shape)))
+    B, C, H, W = input1.shape
+    oc, oh, ow = correlation_output_shape(C, H, W, pad_size, kernel_size, max_displacement, stride1, stride2)
+    if tuple(out.shape) != (B, oc, oh, ow) or out.dtype != torch.float32:
+        raise ValueError("correlation: out must be float32 %s" % ((B, oc, oh, ow),))
+    if out.stride()[1:] != (oh * ow, ow, 1):
+        raise ValueError("correlation: out must be a dense channel slice")
+    L = _lib.lib()
+    nbytes = L.dtt_correlation_forward_workspace_bytes(B, C, H, W, pad_size, kernel_size, max_displacement, stride1,
+                                                       stride2)
+    ws = _workspace(nbytes, input1.device)
+    with torch.cuda.device(input1.device):
+        check(L.dtt_correlation_forward(ptr(out), B, oc, oh, ow, out.stride(0), ptr(input1), C, H, W, ptr(input2),
+                                        ptr(ws), nbytes, pad_size, kernel_size, max_displacement, stride1, stride2,
+                                        corr_multiply, stream_ptr(input1.device)), "correlation forward")
+    return out
+
+
+class CorrelationFunction(Function):
+    @staticmethod
+    def forward(ctx, input1, input2, pad_size, kernel_size, max_displacement, stride1, stride2, corr_multiply):
+        require_gpu(input1, input2)
+        ctx.save_for_backward(input1, input2)
+        ctx.params = (pad_size, kernel_size, max_displacement, stride1, stride2, corr_multiply)
+        B, C, H, W = input1.shape
+        oc, oh, ow = correlation_output_shape(C, H, W, pad_size, kernel_size, max_displacement, stride1, stride2)
+        out = torch.empty((B, oc, oh, ow), dtype=torch.float32, device=input1.device)
+        return correlation_forward_into(out, input1, input2, pad_size, kernel_size, max_displacement, stride1,
+                                        stride2, corr_multiply)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        input1, input2 = ctx.saved_tensors
+        pad_size, kernel_size, max_displacement, stride1, stride2, corr_multiply = ctx.params
+        grad_output = grad_output.contiguous()
+        B, C, H, W = input1.shape
+        g1 = torch.empty_like(input1)
+        g2 = torch.empty_like(input2)
+        with torch.cuda.device(input1.device):
+            check(_lib.lib().dtt_correlation_backward(ptr(grad_output), grad_output.shape[0], grad_output.shape[1],
+                                                      grad_output.shape[2], grad_output.shape[3], ptr(input1), C, H,
+                                                      W, ptr(input2), ptr(g1), ptr(g2), pad_size, kernel_size,
+                                                      max_displacement, stride1, stride2, corr_multiply,
+                                                      stream_ptr(input1.device)), "correlation backward")
+        return g1, g2, None, None, None, None, None, None
+
+
+class Correlation(nn.Module):
+    """correlation/modules/correlation.py:5-13 (same argument order and defaults)."""
+
+    def __init__(self, pad_size=0, kernel_size=0, max_displacement=0, stride1=1, stride2=2, corr_multiply=1):
+        super().__init__()
+        self.pad_size = pad_size
+        self.kernel_size = kernel_size
+        self.max_displacement = max_displacement
+        self.stride1 = stride1
+        self.stride2 = stride2
+        self.corr_multiply = corr_multiply
+
+    def forward(self, input1, input2):
+        return CorrelationFunction.apply(input1, input2, self.pad_size, self.kernel_size, self.max_displacement,
+                                         self.stride1, self.stride2, self.corr_multiply)
+
+    def extra_repr(self):
+        return "pad_size=%d, kernel_size=%d, max_displacement=%d, stride1=%d, stride2=%d" % (
+            self.pad_size, self.kernel_size, self.max_displacement, self.stride1, self.stride2)
+
+
+# ---------------------------------------------------------------------------------- PSRoI pooling
+def _check_rois(rois):
+    if rois.dim() != 2 or rois.size(1) != 5:
+        # psroi_pooling_cuda.c:17-21 returns 0 when rois.size(1) != 5
+        raise ValueError("rois must have shape (R, 5) [batch_idx, x1, y1, x2, y2], got %s" % (tuple(rois.shape),))
+    require_f32_contig("rois", rois)
+
+
+class PSRoIPoolFunction(Function):
+    @staticmethod
+    def forward(ctx, features, rois, pooled_height, pooled_width, spatial_scale, group_size, output_dim):
+        require_gpu(features, rois)
+        require_f32_contig("features", features)
+        _check_rois(rois)
+        B, C, H, W = features.shape
+        R = rois.size(0)
+        out = torch.empty((R, output_dim, pooled_height, pooled_width), dtype=torch.float32, device=features.device)
+        with torch.cuda.device(features.device):
+            check(_lib.lib().dtt_psroi_pool_forward(ptr(features), spatial_scale, B, R, H, W, C, pooled_height,
+                                                    pooled_width, ptr(rois), group_size, output_dim, ptr(out), None,
+                                                    stream_ptr(features.device)), "psroi_pool forward")
+        ctx.save_for_backward(rois)
+        ctx.cfg = (pooled_height, pooled_width, spatial_scale, group_size, output_dim, tuple(features.shape))
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        (rois,) = ctx.saved_tensors
+        pooled_height, pooled_width, spatial_scale, group_size, output_dim, fshape = ctx.cfg
+        B, C, H, W = fshape
+        grad_output = grad_output.contiguous()
+        grad_input = torch.empty(fshape, dtype=torch.float32, device=grad_output.device)
+        with torch.cuda.device(grad_output.device):
+            check(_lib.lib().dtt_psroi_pool_backward(ptr(grad_output), None, B, rois.size(0), spatial_scale, C, H, W,
+                                                     pooled_width, pooled_height, output_dim, group_size,
+                                                     ptr(grad_input), ptr(rois), stream_ptr(grad_output.device)),
+                  "psroi_pool backward")
+        return grad_input, None, None, None, None, None, None
+
+
+class _PSRoIPooling(nn.Module):
+    """psroi_pooling/modules/psroi_pool.py:7-18."""
+
+    def __init__(self, pooled_height, pooled_width, spatial_scale, group_size, output_dim):
+        super().__init__()
+        self.pooled_width = int(pooled_width)
+        self.pooled_height = int(pooled_height)
+        self.spatial_scale = float(spatial_scale)
+        self.group_size = int(group_size)
+        self.output_dim = int(output_dim)
+
+    def forward(self, features, rois):
+        return PSRoIPoolFunction.apply(features, rois, self.pooled_height, self.pooled_width, self.spatial_scale,
+                                       self.group_size, self.output_dim)
+
+
+def psroi_pool_vote(features, rois, pooled_height, pooled_width, spatial_scale, group_size, output_dim):
+    """Inference-only fused PSRoI pool + AvgPool2d((P,P)) vote (rfcn.py:62-64, 136-140): returns
+    (pooled (R, od, P, P), vote (R, od))."""
+    require_gpu(features, rois)
+    require_f32_contig("features", features)
+    _check_rois(rois)
+    B, C, H, W = features.shape
+    R = rois.size(0)
+    pooled = torch.empty((R, output_dim, pooled_height, pooled_width), dtype=torch.float32, device=features.device)
+    vote = torch.empty((R, output_dim), dtype=torch.float32, device=features.device)
+    with torch.cuda.device(features.device):
+        check(_lib.lib().dtt_psroi_pool_vote_forward(ptr(features), spatial_scale, B, R, H, W, C, pooled_height,
+                                                     pooled_width, ptr(rois), group_size, output_dim, ptr(pooled),
+                                                     ptr(vote), stream_ptr(features.device)), "psroi_pool vote")
+    return pooled, vote
+
+
+# -------------------------------------------------------------------------------------------- NMS
+def nms(dets, thresh, force_cpu=False, max_keep=0):
+    """nms/nms_wrapper.py:11-18: dets (N, 5) [x1,y1,x2,y2,score] sorted by descending score ->
+    int32 (n_keep, 1) indices, or [] for empty input.  The greedy sweep runs on the device; the only
+    host synchronisation is reading n_keep to size the result (the reference does the same,
+    nms_gpu.py:10 `keep[:num_out[0]]`)."""
+    if dets.shape[0] == 0:
+        return []
+    if force_cpu:
+        raise RuntimeError("force_cpu=True: there is no CPU NMS in this package (GPU-only hot path)")
+    require_gpu(dets)
+    require_f32_contig("dets", dets)
+    n, dim = dets.shape
+    L = _lib.lib()
+    keep = torch.empty((n,), dtype=torch.int32, device=dets.device)
+    num = torch.empty((1,), dtype=torch.int32, device=dets.device)
+    nbytes = L.dtt_nms_workspace_bytes(n)
+    ws = _workspace(nbytes, dets.device)
+    with torch.cuda.device(dets.device):
+        check(L.dtt_nms(ptr(keep), ptr(num), ptr(dets), n, dim, float(thresh), int(max_keep), ptr(ws), nbytes,
+                        stream_ptr(dets.device)), "nms")
+    return keep[: int(num.item())].view(-1, 1)
+
+
+# -------------------------------------------------------------------------------------- RoI Align
+class RoIAlignFunction(Function):
+    @staticmethod
+    def forward(ctx, features, rois, aligned_height, aligned_width, spatial_scale):
+        require_gpu(features, rois)
+        require_f32_contig("features", features)
+        _check_rois(rois)
+        B, C, H, W = features.shape
+        R = rois.size(0)
+        out = torch.empty((R, C, aligned_height, aligned_width), dtype=torch.float32, device=features.device)
+        with torch.cuda.device(features.device):
+            check(_lib.lib().dtt_roi_align_forward(ptr(features), spatial_scale, R, H, W, C, aligned_height,
+                                                   aligned_width, ptr(rois), ptr(out), 0,
+                                                   stream_ptr(features.device)), "roi_align forward")
+        ctx.save_for_backward(rois)
+        ctx.cfg = (aligned_height, aligned_width, spatial_scale, tuple(features.shape))
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        (rois,) = ctx.saved_tensors
+        ah, aw, scale, fshape = ctx.cfg
+        B, C, H, W = fshape
+        grad_output = grad_output.contiguous()
+        grad_input = torch.zeros(fshape, dtype=torch.float32, device=grad_output.device)
+        with torch.cuda.device(grad_output.device):
+            check(_lib.lib().dtt_roi_align_backward(ptr(grad_output), scale, B, rois.size(0), H, W, C, ah, aw,
+                                                    ptr(rois), ptr(grad_input), stream_ptr(grad_output.device)),
+                  "roi_align backward")
+        return grad_input, None, None, None, None
+
+
+def _roi_align_pooled(features, rois, h, w, scale, mode):
+    require_gpu(features, rois)
+    require_f32_contig("features", features)
+    _check_rois(rois)
+    B, C, H, W = features.shape
+    out = torch.empty((rois.size(0), C, h, w), dtype=torch.float32, device=features.device)
+    with torch.cuda.device(features.device):
+        check(_lib.lib().dtt_roi_align_forward(ptr(features), scale, rois.size(0), H, W, C, h, w, ptr(rois),
+                                               ptr(out), mode, stream_ptr(features.device)), "roi_align forward")
+    return out
+
+
+class RoIAlign(nn.Module):
+    """roi_align/modules/roi_align.py:6-16."""
+
+    def __init__(self, aligned_height, aligned_width, spatial_scale):
+        super().__init__()
+        self.aligned_width = int(aligned_width)
+        self.aligned_height = int(aligned_height)
+        self.spatial_scale = float(spatial_scale)
+
+    def forward(self, features, rois):
+        return RoIAlignFunction.apply(features, rois, self.aligned_height, self.aligned_width, self.spatial_scale)
+
+
+class RoIAlignAvg(RoIAlign):
+    """roi_align/modules/roi_align.py:18-29: samples on (h+1)x(w+1), then avg_pool2d(2, stride 1).
+    Without autograd the pooling is fused into the sampling kernel."""
+
+    def forward(self, features, rois):
+        if torch.is_grad_enabled() and features.requires_grad:
+            x = RoIAlignFunction.apply(features, rois, self.aligned_height + 1, self.aligned_width + 1,
+                                       self.spatial_scale)
+            return torch.nn.functional.avg_pool2d(x, kernel_size=2, stride=1)
+        return _roi_align_pooled(features, rois, self.aligned_height, self.aligned_width, self.spatial_scale, 1)
+
+
+class RoIAlignMax(RoIAlign):
+    """roi_align/modules/roi_align.py:31-42."""
+
+    def forward(self, features, rois):
+        if torch.is_grad_enabled() and features.requires_grad:
+            x = RoIAlignFunction.apply(features, rois, self.aligned_height + 1, self.aligned_width + 1,
+                                       self.spatial_scale)
+            return torch.nn.functional.max_pool2d(x, kernel_size=2, stride=1)
+        return _roi_align_pooled(features, rois, self.aligned_height, self.aligned_width, self.spatial_scale, 2)
+
+
+# ---------------------------------------------------------------------------------- RoI max pool
+class RoIPoolFunction(Function):
+    @staticmethod
+    def forward(ctx, features, rois, pooled_height, pooled_width, spatial_scale):
+        require_gpu(features, rois)
+        require_f32_contig("features", features)
+        _check_rois(rois)
+        B, C, H, W = features.shape
+        R = rois.size(0)
+        out = torch.empty((R, C, pooled_height, pooled_width), dtype=torch.float32, device=features.device)
+        argmax = torch.empty((R, C, pooled_height, pooled_width), dtype=torch.int32, device=features.device)
+        with torch.cuda.device(features.device):
+            check(_lib.lib().dtt_roi_pool_forward(ptr(features), spatial_scale, R, H, W, C, pooled_height,
+                                                  pooled_width, ptr(rois), ptr(out), ptr(argmax),
+                                                  stream_ptr(features.device)), "roi_pool forward")
+        ctx.save_for_backward(rois, argmax)
+        ctx.cfg = (pooled_height, pooled_width, spatial_scale, tuple(features.shape))
+        ctx.mark_non_differentiable(argmax)
+        return out, argmax
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output, _grad_argmax):
+        rois, argmax = ctx.saved_tensors
+        ph, pw, scale, fshape = ctx.cfg
+        B, C, H, W = fshape
+        grad_output = grad_output.contiguous()
+        grad_input = torch.zeros(fshape, dtype=torch.float32, device=grad_output.device)
+        with torch.cuda.device(grad_output.device):
+            check(_lib.lib().dtt_roi_pool_backward(ptr(grad_output), scale, B, rois.size(0), H, W, C, ph, pw,
+                                                   ptr(rois), ptr(grad_input), ptr(argmax),
+                                                   stream_ptr(grad_output.device)), "roi_pool backward")
+        return grad_input, None, None, None, None
+
+
+class _RoIPooling(nn.Module):
+    """roi_pooling/modules/roi_pool.py:5-14."""
+
+    def __init__(self, pooled_height, pooled_width, spatial_scale):
+        super().__init__()
+        self.pooled_width = int(pooled_width)
+        self.pooled_height = int(pooled_height)
+        self.spatial_scale = float(spatial_scale)
+
+    def forward(self, features, rois):
+        return RoIPoolFunction.apply(features, rois, self.pooled_height, self.pooled_width, self.spatial_scale)[0]
+
+
+# --------------------------------------------------------------------------------------- RoI crop
+class RoICropFunction(Function):
+    @staticmethod
+    def forward(ctx, input1, input2):
+        """input1: images (B,C,H,W); input2: grids (R,Ho,Wo,2) holding (y, x) in [-1, 1]."""
+        require_gpu(input1, input2)
+        require_f32_contig("input1", input1)
+        require_f32_contig("input2", input2)
+        ib, ic, ih, iw = input1.shape
+        ob, oh, ow, two = input2.shape
+        if two != 2:
+            raise ValueError("grid must have shape (R, Ho, Wo, 2)")
+        out = torch.empty((ob, ic, oh, ow), dtype=torch.float32, device=input1.device)
+        with torch.cuda.device(input1.device):
+            check(_lib.lib().dtt_roi_crop_forward(ic, ow, oh, ob, ic, ih, iw, ib, ptr(input1), ptr(input2), ptr(out),
+                                                  stream_ptr(input1.device)), "roi_crop forward")
+        ctx.save_for_backward(input1, input2)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        input1, input2 = ctx.saved_tensors
+        ib, ic, ih, iw = input1.shape
+        ob, oh, ow, _ = input2.shape
+        grad_output = grad_output.contiguous()
+        grad_input1 = torch.zeros_like(input1)
+        with torch.cuda.device(input1.device):
+            check(_lib.lib().dtt_roi_crop_backward(ic, ow, oh, ob, ic, ih, iw, ib, ptr(input1), ptr(input2),
+                                                   ptr(grad_input1), ptr(grad_output), stream_ptr(input1.device)),
+                  "roi_crop backward")
+        # the reference never writes the grid gradient (roi_crop_cuda_kernel.cu:154-192): zeros
+        return grad_input1, torch.zeros_like(input2)
+
+
+class _RoICrop(nn.Module):
+    """roi_crop/modules/roi_crop.py:4-8."""
+
+    def __init__(self, layout="BHWD"):
+        super().__init__()
+
+    def forward(self, input1, input2):
+        return RoICropFunction.apply(input1, input2)

@@ -1,0 +1,313 @@
+"""Parity of the HIP ops (through the C ABI of libdtt_hip.so) against the CPU oracle.  Needs an MI355X."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle_lib as O
+from oracle import rpn_oracle as ro
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from dtt import _lib
+    _lib.lib()  # must load: no fallback
+    return torch.device("cuda:0")
+
+
+def cu(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def random_rois(rng, n, batch, im_h, im_w, extra=True):
+    x1 = rng.uniform(-20, im_w - 10, size=n)
+    y1 = rng.uniform(-20, im_h - 10, size=n)
+    w = rng.uniform(1, im_w * 0.7, size=n)
+    h = rng.uniform(1, im_h * 0.7, size=n)
+    rois = np.stack([rng.randint(0, batch, size=n), x1, y1, x1 + w, y1 + h], 1).astype(np.float32)
+    if extra and n >= 8:
+        rois[0, 1:] = [0, 0, im_w - 1, im_h - 1]          # full image
+        rois[1, 1:] = [5, 5, 5, 5]                        # 1 px
+        rois[2, 1:] = [im_w + 50, im_h + 50, im_w + 90, im_h + 90]  # fully outside
+        rois[3, 1:] = [16, 32, 16 + 7 * 16 - 1, 32 + 7 * 16 - 1]   # bin edges on exact pixel boundaries
+        rois[4, 1:] = [100.5, 50.5, 30.5, 20.5]           # inverted
+        rois[5, 1:] = [-40, -40, 30, 30]                  # straddles the border
+        rois[6, 1:] = np.round(rois[6, 1:])               # integer coordinates
+        rois[7, 1:] = rois[7, 1:] + 0.5                   # .5 coordinates (round half away from zero)
+    return rois
+
+
+# ----------------------------------------------------------------------------------------------- NMS
+def clustered_dets(rng, n, spread=400.0):
+    centers = rng.uniform(0, spread, size=(max(n // 12, 1), 2))
+    c = centers[rng.randint(0, len(centers), size=n)] + rng.normal(0, 6, size=(n, 2))
+    wh = rng.uniform(20, 120, size=(n, 2))
+    boxes = np.concatenate([c - wh / 2, c + wh / 2], 1)
+    scores = np.sort(rng.uniform(0, 1, size=n))[::-1]
+    return np.concatenate([boxes, scores[:, None]], 1).astype(np.float32)
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 300, 1000, 1024, 1025, 2049, 6000])
+@pytest.mark.parametrize("thresh", [0.7, 0.3])
+def test_nms_bit_exact(dev, n, thresh):
+    from dtt.ops import nms
+    rng = np.random.RandomState(n * 7 + int(thresh * 10))
+    dets = clustered_dets(rng, n)
+    if n >= 64:
+        dets[10, :4] = dets[3, :4]  # exact duplicates
+        dets[40, :4] = dets[3, :4]
+    ref = O.nms(dets, thresh)
+    got = nms(cu(dets, dev), thresh)
+    assert got.dtype == torch.int32 and got.dim() == 2 and got.size(1) == 1
+    np.testing.assert_array_equal(got.cpu().numpy().ravel(), ref)
+
+
+def test_nms_empty_and_max_keep(dev):
+    from dtt.ops import nms
+    assert nms(torch.zeros((0, 5), device=dev), 0.7) == []
+    rng = np.random.RandomState(5)
+    dets = clustered_dets(rng, 3000)
+    ref = O.nms(dets, 0.7)
+    for mk in (1, 17, 300, len(ref), len(ref) + 5):
+        got = nms(cu(dets, dev), 0.7, max_keep=mk).cpu().numpy().ravel()
+        np.testing.assert_array_equal(got, ref[:mk])
+
+
+def test_nms_threshold_boundary(dev):
+    """IoU within an ulp of the threshold: strict '>' and the exact fp32 op order decide."""
+    from dtt.ops import nms
+    rng = np.random.RandomState(9)
+    n = 512
+    base = np.array([10, 10, 109, 109], dtype=np.float32)
+    dets = np.zeros((n, 5), dtype=np.float32)
+    for i in range(n):
+        # boxes overlapping `base` with IoU spread tightly around 0.7
+        shift = rng.uniform(16.5, 18.5)
+        dets[i, :4] = base + np.float32([shift * (i % 2), shift * ((i + 1) % 2), shift * (i % 2), shift * ((i + 1) % 2)])
+    dets[0, :4] = base
+    dets[:, 4] = np.linspace(1, 0, n)
+    np.testing.assert_array_equal(nms(cu(dets, dev), 0.7).cpu().numpy().ravel(), O.nms(dets, 0.7))
+
+
+# --------------------------------------------------------------------------------------------- PSRoI
+@pytest.mark.parametrize("B,od,H,W,R", [(2, 4, 38, 67, 300), (1, 31, 19, 32, 64), (3, 5, 24, 40, 37)])
+def test_psroi_forward_bit_exact_and_backward(dev, B, od, H, W, R):
+    from dtt.ops import _PSRoIPooling
+    rng = np.random.RandomState(od * 100 + R)
+    G7 = 7
+    feat = rng.normal(size=(B, od * G7 * G7, H, W)).astype(np.float32)
+    rois = random_rois(rng, R, B, H * 16, W * 16)
+    ref, ref_map = O.psroi_pool_forward(feat, rois, G7, G7, 1.0 / 16, G7, od)
+    m = _PSRoIPooling(G7, G7, 1.0 / 16.0, G7, od)
+    ft = cu(feat, dev).requires_grad_(True)
+    out = m(ft, cu(rois, dev))
+    np.testing.assert_array_equal(out.detach().cpu().numpy(), ref)  # same summation order -> identical bits
+    gout = rng.normal(size=ref.shape).astype(np.float32)
+    out.backward(cu(gout, dev))
+    gref = O.psroi_pool_backward(gout, rois, feat.shape, G7, G7, 1.0 / 16, G7, od, ref_map)
+    np.testing.assert_allclose(ft.grad.cpu().numpy(), gref, rtol=1e-5, atol=1e-5)
+
+
+def test_psroi_vote_and_empty(dev):
+    from dtt.ops import _PSRoIPooling, psroi_pool_vote
+    rng = np.random.RandomState(1)
+    feat = rng.normal(size=(2, 4 * 49, 20, 30)).astype(np.float32)
+    rois = random_rois(rng, 50, 2, 320, 480)
+    ref, _ = O.psroi_pool_forward(feat, rois, 7, 7, 1 / 16.0, 7, 4)
+    pooled, vote = psroi_pool_vote(cu(feat, dev), cu(rois, dev), 7, 7, 1 / 16.0, 7, 4)
+    np.testing.assert_array_equal(pooled.cpu().numpy(), ref)
+    np.testing.assert_allclose(vote.cpu().numpy(), ref.reshape(50, 4, 49).mean(2), rtol=1e-5, atol=1e-6)
+    out = _PSRoIPooling(7, 7, 1 / 16.0, 7, 4)(cu(feat, dev), torch.zeros((0, 5), device=dev))
+    assert tuple(out.shape) == (0, 4, 7, 7)
+    with pytest.raises(ValueError):
+        _PSRoIPooling(7, 7, 1 / 16.0, 7, 4)(cu(feat, dev), torch.zeros((3, 4), device=dev))
+
+
+# --------------------------------------------------------------------------------------- correlation
+CORR_CASES = [
+    # B, C, H, W, pad, k, d, s1, s2
+    (2, 64, 20, 27, 8, 1, 8, 1, 1),     # conv4/conv5 geometry (R = 8)
+    (1, 48, 37, 45, 8, 1, 8, 2, 2),     # conv3 geometry (stride 2, R = 4)
+    (1, 20, 18, 22, 16, 1, 16, 1, 1),   # config-5 geometry (R = 16)
+    (2, 19, 9, 11, 4, 1, 4, 1, 1),      # C not a multiple of the channel chunk, tiny map
+    (1, 33, 21, 17, 3, 1, 3, 1, 1),     # R = 3 (padded up to the R <= 4 instantiation)
+    (1, 16, 16, 16, 6, 1, 4, 1, 1),     # pad > displacement
+    (1, 8, 12, 13, 4, 3, 4, 1, 2),      # kernel_size 3, stride2 != stride1 -> generic path
+]
+
+
+@pytest.mark.parametrize("case", CORR_CASES)
+def test_correlation_forward(dev, case):
+    from dtt.ops import Correlation
+    B, C, H, W, pad, k, d, s1, s2 = case
+    rng = np.random.RandomState(sum(case))
+    x1 = np.maximum(rng.normal(size=(B, C, H, W)), 0).astype(np.float32)
+    x2 = np.maximum(np.roll(x1, (1, -2), (2, 3)) + 0.3 * rng.normal(size=x1.shape), 0).astype(np.float32)
+    ref = O.correlation_forward(x1, x2, pad, k, d, s1, s2)
+    out = Correlation(pad, k, d, s1, s2)(cu(x1, dev), cu(x2, dev)).cpu().numpy()
+    assert out.shape == ref.shape
+    np.testing.assert_allclose(out, ref, rtol=0, atol=1e-4)  # north-star tolerance: 1e-4 fp32
+    assert np.abs(out - ref).max() < 2e-6 * max(1.0, np.abs(ref).max() * C ** 0.5)
+
+
+@pytest.mark.parametrize("case", CORR_CASES[:6])
+def test_correlation_backward(dev, case):
+    from dtt.ops import Correlation
+    B, C, H, W, pad, k, d, s1, s2 = case
+    rng = np.random.RandomState(sum(case) + 1)
+    x1 = rng.normal(size=(B, C, H, W)).astype(np.float32)
+    x2 = rng.normal(size=(B, C, H, W)).astype(np.float32)
+    t1, t2 = cu(x1, dev).requires_grad_(True), cu(x2, dev).requires_grad_(True)
+    out = Correlation(pad, k, d, s1, s2)(t1, t2)
+    gout = rng.normal(size=tuple(out.shape)).astype(np.float32)
+    out.backward(cu(gout, dev))
+    g1, g2 = O.correlation_backward(gout, x1, x2, pad, k, d, s1, s2)
+    np.testing.assert_allclose(t1.grad.cpu().numpy(), g1, rtol=0, atol=1e-4)
+    np.testing.assert_allclose(t2.grad.cpu().numpy(), g2, rtol=0, atol=1e-4)
+
+
+def test_correlation_into_concat_slice(dev):
+    from dtt.ops import correlation_forward_into
+    rng = np.random.RandomState(4)
+    x1 = rng.normal(size=(2, 32, 14, 18)).astype(np.float32)
+    x2 = rng.normal(size=(2, 32, 14, 18)).astype(np.float32)
+    ref = O.correlation_forward(x1, x2, 8, 1, 8, 1, 1)
+    buf = torch.full((2, 10 + 289 + 7, 14, 18), 5.0, device=dev)
+    correlation_forward_into(buf[:, 10:299], cu(x1, dev), cu(x2, dev), 8, 1, 8, 1, 1)
+    np.testing.assert_allclose(buf[:, 10:299].cpu().numpy(), ref, atol=1e-4)
+    assert (buf[:, :10] == 5).all() and (buf[:, 299:] == 5).all()
+
+
+# ------------------------------------------------------------------------------ RoI align/pool/crop
+def test_roi_align(dev):
+    from dtt.ops import RoIAlign, RoIAlignAvg, RoIAlignMax
+    rng = np.random.RandomState(2)
+    B, C, H, W, R = 2, 16, 23, 31, 40
+    feat = rng.normal(size=(B, C, H, W)).astype(np.float32)
+    rois = random_rois(rng, R, B, H * 16, W * 16)
+    ref8 = O.roi_align_forward(feat, rois, 8, 8, 1 / 16.0)
+    ft = cu(feat, dev).requires_grad_(True)
+    out = RoIAlign(8, 8, 1 / 16.0)(ft, cu(rois, dev))
+    np.testing.assert_array_equal(out.detach().cpu().numpy(), ref8)
+    gout = rng.normal(size=ref8.shape).astype(np.float32)
+    out.backward(cu(gout, dev))
+    np.testing.assert_allclose(ft.grad.cpu().numpy(), O.roi_align_backward(gout, rois, feat.shape, 8, 8, 1 / 16.0),
+                               rtol=1e-5, atol=1e-5)
+    t8 = torch.from_numpy(ref8)
+    with torch.no_grad():
+        avg = RoIAlignAvg(7, 7, 1 / 16.0)(cu(feat, dev), cu(rois, dev)).cpu()
+        mx = RoIAlignMax(7, 7, 1 / 16.0)(cu(feat, dev), cu(rois, dev)).cpu()
+    np.testing.assert_allclose(avg.numpy(), torch.nn.functional.avg_pool2d(t8, 2, 1).numpy(), rtol=1e-6, atol=1e-6)
+    np.testing.assert_array_equal(mx.numpy(), torch.nn.functional.max_pool2d(t8, 2, 1).numpy())
+    # autograd path of RoIAlignAvg = unfused sampling + avg_pool2d
+    ft2 = cu(feat, dev).requires_grad_(True)
+    avg2 = RoIAlignAvg(7, 7, 1 / 16.0)(ft2, cu(rois, dev))
+    np.testing.assert_allclose(avg2.detach().cpu().numpy(), avg.numpy(), rtol=1e-6, atol=1e-6)
+    avg2.sum().backward()
+    assert torch.isfinite(ft2.grad).all()
+
+
+def test_roi_pool(dev):
+    from dtt.ops import RoIPoolFunction, _RoIPooling
+    rng = np.random.RandomState(3)
+    B, C, H, W, R = 2, 12, 20, 26, 48
+    feat = rng.normal(size=(B, C, H, W)).astype(np.float32)
+    rois = random_rois(rng, R, B, H * 16, W * 16)
+    ref, ref_arg = O.roi_pool_forward(feat, rois, 7, 7, 1 / 16.0)
+    ft = cu(feat, dev).requires_grad_(True)
+    out, arg = RoIPoolFunction.apply(ft, cu(rois, dev), 7, 7, 1 / 16.0)
+    np.testing.assert_array_equal(out.detach().cpu().numpy(), ref)
+    np.testing.assert_array_equal(arg.cpu().numpy(), ref_arg)
+    gout = rng.normal(size=ref.shape).astype(np.float32)
+    out.backward(cu(gout, dev))
+    gref = O.roi_pool_backward(gout, rois, ref_arg, feat.shape, 7, 7, 1 / 16.0)
+    np.testing.assert_allclose(ft.grad.cpu().numpy(), gref, rtol=1e-5, atol=1e-5)
+    assert tuple(_RoIPooling(7, 7, 1 / 16.0)(cu(feat, dev), cu(rois, dev)).shape) == (R, C, 7, 7)
+
+
+def test_roi_crop(dev):
+    from dtt.ops import _RoICrop
+    rng = np.random.RandomState(6)
+    B, C, H, W, RPI, Gs = 2, 8, 15, 19, 5, 7
+    img = rng.normal(size=(B, C, H, W)).astype(np.float32)
+    grid = rng.uniform(-1.3, 1.3, size=(B * RPI, Gs, Gs, 2)).astype(np.float32)
+    ref = O.roi_crop_forward(img, grid)
+    it = cu(img, dev).requires_grad_(True)
+    out = _RoICrop()(it, cu(grid, dev))
+    np.testing.assert_array_equal(out.detach().cpu().numpy(), ref)
+    gout = rng.normal(size=ref.shape).astype(np.float32)
+    out.backward(cu(gout, dev))
+    np.testing.assert_allclose(it.grad.cpu().numpy(), O.roi_crop_backward(img, grid, gout), rtol=1e-5, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------ proposal layer
+def _proposal_inputs(rng, B, A, H, W):
+    logits = rng.normal(0, 2, size=(B, 2, A * H, W)).astype(np.float32)
+    prob = torch.softmax(torch.from_numpy(logits), 1).view(B, 2 * A, H, W).numpy()
+    bbox = rng.normal(0, 0.4, size=(B, 4 * A, H, W)).astype(np.float32)
+    info = np.tile(np.array([[H * 16.0, W * 16.0, 1.0]], dtype=np.float32), (B, 1))
+    info[-1, :2] -= 7
+    return prob, bbox, info
+
+
+@pytest.mark.parametrize("B,H,W,pre,post", [(2, 19, 32, 6000, 300), (2, 38, 67, 6000, 300), (1, 38, 67, 12000, 2000),
+                                           (2, 6, 8, 6000, 300), (3, 10, 12, 500, 50)])
+def test_proposal_layer_vs_oracle(dev, B, H, W, pre, post):
+    from dtt.rpn import generate_anchors, proposal_forward
+    rng = np.random.RandomState(B * 1000 + H)
+    base = generate_anchors(scales=(4, 8, 16, 32))
+    prob, bbox, info = _proposal_inputs(rng, B, base.shape[0], H, W)
+    prob[0, base.shape[0]:, 0, :5] = prob[0, base.shape[0], 0, 0]  # inject exact score ties
+    ref, nref = ro.proposal_layer(prob, bbox, info, base, 16, pre, post, 0.7, O.nms)
+    rois, num = proposal_forward(cu(prob, dev), cu(bbox, dev), cu(info, dev),
+                                 torch.from_numpy(base).float(), 16, pre, post, 0.7)
+    np.testing.assert_array_equal(num.cpu().numpy(), nref)
+    np.testing.assert_array_equal(rois.cpu().numpy(), ref)  # bit-exact rows, order and zero padding
+
+
+@pytest.mark.parametrize("case", ["test_19x32", "train_19x32", "test_6x8", "test_small_pre"])
+def test_proposal_layer_vs_reference_golden(dev, case):
+    from dtt.rpn import generate_anchors, proposal_forward
+    g = np.load(os.path.join(G, "proposal.npz"))
+    base = generate_anchors(scales=g["scales"], ratios=g["ratios"])
+    stride, pre, post = (int(v) for v in g[case + "/params"])
+    rois, _ = proposal_forward(cu(g[case + "/cls_prob"], dev), cu(g[case + "/bbox_pred"], dev),
+                               cu(g[case + "/im_info"], dev), torch.from_numpy(base).float(), stride, pre, post,
+                               float(g[case + "/nms_thresh"][0]))
+    np.testing.assert_allclose(rois.cpu().numpy(), g[case + "/rois"], rtol=1e-6, atol=2e-4)
+
+
+# ------------------------------------------------------------------------------ anchor target layer
+@pytest.mark.parametrize("case", ["b2_19x32", "b3_12x20", "b2_38x67"])
+def test_anchor_target_vs_reference_golden(dev, case):
+    from dtt.rpn import anchor_target_forward, generate_anchors
+    g = np.load(os.path.join(G, "anchor_target.npz"))
+    base = generate_anchors(scales=g["scales"], ratios=g["ratios"])
+    H, W = (int(v) for v in g[case + "/hw"])
+    np.random.seed(int(g["rng_seed"][0]))
+    lab, tgt, inw, outw = anchor_target_forward(cu(g[case + "/gt_boxes"], dev), torch.from_numpy(g[case + "/im_info"]),
+                                                torch.from_numpy(base).float(), H, W, 16)
+    np.testing.assert_array_equal(lab.cpu().numpy(), g[case + "/labels"])
+    np.testing.assert_array_equal(inw.cpu().numpy(), g[case + "/inside"])
+    np.testing.assert_array_equal(outw.cpu().numpy(), g[case + "/outside"])
+    np.testing.assert_allclose(tgt.cpu().numpy(), g[case + "/bbox_targets"], rtol=1e-6, atol=1e-6)
+
+
+def test_anchor_target_vs_oracle_bit_exact(dev):
+    from dtt.rpn import anchor_target_forward, generate_anchors
+    g = np.load(os.path.join(G, "anchor_target.npz"))
+    base = generate_anchors(scales=g["scales"], ratios=g["ratios"])
+    case = "b2_38x67"
+    H, W = (int(v) for v in g[case + "/hw"])
+    np.random.seed(11)
+    ref = ro.anchor_target_layer(g[case + "/gt_boxes"], g[case + "/im_info"], base, H, W, 16)
+    np.random.seed(11)
+    got = anchor_target_forward(cu(g[case + "/gt_boxes"], dev), torch.from_numpy(g[case + "/im_info"]),
+                                torch.from_numpy(base).float(), H, W, 16)
+    for a, b in zip(got, ref):
+        np.testing.assert_array_equal(a.cpu().numpy(), b)
