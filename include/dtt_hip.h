@@ -126,8 +126,8 @@ int dtt_roi_align_backward(const float* top_diff, float spatial_scale, int batch
 /* ---------------------------------------------------------------- RoI (max) pooling
  * Replaces ROIPoolForwardLaucher  (roi_pooling/src/roi_pooling_kernel.cu:95-126)
  *      and ROIPoolBackwardLaucher (roi_pooling/src/roi_pooling_kernel.cu:205-234).
- * bottom_diff must be zeroed by the caller: the backward scatters top_diff through argmax
- * (equivalent to the reference's O(pixels x RoIs) gather).
+ * bottom_diff must be zeroed by the caller: the backward scatters top_diff through argmax after
+ * re-applying the admission tests of the reference's O(pixels x RoIs) gather (same result).
  */
 int dtt_roi_pool_forward(const float* bottom_data, float spatial_scale, int num_rois, int height,
                          int width, int channels, int pooled_height, int pooled_width,

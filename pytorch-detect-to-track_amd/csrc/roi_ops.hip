@@ -150,14 +150,43 @@ __global__ __launch_bounds__(kThreads) void roi_pool_fwd(long nthreads, const fl
   }
 }
 
-// Scatter form of roi_pooling_kernel.cu:128-203: bottom_diff[argmax] += top_diff.  An element's argmax
-// can only be inside its own bin, which is exactly the set the reference's gather enumerates.
+// Scatter form of roi_pooling_kernel.cu:128-203.  The reference gathers: every bottom element visits every
+// RoI that contains it and every pooled unit that could have pooled it, adding top_diff where argmax matches.
+// Here each pooled unit scatters to its argmax, after re-applying the reference's two admission tests
+// (element inside the rounded RoI, pooled unit inside the feasible [phstart, phend) x [pwstart, pwend) window),
+// so malformed RoIs drop their gradient exactly as the reference does.
 __global__ __launch_bounds__(kThreads) void roi_pool_bwd(long nthreads, const float* __restrict__ top_diff,
-                                                         const int* __restrict__ argmax_data,
+                                                         const int* __restrict__ argmax_data, float spatial_scale,
+                                                         int height, int width, int channels, int pooled_height,
+                                                         int pooled_width, const float* __restrict__ bottom_rois,
                                                          float* __restrict__ bottom_diff) {
   for (long index = (long)blockIdx.x * kThreads + threadIdx.x; index < nthreads; index += (long)gridDim.x * kThreads) {
     const int a = argmax_data[index];
-    if (a >= 0) atomicAdd(bottom_diff + a, top_diff[index]);
+    if (a < 0) continue;
+    const int pw = index % pooled_width;
+    const int ph = (index / pooled_width) % pooled_height;
+    const int n = index / pooled_width / pooled_height / channels;
+    const int w = a % width, h = (a / width) % height;
+    const float* roi = bottom_rois + (long)n * 5;
+    const int roi_start_w = (int)roundf(roi[1] * spatial_scale);
+    const int roi_start_h = (int)roundf(roi[2] * spatial_scale);
+    const int roi_end_w = (int)roundf(roi[3] * spatial_scale);
+    const int roi_end_h = (int)roundf(roi[4] * spatial_scale);
+    if (!(w >= roi_start_w && w <= roi_end_w && h >= roi_start_h && h <= roi_end_h)) continue;
+    const int roi_width = (int)fmaxf((float)(roi_end_w - roi_start_w + 1), 1.f);
+    const int roi_height = (int)fmaxf((float)(roi_end_h - roi_start_h + 1), 1.f);
+    const float bin_size_h = (float)(roi_height) / (float)(pooled_height);
+    const float bin_size_w = (float)(roi_width) / (float)(pooled_width);
+    int phstart = (int)floorf((float)(h - roi_start_h) / bin_size_h);
+    int phend = (int)ceilf((float)(h - roi_start_h + 1) / bin_size_h);
+    int pwstart = (int)floorf((float)(w - roi_start_w) / bin_size_w);
+    int pwend = (int)ceilf((float)(w - roi_start_w + 1) / bin_size_w);
+    phstart = (int)fminf(fmaxf((float)phstart, 0.f), (float)pooled_height);
+    phend = (int)fminf(fmaxf((float)phend, 0.f), (float)pooled_height);
+    pwstart = (int)fminf(fmaxf((float)pwstart, 0.f), (float)pooled_width);
+    pwend = (int)fminf(fmaxf((float)pwend, 0.f), (float)pooled_width);
+    if (ph < phstart || ph >= phend || pw < pwstart || pw >= pwend) continue;
+    atomicAdd(bottom_diff + a, top_diff[index]);
   }
 }
 
@@ -290,12 +319,13 @@ extern "C" int dtt_roi_pool_backward(const float* top_diff, float spatial_scale,
                                      int height, int width, int channels, int pooled_height, int pooled_width,
                                      const float* bottom_rois, float* bottom_diff, const int* argmax_data,
                                      void* stream) {
-  (void)spatial_scale; (void)batch_size; (void)height; (void)width; (void)bottom_rois;
+  (void)batch_size;
   const long n = (long)num_rois * channels * pooled_height * pooled_width;
   if (n == 0) return 1;
-  DTT_REQUIRE(top_diff && bottom_diff && argmax_data, "roi_pool backward: null pointer");
+  DTT_REQUIRE(top_diff && bottom_diff && argmax_data && bottom_rois, "roi_pool backward: null pointer");
   hipLaunchKernelGGL(roi_pool_bwd, dim3(grid_for(n)), dim3(kThreads), 0, static_cast<hipStream_t>(stream), n,
-                     top_diff, argmax_data, bottom_diff);
+                     top_diff, argmax_data, spatial_scale, height, width, channels, pooled_height, pooled_width,
+                     bottom_rois, bottom_diff);
   DTT_CHECK_LAUNCH("roi_pool_bwd");
   return 1;
 }
