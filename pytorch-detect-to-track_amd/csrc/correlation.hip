@@ -52,9 +52,13 @@ struct Cfg {
 };
 
 // grid: (tiles, ksplit, batch).  ws layout: [ksplit][batch][tile][wave][nb][reg][lane].
-template <int NBR>
-__global__ __launch_bounds__(kThreads) void corr_fwd_mfma(const float* __restrict__ in1, const float* __restrict__ in2,
-                                                          float* __restrict__ ws, FastGeom g) {
+// Software pipeline per 16-channel chunk: the global loads of chunk i+1 are issued (unconditionally, to
+// clamped addresses) before the MFMA phase of chunk i and land in registers while the matrix pipe works;
+// they are written to LDS after the phase's barrier.
+template <int NBR, bool PIPE, int MINW>
+__global__ __launch_bounds__(kThreads, MINW) void corr_fwd_mfma(const float* __restrict__ in1,
+                                                                const float* __restrict__ in2,
+                                                                float* __restrict__ ws, FastGeom g) {
   using K = Cfg<NBR>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* l2 = lds;                  // [kKc][PS2]
@@ -66,31 +70,34 @@ __global__ __launch_bounds__(kThreads) void corr_fwd_mfma(const float* __restric
   const int ty0 = (tile / g.tiles_x) * kTile, tx0 = (tile % g.tiles_x) * kTile;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int my = wave >> 1, mx = wave & 1;
-  const long plane = (long)g.H * g.W;
+  const int plane = g.H * g.W;
   const int c_begin = ks * g.c_per_split;
   const int c_end = min(g.C, c_begin + g.c_per_split);
 
   // ---- per-thread staging descriptors (identical for every channel)
   int goff2[K::ELEMS], loff2[K::ELEMS];
+  bool ok2[K::ELEMS];
 #pragma unroll
   for (int e = 0; e < K::ELEMS; ++e) {
     const int idx = tid + e * kThreads;
     const int hr = idx / K::HR, hc = idx - hr * K::HR;
     const int gy = g.origin + (ty0 - g.R + hr) * g.s, gx = g.origin + (tx0 - g.R + hc) * g.s;
-    const bool ok = idx < K::HR * K::HR && gy >= 0 && gy < g.H && gx >= 0 && gx < g.W;
-    goff2[e] = ok ? gy * g.W + gx : -1;
-    loff2[e] = idx < K::HR * K::HR ? hr * K::HRS + hc : -1;
+    const bool in_lds = idx < K::HR * K::HR;
+    ok2[e] = in_lds && gy >= 0 && gy < g.H && gx >= 0 && gx < g.W;
+    goff2[e] = ok2[e] ? gy * g.W + gx : 0;
+    loff2[e] = in_lds ? hr * K::HRS + hc : -1;
   }
-  int goff1, loff1, ch1;
+  int goff1;
+  bool ok1;
+  const int ch1 = tid >> 6;  // 4 channels per pass
   {
     const int p = tid & 63;
-    ch1 = tid >> 6;  // 4 channels per pass
     const int py = p >> 3, px = p & 7;
     const int gy = g.origin + (ty0 + py) * g.s, gx = g.origin + (tx0 + px) * g.s;
-    const bool ok = gy >= 0 && gy < g.H && gx >= 0 && gx < g.W && (ty0 + py) < g.oh && (tx0 + px) < g.ow;
-    goff1 = ok ? gy * g.W + gx : -1;
-    loff1 = p;
+    ok1 = gy >= 0 && gy < g.H && gx >= 0 && gx < g.W && (ty0 + py) < g.oh && (tx0 + px) < g.ow;
+    goff1 = ok1 ? gy * g.W + gx : 0;
   }
+  const int loff1 = tid & 63;
 
   // ---- MFMA operand addresses
   const int kq_lane = lane >> 4;               // k index inside a quad
@@ -105,24 +112,7 @@ __global__ __launch_bounds__(kThreads) void corr_fwd_mfma(const float* __restric
   const float* p1 = in1 + (long)n * g.C * plane;
   const float* p2 = in2 + (long)n * g.C * plane;
 
-  for (int c0 = c_begin; c0 < c_end; c0 += kKc) {
-    // stage frame t+tau halo and frame t tile for channels [c0, c0 + kKc)
-#pragma unroll 4
-    for (int cc = 0; cc < kKc; ++cc) {
-      const int c = c0 + cc;
-      const float* src = p2 + (long)c * plane;
-      const bool cok = c < c_end;
-#pragma unroll
-      for (int e = 0; e < K::ELEMS; ++e) {
-        if (loff2[e] >= 0) l2[cc * K::PS2 + loff2[e]] = (cok && goff2[e] >= 0) ? src[goff2[e]] : 0.f;
-      }
-    }
-#pragma unroll
-    for (int cc = 0; cc < kKc; cc += 4) {
-      const int c = c0 + cc + ch1;
-      l1[(cc + ch1) * kPS1 + loff1] = (c < c_end && goff1 >= 0) ? p1[(long)c * plane + goff1] : 0.f;
-    }
-    __syncthreads();
+  auto mfma_phase = [&]() {
 #pragma unroll
     for (int kq = 0; kq < kKc / 4; ++kq) {
       const float a = l1[kq * 4 * kPS1 + a_off];
@@ -135,7 +125,79 @@ __global__ __launch_bounds__(kThreads) void corr_fwd_mfma(const float* __restric
           acc[nby * NBR + nbx] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[nby * NBR + nbx], 0, 0, 0);
         }
     }
+  };
+
+  if constexpr (PIPE) {
+    float st2[kKc][K::ELEMS];
+    float st1[kKc / 4];
+    auto issue_loads = [&](int c0) {
+#pragma unroll
+      for (int cc = 0; cc < kKc; ++cc) {
+        const int c = min(c0 + cc, g.C - 1);  // clamped: out-of-slice channels are zeroed at write time
+        const float* src = p2 + (long)c * plane;
+#pragma unroll
+        for (int e = 0; e < K::ELEMS; ++e) st2[cc][e] = src[goff2[e]];
+      }
+#pragma unroll
+      for (int q = 0; q < kKc / 4; ++q) {
+        const int c = min(c0 + q * 4 + ch1, g.C - 1);
+        st1[q] = p1[(long)c * plane + goff1];
+      }
+    };
+    auto write_lds = [&](int c0) {
+#pragma unroll
+      for (int cc = 0; cc < kKc; ++cc) {
+        const bool cok = (c0 + cc) < c_end;
+#pragma unroll
+        for (int e = 0; e < K::ELEMS; ++e)
+          if (e < K::ELEMS - 1 || loff2[e] >= 0) l2[cc * K::PS2 + loff2[e]] = (cok && ok2[e]) ? st2[cc][e] : 0.f;
+      }
+#pragma unroll
+      for (int q = 0; q < kKc / 4; ++q) {
+        const int cc = q * 4 + ch1;
+        l1[cc * kPS1 + loff1] = ((c0 + cc) < c_end && ok1) ? st1[q] : 0.f;
+      }
+    };
+    issue_loads(c_begin);
+    write_lds(c_begin);
     __syncthreads();
+    for (int c0 = c_begin; c0 < c_end; c0 += kKc) {
+      const bool more = c0 + kKc < c_end;
+      if (more) issue_loads(c0 + kKc);
+      mfma_phase();
+      __syncthreads();
+      if (more) {
+        write_lds(c0 + kKc);
+        __syncthreads();
+      }
+    }
+  } else {
+    // register-lean variant (large displacement windows): stage 4 channels at a time, no prefetch
+    for (int c0 = c_begin; c0 < c_end; c0 += kKc) {
+#pragma unroll 1
+      for (int cq = 0; cq < kKc; cq += 4) {
+        float st[4][K::ELEMS];
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          const float* src = p2 + (long)min(c0 + cq + cc, g.C - 1) * plane;
+#pragma unroll
+          for (int e = 0; e < K::ELEMS; ++e) st[cc][e] = src[goff2[e]];
+        }
+        const float v1 = p1[(long)min(c0 + cq + ch1, g.C - 1) * plane + goff1];
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          const bool cok = (c0 + cq + cc) < c_end;
+#pragma unroll
+          for (int e = 0; e < K::ELEMS; ++e)
+            if (e < K::ELEMS - 1 || loff2[e] >= 0)
+              l2[(cq + cc) * K::PS2 + loff2[e]] = (cok && ok2[e]) ? st[cc][e] : 0.f;
+        }
+        l1[(cq + ch1) * kPS1 + loff1] = ((c0 + cq + ch1) < c_end && ok1) ? v1 : 0.f;
+      }
+      __syncthreads();
+      mfma_phase();
+      __syncthreads();
+    }
   }
 
   // ---- partial sums to the workspace, fragment order (each store instruction = 256 contiguous bytes)
@@ -146,39 +208,48 @@ __global__ __launch_bounds__(kThreads) void corr_fwd_mfma(const float* __restric
     for (int r = 0; r < 4; ++r) w[(nb * 4 + r) * 64 + lane] = acc[nb][r];
 }
 
-// grid: (tiles * 4 waves, batch).  Sums the channel slices in slice order, divides by nelems
+// grid: (tiles * 4 waves, NBR block rows, batch).  One workgroup sums the channel slices of one N-block row
+// of one wave's fragment (slice order fixed -> deterministic), divides by nelems
 // (correlation_cuda_kernel.cu:100 `reduce_sum / nelems`) and scatters the in-window entries to NCHW.
 template <int NBR>
 __global__ __launch_bounds__(kThreads) void corr_fwd_reduce(const float* __restrict__ ws, float* __restrict__ out,
                                                             long out_batch_stride, FastGeom g, float nelems) {
   using K = Cfg<NBR>;
-  extern __shared__ __attribute__((aligned(16))) float frag[];  // [NB*4][64]
+  constexpr int ROW = NBR * 256;                 // floats of one N-block row: [nbx][reg][lane]
+  __shared__ __attribute__((aligned(16))) float frag[ROW];
   const int ntiles = g.tiles_x * g.tiles_y;
-  const int tile = blockIdx.x >> 2, wave = blockIdx.x & 3, n = blockIdx.y;
-  const int nbatch = gridDim.y;
+  const int tile = blockIdx.x >> 2, wave = blockIdx.x & 3, nby = blockIdx.y, n = blockIdx.z;
+  const int nbatch = gridDim.z;
   const int tid = threadIdx.x;
   constexpr int FR = K::NB * 256;
   const long slice_stride = (long)nbatch * ntiles * 4 * FR;
-  const float* src = ws + (((long)n * ntiles + tile) * 4 + wave) * (long)FR;
-  for (int i = tid; i < FR; i += kThreads) {
-    float s = src[i];
-    for (int k = 1; k < g.ksplit; ++k) s += src[i + k * slice_stride];
-    frag[i] = s;
+  const float4* src = reinterpret_cast<const float4*>(ws + (((long)n * ntiles + tile) * 4 + wave) * (long)FR + nby * ROW);
+  const long slice4 = slice_stride / 4;
+  for (int i = tid; i < ROW / 4; i += kThreads) {
+    float4 s = src[i];
+    for (int k = 1; k < g.ksplit; ++k) {
+      const float4 v = src[i + k * slice4];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    reinterpret_cast<float4*>(frag)[i] = s;
   }
   __syncthreads();
   const int ty0 = (tile / g.tiles_x) * kTile + (wave >> 1) * 4, tx0 = (tile % g.tiles_x) * kTile + (wave & 1) * 4;
   float* o = out + (long)n * out_batch_stride;
-  const int total = g.oc * 16;
+  // outputs whose halo row hr = tj + iy falls in this block row: tj in [4*nby - 3, 4*nby + 3]
+  const int tj_lo = max(0, 4 * nby - 3), tj_hi = min(g.D - 1, 4 * nby + 3);
+  const int total = (tj_hi - tj_lo + 1) * g.D * 16;
   for (int idx = tid; idx < total; idx += kThreads) {
-    const int tc = idx >> 4, p = idx & 15;
+    const int p = idx & 15, q = idx >> 4;
+    const int tj = tj_lo + q / g.D, ti = q % g.D;  // already offset by +R
     const int iy = p >> 2, ix = p & 3;
+    const int hr = tj + iy;
+    if ((hr >> 2) != nby) continue;
     const int y = ty0 + iy, x = tx0 + ix;
     if (y >= g.oh || x >= g.ow) continue;
-    const int tj = tc / g.D, ti = tc - tj * g.D;  // already offset by +R
-    const int hr = tj + iy, hc = ti + ix;         // halo row/col relative to this wave's halo origin
-    const int nb = (hr >> 2) * NBR + (hc >> 2);
+    const int hc = ti + ix;
     const int lane = iy * 16 + (hr & 3) * 4 + (hc & 3);
-    o[((long)tc * g.oh + y) * g.ow + x] = frag[(nb * 4 + ix) * 64 + lane] / nelems;
+    o[((long)(tj * g.D + ti) * g.oh + y) * g.ow + x] = frag[((hc >> 2) * 4 + ix) * 64 + lane] / nelems;
   }
 }
 
@@ -300,7 +371,7 @@ size_t ws_bytes(const FastGeom& g, int batch) {
   return (size_t)g.ksplit * batch * g.tiles_x * g.tiles_y * 4 * Cfg<NBR>::NB * 256 * sizeof(float);
 }
 
-template <int NBR>
+template <int NBR, bool PIPE, int MINW>
 int launch_fast(float* output, long out_batch_stride, const float* in1, const float* in2, void* workspace,
                 size_t workspace_bytes, const FastGeom& g, int batch, hipStream_t stream) {
   using K = Cfg<NBR>;
@@ -309,19 +380,17 @@ int launch_fast(float* output, long out_batch_stride, const float* in1, const fl
               workspace_bytes, need);
   static bool attr = false;
   if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(corr_fwd_mfma<NBR>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(corr_fwd_mfma<NBR, PIPE, MINW>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(corr_fwd_reduce<NBR>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    DTT_REQUIRE(e == hipSuccess && e2 == hipSuccess, "correlation: cannot raise dynamic LDS limit");
+    DTT_REQUIRE(e == hipSuccess, "correlation: cannot raise dynamic LDS limit");
     attr = true;
   }
   const int ntiles = g.tiles_x * g.tiles_y;
-  hipLaunchKernelGGL(corr_fwd_mfma<NBR>, dim3(ntiles, g.ksplit, batch), dim3(kThreads), K::LDS, stream, in1, in2,
+  hipLaunchKernelGGL((corr_fwd_mfma<NBR, PIPE, MINW>), dim3(ntiles, g.ksplit, batch), dim3(kThreads), K::LDS, stream, in1, in2,
                      static_cast<float*>(workspace), g);
   DTT_CHECK_LAUNCH("corr_fwd_mfma");
-  hipLaunchKernelGGL(corr_fwd_reduce<NBR>, dim3(ntiles * 4, batch), dim3(kThreads), (size_t)K::NB * 256 * sizeof(float),
-                     stream, static_cast<const float*>(workspace), output, out_batch_stride, g, (float)g.C);
+  hipLaunchKernelGGL(corr_fwd_reduce<NBR>, dim3(ntiles * 4, NBR, batch), dim3(kThreads), 0, stream,
+                     static_cast<const float*>(workspace), output, out_batch_stride, g, (float)g.C);
   DTT_CHECK_LAUNCH("corr_fwd_reduce");
   return 1;
 }
@@ -376,9 +445,9 @@ extern "C" int dtt_correlation_forward(float* output, int ob, int oc, int oh, in
   int nbr;
   if (fast_path(kernel_size, stride1, stride2, max_displacement, &nbr)) {
     const FastGeom g = make_geom(ob, ic, ih, iw, oc, oh, ow, pad_size, max_displacement, stride1);
-    if (nbr == 3) return launch_fast<3>(output, out_batch_stride, input1, input2, workspace, workspace_bytes, g, ob, stream);
-    if (nbr == 5) return launch_fast<5>(output, out_batch_stride, input1, input2, workspace, workspace_bytes, g, ob, stream);
-    return launch_fast<9>(output, out_batch_stride, input1, input2, workspace, workspace_bytes, g, ob, stream);
+    if (nbr == 3) return launch_fast<3, true, 2>(output, out_batch_stride, input1, input2, workspace, workspace_bytes, g, ob, stream);
+    if (nbr == 5) return launch_fast<5, true, 2>(output, out_batch_stride, input1, input2, workspace, workspace_bytes, g, ob, stream);
+    return launch_fast<9, false, 1>(output, out_batch_stride, input1, input2, workspace, workspace_bytes, g, ob, stream);
   }
   hipLaunchKernelGGL(corr_fwd_generic, dim3(ow, oh, ob), dim3(64), 0, stream, input1, input2, output,
                      out_batch_stride, ic, ih, iw, oc, oh, ow, pad_size, kernel_size, max_displacement, stride1, stride2);

@@ -114,63 +114,112 @@ __global__ __launch_bounds__(kSweepThreads) void nms_sweep_kernel(
     const int rows = min(kSuper, n - base);
     const int w0 = sc * kSuperWords;
     const int nw = min(kSuperWords, cb - w0);
-    // ---- A: stage the diagonal super-block
-    for (int idx = tid; idx < rows * nw; idx += kSweepThreads) {
-      const int r = idx / nw, j = idx - r * nw;
-      sb[r * kRowStride + j] = ((r >> 6) <= j) ? m[(long)(base + r) * col_blocks + w0 + j] : 0ULL;
+    // ---- A: stage the diagonal super-block (unconditional loads, 4 in flight per thread; words left
+    //         of a row's own block were never written by the mask kernel and are replaced by 0)
+    {
+      const int total = rows * nw;
+      for (int i0 = tid; i0 < total; i0 += 4 * kSweepThreads) {
+        unsigned long long v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int idx = min(i0 + u * kSweepThreads, total - 1);
+          const int r = idx / nw, j = idx - r * nw;
+          v[u] = m[(long)(base + r) * col_blocks + w0 + j];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int idx = i0 + u * kSweepThreads;
+          if (idx < total) {
+            const int r = idx / nw, j = idx - r * nw;
+            sb[r * kRowStride + j] = ((r >> 6) <= j) ? v[u] : 0ULL;
+          }
+        }
+      }
     }
     __syncthreads();
-    // ---- B: serial part, wave 0 only
+    // ---- B: serial part, wave 0 only.  Lanes 0..15 hold the removal words of this super-chunk in a
+    //         register (R); per chunk the keep decision only iterates over alive boxes whose diagonal
+    //         word is non-zero (a box that suppresses nothing inside its chunk cannot change the outcome
+    //         of its neighbours), then lane j ORs the kept rows' word j into R with plain LDS reads.
     if (wave == 0) {
       int total = __builtin_amdgcn_readfirstlane(ctl[1]);
       int nk = 0;
       bool done = false;
+      unsigned long long R = (lane < nw) ? remv[w0 + lane] : 0ULL;
       for (int c = 0; c < nw && !done; ++c) {
-        unsigned long long r = uniform64(remv[w0 + c]);
+        const unsigned long long r = readlane64(R, c);
         const int rows_c = min(kTile, rows - c * kTile);
         const unsigned long long valid = rows_c == kTile ? ~0ULL : ((1ULL << rows_c) - 1ULL);
         const unsigned long long d = (lane < rows_c) ? sb[(c * kTile + lane) * kRowStride + c] : 0ULL;
+        const unsigned long long nz = __ballot(d != 0ULL);
         unsigned long long alive = ~r & valid;
-        unsigned long long kept = 0;
-        int room = limit - total;
-        while (alive != 0 && room > 0) {
-          const int i = __builtin_ctzll(alive);
-          kept |= 1ULL << i;
-          --room;
-          r |= readlane64(d, i);
+        unsigned long long cand = alive & nz;
+        while (cand != 0) {
+          const int i = __builtin_ctzll(cand);
+          alive &= ~readlane64(d, i);  // d_i only has bits above i (mask kernel starts at t + 1)
           const unsigned long long above = (i == 63) ? 0ULL : (~0ULL << (i + 1));
-          alive = ~r & valid & above;
+          cand = alive & nz & above;
         }
+        unsigned long long kept = alive;
+        const int room = limit - total;
+        for (int extra = __builtin_popcountll(kept) - room; extra > 0; --extra)
+          kept &= ~(1ULL << (63 - __builtin_clzll(kept)));
         const int nkept = __builtin_popcountll(kept);
-        const bool mine = (kept >> lane) & 1ULL;
-        if (mine) {
+        if ((kept >> lane) & 1ULL) {
           const int rank = __builtin_popcountll(kept & ((1ULL << lane) - 1ULL));
-          const int row = c * kTile + lane;
-          kept_list[nk + rank] = row;
-          if (keep) keep[total + rank] = base + row;
-          for (int j = c + 1; j < nw; ++j) {
-            const unsigned long long v = sb[row * kRowStride + j];
-            if (v) atomicOr(&remv[w0 + j], v);
-          }
+          kept_list[nk + rank] = c * kTile + lane;
+          if (keep) keep[total + rank] = base + c * kTile + lane;
         }
         nk += nkept;
         total += nkept;
         if (total >= limit) done = true;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // LDS atomics visible to next column read
+        if (!done && c + 1 < nw) {
+          const bool owner = lane > c && lane < nw;
+          const unsigned long long* col = sb + (size_t)(c * kTile) * kRowStride + (owner ? lane : 0);
+          unsigned long long kk = kept, accw = 0;
+          while (kk != 0) {
+            unsigned long long v[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              if (kk != 0) {
+                const int i = __builtin_ctzll(kk);
+                kk &= kk - 1;
+                v[u] = col[i * kRowStride];
+              }
+            }
+            accw |= (v[0] | v[1]) | (v[2] | v[3]);
+          }
+          if (owner) R |= accw;
+        }
       }
       if (lane == 0) { ctl[0] = nk; ctl[1] = total; ctl[2] = done ? 1 : 0; }
     }
     __syncthreads();
     const int nk = ctl[0];
     const bool done = ctl[2] != 0;
-    // ---- C: kept rows suppress boxes of the later super-chunks
+    // ---- C: kept rows suppress boxes of the later super-chunks.  Thread (j, slice) ORs the words of
+    //         column j over its share of the kept rows in registers (8 independent loads in flight),
+    //         then merges with one LDS atomic.
     const int wnext = w0 + nw;
     const int nrem = cb - wnext;
     if (!done && nrem > 0 && nk > 0) {
-      for (int idx = tid; idx < nk * nrem; idx += kSweepThreads) {
-        const int k = idx / nrem, j = wnext + (idx - k * nrem);
-        const unsigned long long v = m[(long)(base + kept_list[k]) * col_blocks + j];
-        if (v) atomicOr(&remv[j], v);
+      int jt = 64;
+      while (jt < nrem && jt < kSweepThreads) jt <<= 1;
+      const int nslice = kSweepThreads / jt;
+      const int j = tid % jt, sl = tid / jt;
+      for (int jj = j; jj < nrem; jj += jt) {
+        unsigned long long accw = 0;
+        const unsigned long long* col = m + (long)base * col_blocks + wnext + jj;
+        int k = sl;
+        for (; k + 7 * nslice < nk; k += 8 * nslice) {
+          unsigned long long v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v[u] = col[(long)kept_list[k + u * nslice] * col_blocks];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) accw |= v[u];
+        }
+        for (; k < nk; k += nslice) accw |= col[(long)kept_list[k] * col_blocks];
+        if (accw) atomicOr(&remv[wnext + jj], accw);
       }
     }
     __syncthreads();

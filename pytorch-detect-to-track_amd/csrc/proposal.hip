@@ -3,8 +3,9 @@
 // Replaces _ProposalLayer.forward (reference rpn/proposal_layer.py:49-161): numpy meshgrid + H2D every
 // call, decode/clip of all K*A anchors, a full torch.sort of the B x K*A scores, then a Python loop of
 // per-image NMS round trips.  Here:
-//   1. proposal_select_sort (one 1024-thread workgroup per image): radix-select the pre_nms_topN best
-//      (score, index) keys straight from the NCHW score map, bitonic-sort just those in LDS, and decode +
+//   1. proposal_select_sort (one 1024-thread workgroup per image): select the pre_nms_topN best
+//      (score, index) keys straight from the NCHW score map (exact bisection on the key bits, keys cached in
+//      registers), bitonic-sort just those in LDS, and decode +
 //      clip only the survivors (bbox_transform.py:108-134, 156-173).  Keys are (descending score,
 //      ascending anchor index), a total order, so the result is deterministic.
 //   2. the batched NMS of nms.hip (mask tiles + on-device sweep) whose epilogue writes the zero-padded
@@ -31,7 +32,28 @@ struct PropGeom {
   int P;                   // power-of-two sort size >= topn
 };
 
-// LDS: buf[P] u64 | hist[256] | ctl[8]
+constexpr int kEPT = 32;     // score keys cached in registers per thread (n <= 32768), else re-read from L2
+
+// Block-wide sum of a per-wave (uniform) count: lane 0 of each wave posts it, everybody adds the 16 posts.
+__device__ __forceinline__ unsigned block_sum(unsigned wave_count, unsigned* wsum) {
+  const int tid = threadIdx.x;
+  if ((tid & 63) == 0) wsum[tid >> 6] = wave_count;
+  __syncthreads();
+  unsigned tot = 0;
+#pragma unroll
+  for (int w = 0; w < kThreads / 64; ++w) tot += wsum[w];
+  __syncthreads();
+  return tot;
+}
+
+// LDS: buf[P] u64 | wsum[16] | ctl[8]
+// Slot e of thread tid is score-map element m = tid + e*kThreads in MEMORY order (m = a*K + k, coalesced);
+// its flattened anchor index is t = k*A + a (proposal_layer.py:102-103).
+//
+// Selection of the topn best keys is an exact MSB-first bisection on the key bits: 32 rounds of
+// "how many keys are below this pivot", each a compare + ballot + popcount per cached key and one
+// 16-way sum through LDS -- no atomics, no histogram, insensitive to how skewed the scores are.
+template <bool CACHE>
 __global__ __launch_bounds__(kThreads) void proposal_select_sort(const float* __restrict__ cls_prob,
                                                                  const float* __restrict__ bbox_pred,
                                                                  const float* __restrict__ im_info,
@@ -39,57 +61,102 @@ __global__ __launch_bounds__(kThreads) void proposal_select_sort(const float* __
                                                                  float* __restrict__ boxes_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned long long* buf = reinterpret_cast<unsigned long long*>(smem);
-  unsigned* hist = reinterpret_cast<unsigned*>(buf + g.P);
-  unsigned* ctl = hist + 256;  // [0..1] prefix (hi, lo), [2] remaining, [3] fill counter
-  const int b = blockIdx.x, tid = threadIdx.x;
-  // fg scores: channel A + a, cell k  ->  flattened anchor index t = k*A + a (proposal_layer.py:102-103)
-  const float* sc = cls_prob + ((long)b * 2 * g.A + g.A) * g.K;
+  unsigned* wsum = reinterpret_cast<unsigned*>(buf + g.P);
+  unsigned* ctl = wsum + 16;  // [3] fill counter
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const float* sc = cls_prob + ((long)b * 2 * g.A + g.A) * g.K;  // fg scores: channels A .. 2A-1
+  const int nslots = (g.n + kThreads - 1) / kThreads;
 
-  auto key64_of = [&](int m) -> unsigned long long {  // m = memory order index a*K + k
+  unsigned kc[kEPT];
+  if constexpr (CACHE) {
+#pragma unroll
+    for (int e = 0; e < kEPT; ++e) {
+      const int m = tid + e * kThreads;
+      kc[e] = m < g.n ? desc_key(sc[m]) : 0xFFFFFFFFu;  // padding is never below a pivot
+    }
+  }
+  auto t_of = [&](int m) -> unsigned {
     const int a = m / g.K, k = m - a * g.K;
-    const unsigned t = (unsigned)(k * g.A + a);
-    return ((unsigned long long)desc_key(sc[m]) << 32) | t;
+    return (unsigned)(k * g.A + a);
+  };
+  // number of keys strictly below `pivot`, over the whole image
+  auto count_below = [&](unsigned pivot) -> unsigned {
+    unsigned c = 0;
+    if constexpr (CACHE) {
+#pragma unroll
+      for (int e = 0; e < kEPT; ++e) c += (unsigned)__builtin_popcountll(__ballot(kc[e] < pivot));
+    } else {
+      for (int e = 0; e < nslots; ++e) {
+        const int m = tid + e * kThreads;
+        c += (unsigned)__builtin_popcountll(__ballot(m < g.n && desc_key(sc[min(m, g.n - 1)]) < pivot));
+      }
+    }
+    return block_sum(c, wsum);
   };
 
-  unsigned long long thr = ~0ULL;  // select key64 <= thr
+  unsigned thr_hi = 0xFFFFFFFFu, thr_lo = 0xFFFFFFFFu;  // select (key32, t) <= (thr_hi, thr_lo)
   if (g.topn < g.n) {
-    // ---- MSB-first radix select of the topn-th smallest 64-bit key, 8 bits per pass
-    if (tid == 0) { ctl[0] = 0; ctl[1] = 0; ctl[2] = (unsigned)g.topn; }
-    unsigned long long prefix = 0;
-    for (int pass = 0; pass < 8; ++pass) {
-      const int shift = 56 - 8 * pass;
-      if (tid < 256) hist[tid] = 0;
-      __syncthreads();
-      const unsigned long long himask = pass == 0 ? 0ULL : (~0ULL << (shift + 8));
-      for (int m = tid; m < g.n; m += kThreads) {
-        const unsigned long long k64 = key64_of(m);
-        if ((k64 & himask) == prefix) atomicAdd(&hist[(unsigned)(k64 >> shift) & 255u], 1u);
-      }
-      __syncthreads();
-      if (tid == 0) {
-        unsigned rem = ctl[2], cum = 0;
-        int d = 0;
-        for (; d < 256; ++d) {
-          if (cum + hist[d] >= rem) break;
-          cum += hist[d];
-        }
-        ctl[2] = rem - cum;
-        const unsigned long long np = prefix | ((unsigned long long)d << shift);
-        ctl[0] = (unsigned)(np >> 32);
-        ctl[1] = (unsigned)np;
-      }
-      __syncthreads();
-      prefix = ((unsigned long long)ctl[0] << 32) | ctl[1];
-      __syncthreads();
+    // largest T with count(key < T) < topn  ==  the topn-th smallest key
+    unsigned T = 0;
+#pragma unroll 1
+    for (int bit = 31; bit >= 0; --bit) {
+      const unsigned test = T | (1u << bit);
+      if (count_below(test) < (unsigned)g.topn) T = test;
     }
-    thr = prefix;  // keys are unique, so exactly topn keys are <= thr
+    thr_hi = T;
+    const unsigned below = count_below(T);
+    const unsigned upto = T == 0xFFFFFFFFu ? (unsigned)g.n : count_below(T + 1u);
+    const unsigned need = (unsigned)g.topn - below;  // how many of the keys tied at T are wanted
+    if (upto - below != need) {
+      // resolve the tie on the anchor index (lower index first): same bisection over t, tied keys only
+      unsigned Tt = 0;
+      int tb = 0;
+      while ((1u << tb) < (unsigned)g.n) ++tb;
+#pragma unroll 1
+      for (int bit = tb - 1; bit >= 0; --bit) {
+        const unsigned test = Tt | (1u << bit);
+        unsigned c = 0;
+        for (int e = 0; e < nslots; ++e) {
+          const int m = tid + e * kThreads;
+          const int mm = min(m, g.n - 1);
+          c += (unsigned)__builtin_popcountll(__ballot(m < g.n && desc_key(sc[mm]) == T && t_of(mm) < test));
+        }
+        if (block_sum(c, wsum) < need) Tt = test;
+      }
+      thr_lo = Tt;
+    }
   }
-  // ---- compact the selected keys into LDS (any order), pad, sort
+  // ---- compact the selected keys into LDS (any order; one LDS atomic per wave), pad, sort
   if (tid == 0) ctl[3] = 0;
   __syncthreads();
-  for (int m = tid; m < g.n; m += kThreads) {
-    const unsigned long long k64 = key64_of(m);
-    if (k64 <= thr) buf[atomicAdd(&ctl[3], 1u)] = k64;
+  {
+    auto push = [&](bool take, unsigned long long k64) {
+      const unsigned long long mk = __ballot(take);
+      if (mk) {
+        unsigned basei = 0;
+        const int leader = __builtin_ctzll(mk);
+        if (lane == leader) basei = atomicAdd(&ctl[3], (unsigned)__builtin_popcountll(mk));
+        basei = __builtin_amdgcn_readlane(basei, leader);
+        if (take) buf[basei + __builtin_popcountll(mk & ((1ULL << lane) - 1ULL))] = k64;
+      }
+    };
+    if constexpr (CACHE) {
+#pragma unroll
+      for (int e = 0; e < kEPT; ++e) {
+        const int m = tid + e * kThreads;
+        const unsigned t = t_of(min(m, g.n - 1));
+        const bool take = m < g.n && (kc[e] < thr_hi || (kc[e] == thr_hi && t <= thr_lo));
+        push(take, ((unsigned long long)kc[e] << 32) | t);
+      }
+    } else {
+      for (int e = 0; e < nslots; ++e) {
+        const int m = tid + e * kThreads;
+        const unsigned k32 = desc_key(sc[min(m, g.n - 1)]);
+        const unsigned t = t_of(min(m, g.n - 1));
+        const bool take = m < g.n && (k32 < thr_hi || (k32 == thr_hi && t <= thr_lo));
+        push(take, ((unsigned long long)k32 << 32) | t);
+      }
+    }
   }
   for (int i = g.topn + tid; i < g.P; i += kThreads) buf[i] = ~0ULL;
   __syncthreads();
@@ -187,16 +254,22 @@ extern "C" int dtt_proposal_forward(const float* cls_prob, const float* bbox_pre
   w += align_up((size_t)batch * g.topn * sizeof(int), 256);
   int* num_ws = reinterpret_cast<int*>(w);
 
-  const size_t lds = (size_t)g.P * 8 + 256 * 4 + 8 * 4;
+  const size_t lds = (size_t)g.P * 8 + (16 + 8) * 4;
   static bool attr = false;
   if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(proposal_select_sort),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(proposal_select_sort<true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    DTT_REQUIRE(e == hipSuccess, "proposal: cannot raise dynamic LDS limit: %s", hipGetErrorString(e));
+    hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(proposal_select_sort<false>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    DTT_REQUIRE(e == hipSuccess && e2 == hipSuccess, "proposal: cannot raise dynamic LDS limit");
     attr = true;
   }
-  hipLaunchKernelGGL(proposal_select_sort, dim3(batch), dim3(kThreads), lds, stream, cls_prob, bbox_pred, im_info,
-                     anchors, g, boxes);
+  if (g.n <= kEPT * kThreads)
+    hipLaunchKernelGGL(proposal_select_sort<true>, dim3(batch), dim3(kThreads), lds, stream, cls_prob, bbox_pred,
+                       im_info, anchors, g, boxes);
+  else
+    hipLaunchKernelGGL(proposal_select_sort<false>, dim3(batch), dim3(kThreads), lds, stream, cls_prob, bbox_pred,
+                       im_info, anchors, g, boxes);
   DTT_CHECK_LAUNCH("proposal_select_sort");
   return dtt_nms_batched_launch(boxes, 4, (long)g.topn * 4, nullptr, g.topn, batch, nms_thresh, post_nms_topN, mask,
                                 (long)(mask_per_image / sizeof(unsigned long long)), keep, g.topn,
