@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""bench.py -- frame-pairs/sec of the Res-101 Detect-to-Track forward at 600 px on N MI355X (one process
+per GPU), with the roofline of the dominant hot-path kernel and a CPU baseline.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one D&T inference forward over one synthetic batch of `--batch` frame pairs per GPU
+(BASELINE.json configs[2]: Res-101 D&T siamese 2-frame, 600 px, correlation d=8 + PSRoI, bs=2, 1 x MI355X);
+the batch is resident in HBM before the timed region.  Per GPU work is fixed as N grows (weak scaling); the
+inference path shards by video snippet with no collective.  `--mode train` times a
+full training step (forward + backward + SGD, gradients all-reduced over RCCL).
+
+The one JSON line carries, besides the contract fields:
+  roofline      the dominant hot-path kernel (conv5 cross-frame correlation, exact-f32 MFMA): algorithmic
+                FLOPs per launch / its launch duration measured with HIP events on the launch stream
+                inside the timed region (C-ABI hook dtt_profile_attach)
+  cpu_baseline  the same forward for ONE frame pair through stock PyTorch CPU convolutions + the CPU
+                oracle of every hot-path op (oracle/cpu_graph.py), on this box's host cores
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "pytorch-detect-to-track_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: dense f32-input MFMA peak
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=2, help="frame pairs per GPU per step")
+    ap.add_argument("--mode", choices=("infer", "train"), default="infer")
+    ap.add_argument("--height", type=int, default=600)
+    ap.add_argument("--width", type=int, default=1067)
+    ap.add_argument("--layers", type=int, default=101)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+class KernelTimer:
+    """HIP events recorded by libdtt_hip.so around every launch of one kernel (dtt_profile_attach)."""
+
+    def __init__(self, tag, n, device):
+        from dtt import _lib
+        self.lib = _lib.lib()
+        self.tag = tag
+        self.n = n
+        self.begin = [torch.cuda.Event(enable_timing=True) for _ in range(n)]
+        self.end = [torch.cuda.Event(enable_timing=True) for _ in range(n)]
+        s = torch.cuda.current_stream(device)
+        for e in self.begin + self.end:
+            e.record(s)  # forces creation of the underlying hipEvent_t
+        torch.cuda.synchronize(device)
+        self._b = (ctypes.c_void_p * n)(*[e.cuda_event for e in self.begin])
+        self._e = (ctypes.c_void_p * n)(*[e.cuda_event for e in self.end])
+
+    def attach(self):
+        self.lib.dtt_profile_attach(self.tag.encode(), self._b, self._e, self.n)
+
+    def detach(self):
+        used = self.lib.dtt_profile_count()
+        self.lib.dtt_profile_attach(None, None, None, 0)
+        return used
+
+    def durations_us(self, used):
+        return [self.begin[i].elapsed_time(self.end[i]) * 1e3 for i in range(used)]
+
+
+def cpu_baseline(args, cfg):
+    """One frame pair through the CPU graph (stock PyTorch convs + oracle ops) on the host cores."""
+    from dtt.synth import build_model, calibrate_batchnorm_, make_batch
+    from oracle import cpu_graph, oracle_lib
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    # many-core hosts: beyond ~32 threads the fp32 CPU convolutions of a single 600x1067 image stop scaling
+    # (and oversubscribed OpenMP teams get much slower), so the baseline uses at most 32 cores and says so
+    ncores = max(1, min(avail, 32))
+    torch.set_num_threads(ncores)
+    oracle_lib.set_num_threads(ncores)
+    m = build_model(args.layers, cfg=cfg).eval()
+    im, info, _, _ = make_batch(1, args.height, args.width, seed=3)
+    calibrate_batchnorm_(m, im[:, 0])
+    t0 = time.time()
+    cpu_graph.rfcn_forward_test(m, im, info, cfg)
+    dt = time.time() - t0
+    return {"value": round(1.0 / dt, 4), "unit": "frame-pairs/s", "cores": int(ncores), "host_cores": int(avail),
+            "kind": "port",
+            "sample": "1 frame pair (B=1, %dx%d, Res-%d D&T test forward), one pass: torch CPU fp32 convs + "
+                      "oracle/ ops (OpenMP over independent outputs), %.1f s" % (args.height, args.width, args.layers, dt)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    from dtt.config import apply_dataset_defaults, cfg
+    from dtt.synth import build_model, calibrate_batchnorm_, make_batch
+    apply_dataset_defaults("imagenet_vid")
+    torch.backends.cudnn.benchmark = True
+
+    model = build_model(args.layers, cfg=cfg).to(dev)
+    im, info, gt, nb = make_batch(args.batch, args.height, args.width, seed=3 + rank, device=dev)
+    calibrate_batchnorm_(model, im[:, 0])
+    if args.mode == "train":
+        from dtt.dist import DataParallelSnippets, make_optimizer
+        model.train()
+        runner = DataParallelSnippets(model, world)
+        opt = make_optimizer(model, cfg, lr=1e-4)
+
+        def step():
+            runner.zero_grad(set_to_none=True)
+            out = runner(im, info, gt, nb)
+            loss = out[4].mean() + out[5].mean() + out[6].mean() + out[7].mean() + out[9].mean()
+            loss.backward()
+            runner.finish_gradients()
+            opt.step()
+    else:
+        model.eval()
+
+        def step():
+            with torch.no_grad():
+                return model(im, info, gt, nb)
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    launches_per_step = 3  # conv3, conv4, conv5 correlations, in that order
+    kt = KernelTimer("corr_fwd_mfma", launches_per_step * args.steps, dev)
+    kt.attach()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    used = kt.detach()
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        durs = kt.durations_us(used)
+        conv5 = durs[2::launches_per_step]
+        avg5 = sum(conv5) / max(len(conv5), 1)
+        B = args.batch
+        H16, W16 = -(-args.height // 16), -(-args.width // 16)
+        flops = 2.0 * 2048 * 289 * H16 * W16 * B           # 2*C*D^2*oH*oW per frame pair
+        bytes_ = (2 * 2048 * H16 * W16 * 4 + 289 * H16 * W16 * 4) * B
+        achieved = flops / (avg5 * 1e-6) / 1e12 if avg5 > 0 else 0.0
+        pairs = args.batch * world * args.steps
+        out = {
+            "metric": "frame-pairs/sec (600px, Res101 D&T)",
+            "value": round(pairs / elapsed, 3),
+            "unit": "frame-pairs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "Res-%d D&T siamese 2-frame %s step, %dx%d, correlation d=8 + PSRoI, bs=%d per GPU "
+                                   "(BASELINE.json configs[2]); random-init weights, BN statistics calibrated on the "
+                                   "synthetic input" % (args.layers, "inference" if args.mode == "infer" else "training",
+                                                        args.height, args.width, args.batch),
+                       "global_batch": args.batch * world, "parallelism": "dp%d (per-snippet sharding%s)" %
+                       (world, ", RCCL gradient all-reduce" if args.mode == "train" else ", no collective")},
+            "roofline": {"kernel": "corr_fwd_mfma<5> (conv5 correlation, 2048 ch, d=8)", "bound": "mfma",
+                         "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "launch_us": round(avg5, 2), "launches_timed": len(conv5),
+                         "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": bytes_,
+                         "hbm_view": {"achieved_GBs": round(bytes_ / (avg5 * 1e-6) / 1e9, 1) if avg5 > 0 else 0.0,
+                                      "peak_GBs": HBM_PEAK_GBS}},
+        }
+        if world == 1 and not args.no_cpu_baseline and args.mode == "infer":
+            out["cpu_baseline"] = cpu_baseline(args, cfg)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -28,6 +28,11 @@ void dtt_set_error(const char* fmt, ...);
     }                             \
   } while (0)
 
+// Optional per-kernel timing hook (bench.py / rocprof cross-check): when a tag is attached, the launcher of
+// the kernel with that tag brackets each launch with hipEventRecord on the launch stream.
+void dtt_prof_begin(const char* tag, hipStream_t stream);
+void dtt_prof_end(const char* tag, hipStream_t stream);
+
 static inline int dtt_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // XCD-aware remap of a linear workgroup id (8 XCDs; block b runs on XCD b % 8): gives each XCD a

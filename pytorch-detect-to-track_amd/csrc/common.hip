@@ -14,3 +14,47 @@ void dtt_set_error(const char* fmt, ...) {
 
 extern "C" const char* dtt_last_error(void) { return g_err; }
 extern "C" int dtt_abi_version(void) { return 1; }
+
+// ---- per-kernel timing hook --------------------------------------------------------------------------
+namespace {
+struct ProfState {
+  char tag[64];
+  hipEvent_t* begin;
+  hipEvent_t* end;
+  int capacity;
+  int used;
+  bool open;
+} g_prof = {"", nullptr, nullptr, 0, 0, false};
+}  // namespace
+
+// begin_events / end_events: arrays of `n` hipEvent_t handles owned by the caller.  Launch i of the kernel
+// named `tag` records begin_events[i] / end_events[i] around itself, until n launches have been recorded.
+// Pass tag = NULL (or n = 0) to detach.  Returns the number of launches recorded so far for the previous tag.
+extern "C" int dtt_profile_attach(const char* tag, void** begin_events, void** end_events, int n) {
+  const int prev = g_prof.used;
+  if (!tag || n <= 0) {
+    g_prof.tag[0] = 0; g_prof.begin = g_prof.end = nullptr; g_prof.capacity = g_prof.used = 0; g_prof.open = false;
+    return prev;
+  }
+  strncpy(g_prof.tag, tag, sizeof(g_prof.tag) - 1);
+  g_prof.tag[sizeof(g_prof.tag) - 1] = 0;
+  g_prof.begin = reinterpret_cast<hipEvent_t*>(begin_events);
+  g_prof.end = reinterpret_cast<hipEvent_t*>(end_events);
+  g_prof.capacity = n;
+  g_prof.used = 0;
+  g_prof.open = false;
+  return prev;
+}
+extern "C" int dtt_profile_count(void) { return g_prof.used; }
+
+void dtt_prof_begin(const char* tag, hipStream_t stream) {
+  if (g_prof.capacity == 0 || g_prof.used >= g_prof.capacity || strcmp(tag, g_prof.tag) != 0) return;
+  (void)hipEventRecord(g_prof.begin[g_prof.used], stream);
+  g_prof.open = true;
+}
+void dtt_prof_end(const char* tag, hipStream_t stream) {
+  if (!g_prof.open || strcmp(tag, g_prof.tag) != 0) return;
+  (void)hipEventRecord(g_prof.end[g_prof.used], stream);
+  g_prof.used++;
+  g_prof.open = false;
+}

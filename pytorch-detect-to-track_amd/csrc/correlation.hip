@@ -386,11 +386,15 @@ int launch_fast(float* output, long out_batch_stride, const float* in1, const fl
     attr = true;
   }
   const int ntiles = g.tiles_x * g.tiles_y;
+  dtt_prof_begin("corr_fwd_mfma", stream);
   hipLaunchKernelGGL((corr_fwd_mfma<NBR, PIPE, MINW>), dim3(ntiles, g.ksplit, batch), dim3(kThreads), K::LDS, stream, in1, in2,
                      static_cast<float*>(workspace), g);
+  dtt_prof_end("corr_fwd_mfma", stream);
   DTT_CHECK_LAUNCH("corr_fwd_mfma");
+  dtt_prof_begin("corr_fwd_reduce", stream);
   hipLaunchKernelGGL(corr_fwd_reduce<NBR>, dim3(ntiles * 4, NBR, batch), dim3(kThreads), 0, stream,
                      static_cast<const float*>(workspace), output, out_batch_stride, g, (float)g.C);
+  dtt_prof_end("corr_fwd_reduce", stream);
   DTT_CHECK_LAUNCH("corr_fwd_reduce");
   return 1;
 }

@@ -275,12 +275,16 @@ int dtt_nms_batched_launch(const float* boxes, int boxes_dim, long box_batch_str
     attr_set = true;
   }
   dim3 grid(cb, cb, batch);
+  dtt_prof_begin("nms_mask", stream);
   hipLaunchKernelGGL(nms_mask_kernel, grid, dim3(kTile), 0, stream, boxes, boxes_dim, box_batch_stride,
                      n_per_image, n_max, thresh, mask, mask_batch_stride, cb);
+  dtt_prof_end("nms_mask", stream);
   DTT_CHECK_LAUNCH("nms_mask_kernel");
+  dtt_prof_begin("nms_sweep", stream);
   hipLaunchKernelGGL(nms_sweep_kernel, dim3(batch), dim3(kSweepThreads), lds, stream, mask, mask_batch_stride,
                      n_per_image, n_max, cb, max_keep, keep_out, keep_batch_stride, num_out, boxes, boxes_dim,
                      box_batch_stride, rois_out, rois_rows);
+  dtt_prof_end("nms_sweep", stream);
   DTT_CHECK_LAUNCH("nms_sweep_kernel");
   return 1;
 }

@@ -264,12 +264,14 @@ extern "C" int dtt_proposal_forward(const float* cls_prob, const float* bbox_pre
     DTT_REQUIRE(e == hipSuccess && e2 == hipSuccess, "proposal: cannot raise dynamic LDS limit");
     attr = true;
   }
+  dtt_prof_begin("proposal_select_sort", stream);
   if (g.n <= kEPT * kThreads)
     hipLaunchKernelGGL(proposal_select_sort<true>, dim3(batch), dim3(kThreads), lds, stream, cls_prob, bbox_pred,
                        im_info, anchors, g, boxes);
   else
     hipLaunchKernelGGL(proposal_select_sort<false>, dim3(batch), dim3(kThreads), lds, stream, cls_prob, bbox_pred,
                        im_info, anchors, g, boxes);
+  dtt_prof_end("proposal_select_sort", stream);
   DTT_CHECK_LAUNCH("proposal_select_sort");
   return dtt_nms_batched_launch(boxes, 4, (long)g.topn * 4, nullptr, g.topn, batch, nms_thresh, post_nms_topN, mask,
                                 (long)(mask_per_image / sizeof(unsigned long long)), keep, g.topn,

@@ -195,9 +195,11 @@ extern "C" int dtt_psroi_pool_forward(const float* bottom_data, float spatial_sc
   if (plane_path_ok(height, width, pooled_height, pooled_width, group_size)) {
     const size_t lds = (size_t)height * width * sizeof(float);
     if (!raise_lds(reinterpret_cast<const void*>(psroi_fwd_plane), lds)) return 0;
+    dtt_prof_begin("psroi_fwd_plane", stream);
     hipLaunchKernelGGL(psroi_fwd_plane, dim3(channels, batch_size), dim3(kThreads), lds, stream, bottom_data,
                        spatial_scale, num_rois, height, width, channels, pooled_height, pooled_width, bottom_rois,
                        group_size, output_dim, top_data, mapping_channel);
+    dtt_prof_end("psroi_fwd_plane", stream);
   } else {
     const long n = (long)num_rois * output_dim * pooled_height * pooled_width;
     hipLaunchKernelGGL(psroi_fwd_generic, dim3(min(dtt_cdiv(n, 256), 65535)), dim3(256), 0, stream, n, bottom_data,

@@ -23,6 +23,8 @@ _Z = ctypes.c_size_t
 SIGNATURES = {
     "dtt_abi_version": (_I, []),
     "dtt_last_error": (ctypes.c_char_p, []),
+    "dtt_profile_attach": (_I, [ctypes.c_char_p, _P, _P, _I]),
+    "dtt_profile_count": (_I, []),
     "dtt_correlation_output_shape": (_I, [_I] * 8 + [ctypes.POINTER(_I)] * 3),
     "dtt_correlation_forward_workspace_bytes": (_Z, [_I] * 9),
     "dtt_correlation_forward": (_I, [_P, _I, _I, _I, _I, _L, _P, _I, _I, _I, _P, _P, _Z, _I, _I, _I, _I, _I, _I, _P]),

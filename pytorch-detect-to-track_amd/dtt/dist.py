@@ -1,0 +1,149 @@
+"""Per-snippet data parallelism: one process per GPU, gradients (only) all-reduced over RCCL / xGMI.
+
+Replaces the reference's single-process `nn.DataParallel` (trainval_net.py:310-311), which re-broadcasts all
+~55 M parameters GPU0 -> others every step and reduces gradients onto GPU 0.  Here every rank keeps its own
+replica (identical after the one broadcast at construction), runs its shard of video snippets -- both frames
+of a pair always stay on one GPU, exactly as DataParallel's dim-0 scatter did -- and the only collective is a
+bucketed gradient all-reduce that overlaps with the rest of backward:
+  * trainable gradients are views into a few flat fp32 buckets (default 32 MiB: on 8 GPUs a ring all-reduce
+    is bound by one xGMI link (~153 GB/s), so a 32 MiB bucket costs ~0.4 ms -- large enough to amortise the
+    launch, small enough that the first bucket is on the wire while layer3/layer2 are still in backward);
+  * buckets are filled in reverse registration order (the order autograd produces gradients) and each one
+    is all-reduced asynchronously as soon as its last gradient has been accumulated;
+  * `finish_gradients()` waits for the outstanding handles and divides by the world size.
+Inference needs no communication at all (results stay per rank).
+With world_size == 1 everything degenerates to a plain module call.
+"""
+import torch
+import torch.distributed as dist
+from torch import nn
+
+
+class DataParallelSnippets(nn.Module):
+    def __init__(self, module, world_size=None, bucket_bytes=32 << 20, process_group=None):
+        super().__init__()
+        self.module = module
+        self.group = process_group
+        self.world = world_size if world_size is not None else (dist.get_world_size() if dist.is_initialized() else 1)
+        self._handles = []
+        self._buckets = []
+        self._pending = {}
+        if self.world > 1:
+            self._sync_initial_state()
+            self._build_buckets(bucket_bytes)
+
+    # ------------------------------------------------------------------ setup
+    def _sync_initial_state(self):
+        with torch.no_grad():
+            seen = set()
+            for t in list(self.module.parameters()) + list(self.module.buffers()):
+                if t.data_ptr() in seen or not t.is_floating_point():
+                    continue
+                seen.add(t.data_ptr())
+                dist.broadcast(t.data, src=0, group=self.group)
+
+    def _build_buckets(self, bucket_bytes):
+        params, seen = [], set()
+        for p in self.module.parameters():
+            if p.requires_grad and id(p) not in seen:  # RFCN_net is registered under two names
+                seen.add(id(p))
+                params.append(p)
+        params.reverse()  # gradients arrive roughly in reverse registration order
+        cur, cur_bytes = [], 0
+        groups = []
+        for p in params:
+            nbytes = p.numel() * p.element_size()
+            if cur and cur_bytes + nbytes > bucket_bytes:
+                groups.append(cur)
+                cur, cur_bytes = [], 0
+            cur.append(p)
+            cur_bytes += nbytes
+        if cur:
+            groups.append(cur)
+        for bi, grp in enumerate(groups):
+            flat = torch.zeros(sum(p.numel() for p in grp), dtype=grp[0].dtype, device=grp[0].device)
+            off = 0
+            for p in grp:
+                p.grad = flat[off:off + p.numel()].view_as(p)  # gradients accumulate straight into the bucket
+                off += p.numel()
+                p.register_post_accumulate_grad_hook(self._make_hook(bi))
+            self._buckets.append((flat, grp))
+        self._reset_pending()
+
+    def _reset_pending(self):
+        self._pending = {bi: len(grp) for bi, (_, grp) in enumerate(self._buckets)}
+
+    def _make_hook(self, bucket_index):
+        def hook(param):
+            self._pending[bucket_index] -= 1
+            if self._pending[bucket_index] == 0:
+                flat, grp = self._buckets[bucket_index]
+                # a parameter whose .grad was re-pointed (e.g. by zero_grad(set_to_none=True)) is copied back in
+                off = 0
+                for p in grp:
+                    view = flat[off:off + p.numel()].view_as(p)
+                    if p.grad is not None and p.grad.data_ptr() != view.data_ptr():
+                        view.copy_(p.grad)
+                        p.grad = view
+                    off += p.numel()
+                self._handles.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        return hook
+
+    # ------------------------------------------------------------------ step API
+    def forward(self, *args, **kwargs):
+        return self.module(*args, **kwargs)
+
+    def zero_grad(self, set_to_none=False):
+        for flat, _ in self._buckets:
+            flat.zero_()
+        if self.world == 1:
+            self.module.zero_grad(set_to_none=set_to_none)
+
+    def finish_gradients(self):
+        """Wait for the in-flight bucket all-reduces and average.  Parameters that received no gradient this
+        step (unused branches) still have their bucket reduced so all ranks stay in lockstep."""
+        if self.world == 1:
+            return
+        for bi, left in self._pending.items():
+            if left > 0:
+                self._handles.append(dist.all_reduce(self._buckets[bi][0], op=dist.ReduceOp.SUM, group=self.group,
+                                                     async_op=True))
+        for h in self._handles:
+            h.wait()
+        self._handles = []
+        inv = 1.0 / self.world
+        for flat, _ in self._buckets:
+            flat.mul_(inv)
+        self._reset_pending()
+
+    def state_dict(self, *a, **k):  # checkpoints hold the bare module's keys (trainval_net.py:422 unwraps too)
+        return self.module.state_dict(*a, **k)
+
+
+def shard_snippets(n_snippets, rank, world):
+    """Contiguous, balanced split of snippet indices [0, n) across ranks (DataParallel scatter semantics)."""
+    base, rem = divmod(n_snippets, world)
+    start = rank * base + min(rank, rem)
+    return range(start, start + base + (1 if rank < rem else 0))
+
+
+def make_optimizer(model, cfg, lr=None, optimizer="sgd"):
+    """Per-parameter groups of trainval_net.py:280-294: biases get lr*(DOUBLE_BIAS+1) and no weight decay
+    unless BIAS_DECAY."""
+    T = cfg.TRAIN
+    lr = T.LEARNING_RATE if lr is None else lr
+    groups, seen = [], set()
+    for name, p in model.named_parameters():
+        if not p.requires_grad or id(p) in seen:
+            continue
+        seen.add(id(p))
+        if "bias" in name:
+            groups.append({"params": [p], "lr": lr * (T.DOUBLE_BIAS + 1),
+                           "weight_decay": T.WEIGHT_DECAY if T.BIAS_DECAY else 0})
+        else:
+            groups.append({"params": [p], "lr": lr, "weight_decay": T.WEIGHT_DECAY})
+    if optimizer == "adam":
+        for g in groups:
+            g["lr"] *= 0.1
+        return torch.optim.Adam(groups)
+    return torch.optim.SGD(groups, momentum=T.MOMENTUM)

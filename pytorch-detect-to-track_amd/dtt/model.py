@@ -1,0 +1,367 @@
+"""Detect-to-Track R-FCN graph that hosts the hot-path ops (PyTorch-ROCm is plumbing here: the trunk and
+the dense convolutions run on MIOpen / rocBLAS; everything the reference implemented as custom CUDA or
+per-image Python loops goes through libdtt_hip.so).
+
+Drop-in contract (paths relative to the reference's lib/model/):
+  * `_RPN(din).forward(base_feat, im_info, gt_boxes, num_boxes)` -> (rois, loss_cls, loss_box)   rpn/rpn.py:58-107
+  * `_RFCN.forward(im_data (B,2,3,H,W), im_info (B,2,3), gt_boxes (B,2,G,6), num_boxes (B,2,1))` -> the 10-tuple
+    of faster_rcnn/rfcn.py:249-250
+  * `resnet(classes, num_layers, pretrained, pretrained_rfcn, class_agnostic)` + `.create_architecture()`
+    faster_rcnn/resnet.py:247-312, with the same state_dict keys (RFCN_base.{0,1,4,5,6,7}.*,
+    RFCN_base.RFCN_net.* and its alias RFCN_net.*, RFCN_rpn.*, RFCN_cls_net.*, RFCN_bbox_net.*, corr_bbox_net.*)
+    so `rfcn_detect_track_*.pth` checkpoints load and save unchanged.
+Differences that are deliberate: `num_layers` is honoured (the reference always builds ResNet-101,
+resnet.py:259); `rois_label` is reshaped to (n_legs, B, -1) instead of the hard-wired view(2, 2, -1)
+(rfcn.py:220); the three correlations write straight into the tracking concat buffer.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .config import cfg as _global_cfg
+from .ops import Correlation, _PSRoIPooling, correlation_forward_into, correlation_output_shape, psroi_pool_vote
+from .rpn import _AnchorTargetLayer, _ProposalLayer
+from .targets import _ProposalTargetLayer, _TrackingProposalTargetLayer
+
+
+def _smooth_l1_loss(bbox_pred, bbox_targets, bbox_inside_weights, bbox_outside_weights, sigma=1.0, dim=(1,)):
+    """utils/net_utils.py:73-87."""
+    s2 = sigma ** 2
+    d = bbox_inside_weights * (bbox_pred - bbox_targets)
+    ad = d.abs()
+    quad = (ad < 1.0 / s2).detach().float()
+    loss = bbox_outside_weights * (d.pow(2) * (s2 / 2.0) * quad + (ad - 0.5 / s2) * (1.0 - quad))
+    for i in sorted(dim, reverse=True):
+        loss = loss.sum(i)
+    return loss.mean()
+
+
+# ----------------------------------------------------------------------------------------- trunk
+class Bottleneck(nn.Module):
+    """Caffe-style bottleneck: the stride sits on the first 1x1 conv (resnet.py:66-107)."""
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, dilation=1, dilate_first_conv=False):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, kernel_size=1, stride=stride, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, kernel_size=3, stride=1, padding=dilation if dilation > 1 else 1,
+                               bias=False, dilation=dilation if dilation > 1 else 1)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, kernel_size=1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(out))
+        res = x if self.downsample is None else self.downsample(x)
+        return self.relu(out + res)
+
+
+_DEPTHS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}
+
+
+def _make_stage(inplanes, planes, blocks, stride=1, dilation=1):
+    down = None
+    if stride != 1 or inplanes != planes * 4:
+        down = nn.Sequential(nn.Conv2d(inplanes, planes * 4, kernel_size=1, stride=stride, bias=False),
+                             nn.BatchNorm2d(planes * 4))
+    layers = [Bottleneck(inplanes, planes, stride, down, dilation=dilation)]
+    layers += [Bottleneck(planes * 4, planes, dilation=dilation) for _ in range(1, blocks)]
+    return nn.Sequential(*layers)
+
+
+def _trunk(num_layers):
+    """conv1, bn1, relu, maxpool(ceil), layer1..3, dilated layer4 (stride 16 overall, resnet.py:110-125)."""
+    d = _DEPTHS[num_layers]
+    mods = [nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False), nn.BatchNorm2d(64), nn.ReLU(inplace=True),
+            nn.MaxPool2d(kernel_size=3, stride=2, padding=0, ceil_mode=True),
+            _make_stage(64, 64, d[0]), _make_stage(256, 128, d[1], stride=2), _make_stage(512, 256, d[2], stride=2),
+            _make_stage(1024, 512, d[3], stride=1, dilation=2)]
+    seq = nn.Sequential(*mods)
+    for m in seq.modules():
+        if isinstance(m, nn.Conv2d):
+            n = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
+            m.weight.data.normal_(0, math.sqrt(2.0 / n))
+    return seq
+
+
+# ------------------------------------------------------------------------------------------- RPN
+class _RPN(nn.Module):
+    """rpn/rpn.py:16-107."""
+
+    def __init__(self, din, cfg=None):
+        super().__init__()
+        self._cfg = cfg or _global_cfg
+        c = self._cfg
+        self.din = din
+        self.anchor_scales = c.ANCHOR_SCALES
+        self.anchor_ratios = c.ANCHOR_RATIOS
+        self.feat_stride = c.FEAT_STRIDE[0]
+        self.RPN_Conv = nn.Conv2d(self.din, 512, 3, 1, 1, bias=True)
+        self.nc_score_out = len(self.anchor_scales) * len(self.anchor_ratios) * 2
+        self.RPN_cls_score = nn.Conv2d(512, self.nc_score_out, 1, 1, 0)
+        self.nc_bbox_out = len(self.anchor_scales) * len(self.anchor_ratios) * 4
+        self.RPN_bbox_pred = nn.Conv2d(512, self.nc_bbox_out, 1, 1, 0)
+        self.RPN_proposal = _ProposalLayer(self.feat_stride, self.anchor_scales, self.anchor_ratios, cfg=c)
+        self.RPN_anchor_target = _AnchorTargetLayer(self.feat_stride, self.anchor_scales, self.anchor_ratios, cfg=c)
+        self.rpn_loss_cls = 0
+        self.rpn_loss_box = 0
+
+    @staticmethod
+    def reshape(x, d):
+        s = x.size()
+        return x.view(s[0], int(d), int(float(s[1] * s[2]) / float(d)), s[3])
+
+    def forward(self, base_feat, im_info, gt_boxes, num_boxes):
+        B = base_feat.size(0)
+        conv1 = F.relu(self.RPN_Conv(base_feat), inplace=True)
+        cls_score = self.RPN_cls_score(conv1)
+        cls_score_r = self.reshape(cls_score, 2)
+        cls_prob = self.reshape(F.softmax(cls_score_r, dim=1), self.nc_score_out)
+        bbox_pred = self.RPN_bbox_pred(conv1)
+        key = "TRAIN" if self.training else "TEST"
+        rois = self.RPN_proposal((cls_prob.detach(), bbox_pred.detach(), im_info, key))
+        self.rpn_loss_cls = 0
+        self.rpn_loss_box = 0
+        if self.training:
+            assert gt_boxes is not None
+            labels, tgt, w_in, w_out = self.RPN_anchor_target((cls_score.detach(), gt_boxes[:, :, :5], im_info, num_boxes))
+            score = cls_score_r.permute(0, 2, 3, 1).contiguous().view(B, -1, 2)
+            label = labels.view(B, -1)
+            keep = label.view(-1).ne(-1).nonzero().view(-1)
+            score = torch.index_select(score.view(-1, 2), 0, keep)
+            label = torch.index_select(label.view(-1), 0, keep).long()
+            self.rpn_loss_cls = F.cross_entropy(score, label)
+            self.rpn_loss_box = _smooth_l1_loss(bbox_pred, tgt, w_in, w_out, sigma=3, dim=[1, 2, 3])
+        return rois, self.rpn_loss_cls, self.rpn_loss_box
+
+
+# ------------------------------------------------------------------------------------------ RFCN
+class _RFCN(nn.Module):
+    """faster_rcnn/rfcn.py:22-272."""
+
+    def __init__(self, classes, class_agnostic, cfg=None):
+        super().__init__()
+        self._cfg = cfg or _global_cfg
+        c = self._cfg
+        self.classes = classes
+        self.n_classes = len(classes)
+        self.n_reg_classes = 1 if class_agnostic else len(classes)
+        self.class_agnostic = class_agnostic
+        self.RFCN_loss_cls = 0
+        self.RFCN_loss_bbox = 0
+        P = c.POOLING_SIZE
+        self.RFCN_rpn = _RPN(self.dout_base_model, cfg=c)
+        self.RFCN_proposal_target = _ProposalTargetLayer(self.n_classes, cfg=c)
+        self.RFCN_tracking_proposal_target = _TrackingProposalTargetLayer(self.n_classes, cfg=c)
+        self.RFCN_psroi_cls_pool = _PSRoIPooling(P, P, spatial_scale=1.0 / 16.0, group_size=7, output_dim=self.n_classes)
+        self.RFCN_psroi_loc_pool = _PSRoIPooling(P, P, spatial_scale=1.0 / 16.0, group_size=7,
+                                                 output_dim=4 * self.n_reg_classes)
+        self.grid_size = P * 2 if c.CROP_RESIZE_WITH_MAX_POOL else P
+        self.RFCN_cls_net = nn.Conv2d(512, self.n_classes * 7 * 7, [1, 1], padding=0, stride=1)
+        nn.init.normal_(self.RFCN_cls_net.weight, 0.0, 0.01)
+        self.RFCN_bbox_net = nn.Conv2d(512, 4 * self.n_reg_classes * 7 * 7, [1, 1], padding=0, stride=1)
+        nn.init.normal_(self.RFCN_bbox_net.weight, 0.0, 0.01)
+        self.conv3_corr_layer = Correlation(pad_size=8, kernel_size=1, max_displacement=8, stride1=2, stride2=2)
+        self.conv4_corr_layer = Correlation(pad_size=8, kernel_size=1, max_displacement=8, stride1=1, stride2=1)
+        self.conv5_corr_layer = Correlation(pad_size=8, kernel_size=1, max_displacement=8, stride1=1, stride2=1)
+        self.RFCN_cls_score = nn.AvgPool2d((7, 7), stride=(7, 7))
+        self.RFCN_bbox_pred = nn.AvgPool2d((7, 7), stride=(7, 7))
+        self.RFCN_tracking_pred = nn.AvgPool2d((7, 7), stride=(7, 7))
+
+    # -- pooling + vote: autograd path = op + AvgPool2d (reference graph); inference = fused kernel pair
+    def _pool_vote(self, pool, vote, feat, rois):
+        if torch.is_grad_enabled() and feat.requires_grad:
+            return vote(pool(feat, rois)).squeeze(3).squeeze(2)
+        return psroi_pool_vote(feat, rois, pool.pooled_height, pool.pooled_width, pool.spatial_scale,
+                               pool.group_size, pool.output_dim)[1]
+
+    def _tracking_features(self, rfcn_bbox, conv3, conv4, conv5):
+        """cat([bbox_t, bbox_t+tau, corr3, corr4, corr5], 1) (rfcn.py:166-174).  Without autograd the
+        correlations write directly into their channel slices of the concat buffer."""
+        layers = (self.conv3_corr_layer, self.conv4_corr_layer, self.conv5_corr_layer)
+        feats = (conv3, conv4, conv5)
+        need_grad = torch.is_grad_enabled() and any(f.requires_grad for pair in feats for f in pair)
+        if need_grad or len(rfcn_bbox) != 2:
+            out = list(rfcn_bbox)
+            n = len(rfcn_bbox)
+            for i in range(n - 1):
+                for j in range(i + 1, n):
+                    out += [l(f[i], f[j]) for l, f in zip(layers, feats)]
+            return torch.cat(out, dim=1)
+        B, cb, H, W = rfcn_bbox[0].shape
+        chans = [correlation_output_shape(f[0].size(1), f[0].size(2), f[0].size(3), l.pad_size, l.kernel_size,
+                                          l.max_displacement, l.stride1, l.stride2)[0] for l, f in zip(layers, feats)]
+        buf = torch.empty((B, 2 * cb + sum(chans), H, W), dtype=torch.float32, device=rfcn_bbox[0].device)
+        buf[:, :cb] = rfcn_bbox[0]
+        buf[:, cb:2 * cb] = rfcn_bbox[1]
+        off = 2 * cb
+        for l, f, ch in zip(layers, feats, chans):
+            correlation_forward_into(buf[:, off:off + ch], f[0].contiguous(), f[1].contiguous(), l.pad_size,
+                                     l.kernel_size, l.max_displacement, l.stride1, l.stride2, l.corr_multiply)
+            off += ch
+        return buf
+
+    def forward(self, im_data, im_info, gt_boxes, num_boxes):
+        im_data = im_data.permute(1, 0, 2, 3, 4).contiguous()  # (n_legs, B, C, H, W)
+        im_info = im_info.permute(1, 0, 2).contiguous().detach()
+        gt_boxes = gt_boxes.permute(1, 0, 2, 3).contiguous().detach()
+        num_boxes = num_boxes.permute(1, 0, 2).contiguous().detach()
+        B = im_data.size(1)
+        n_legs = im_data.size(0)
+        dev = im_data.device
+        conv3, conv4, conv5, rois, rois_label = [], [], [], [], []
+        rpn_loss_cls, rpn_loss_bbox, rfcn_bbox, cls_prob, bbox_pred = [], [], [], [], []
+        loss_cls, loss_bbox = [], []
+        for leg in range(n_legs):
+            c3, c4, c5, top = self._im_to_head(im_data[leg])
+            conv3.append(c3); conv4.append(c4); conv5.append(c5)
+            cls_map = self.RFCN_cls_net(top)
+            bbox_map = self.RFCN_bbox_net(top)
+            rfcn_bbox.append(bbox_map)
+            leg_rois, l_cls, l_box = self.RFCN_rpn(top, im_info[leg], gt_boxes[leg][:, :, :5], num_boxes[leg])
+            if self.training:
+                leg_rois, label, target, w_in, w_out = self.RFCN_proposal_target(leg_rois, gt_boxes[leg][:, :, :5],
+                                                                                  num_boxes[leg])
+                label = label.view(-1).long()
+                target = target.view(-1, target.size(2))
+                w_in = w_in.view(-1, w_in.size(2))
+                w_out = w_out.view(-1, w_out.size(2))
+                rois_label.append(label)
+            else:
+                label = target = w_in = w_out = None
+                l_cls = torch.zeros(1, device=dev)
+                l_box = torch.zeros(1, device=dev)
+            rois.append(leg_rois)
+            rpn_loss_cls.append(l_cls.view(1)); rpn_loss_bbox.append(l_box.view(1))
+            flat = leg_rois.view(-1, 5)
+            score = self._pool_vote(self.RFCN_psroi_cls_pool, self.RFCN_cls_score, cls_map, flat)
+            prob = F.softmax(score, dim=1)
+            pred = self._pool_vote(self.RFCN_psroi_loc_pool, self.RFCN_bbox_pred, bbox_map, flat)
+            if self.training and not self.class_agnostic:
+                pv = pred.view(pred.size(0), int(pred.size(1) / 4), 4)
+                pred = torch.gather(pv, 1, label.view(-1, 1, 1).expand(label.size(0), 1, 4)).squeeze(1)
+            if self.training:
+                loss_cls.append(F.cross_entropy(score, label).view(1))
+                loss_bbox.append(_smooth_l1_loss(pred, target, w_in, w_out).view(1))
+            else:
+                loss_cls.append(torch.zeros(1, device=dev)); loss_bbox.append(torch.zeros(1, device=dev))
+            cls_prob.append(prob.view(B, leg_rois.size(1), -1))
+            bbox_pred.append(pred.view(B, leg_rois.size(1), -1))
+
+        tracking_feat = self._tracking_features(rfcn_bbox, conv3, conv4, conv5)
+        tracking_reg = self.corr_bbox_net(tracking_feat)
+        if self.training:
+            trk_rois, trk_label, trk_target, trk_in, trk_out = self.RFCN_tracking_proposal_target(gt_boxes, num_boxes)
+            trk_target = trk_target.view(-1, trk_target.size(2))
+            trk_in = trk_in.view(-1, trk_in.size(2))
+            trk_out = trk_out.view(-1, trk_out.size(2))
+        else:
+            trk_rois = rois[0].clone()  # tracking RoIs = frame-t RoIs (rfcn.py:192)
+        tracking_pred = self._pool_vote(self.RFCN_psroi_loc_pool, self.RFCN_tracking_pred, tracking_reg,
+                                        trk_rois.contiguous().view(-1, 5))
+        if self.training:
+            tracking_loss = _smooth_l1_loss(tracking_pred, trk_target, trk_in, trk_out)
+        else:
+            tracking_loss = torch.zeros(1, device=dev)
+        rois = torch.stack(rois, 0)
+        cls_prob = torch.stack(cls_prob, 0)
+        bbox_pred = torch.stack(bbox_pred, 0)
+        if rois_label:
+            rois_label = torch.stack(rois_label, 0).view(n_legs, B, -1)
+        return (rois, cls_prob, bbox_pred, tracking_pred, torch.stack(rpn_loss_cls, 0), torch.stack(rpn_loss_bbox, 0),
+                torch.stack(loss_cls, 0), torch.stack(loss_bbox, 0), rois_label, tracking_loss)
+
+    def _init_weights(self):
+        if not getattr(self, "pretrained_rfcn", False):
+            for m in (self.RFCN_rpn.RPN_Conv, self.RFCN_rpn.RPN_cls_score, self.RFCN_rpn.RPN_bbox_pred):
+                m.weight.data.normal_(0, 0.01)
+                m.bias.data.zero_()
+
+    def create_architecture(self):
+        self._init_modules()
+        self._init_weights()
+
+
+class resnet(_RFCN):
+    """faster_rcnn/resnet.py:247-345."""
+
+    def __init__(self, classes, num_layers=101, pretrained=False, pretrained_rfcn=False, class_agnostic=False, cfg=None):
+        self.model_path = "data/pretrained_model/res101.pth"
+        self.model_rfcn_path = "data/pretrained_model/rfcn_detect.pth"
+        self.dout_base_model = 512
+        self.num_layers = num_layers
+        self.pretrained = pretrained
+        self.pretrained_rfcn = pretrained_rfcn
+        super().__init__(classes, class_agnostic, cfg=cfg)
+
+    def _init_modules(self):
+        base = _trunk(self.num_layers)
+        if self.pretrained:
+            sd = torch.load(self.model_path, map_location="cpu")
+            names = ["conv1", "bn1", None, None, "layer1", "layer2", "layer3", "layer4"]
+            own = base.state_dict()
+            remap = {}
+            for k, v in sd.items():
+                head, _, rest = k.partition(".")
+                if head in names:
+                    nk = "%d.%s" % (names.index(head), rest)
+                    if nk in own:
+                        remap[nk] = v
+            base.load_state_dict(remap, strict=False)
+        self.RFCN_base = base
+        for idx in (0, 1):
+            for p in self.RFCN_base[idx].parameters():
+                p.requires_grad = False
+        fixed = self._cfg.RESNET.FIXED_BLOCKS
+        assert 0 <= fixed < 4
+        for blk, idx in ((3, 6), (2, 5), (1, 4)):
+            if fixed >= blk:
+                for p in self.RFCN_base[idx].parameters():
+                    p.requires_grad = False
+        for m in self.RFCN_base.modules():
+            if isinstance(m, nn.BatchNorm2d):
+                for p in m.parameters():
+                    p.requires_grad = False
+        # position-sensitive feature conv: 3x3, dilation 6 (resnet.py:296-301); registered under both names
+        self.RFCN_net = nn.Conv2d(2048, 512, kernel_size=3, padding=6, stride=1, dilation=6)
+        self.RFCN_base.add_module("RFCN_net", self.RFCN_net)
+        self.RFCN_base.add_module("resnet", nn.ReLU(inplace=True))
+        nn.init.kaiming_normal_(self.RFCN_net.weight)
+        if self.pretrained_rfcn:
+            sd = torch.load(self.model_rfcn_path, map_location="cpu")["model"]
+            own = self.state_dict()
+            self.load_state_dict({k: v for k, v in sd.items() if k in own}, strict=False)
+        tracking_in = 2 * 4 * self.n_reg_classes * 49 + 81 + 289 + 289  # 1051 when class agnostic (resnet.py:311)
+        self.corr_bbox_net = nn.Conv2d(tracking_in, 4 * self.n_reg_classes * 7 * 7, [1, 1], padding=0, stride=1)
+        nn.init.normal_(self.corr_bbox_net.weight, 0.0, 0.01)
+
+    def train(self, mode=True):
+        nn.Module.train(self, mode)
+        if mode:
+            self.RFCN_base.eval()
+            for idx in (5, 6, 7, 8):
+                self.RFCN_base[idx].train()
+            for m in self.RFCN_base.modules():
+                if isinstance(m, nn.BatchNorm2d):
+                    m.eval()
+        return self
+
+    def _im_to_head(self, x):
+        b = self.RFCN_base
+        x = b[3](b[2](b[1](b[0](x))))
+        conv3 = b[5](b[4](x))
+        conv4 = b[6](conv3)
+        conv5 = b[7](conv4)
+        top = b[9](b[8](conv5))
+        return conv3, conv4, conv5, top
+
+
+IMAGENET_VID_CLASSES = ["__background__"] + ["class_%d" % i for i in range(1, 31)]

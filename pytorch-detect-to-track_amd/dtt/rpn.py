@@ -102,7 +102,7 @@ def subsample_disable_lists(labels_np, counts, rpn_batchsize, fg_fraction, rng=n
             bg_inds = np.nonzero(labels_np[i] == 0)[0]
             perm = rng.permutation(bg_inds.size)
             dis.append(bg_inds[perm[: bg_inds.size - num_bg]])
-            bg_left = num_bg
+            bg_left = max(num_bg, 0)  # a negative quota (fg alone overflows the batch) disables every bg
         disable.append(np.concatenate(dis).astype(np.int32) if dis else np.zeros((0,), np.int32))
         after.append((fg_left, bg_left))
     return disable, after

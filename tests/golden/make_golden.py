@@ -190,6 +190,52 @@ def main():
     cases["ratios"] = np.array(ratios)
     cases["rng_seed"] = np.array([cfg.RNG_SEED])
     np.savez_compressed(os.path.join(HERE, "anchor_target.npz"), **cases)
+    # ---------------------------------------------------------------- 5. RoI / tracking target samplers
+    # proposal_target_layer_cascade.py:130 uses the torch-0.3 `Tensor.index(idx)`; give the harness's torch that
+    # method (== advanced indexing) so the reference file runs unmodified.
+    torch.Tensor.index = lambda self, idx: self[idx]  # (current torch has an unrelated Tensor.index; harness only)
+    from model.rpn.proposal_target_layer_cascade import _ProposalTargetLayer
+    from model.rpn.tracking_proposal_target_layer import _TrackingProposalTargetLayer
+    cases = {}
+    r = np.random.RandomState(31)
+    Bp, G, R = 2, 30, 300
+    gtb = np.zeros((2, Bp, G, 6), dtype=np.float32)  # (legs, B, G, 6)
+    nbx = np.zeros((2, Bp, 1), dtype=np.int64)
+    for b in range(Bp):
+        n = r.randint(2, 6)
+        ids = r.permutation(10)[:n] + 1
+        for leg in range(2):
+            order = r.permutation(n) if leg == 1 else np.arange(n)
+            keep = n if not (leg == 1 and b == 1) else n - 1   # one track disappears in frame t+tau of image 1
+            for j, o in enumerate(order[:keep]):
+                x1, y1 = r.uniform(0, 600), r.uniform(0, 300)
+                w, h = r.uniform(60, 300), r.uniform(60, 250)
+                gtb[leg, b, j] = [x1, y1, x1 + w, y1 + h, r.randint(1, 31), ids[o]]
+            nbx[leg, b, 0] = keep
+    rois = np.zeros((Bp, R, 5), dtype=np.float32)
+    xy = r.uniform(0, 700, size=(Bp, R, 2))
+    wh = r.uniform(30, 300, size=(Bp, R, 2))
+    rois[:, :, 1:3] = xy
+    rois[:, :, 3:5] = xy + wh
+    for b in range(Bp):  # some proposals close to gt boxes -> foreground
+        for j in range(int(nbx[0, b, 0])):
+            for k in range(8):
+                rois[b, 20 * j + k, 1:5] = gtb[0, b, j, :4] + r.normal(0, 6, size=4)
+        rois[b, :, 0] = b
+    np.random.seed(cfg.RNG_SEED)
+    ptl = _ProposalTargetLayer(31)
+    o = ptl(torch.from_numpy(rois), torch.from_numpy(gtb[0][:, :, :5].copy()), torch.from_numpy(nbx[0]))
+    for name, t in zip(("rois", "labels", "targets", "inside", "outside"), o):
+        cases["pt/" + name] = t2n(t)
+    cases["pt/in_rois"] = rois
+    cases["gt_boxes"] = gtb
+    cases["num_boxes"] = nbx
+    ttl = _TrackingProposalTargetLayer(31)
+    o = ttl(torch.from_numpy(gtb), torch.from_numpy(nbx))
+    for name, t in zip(("rois", "labels", "targets", "inside", "outside"), o):
+        cases["tt/" + name] = t2n(t)
+    cases["rng_seed"] = np.array([cfg.RNG_SEED])
+    np.savez_compressed(os.path.join(HERE, "targets.npz"), **cases)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")

@@ -1,0 +1,71 @@
+"""No-GPU checks of the drop-in boundary: the C-ABI library builds for gfx950, loads, and exports exactly
+the symbols include/dtt_hip.h declares; the Python binding table matches the header; ops refuse CPU tensors
+instead of falling back."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "dtt_hip.h")
+
+
+def declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(dtt_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_are_exported_and_bound():
+    from dtt import _lib
+    lib = _lib.lib()
+    names = declared_symbols()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), "libdtt_hip.so does not export %s" % n
+    assert set(names) == set(_lib.SIGNATURES), set(names) ^ set(_lib.SIGNATURES)
+    assert lib.dtt_abi_version() == 1
+
+
+def test_header_is_plain_c():
+    src = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)  # declarations only, comments stripped
+    for forbidden in ("torch", "at::", "Tensor", "hip/hip_runtime", "#include <hip"):
+        assert forbidden not in src, forbidden
+
+
+def test_shape_and_workspace_queries_run_without_gpu():
+    from dtt import _lib
+    from dtt.ops import correlation_output_shape
+    assert correlation_output_shape(512, 75, 134, 8, 1, 8, 2, 2) == (81, 38, 67)      # conv3 (rfcn.py:58)
+    assert correlation_output_shape(2048, 38, 67, 8, 1, 8, 1, 1) == (289, 38, 67)     # conv5
+    assert correlation_output_shape(1024, 36, 63, 16, 1, 16, 1, 1) == (1089, 36, 63)  # config 5
+    assert correlation_output_shape(8, 20, 20, 3, 3, 4, 1, 2)[0] == 25
+    with pytest.raises(RuntimeError):
+        correlation_output_shape(8, 4, 4, 0, 1, 8, 1, 1)  # empty output -> error string, not exit()
+    assert "empty output" in _lib.last_error()
+    L = _lib.lib()
+    assert L.dtt_nms_workspace_bytes(6000) == 6000 * 94 * 8
+    assert L.dtt_proposal_workspace_bytes(2, 12, 38, 67, 6000) > 2 * 6000 * 94 * 8
+    assert L.dtt_correlation_forward_workspace_bytes(2, 2048, 38, 67, 8, 1, 8, 1, 1) > 0
+
+
+def test_ops_refuse_cpu_tensors():
+    from dtt.ops import Correlation, _PSRoIPooling, _RoICrop, _RoIPooling, RoIAlignAvg, nms
+    x = torch.zeros(1, 49 * 2, 8, 8)
+    rois = torch.tensor([[0.0, 0, 0, 31, 31]])
+    for fn in (lambda: _PSRoIPooling(7, 7, 1 / 16.0, 7, 2)(x, rois), lambda: Correlation(4, 1, 4, 1, 1)(x, x),
+               lambda: RoIAlignAvg(7, 7, 1 / 16.0)(x, rois), lambda: _RoIPooling(7, 7, 1 / 16.0)(x, rois),
+               lambda: _RoICrop()(x, torch.zeros(1, 7, 7, 2)), lambda: nms(torch.rand(4, 5), 0.5)):
+        with pytest.raises(RuntimeError, match="GPU only"):
+            fn()
+    assert nms(torch.zeros(0, 5), 0.5) == []  # nms_wrapper.py:13-14
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from dtt import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.DttLibraryError, match="no CPU"):
+        _lib.lib()

@@ -1,0 +1,89 @@
+"""The N > 1 path on CPU: world_size-2 gloo processes running DataParallelSnippets (bucketed gradient
+all-reduce, per-snippet sharding) must reproduce the single-process gradients of the full batch."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+from torch import nn
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class Toy(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.a = nn.Conv2d(3, 8, 3, padding=1)
+        self.b = nn.Conv2d(8, 8, 1)
+        self.shared = nn.Conv2d(8, 4, 1)
+        self.alias = self.shared            # one module under two names, like RFCN_net
+        self.unused = nn.Linear(4, 4)       # never receives a gradient
+        self.frozen = nn.Conv2d(4, 4, 1)
+        for p in self.frozen.parameters():
+            p.requires_grad = False
+
+    def forward(self, x):
+        return self.frozen(self.alias(torch.relu(self.b(torch.relu(self.a(x)))))).mean(dim=(1, 2, 3))
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "pytorch-detect-to-track_amd")]
+    from dtt.dist import DataParallelSnippets, shard_snippets
+    torch.manual_seed(100 + rank)  # different init per rank: the wrapper must broadcast rank 0's weights
+    model = Toy()
+    dp = DataParallelSnippets(model, world, bucket_bytes=1024)  # tiny buckets -> several all-reduces
+    g = torch.Generator().manual_seed(0)
+    data = torch.randn(6, 3, 8, 8, generator=g)
+    mine = list(shard_snippets(6, rank, world))
+    grads = []
+    for step in range(2):  # two steps: buckets must be reusable
+        dp.zero_grad(set_to_none=True)
+        loss = dp(data[mine]).sum() / 6.0 * world   # per-rank mean convention: sum/N_global * world -> avg over ranks
+        loss.backward()
+        dp.finish_gradients()
+        grads.append({n: p.grad.clone() for n, p in model.named_parameters() if p.requires_grad and p.grad is not None})
+    w0 = {n: p.detach().clone() for n, p in model.named_parameters()}
+    if rank == 0:
+        q.put((w0, grads))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradients_match_single_process():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_worker, args=(r, world, _free_port() if r < 0 else PORT, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    w0, grads = q.get()
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    torch.manual_seed(100)  # rank 0's initial weights
+    ref = Toy()
+    for n, p in ref.named_parameters():
+        assert torch.equal(p.detach(), w0[n]), n
+    g = torch.Generator().manual_seed(0)
+    data = torch.randn(6, 3, 8, 8, generator=g)
+    (ref(data).sum() / 6.0).backward()
+    for step in range(2):
+        for n, p in ref.named_parameters():
+            if p.requires_grad and p.grad is not None and n in grads[step]:
+                torch.testing.assert_close(grads[step][n], p.grad, rtol=1e-5, atol=1e-6)
+    assert "unused.weight" in grads[0] and float(grads[0]["unused.weight"].abs().max()) == 0.0
+
+
+PORT = _free_port()

