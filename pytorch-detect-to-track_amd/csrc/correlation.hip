@@ -25,7 +25,16 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kKc = 16;       // channels per LDS chunk
+#ifndef DTT_CORR_ABLATE
+#define DTT_CORR_ABLATE 0     // developer ablations for tools/corr_tune.py: 1 = no global loads, 2 = also no LDS
+#endif                        // writes, 3 = also no barriers (results are wrong for any value but 0)
+#ifndef DTT_CORR_KC
+#define DTT_CORR_KC 8
+#endif
+#ifndef DTT_CORR_MINW
+#define DTT_CORR_MINW 3
+#endif
+constexpr int kKc = DTT_CORR_KC;  // channels per LDS chunk
 constexpr int kTile = 8;      // output tile edge (lattice pixels)
 constexpr int kThreads = 256; // 4 waves, one 4x4 M-block each
 constexpr int kPS1 = 68;      // frame-t plane stride (64 px, +4: second k pair lands on the other banks)
@@ -48,10 +57,10 @@ struct Cfg {
   static constexpr int PS2 = ((HR * HRS + 7) / 8) * 8 + 4;     // plane stride = 4 mod 8
   static constexpr int NB = NBR * NBR;                         // N-blocks per wave
   static constexpr int ELEMS = (HR * HR + kThreads - 1) / kThreads;
-  static constexpr size_t LDS = (size_t)kKc * (PS2 + kPS1) * sizeof(float);
+  static constexpr size_t LDS = (size_t)kKc * (PS2 + kPS1) * sizeof(float) + 16;  // + spare slot for idle lanes
 };
 
-// grid: (tiles, ksplit, batch).  ws layout: [ksplit][batch][tile][wave][nb][reg][lane].
+// grid: tiles * ksplit * batch (1-D).  ws layout: [ksplit][batch][tile][wave][nb][reg][lane].
 // Software pipeline per 16-channel chunk: the global loads of chunk i+1 are issued (unconditionally, to
 // clamped addresses) before the MFMA phase of chunk i and land in registers while the matrix pipe works;
 // they are written to LDS after the phase's barrier.
@@ -64,9 +73,13 @@ __global__ __launch_bounds__(kThreads, MINW) void corr_fwd_mfma(const float* __r
   float* l2 = lds;                  // [kKc][PS2]
   float* l1 = lds + kKc * K::PS2;   // [kKc][kPS1]
 
+  // 1-D grid of tiles x channel slices x batch.  Work items are ordered (batch, slice, tile) and each XCD gets a
+  // contiguous range of them, so the ~9x halo re-reads of one channel slice (a few MB) hit that XCD's own L2.
   const int ntiles = g.tiles_x * g.tiles_y;
-  const int tile = dtt_xcd_remap(blockIdx.x, ntiles);
-  const int ks = blockIdx.y, n = blockIdx.z;
+  const int item = dtt_xcd_remap(blockIdx.x, gridDim.x);
+  const int tile = item % ntiles;
+  const int ks = (item / ntiles) % g.ksplit, n = item / (ntiles * g.ksplit);
+  const int nbatch = gridDim.x / (ntiles * g.ksplit);
   const int ty0 = (tile / g.tiles_x) * kTile, tx0 = (tile % g.tiles_x) * kTile;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int my = wave >> 1, mx = wave & 1;
@@ -85,7 +98,7 @@ __global__ __launch_bounds__(kThreads, MINW) void corr_fwd_mfma(const float* __r
     const bool in_lds = idx < K::HR * K::HR;
     ok2[e] = in_lds && gy >= 0 && gy < g.H && gx >= 0 && gx < g.W;
     goff2[e] = ok2[e] ? gy * g.W + gx : 0;
-    loff2[e] = in_lds ? hr * K::HRS + hc : -1;
+    loff2[e] = in_lds ? hr * K::HRS + hc : K::PS2 - 1;  // surplus threads dump into the plane's unused pad word
   }
   int goff1;
   bool ok1;
@@ -98,6 +111,10 @@ __global__ __launch_bounds__(kThreads, MINW) void corr_fwd_mfma(const float* __r
     goff1 = ok1 ? gy * g.W + gx : 0;
   }
   const int loff1 = tid & 63;
+  unsigned m2[K::ELEMS];
+#pragma unroll
+  for (int e = 0; e < K::ELEMS; ++e) m2[e] = ok2[e] ? 0xFFFFFFFFu : 0u;
+  const unsigned m1 = ok1 ? 0xFFFFFFFFu : 0u;
 
   // ---- MFMA operand addresses
   const int kq_lane = lane >> 4;               // k index inside a quad
@@ -145,19 +162,22 @@ __global__ __launch_bounds__(kThreads, MINW) void corr_fwd_mfma(const float* __r
       }
     };
     auto write_lds = [&](int c0) {
+      // branch-free: zero padding / channel tail by AND-mask, every thread stores every element
 #pragma unroll
       for (int cc = 0; cc < kKc; ++cc) {
-        const bool cok = (c0 + cc) < c_end;
+        const unsigned cmask = (c0 + cc) < c_end ? 0xFFFFFFFFu : 0u;
 #pragma unroll
         for (int e = 0; e < K::ELEMS; ++e)
-          if (e < K::ELEMS - 1 || loff2[e] >= 0) l2[cc * K::PS2 + loff2[e]] = (cok && ok2[e]) ? st2[cc][e] : 0.f;
+          l2[cc * K::PS2 + loff2[e]] = __uint_as_float(__float_as_uint(st2[cc][e]) & (cmask & m2[e]));
       }
 #pragma unroll
       for (int q = 0; q < kKc / 4; ++q) {
         const int cc = q * 4 + ch1;
-        l1[cc * kPS1 + loff1] = ((c0 + cc) < c_end && ok1) ? st1[q] : 0.f;
+        const unsigned cmask = (c0 + cc) < c_end ? 0xFFFFFFFFu : 0u;
+        l1[cc * kPS1 + loff1] = __uint_as_float(__float_as_uint(st1[q]) & (cmask & m1));
       }
     };
+#if DTT_CORR_ABLATE == 0
     issue_loads(c_begin);
     write_lds(c_begin);
     __syncthreads();
@@ -171,6 +191,26 @@ __global__ __launch_bounds__(kThreads, MINW) void corr_fwd_mfma(const float* __r
         __syncthreads();
       }
     }
+#else
+#pragma unroll
+    for (int cc = 0; cc < kKc; ++cc)
+#pragma unroll
+      for (int e = 0; e < K::ELEMS; ++e) st2[cc][e] = (float)(tid + cc + e);
+#pragma unroll
+    for (int q = 0; q < kKc / 4; ++q) st1[q] = (float)(tid + q);
+    write_lds(c_begin);
+    __syncthreads();
+    for (int c0 = c_begin; c0 < c_end; c0 += kKc) {
+      const bool more = c0 + kKc < c_end;
+      mfma_phase();
+      if (DTT_CORR_ABLATE < 3) __syncthreads();
+      if (more) {
+        if (DTT_CORR_ABLATE < 2) write_lds(c0 + kKc);
+        if (DTT_CORR_ABLATE < 3) __syncthreads();
+      }
+    }
+    (void)issue_loads;
+#endif
   } else {
     // register-lean variant (large displacement windows): stage 4 channels at a time, no prefetch
     for (int c0 = c_begin; c0 < c_end; c0 += kKc) {
@@ -186,13 +226,13 @@ __global__ __launch_bounds__(kThreads, MINW) void corr_fwd_mfma(const float* __r
         const float v1 = p1[(long)min(c0 + cq + ch1, g.C - 1) * plane + goff1];
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc) {
-          const bool cok = (c0 + cq + cc) < c_end;
+          const unsigned cmask = (c0 + cq + cc) < c_end ? 0xFFFFFFFFu : 0u;
 #pragma unroll
           for (int e = 0; e < K::ELEMS; ++e)
-            if (e < K::ELEMS - 1 || loff2[e] >= 0)
-              l2[(cq + cc) * K::PS2 + loff2[e]] = (cok && ok2[e]) ? st[cc][e] : 0.f;
+            l2[(cq + cc) * K::PS2 + loff2[e]] = __uint_as_float(__float_as_uint(st[cc][e]) & (cmask & m2[e]));
         }
-        l1[(cq + ch1) * kPS1 + loff1] = ((c0 + cq + ch1) < c_end && ok1) ? v1 : 0.f;
+        l1[(cq + ch1) * kPS1 + loff1] =
+            __uint_as_float(__float_as_uint(v1) & (((c0 + cq + ch1) < c_end ? 0xFFFFFFFFu : 0u) & m1));
       }
       __syncthreads();
       mfma_phase();
@@ -201,7 +241,181 @@ __global__ __launch_bounds__(kThreads, MINW) void corr_fwd_mfma(const float* __r
   }
 
   // ---- partial sums to the workspace, fragment order (each store instruction = 256 contiguous bytes)
-  float* w = ws + ((((long)ks * gridDim.z + n) * ntiles + tile) * 4 + wave) * (long)(K::NB * 256);
+  float* w = ws + ((((long)ks * nbatch + n) * ntiles + tile) * 4 + wave) * (long)(K::NB * 256);
+#pragma unroll
+  for (int nb = 0; nb < K::NB; ++nb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) w[(nb * 4 + r) * 64 + lane] = acc[nb][r];
+}
+
+// Stride-1 variant of the kernel above with 16-byte staging: every thread moves float4 groups
+// (global_load_dwordx4 at 4-byte alignment -- gfx950 runs in unaligned-access mode -- and ds_write_b128), 10 loads
+// + 10 LDS stores per thread per chunk instead of 52 + 52.  Requires C % 16 == 0 (no channel tail) and W >= 4.
+// Groups that straddle the left / right image edge are loaded from the clamped in-row position and rotated
+// into place (workgroup-uniform slow path); out-of-image components are zeroed by mask.
+template <int NBR, int MINW>
+__global__ __launch_bounds__(kThreads, MINW) void corr_fwd_mfma_v4(const float* __restrict__ in1,
+                                                                   const float* __restrict__ in2,
+                                                                   float* __restrict__ ws, FastGeom g) {
+  using K = Cfg<NBR>;
+  constexpr int G4 = K::HR / 4;             // float4 groups per halo row
+  constexpr int PL4 = K::HR * G4;           // groups per channel plane
+  constexpr int N4 = (kKc * PL4 + kThreads - 1) / kThreads;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* l2 = lds;                  // [kKc][PS2]
+  float* l1 = lds + kKc * K::PS2;   // [kKc][kPS1]
+
+  const int ntiles = g.tiles_x * g.tiles_y;
+  const int item = dtt_xcd_remap(blockIdx.x, gridDim.x);
+  const int tile = item % ntiles;
+  const int ks = (item / ntiles) % g.ksplit, n = item / (ntiles * g.ksplit);
+  const int nbatch = gridDim.x / (ntiles * g.ksplit);
+  const int ty0 = (tile / g.tiles_x) * kTile, tx0 = (tile % g.tiles_x) * kTile;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int my = wave >> 1, mx = wave & 1;
+  const int plane = g.H * g.W;
+  const int c_begin = ks * g.c_per_split;
+  const int c_end = min(g.C, c_begin + g.c_per_split);
+
+  // descriptor of one float4 group: global offset (channel-in-chunk included), LDS offset, 4 validity bits,
+  // rotation delta = wanted_start - loaded_start
+  auto describe = [&](int cc, int gy, int start, bool live, int& goff, unsigned& bits, int& delta) {
+    const bool row_ok = live && gy >= 0 && gy < g.H;
+    bits = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bits |= (row_ok && start + j >= 0 && start + j < g.W) ? (1u << j) : 0u;
+    const int ld = min(max(start, 0), g.W - 4);
+    delta = bits ? start - ld : 0;
+    goff = bits ? cc * plane + gy * g.W + ld : 0;
+  };
+  int goff2[N4], loff2[N4], dl2[N4];
+  unsigned vb2[N4];
+  bool fix = false;
+#pragma unroll
+  for (int i = 0; i < N4; ++i) {
+    const int f = tid + i * kThreads;
+    const bool live = f < kKc * PL4;
+    const int cc = live ? f / PL4 : 0, r = live ? f - cc * PL4 : 0;
+    const int hr = r / G4, q = r - hr * G4;
+    describe(cc, g.origin + ty0 - g.R + hr, g.origin + tx0 - g.R + 4 * q, live, goff2[i], vb2[i], dl2[i]);
+    loff2[i] = live ? cc * K::PS2 + hr * K::HRS + 4 * q : kKc * K::PS2 + kKc * kPS1;  // dead lanes -> spare slot
+    fix |= dl2[i] != 0;
+  }
+  int goff1, loff1, dl1;
+  unsigned vb1;
+  {
+    const int cc = tid >> 4, r = tid & 15, py = r >> 1, q = r & 1;
+    const bool live = (ty0 + py) < g.oh;
+    describe(cc, g.origin + ty0 + py, g.origin + tx0 + 4 * q, live, goff1, vb1, dl1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (tx0 + 4 * q + j >= g.ow) vb1 &= ~(1u << j);
+    loff1 = cc * kPS1 + py * kTile + 4 * q;
+    fix |= dl1 != 0;
+  }
+  const bool wg_fix = __syncthreads_or(fix);
+
+  const int kq_lane = lane >> 4;
+  const int ij = lane & 15;
+  const int a_off = kq_lane * kPS1 + (my * 4 + (ij >> 2)) * kTile + mx * 4 + (ij & 3);
+  const int b_off = kq_lane * K::PS2 + (my * 4 + (ij >> 2)) * K::HRS + mx * 4 + (ij & 3);
+
+  f32x4 acc[K::NB];
+#pragma unroll
+  for (int i = 0; i < K::NB; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const float* p1 = in1 + (long)n * g.C * plane;
+  const float* p2 = in2 + (long)n * g.C * plane;
+
+  f32x4 st2[N4], st1;
+
+  auto load16 = [](const float* p) -> f32x4 {  // 16-byte load at 4-byte alignment (global_load_dwordx4)
+    f32x4 v;
+    __builtin_memcpy(&v, p, 16);
+    return v;
+  };
+  auto issue_loads = [&](int c0) {
+    const float* b2 = p2 + (long)c0 * plane;
+    const float* b1 = p1 + (long)c0 * plane;
+#pragma unroll
+    for (int i = 0; i < N4; ++i) st2[i] = load16(b2 + goff2[i]);
+    st1 = load16(b1 + goff1);
+  };
+  auto place = [&](const f32x4 v, unsigned bits, int delta, bool rotate) -> f32x4 {
+    f32x4 o = v;
+    if (rotate) {  // wanted component j = loaded component j + delta
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = j + delta;
+        float x = v[0];
+        x = k == 1 ? v[1] : x;
+        x = k == 2 ? v[2] : x;
+        x = k == 3 ? v[3] : x;
+        o[j] = x;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      o[j] = __uint_as_float(__float_as_uint(o[j]) & (unsigned)(-(int)((bits >> j) & 1u)));
+    return o;
+  };
+  auto write_lds = [&]() {
+    if (wg_fix) {  // one workgroup-uniform branch around the whole store pass
+#pragma unroll
+      for (int i = 0; i < N4; ++i) *reinterpret_cast<f32x4*>(l2 + loff2[i]) = place(st2[i], vb2[i], dl2[i], true);
+      *reinterpret_cast<f32x4*>(l1 + loff1) = place(st1, vb1, dl1, true);
+    } else {
+#pragma unroll
+      for (int i = 0; i < N4; ++i) *reinterpret_cast<f32x4*>(l2 + loff2[i]) = place(st2[i], vb2[i], 0, false);
+      *reinterpret_cast<f32x4*>(l1 + loff1) = place(st1, vb1, 0, false);
+    }
+  };
+  // MFMA phase: kKc/4 k-quads x NB column blocks, flattened, with the B operand read PF MFMAs ahead of its use
+  // (the compiler otherwise issues ds_read -> s_waitcnt lgkmcnt(0) -> mfma back to back and exposes the LDS
+  // latency on every pair).
+  auto mfma_phase = [&]() {
+    constexpr int TOT = (kKc / 4) * K::NB;
+    constexpr int PF = 4;
+    auto b_at = [&](int t) -> float {
+      const int kq = t / K::NB, nb = t - kq * K::NB;
+      return l2[kq * 4 * K::PS2 + b_off + (nb / NBR) * 4 * K::HRS + (nb % NBR) * 4];
+    };
+    float ring[PF];
+#pragma unroll
+    for (int t = 0; t < PF; ++t) ring[t] = b_at(t);
+    float a = l1[a_off];
+#pragma unroll
+    for (int t = 0; t < TOT; ++t) {
+      const int kq = t / K::NB, nb = t - kq * K::NB;
+      const float b = ring[t % PF];
+      if (t + PF < TOT) ring[t % PF] = b_at(t + PF);
+      acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[nb], 0, 0, 0);
+      if (nb == K::NB - 1 && kq + 1 < kKc / 4) a = l1[(kq + 1) * 4 * kPS1 + a_off];
+    }
+  };
+
+  issue_loads(c_begin);
+  write_lds();
+  __syncthreads();
+  for (int c0 = c_begin; c0 < c_end; c0 += kKc) {
+    const bool more = c0 + kKc < c_end;
+#if DTT_CORR_ABLATE == 4   // all chunks re-read the first chunk's channels: L2-resident working set
+    if (more) issue_loads(c_begin);
+#elif DTT_CORR_ABLATE == 5 // no global loads at all (LDS rewritten with stale registers)
+#else
+    if (more) issue_loads(c0 + kKc);
+#endif
+    mfma_phase();
+    __syncthreads();
+    if (more) {
+#if DTT_CORR_ABLATE != 6   // 6: loads issued but never consumed / no LDS writes
+      write_lds();
+#endif
+      __syncthreads();
+    }
+  }
+
+  float* w = ws + ((((long)ks * nbatch + n) * ntiles + tile) * 4 + wave) * (long)(K::NB * 256);
 #pragma unroll
   for (int nb = 0; nb < K::NB; ++nb)
 #pragma unroll
@@ -353,9 +567,19 @@ FastGeom make_geom(int batch, int C, int H, int W, int oc, int oh, int ow, int p
   g.D = 2 * g.R + 1;
   g.tiles_x = (ow + kTile - 1) / kTile;
   g.tiles_y = (oh + kTile - 1) / kTile;
-  // enough workgroups to cover 256 CUs about 3x, slices a multiple of the 16-channel chunk
-  const int tiles = g.tiles_x * g.tiles_y * batch;
-  int ks = (768 + tiles - 1) / tiles;
+  // Channel slices: about 3 workgroups per CU (more only inflates the split-K partials), and slices x batch a
+  // multiple of the 8 XCDs so that every slice's halo re-reads stay inside one XCD's L2 (measured: 8 slices at
+  // B=2 beat 6, 10, 12 and 16 by 6-25 %).
+  const int tiles = g.tiles_x * g.tiles_y;
+#ifdef DTT_CORR_KSPLIT
+  int ks = DTT_CORR_KSPLIT;
+#else
+  int gcd = 8, bb = batch;
+  while (bb) { const int t = gcd % bb; gcd = bb; bb = t; }
+  const int step = 8 / gcd;
+  int ks = (int)(720.0 / ((double)tiles * batch) / step + 0.5) * step;
+  if (ks < step) ks = step;
+#endif
   const int max_ks = (C + kKc - 1) / kKc;
   if (ks > max_ks) ks = max_ks;
   if (ks < 1) ks = 1;
@@ -371,7 +595,7 @@ size_t ws_bytes(const FastGeom& g, int batch) {
   return (size_t)g.ksplit * batch * g.tiles_x * g.tiles_y * 4 * Cfg<NBR>::NB * 256 * sizeof(float);
 }
 
-template <int NBR, bool PIPE, int MINW>
+template <int NBR, bool PIPE, int MINW, bool VEC4>
 int launch_fast(float* output, long out_batch_stride, const float* in1, const float* in2, void* workspace,
                 size_t workspace_bytes, const FastGeom& g, int batch, hipStream_t stream) {
   using K = Cfg<NBR>;
@@ -381,14 +605,26 @@ int launch_fast(float* output, long out_batch_stride, const float* in1, const fl
   static bool attr = false;
   if (!attr) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(corr_fwd_mfma<NBR, PIPE, MINW>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    DTT_REQUIRE(e == hipSuccess, "correlation: cannot raise dynamic LDS limit");
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)K::LDS);
+    hipError_t e2 = hipSuccess;
+    if constexpr (VEC4)
+      e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(corr_fwd_mfma_v4<NBR, MINW>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)K::LDS);
+    DTT_REQUIRE(e == hipSuccess && e2 == hipSuccess, "correlation: cannot raise dynamic LDS limit");
     attr = true;
   }
   const int ntiles = g.tiles_x * g.tiles_y;
   dtt_prof_begin("corr_fwd_mfma", stream);
-  hipLaunchKernelGGL((corr_fwd_mfma<NBR, PIPE, MINW>), dim3(ntiles, g.ksplit, batch), dim3(kThreads), K::LDS, stream, in1, in2,
-                     static_cast<float*>(workspace), g);
+  bool use_v4 = false;
+  if constexpr (VEC4) use_v4 = g.s == 1 && g.C % kKc == 0 && g.W >= 4;
+  if constexpr (VEC4) {
+    if (use_v4)
+      hipLaunchKernelGGL((corr_fwd_mfma_v4<NBR, MINW>), dim3(ntiles * g.ksplit * batch), dim3(kThreads), K::LDS, stream,
+                         in1, in2, static_cast<float*>(workspace), g);
+  }
+  if (!use_v4)
+    hipLaunchKernelGGL((corr_fwd_mfma<NBR, PIPE, MINW>), dim3(ntiles * g.ksplit * batch), dim3(kThreads), K::LDS, stream,
+                       in1, in2, static_cast<float*>(workspace), g);
   dtt_prof_end("corr_fwd_mfma", stream);
   DTT_CHECK_LAUNCH("corr_fwd_mfma");
   dtt_prof_begin("corr_fwd_reduce", stream);
@@ -449,9 +685,9 @@ extern "C" int dtt_correlation_forward(float* output, int ob, int oc, int oh, in
   int nbr;
   if (fast_path(kernel_size, stride1, stride2, max_displacement, &nbr)) {
     const FastGeom g = make_geom(ob, ic, ih, iw, oc, oh, ow, pad_size, max_displacement, stride1);
-    if (nbr == 3) return launch_fast<3, true, 2>(output, out_batch_stride, input1, input2, workspace, workspace_bytes, g, ob, stream);
-    if (nbr == 5) return launch_fast<5, true, 2>(output, out_batch_stride, input1, input2, workspace, workspace_bytes, g, ob, stream);
-    return launch_fast<9, false, 1>(output, out_batch_stride, input1, input2, workspace, workspace_bytes, g, ob, stream);
+    if (nbr == 3) return launch_fast<3, true, DTT_CORR_MINW, true>(output, out_batch_stride, input1, input2, workspace, workspace_bytes, g, ob, stream);
+    if (nbr == 5) return launch_fast<5, true, DTT_CORR_MINW, true>(output, out_batch_stride, input1, input2, workspace, workspace_bytes, g, ob, stream);
+    return launch_fast<9, false, 1, false>(output, out_batch_stride, input1, input2, workspace, workspace_bytes, g, ob, stream);
   }
   hipLaunchKernelGGL(corr_fwd_generic, dim3(ow, oh, ob), dim3(64), 0, stream, input1, input2, output,
                      out_batch_stride, ic, ih, iw, oc, oh, ow, pad_size, kernel_size, max_displacement, stride1, stride2);
