@@ -551,6 +551,217 @@ __global__ void corr_bwd_simple(const float* __restrict__ gout, const float* __r
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Backward on the matrix cores (kernel_size 1, stride1 == stride2).  With G[p, q] = gradOut[tc(q - p), p] the
+// banded gradient matrix (p: output pixel, q: displaced pixel, zero outside the window),
+//     gradInput1[c, p] = 1/C * sum_q f2[c, q] * G[p, q]         gradInput2[c, q] = 1/C * sum_p f1[c, p] * G[p, q]
+// i.e. for a 4x4 block of target pixels the reduction runs over the (4+2R)^2 halo of the OTHER frame: a
+// [16 channels x 4 halo pixels] x [4 halo pixels x 16 targets] MFMA per step.  The band G does not depend on the
+// channel, so every wave gathers its NB*4 band words from gradOut ONCE into registers (the MFMA B operand)
+// and then streams channel chunks of the other frame through LDS (A operand) -- no split-K, no atomics, each
+// gradient element is written exactly once.  WRT2 selects which gradient (and hence which gather rule).
+template <int NBR, bool WRT2, int MINW>
+__global__ __launch_bounds__(kThreads, MINW) void corr_bwd_mfma(const float* __restrict__ gout,
+                                                                const float* __restrict__ other,
+                                                                float* __restrict__ grad, FastGeom g, int cgroups,
+                                                                float nelems, int toff_y, int toff_x, int tiles_y,
+                                                                int tiles_x) {
+  using K = Cfg<NBR>;
+  constexpr int KB = 16;                               // channels per chunk = MFMA M
+  constexpr int G4 = K::HR / 4, PL4 = K::HR * G4;
+  constexpr int N4 = (KB * PL4 + kThreads - 1) / kThreads;
+  constexpr int NS = (KB * K::HR * K::HR + kThreads - 1) / kThreads;
+  constexpr int PSB = ((K::HR * K::HRS + 31) / 32) * 32 + 2;  // plane stride = 2 (mod 32): A reads conflict free
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // [KB][PSB]
+
+  // targets are tiled on the lattice starting at (toff_y, toff_x): the output pixels for gradInput1, the
+  // displaced pixels that fall inside the image for gradInput2
+  const int ntiles = tiles_x * tiles_y;
+  const int item = dtt_xcd_remap(blockIdx.x, gridDim.x);
+  const int tile = item % ntiles;
+  const int cg = (item / ntiles) % cgroups, n = item / (ntiles * cgroups);
+  const int ty0 = toff_y + (tile / tiles_x) * kTile, tx0 = toff_x + (tile % tiles_x) * kTile;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int my = wave >> 1, mx = wave & 1;
+  const int plane = g.H * g.W;
+  const int c_per = ((g.C + cgroups - 1) / cgroups + KB - 1) / KB * KB;
+  const int c_begin = cg * c_per, c_end = min(g.C, c_begin + c_per);
+
+  // ---- band words: B[k = lane>>4][j = lane&15] for step t = nb*4 + jy  ->  halo pixel (nby*4+jy, nbx*4+k) of this
+  //      wave's halo, target pixel j = (ty, tx) of this wave's 4x4 block
+  const int kx = lane >> 4, jt = lane & 15, tyi = jt >> 2, txi = jt & 3;
+  float band[K::NB * 4];
+  {
+    const float* go = gout + (long)n * g.oc * g.oh * g.ow;
+    const int ty = ty0 + my * 4 + tyi, tx = tx0 + mx * 4 + txi;  // target lattice pixel
+#pragma unroll
+    for (int t = 0; t < K::NB * 4; ++t) {
+      const int nb = t >> 2, jy = t & 3;
+      const int hy = (nb / NBR) * 4 + jy, hx = (nb % NBR) * 4 + kx;  // halo pixel relative to the wave's halo origin
+      const int oy = ty0 + my * 4 - g.R + hy, ox = tx0 + mx * 4 - g.R + hx;  // lattice position of the halo pixel
+      int tj, ti, py, px;
+      if (!WRT2) { tj = hy - tyi; ti = hx - txi; py = ty; px = tx; }           // q = halo, p = target
+      else       { tj = 2 * g.R - (hy - tyi); ti = 2 * g.R - (hx - txi); py = oy; px = ox; }  // p = halo, q = target
+      const bool ok = tj >= 0 && tj < g.D && ti >= 0 && ti < g.D && py >= 0 && py < g.oh && px >= 0 && px < g.ow;
+      band[t] = ok ? go[((long)(tj * g.D + ti) * g.oh + py) * g.ow + px] : 0.f;
+    }
+  }
+
+  // ---- staging descriptors for the halo of the other frame (same geometry as the forward kernel)
+  const bool vec4 = g.s == 1 && g.W >= 4;
+  int goff4[N4], loff4[N4], dl4[N4];
+  unsigned vb4[N4];
+  bool fix = false;
+#pragma unroll
+  for (int i = 0; i < N4; ++i) {
+    const int f = tid + i * kThreads;
+    const bool live = f < KB * PL4;
+    const int cc = live ? f / PL4 : 0, r = live ? f - cc * PL4 : 0;
+    const int hr = r / G4, q = r - hr * G4;
+    const int gy = g.origin + ty0 - g.R + hr, start = g.origin + tx0 - g.R + 4 * q;  // vec4 path: stride 1
+    const bool row_ok = live && gy >= 0 && gy < g.H;
+    unsigned bits = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bits |= (row_ok && start + j >= 0 && start + j < g.W) ? (1u << j) : 0u;
+    const int ld = min(max(start, 0), g.W - 4);
+    vb4[i] = bits;
+    dl4[i] = bits ? start - ld : 0;
+    goff4[i] = bits ? cc * plane + gy * g.W + ld : 0;
+    loff4[i] = live ? cc * PSB + hr * K::HRS + 4 * q : KB * PSB;
+    fix |= dl4[i] != 0;
+  }
+  const bool wg_fix = __syncthreads_or(fix);
+
+  const float* src = other + (long)n * g.C * plane;
+  float* dst = grad + (long)n * g.C * plane;
+  const int a_off = (lane & 15) * PSB + (my * 4) * K::HRS + mx * 4 + kx;  // A[i = channel][k = halo column kx]
+
+  auto load16 = [](const float* p) -> f32x4 { f32x4 v; __builtin_memcpy(&v, p, 16); return v; };
+  f32x4 st[N4];
+
+  auto stage_vec = [&](int c0, bool issue, bool write) {
+    if (issue) {
+#pragma unroll
+      for (int i = 0; i < N4; ++i) st[i] = load16(src + (long)c0 * plane + goff4[i]);
+    }
+    if (write) {
+#pragma unroll
+      for (int i = 0; i < N4; ++i) {
+        f32x4 o = st[i];
+        if (wg_fix) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int k = j + dl4[i];
+            float x = st[i][0];
+            x = k == 1 ? st[i][1] : x;
+            x = k == 2 ? st[i][2] : x;
+            x = k == 3 ? st[i][3] : x;
+            o[j] = x;
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          o[j] = __uint_as_float(__float_as_uint(o[j]) & (unsigned)(-(int)((vb4[i] >> j) & 1u)));
+        *reinterpret_cast<f32x4*>(lds + loff4[i]) = o;
+      }
+    }
+  };
+  // scalar staging for strided lattices (conv3: stride 2), not pipelined
+  auto stage_scalar = [&](int c0) {
+#pragma unroll 4
+    for (int e = 0; e < NS; ++e) {
+      const int f = tid + e * kThreads;
+      if (f < KB * K::HR * K::HR) {
+        const int cc = f / (K::HR * K::HR), r = f - cc * (K::HR * K::HR);
+        const int hr = r / K::HR, hc = r - hr * K::HR;
+        const int gy = g.origin + (ty0 - g.R + hr) * g.s, gx = g.origin + (tx0 - g.R + hc) * g.s;
+        const bool ok = gy >= 0 && gy < g.H && gx >= 0 && gx < g.W && (c0 + cc) < g.C;
+        lds[cc * PSB + hr * K::HRS + hc] = ok ? src[(long)(c0 + cc) * plane + gy * g.W + gx] : 0.f;
+      }
+    }
+  };
+
+  // target pixel of this lane's D column (j = lane & 15) and validity of the write
+  const int wy = g.origin + (ty0 + my * 4 + tyi) * g.s, wx = g.origin + (tx0 + mx * 4 + txi) * g.s;
+  const bool w_ok = wy >= 0 && wy < g.H && wx >= 0 && wx < g.W;
+
+  if (vec4) { stage_vec(c_begin, true, true); } else { stage_scalar(c_begin); }
+  __syncthreads();
+  for (int c0 = c_begin; c0 < c_end; c0 += KB) {
+    const bool more = c0 + KB < c_end;
+    if (vec4 && more) stage_vec(c0 + KB, true, false);
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < K::NB * 4; t += 2) {
+      const int nb0 = t >> 2, jy0 = t & 3, nb1 = (t + 1) >> 2, jy1 = (t + 1) & 3;
+      const float a0 = lds[a_off + ((nb0 / NBR) * 4 + jy0) * K::HRS + (nb0 % NBR) * 4];
+      const float a1 = lds[a_off + ((nb1 / NBR) * 4 + jy1) * K::HRS + (nb1 % NBR) * 4];
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, band[t], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, band[t + 1], acc1, 0, 0, 0);
+    }
+    // D[i = channel (lane>>4)*4 + reg][j = target pixel]
+    if (w_ok) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = c0 + (lane >> 4) * 4 + r;
+        if (c < c_end) dst[(long)c * plane + wy * g.W + wx] = (acc0[r] + acc1[r]) / nelems;
+      }
+    }
+    __syncthreads();
+    if (more) {
+      if (vec4) stage_vec(0, false, true); else stage_scalar(c0 + KB);
+      __syncthreads();
+    }
+  }
+}
+
+template <int NBR>
+size_t bwd_lds_bytes() {
+  using K = Cfg<NBR>;
+  return (size_t)(16 * (((K::HR * K::HRS + 31) / 32) * 32 + 2) + 4) * sizeof(float);
+}
+
+template <int NBR, int MINW>
+int launch_bwd(const float* gout, const float* in1, const float* in2, float* g1, float* g2, const FastGeom& g,
+               int batch, hipStream_t stream) {
+  const size_t lds = bwd_lds_bytes<NBR>();
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(corr_bwd_mfma<NBR, false, MINW>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(corr_bwd_mfma<NBR, true, MINW>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    DTT_REQUIRE(e1 == hipSuccess && e2 == hipSuccess, "correlation backward: cannot raise dynamic LDS limit");
+    attr = true;
+  }
+  const size_t bytes = (size_t)batch * g.C * g.H * g.W * sizeof(float);
+  // pixels that no lattice point maps to (stride > 1, pad != displacement) keep a zero gradient
+  DTT_REQUIRE(hipMemsetAsync(g1, 0, bytes, stream) == hipSuccess && hipMemsetAsync(g2, 0, bytes, stream) == hipSuccess,
+              "correlation backward: memset failed");
+  auto cdiv_floor = [](int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); };
+  // gradInput1: targets = output pixels (lattice 0 .. oh-1)
+  {
+    const int ty = g.tiles_y, tx = g.tiles_x;
+    hipLaunchKernelGGL((corr_bwd_mfma<NBR, false, MINW>), dim3(ty * tx * g.ksplit * batch), dim3(kThreads), lds, stream,
+                       gout, in2, g1, g, g.ksplit, (float)g.C, 0, 0, ty, tx);
+    DTT_CHECK_LAUNCH("corr_bwd_mfma<input1>");
+  }
+  // gradInput2: targets = displaced pixels q = p + disp that fall inside the image
+  {
+    const int qlo_y = -cdiv_floor(g.origin, g.s), qlo_x = qlo_y;               // smallest lattice index with pixel >= 0
+    const int qhi_y = cdiv_floor(g.H - 1 - g.origin, g.s), qhi_x = cdiv_floor(g.W - 1 - g.origin, g.s);
+    const int lo_y = qlo_y > -g.R ? qlo_y : -g.R, lo_x = qlo_x > -g.R ? qlo_x : -g.R;
+    const int hi_y = qhi_y < g.oh - 1 + g.R ? qhi_y : g.oh - 1 + g.R, hi_x = qhi_x < g.ow - 1 + g.R ? qhi_x : g.ow - 1 + g.R;
+    if (hi_y >= lo_y && hi_x >= lo_x) {
+      const int ty = (hi_y - lo_y + kTile) / kTile, tx = (hi_x - lo_x + kTile) / kTile;
+      hipLaunchKernelGGL((corr_bwd_mfma<NBR, true, MINW>), dim3(ty * tx * g.ksplit * batch), dim3(kThreads), lds,
+                         stream, gout, in1, g2, g, g.ksplit, (float)g.C, lo_y, lo_x, ty, tx);
+      DTT_CHECK_LAUNCH("corr_bwd_mfma<input2>");
+    }
+  }
+  return 1;
+}
+
 bool fast_path(int ksize, int s1, int s2, int maxd, int* nbr) {
   if (ksize != 1 || s1 != s2) return false;
   const int R = maxd / s2;
@@ -708,6 +919,12 @@ extern "C" int dtt_correlation_backward(const float* gradOutput, int gob, int go
   if (!dtt_correlation_output_shape(ic, ih, iw, pad_size, kernel_size, max_displacement, stride1, stride2, &eoc, &eoh, &eow))
     return 0;
   DTT_REQUIRE(gob > 0 && goc == eoc && goh == eoh && gow == eow, "correlation backward: gradOutput shape mismatch");
+  int nbr;
+  if (fast_path(kernel_size, stride1, stride2, max_displacement, &nbr) && nbr <= 5 && ic % 16 == 0) {
+    const FastGeom g = make_geom(gob, ic, ih, iw, goc, goh, gow, pad_size, max_displacement, stride1);
+    return nbr == 3 ? launch_bwd<3, 2>(gradOutput, input1, input2, gradInput1, gradInput2, g, gob, stream)
+                    : launch_bwd<5, 2>(gradOutput, input1, input2, gradInput1, gradInput2, g, gob, stream);
+  }
   const long total = (long)gob * ic * ih * iw;
   hipLaunchKernelGGL(corr_bwd_simple, dim3(min(dtt_cdiv(total, 256), 1 << 20)), dim3(256), 0, stream, gradOutput,
                      input1, input2, gradInput1, gradInput2, gob, ic, ih, iw, goc, goh, gow, pad_size,
