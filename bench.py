@@ -141,6 +141,8 @@ def main():
             opt.step()
     else:
         model.eval()
+        from dtt.fuse import fuse_for_inference
+        fuse_for_inference(model)  # frozen BatchNorm folded into the convolutions, fused bias/residual/ReLU epilogue
 
         def step():
             with torch.no_grad():

@@ -216,6 +216,15 @@ int dtt_anchor_target_finish(const float* gt_boxes, int im_h0, int im_w0, const 
                              float* labels_out, float* bbox_targets, float* bbox_inside_weights,
                              float* bbox_outside_weights, void* stream);
 
+/* ---------------------------------------------------------------- fused trunk epilogue
+ * No custom-op counterpart in the reference: replaces the separate BatchNorm (frozen, faster_rcnn/resnet.py:
+ * 290-295, 325-330) / residual add / ReLU passes of its ResNet blocks (resnet.py:88-107) once the BatchNorm
+ * affine has been folded into the convolution.  In place: x[n,c,:] = act(x[n,c,:] + bias[c] (+ residual[n,c,:])).
+ * x (batch, channels, hw) contiguous fp32; residual may be NULL; batch*channels <= 65535 per call.
+ */
+int dtt_bias_act_inplace(float* x, const float* bias, const float* residual, int batch, int channels,
+                         int hw, int relu, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

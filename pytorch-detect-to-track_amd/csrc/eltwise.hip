@@ -1,0 +1,79 @@
+// Fused per-channel bias (+ residual) (+ ReLU) epilogue for the frozen-BatchNorm trunk, gfx950.
+//
+// The reference runs conv -> BatchNorm (frozen, eval mode: resnet.py:290-295, 325-330) -> ReLU and, at the end of a
+// bottleneck, conv -> BatchNorm -> add residual -> ReLU as separate elementwise passes (resnet.py:88-107): 7
+// full-tensor passes per bottleneck.  With the BatchNorm affine folded into the convolution weights (exact
+// algebra, done once at load time in dtt/fuse.py) what remains is y = act(x + bias[c] (+ residual)): one pass,
+// in place, HBM-bound.  One workgroup row per (image, channel) plane so the bias is a scalar; 16-byte accesses on
+// the 16-byte-aligned middle of each plane, scalar head / tail.
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+template <bool RELU, bool RES>
+__global__ __launch_bounds__(kThreads) void bias_act_kernel(float* __restrict__ x, const float* __restrict__ bias,
+                                                            const float* __restrict__ res, int channels, int hw) {
+  const int plane = blockIdx.y;  // n * channels + c
+  const float b = bias[plane % channels];
+  float* px = x + (long)plane * hw;
+  const float* pr = RES ? res + (long)plane * hw : nullptr;
+  // elements before the first 16-byte boundary of this plane
+  const int mis = (int)((reinterpret_cast<uintptr_t>(px) >> 2) & 3);
+  const int head = min(hw, (4 - mis) & 3);
+  const int nvec = (hw - head) >> 2;
+  const int tail0 = head + (nvec << 2);
+  const int t = blockIdx.x * kThreads + threadIdx.x, stride = gridDim.x * kThreads;
+  if (blockIdx.x == 0) {
+    if (threadIdx.x < head) {
+      float v = px[threadIdx.x] + b;
+      if (RES) v += pr[threadIdx.x];
+      px[threadIdx.x] = RELU ? fmaxf(v, 0.f) : v;
+    }
+    const int ti = tail0 + (int)threadIdx.x;
+    if ((int)threadIdx.x < hw - tail0) {
+      float v = px[ti] + b;
+      if (RES) v += pr[ti];
+      px[ti] = RELU ? fmaxf(v, 0.f) : v;
+    }
+  }
+  float4* vx = reinterpret_cast<float4*>(px + head);
+  const bool res_aligned = RES ? ((reinterpret_cast<uintptr_t>(pr + head) & 15) == 0) : true;
+  for (int i = t; i < nvec; i += stride) {
+    float4 v = vx[i];
+    v.x += b; v.y += b; v.z += b; v.w += b;
+    if (RES) {
+      float4 r;
+      if (res_aligned) r = reinterpret_cast<const float4*>(pr + head)[i];
+      else __builtin_memcpy(&r, pr + head + 4 * i, 16);
+      v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+    }
+    if (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    vx[i] = v;
+  }
+}
+
+}  // namespace
+
+extern "C" int dtt_bias_act_inplace(float* x, const float* bias, const float* residual, int batch, int channels,
+                                    int hw, int relu, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  DTT_REQUIRE(x && bias, "bias_act: null pointer");
+  DTT_REQUIRE(batch > 0 && channels > 0 && hw > 0, "bias_act: bad shape");
+  const long planes = (long)batch * channels;
+  // ~8 float4 per thread; planes ride on blockIdx.y
+  int bx = (hw / 4 + kThreads * 8 - 1) / (kThreads * 8);
+  if (bx < 1) bx = 1;
+  dim3 grid(bx, (unsigned)planes);
+  DTT_REQUIRE(planes <= 65535, "bias_act: more than 65535 (image, channel) planes in one call");
+  if (residual) {
+    if (relu) hipLaunchKernelGGL((bias_act_kernel<true, true>), grid, dim3(kThreads), 0, stream, x, bias, residual, channels, hw);
+    else hipLaunchKernelGGL((bias_act_kernel<false, true>), grid, dim3(kThreads), 0, stream, x, bias, residual, channels, hw);
+  } else {
+    if (relu) hipLaunchKernelGGL((bias_act_kernel<true, false>), grid, dim3(kThreads), 0, stream, x, bias, residual, channels, hw);
+    else hipLaunchKernelGGL((bias_act_kernel<false, false>), grid, dim3(kThreads), 0, stream, x, bias, residual, channels, hw);
+  }
+  DTT_CHECK_LAUNCH("bias_act_kernel");
+  return 1;
+}

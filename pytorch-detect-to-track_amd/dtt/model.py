@@ -217,42 +217,58 @@ class _RFCN(nn.Module):
         B = im_data.size(1)
         n_legs = im_data.size(0)
         dev = im_data.device
-        conv3, conv4, conv5, rois, rois_label = [], [], [], [], []
-        rpn_loss_cls, rpn_loss_bbox, rfcn_bbox, cls_prob, bbox_pred = [], [], [], [], []
+        # Both legs of the siamese net go through the trunk and the 1x1 heads as ONE batch of n_legs*B images (the
+        # reference loops over the legs, rfcn.py:95): BatchNorm is frozen and every op is per-image, so the
+        # result is the same, with half the launches and better-filled kernels.
+        flat = im_data.view(n_legs * B, *im_data.shape[2:])
+        c3, c4, c5, top = self._im_to_head(flat)
+        cls_maps = self.RFCN_cls_net(top)
+        bbox_maps = self.RFCN_bbox_net(top)
+        leg = lambda t, i: t[i * B:(i + 1) * B]
+        conv3 = [leg(c3, i) for i in range(n_legs)]
+        conv4 = [leg(c4, i) for i in range(n_legs)]
+        conv5 = [leg(c5, i) for i in range(n_legs)]
+        rfcn_bbox = [leg(bbox_maps, i) for i in range(n_legs)]
+        rois, rois_label = [], []
+        rpn_loss_cls, rpn_loss_bbox, cls_prob, bbox_pred = [], [], [], []
         loss_cls, loss_bbox = [], []
-        for leg in range(n_legs):
-            c3, c4, c5, top = self._im_to_head(im_data[leg])
-            conv3.append(c3); conv4.append(c4); conv5.append(c5)
-            cls_map = self.RFCN_cls_net(top)
-            bbox_map = self.RFCN_bbox_net(top)
-            rfcn_bbox.append(bbox_map)
-            leg_rois, l_cls, l_box = self.RFCN_rpn(top, im_info[leg], gt_boxes[leg][:, :, :5], num_boxes[leg])
-            if self.training:
-                leg_rois, label, target, w_in, w_out = self.RFCN_proposal_target(leg_rois, gt_boxes[leg][:, :, :5],
-                                                                                  num_boxes[leg])
-                label = label.view(-1).long()
-                target = target.view(-1, target.size(2))
-                w_in = w_in.view(-1, w_in.size(2))
-                w_out = w_out.view(-1, w_out.size(2))
-                rois_label.append(label)
-            else:
-                label = target = w_in = w_out = None
-                l_cls = torch.zeros(1, device=dev)
-                l_box = torch.zeros(1, device=dev)
+        if not self.training:
+            # inference: RPN, proposal layer and PSRoI pooling also run once for all n_legs*B images
+            all_rois, _, _ = self.RFCN_rpn(top, im_info.view(n_legs * B, -1), None, None)
+            R = all_rois.size(1)
+            flat_rois = all_rois.view(-1, 5)
+            score = self._pool_vote(self.RFCN_psroi_cls_pool, self.RFCN_cls_score, cls_maps, flat_rois)
+            prob = F.softmax(score, dim=1).view(n_legs, B, R, -1)
+            pred = self._pool_vote(self.RFCN_psroi_loc_pool, self.RFCN_bbox_pred, bbox_maps, flat_rois)
+            pred = pred.view(n_legs, B, R, -1)
+            leg_rois = all_rois.view(n_legs, B, R, 5).clone()
+            leg_rois[..., 0] -= torch.arange(n_legs, device=dev, dtype=leg_rois.dtype).view(n_legs, 1, 1) * B
+            zero = torch.zeros(1, device=dev)
+            for i in range(n_legs):
+                rois.append(leg_rois[i]); cls_prob.append(prob[i]); bbox_pred.append(pred[i])
+                rpn_loss_cls.append(zero); rpn_loss_bbox.append(zero); loss_cls.append(zero); loss_bbox.append(zero)
+        for i in range(n_legs if self.training else 0):
+            # training keeps the reference's per-leg order: anchor-target and RoI sampling draw from numpy's RNG
+            top_i, cls_map, bbox_map = leg(top, i), leg(cls_maps, i), rfcn_bbox[i]
+            leg_rois, l_cls, l_box = self.RFCN_rpn(top_i, im_info[i], gt_boxes[i][:, :, :5], num_boxes[i])
+            leg_rois, label, target, w_in, w_out = self.RFCN_proposal_target(leg_rois, gt_boxes[i][:, :, :5],
+                                                                              num_boxes[i])
+            label = label.view(-1).long()
+            target = target.view(-1, target.size(2))
+            w_in = w_in.view(-1, w_in.size(2))
+            w_out = w_out.view(-1, w_out.size(2))
+            rois_label.append(label)
             rois.append(leg_rois)
             rpn_loss_cls.append(l_cls.view(1)); rpn_loss_bbox.append(l_box.view(1))
-            flat = leg_rois.view(-1, 5)
-            score = self._pool_vote(self.RFCN_psroi_cls_pool, self.RFCN_cls_score, cls_map, flat)
+            flat_rois = leg_rois.view(-1, 5)
+            score = self._pool_vote(self.RFCN_psroi_cls_pool, self.RFCN_cls_score, cls_map, flat_rois)
             prob = F.softmax(score, dim=1)
-            pred = self._pool_vote(self.RFCN_psroi_loc_pool, self.RFCN_bbox_pred, bbox_map, flat)
-            if self.training and not self.class_agnostic:
+            pred = self._pool_vote(self.RFCN_psroi_loc_pool, self.RFCN_bbox_pred, bbox_map, flat_rois)
+            if not self.class_agnostic:
                 pv = pred.view(pred.size(0), int(pred.size(1) / 4), 4)
                 pred = torch.gather(pv, 1, label.view(-1, 1, 1).expand(label.size(0), 1, 4)).squeeze(1)
-            if self.training:
-                loss_cls.append(F.cross_entropy(score, label).view(1))
-                loss_bbox.append(_smooth_l1_loss(pred, target, w_in, w_out).view(1))
-            else:
-                loss_cls.append(torch.zeros(1, device=dev)); loss_bbox.append(torch.zeros(1, device=dev))
+            loss_cls.append(F.cross_entropy(score, label).view(1))
+            loss_bbox.append(_smooth_l1_loss(pred, target, w_in, w_out).view(1))
             cls_prob.append(prob.view(B, leg_rois.size(1), -1))
             bbox_pred.append(pred.view(B, leg_rois.size(1), -1))
 
@@ -355,6 +371,9 @@ class resnet(_RFCN):
         return self
 
     def _im_to_head(self, x):
+        fused = getattr(self, "_fused_trunk", None)
+        if fused is not None and not self.training and not torch.is_grad_enabled() and x.is_cuda:
+            return fused(x)  # dtt.fuse: BatchNorm folded, bias + residual + ReLU in one HIP pass
         b = self.RFCN_base
         x = b[3](b[2](b[1](b[0](x))))
         conv3 = b[5](b[4](x))

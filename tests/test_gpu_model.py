@@ -96,3 +96,36 @@ def test_training_step_runs_and_produces_finite_gradients():
     assert g5 is not None and torch.isfinite(g5).all()
     assert model.RFCN_base[4][0].conv1.weight.grad is None  # FIXED_BLOCKS = 1
     assert not torch.equal(before, model.RFCN_cls_net.weight.detach())
+
+
+def test_fused_inference_trunk_matches_reference_graph():
+    """dtt.fuse (BatchNorm folded into the convolutions + dtt_bias_act_inplace) vs the unfused module graph."""
+    from dtt.config import cfg
+    from dtt.fuse import bias_act_, fuse_for_inference, unfuse
+    from dtt.synth import build_model, calibrate_batchnorm_, make_batch
+    dev = torch.device("cuda:0")
+    rng = np.random.RandomState(0)
+    for shape in ((2, 5, 7, 9), (1, 3, 1, 1), (3, 64, 38, 67), (2, 8, 150, 267)):
+        x = torch.from_numpy(rng.normal(size=shape).astype(np.float32)).to(dev)
+        b = torch.from_numpy(rng.normal(size=shape[1]).astype(np.float32)).to(dev)
+        r = torch.from_numpy(rng.normal(size=shape).astype(np.float32)).to(dev)
+        for res in (None, r):
+            for relu in (True, False):
+                ref = x + b.view(1, -1, 1, 1) + (res if res is not None else 0)
+                ref = torch.relu(ref) if relu else ref
+                got = bias_act_(x.clone(), b, res, relu)
+                assert torch.equal(got, ref), (shape, res is not None, relu)
+        xv = x.clone()[:, :, : shape[2], :]  # odd plane sizes / misaligned planes are covered by the shapes above
+        assert xv.is_contiguous()
+    model = build_model(50, cfg=cfg).to(dev).eval()
+    im, _, _, _ = make_batch(2, 224, 320, seed=9, device=dev)
+    calibrate_batchnorm_(model, im[:, 0])
+    x = im[:, 0].contiguous()
+    with torch.no_grad():
+        ref = model._im_to_head(x)
+        fuse_for_inference(model)
+        got = model._im_to_head(x)
+        unfuse(model)
+    for a, b in zip(got, ref):
+        scale = float(b.abs().max())
+        assert float((a - b).abs().max()) < 2e-4 * max(1.0, scale)
