@@ -181,6 +181,15 @@ def main():
         flops = 2.0 * 2048 * 289 * H16 * W16 * B           # 2*C*D^2*oH*oW per frame pair
         bytes_ = (2 * 2048 * H16 * W16 * 4 + 289 * H16 * W16 * 4) * B
         achieved = flops / (avg5 * 1e-6) / 1e12 if avg5 > 0 else 0.0
+        # HBM bytes per launch come from a separate rocprofv3 --pmc pass (profiles/r01_pmc_conv5.json); only quoted
+        # when this run has the shape that pass was taken on
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_conv5.json")))
+            if (args.batch, args.height, args.width) == (2, 600, 1067):
+                traffic = pmc["traffic_bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            pass
         pairs = args.batch * world * args.steps
         out = {
             "metric": "frame-pairs/sec (600px, Res101 D&T)",
@@ -203,7 +212,7 @@ def main():
                        (world, ", RCCL gradient all-reduce" if args.mode == "train" else ", no collective")},
             "roofline": {"kernel": "corr_fwd_mfma<5> (conv5 correlation, 2048 ch, d=8)", "bound": "mfma",
                          "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                          "launch_us": round(avg5, 2), "launches_timed": len(conv5),
                          "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": bytes_,
                          "hbm_view": {"achieved_GBs": round(bytes_ / (avg5 * 1e-6) / 1e9, 1) if avg5 > 0 else 0.0,
