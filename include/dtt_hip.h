@@ -216,6 +216,19 @@ int dtt_anchor_target_finish(const float* gt_boxes, int im_h0, int im_w0, const 
                              float* labels_out, float* bbox_targets, float* bbox_inside_weights,
                              float* bbox_outside_weights, void* stream);
 
+/* ---------------------------------------------------------------- test-time per-class NMS
+ * Replaces the per-class loop of the reference's test driver (test_net.py:274-301): for every class j >= 1
+ * threshold scores[:, j] > score_thresh, sort descending (ties: lower RoI index first), NMS(nms_thresh), then the
+ * max_per_image cut over all classes (keep score >= the max_per_image-th best) -- one call for all classes of
+ * `images` images, nothing leaves the device.
+ *   scores (images, num_rois, num_classes); boxes (images, num_rois, 4) if class_agnostic else (.., 4*num_classes)
+ *   dets_out (images, num_classes, num_rois, 5) rows [x1,y1,x2,y2,score] in kept order (class 0 unused)
+ *   count_out int32 (images, num_classes); num_rois <= 1024; max_per_image <= 0 disables the cut
+ */
+int dtt_class_nms(const float* scores, const float* boxes, int images, int num_rois, int num_classes,
+                  int class_agnostic, float score_thresh, float nms_thresh, int max_per_image,
+                  float* dets_out, int* count_out, void* stream);
+
 /* ---------------------------------------------------------------- fused trunk epilogue
  * No custom-op counterpart in the reference: replaces the separate BatchNorm (frozen, faster_rcnn/resnet.py:
  * 290-295, 325-330) / residual add / ReLU passes of its ResNet blocks (resnet.py:88-107) once the BatchNorm

@@ -291,3 +291,30 @@ def anchor_target_layer(gt_boxes, im_info, base_anchors, height, width, feat_str
     labels = anchor_target_subsample(a["labels"], rpn_batchsize, fg_fraction, rng)
     return anchor_target_finish(a, labels, gt_boxes, np.asarray(base_anchors).shape[0], height, width,
                                 inside_weight)
+
+
+# ------------------------------------------------------------------------ test-time per-class NMS
+def class_nms(scores, boxes, nms_fn, score_thresh=0.05, nms_thresh=0.3, max_per_image=100, class_agnostic=True):
+    """test_net.py:274-301 for ONE image: scores (R, ncls), boxes (R, 4 | 4*ncls) -> list over classes of
+    (n, 5) arrays.  Sort order: descending score, ties by lower RoI index (declared; torch.sort is unspecified)."""
+    scores = np.asarray(scores, dtype=f32)
+    boxes = np.asarray(boxes, dtype=f32)
+    ncls = scores.shape[1]
+    out = [np.zeros((0, 5), f32)]
+    for j in range(1, ncls):
+        inds = np.nonzero(scores[:, j] > f32(score_thresh))[0]
+        if inds.size == 0:
+            out.append(np.zeros((0, 5), f32))
+            continue
+        s = scores[inds, j]
+        order = np.argsort(-s, kind="stable")
+        b = boxes[inds] if class_agnostic else boxes[inds][:, 4 * j:4 * j + 4]
+        dets = np.hstack([b, s[:, None]]).astype(f32)[order]
+        keep = np.asarray(nms_fn(dets, nms_thresh), dtype=np.int64).reshape(-1)
+        out.append(dets[keep])
+    if max_per_image > 0:
+        allscores = np.hstack([o[:, -1] for o in out[1:]])
+        if allscores.size > max_per_image:
+            th = np.sort(allscores)[-max_per_image]
+            out = [o[o[:, -1] >= th] if k > 0 else o for k, o in enumerate(out)]
+    return out

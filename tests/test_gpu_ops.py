@@ -311,3 +311,32 @@ def test_anchor_target_vs_oracle_bit_exact(dev):
                                 torch.from_numpy(base).float(), H, W, 16)
     for a, b in zip(got, ref):
         np.testing.assert_array_equal(a.cpu().numpy(), b)
+
+
+# ------------------------------------------------------------------------ test-time per-class NMS
+@pytest.mark.parametrize("R,ncls,agnostic,mpi", [(300, 31, True, 100), (300, 31, False, 100), (1000, 31, True, 100),
+                                                  (77, 5, True, 0), (300, 31, True, 5)])
+def test_class_nms_vs_oracle(dev, R, ncls, agnostic, mpi):
+    from dtt.postprocess import class_nms, to_all_boxes
+    rng = np.random.RandomState(R + ncls + mpi)
+    I = 2
+    scores = rng.dirichlet(np.ones(ncls) * 0.3, size=(I, R)).astype(np.float32)
+    scores[0, :7, 3] = scores[0, 0, 3]  # exact ties
+    ctr = rng.uniform(50, 600, size=(I, R, 2))
+    m = min(ctr[:, ::3].shape[1], ctr[:, 1::3].shape[1])
+    ctr[:, ::3][:, :m] = ctr[:, 1::3][:, :m] + rng.normal(0, 5, size=(I, m, 2))  # clusters of near-duplicates
+    wh = rng.uniform(30, 200, size=(I, R, 2))
+    base = np.concatenate([ctr - wh / 2, ctr + wh / 2], 2).astype(np.float32)
+    if agnostic:
+        boxes = base
+    else:
+        boxes = (base[:, :, None, :] + rng.normal(0, 3, size=(I, R, ncls, 4))).reshape(I, R, 4 * ncls).astype(np.float32)
+    dets, counts = class_nms(cu(scores, dev), cu(boxes, dev), 0.05, 0.3, mpi, agnostic)
+    got = to_all_boxes(dets, counts)
+    total = 0
+    for i in range(I):
+        ref = ro.class_nms(scores[i], boxes[i], O.nms, 0.05, 0.3, mpi, agnostic)
+        for j in range(ncls):
+            np.testing.assert_array_equal(got[i][j], ref[j], err_msg="image %d class %d" % (i, j))
+            total += len(ref[j])
+    assert total > 0
