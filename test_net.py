@@ -1,0 +1,110 @@
+#!/usr/bin/env python3
+"""Evaluation driver with the reference's command line (test_net.py:38-86): loads
+`{load_dir}/{net}/{dataset}/rfcn_detect_track_{checksession}_{checkepoch}_{checkpoint}.pth` (or runs random
+weights when the file does not exist and `--dataset synthetic`), runs the D&T forward on frame pairs, decodes the
+boxes (test_net.py:239-266) and applies the per-class NMS + top-100 cut (test_net.py:274-301) -- the latter as
+ONE device launch per pair instead of 30 NMS round trips.  Writes `detections.pkl` with the reference's
+`all_boxes[class][pair]` layout.  The ImageNet VID imdb / evaluator is out of scope (synthetic pairs only).
+"""
+import argparse
+import os
+import pickle
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "pytorch-detect-to-track_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser(description="Test a Detect-to-Track R-FCN network")
+    p.add_argument("--dataset", dest="dataset", default="synthetic", type=str)
+    p.add_argument("--cfg", dest="cfg_file", default="cfgs/res101.yml", type=str)
+    p.add_argument("--net", dest="net", default="res101", type=str)
+    p.add_argument("--set", dest="set_cfgs", default=None, nargs=argparse.REMAINDER)
+    p.add_argument("--load_dir", dest="load_dir", default="output/models", type=str)
+    p.add_argument("--cuda", dest="cuda", action="store_true")
+    p.add_argument("--ls", dest="large_scale", action="store_true")
+    p.add_argument("--mGPUs", dest="mGPUs", action="store_true")
+    p.add_argument("--cag", dest="class_agnostic", action="store_true")
+    p.add_argument("--checksession", dest="checksession", default=1, type=int)
+    p.add_argument("--checkepoch", dest="checkepoch", default=1, type=int)
+    p.add_argument("--checkpoint", dest="checkpoint", default=16470, type=int)
+    p.add_argument("--bs", dest="batch_size", default=1, type=int)
+    p.add_argument("--vis", dest="vis", action="store_true")
+    p.add_argument("--num_pairs", default=10, type=int)
+    p.add_argument("--height", default=600, type=int)
+    p.add_argument("--width", default=1067, type=int)
+    p.add_argument("--out_dir", default="output/detections", type=str)
+    return p.parse_args(argv)
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    from dtt.config import apply_dataset_defaults, cfg, cfg_from_file, cfg_from_list
+    from dtt.fuse import fuse_for_inference
+    from dtt.postprocess import class_nms, decode_detections, to_all_boxes
+    from dtt.synth import build_model, calibrate_batchnorm_, make_batch
+    print("Called with args:")
+    print(args)
+    apply_dataset_defaults("imagenet_vid" if args.dataset == "synthetic" else args.dataset)
+    cfg_file = os.path.join(ROOT, "cfgs", "{}_ls.yml".format(args.net)) if args.large_scale else os.path.join(ROOT, args.cfg_file)
+    cfg_from_file(cfg_file)
+    if args.set_cfgs:
+        cfg_from_list(args.set_cfgs)
+    if args.dataset != "synthetic":
+        raise NotImplementedError("the ImageNet VID imdb / evaluator is outside this repo's scope; use --dataset synthetic")
+    np.random.seed(cfg.RNG_SEED)
+    dev = torch.device("cuda:0")
+    layers = {"res50": 50, "res101": 101, "res152": 152}[args.net]
+    model = build_model(layers, class_agnostic=args.class_agnostic, cfg=cfg).to(dev)
+    load_name = os.path.join(args.load_dir, args.net, args.dataset,
+                             "rfcn_detect_track_{}_{}_{}.pth".format(args.checksession, args.checkepoch, args.checkpoint))
+    if os.path.exists(load_name):
+        ck = torch.load(load_name, map_location=dev)
+        model.load_state_dict(ck["model"])
+        if "pooling_mode" in ck:
+            cfg.POOLING_MODE = ck["pooling_mode"]
+        print("load model successfully! (%s)" % load_name)
+    else:
+        print("no checkpoint at %s: running random-init weights" % load_name)
+        im, _, _, _ = make_batch(1, args.height, args.width, seed=1, device=dev)
+        calibrate_batchnorm_(model, im[:, 0])
+    model.eval()
+    fuse_for_inference(model)
+    max_per_image, thresh = 100, 0.05  # test_net.py:194-199 (vis off)
+    n_classes = model.n_classes
+    all_boxes = [[[] for _ in range(args.num_pairs)] for _ in range(n_classes)]
+    det_time = nms_time = 0.0
+    for i in range(args.num_pairs):
+        im, info, gt, nb = make_batch(args.batch_size, args.height, args.width, seed=10 + i, device=dev)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        with torch.no_grad():
+            rois, cls_prob, bbox_pred, tracking_pred = model(im, info, gt, nb)[:4]
+            boxes = decode_detections(rois[0], bbox_pred[0], info[:, 0], cfg, args.class_agnostic)   # leg 0 (:277)
+        torch.cuda.synchronize()
+        t1 = time.time()
+        dets, counts = class_nms(cls_prob[0], boxes, thresh, cfg.TEST.NMS, max_per_image, args.class_agnostic)
+        per_image = to_all_boxes(dets, counts)
+        t2 = time.time()
+        for j in range(1, n_classes):
+            all_boxes[j][i] = per_image[0][j]
+        det_time += t1 - t0
+        nms_time += t2 - t1
+        sys.stdout.write("im_detect: {:d}/{:d} {:.3f}s {:.3f}s   \r".format(i + 1, args.num_pairs, t1 - t0, t2 - t1))
+        sys.stdout.flush()
+    os.makedirs(args.out_dir, exist_ok=True)
+    with open(os.path.join(args.out_dir, "detections.pkl"), "wb") as f:
+        pickle.dump(all_boxes, f, pickle.HIGHEST_PROTOCOL)
+    print("\nmean detect time %.4fs, mean per-class NMS time %.4fs over %d pairs" %
+          (det_time / args.num_pairs, nms_time / args.num_pairs, args.num_pairs))
+
+
+if __name__ == "__main__":
+    main()

@@ -2,6 +2,8 @@
 the same random weights and synthetic frame pair.  Convolution outputs differ in their last bits between
 MIOpen and the CPU, so proposals are matched with a tolerance rather than bit for bit (the ops themselves
 are bit-checked in test_gpu_ops.py)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -129,3 +131,28 @@ def test_fused_inference_trunk_matches_reference_graph():
     for a, b in zip(got, ref):
         scale = float(b.abs().max())
         assert float((a - b).abs().max()) < 2e-4 * max(1.0, scale)
+
+
+def test_drivers_round_trip_checkpoint(tmp_path):
+    """trainval_net.py writes rfcn_detect_track_{s}_{e}_{step}.pth with the reference's keys; test_net.py loads it,
+    runs the forward + decode + per-class NMS and writes detections.pkl in the all_boxes[class][pair] layout."""
+    import pickle
+    import test_net
+    import trainval_net
+    save = str(tmp_path / "models")
+    trainval_net.main(["--dataset", "synthetic", "--net", "res50", "--bs", "1", "--cag", "--epochs", "1",
+                       "--iters_per_epoch", "2", "--disp_interval", "1", "--save_dir", save, "--height", "224",
+                       "--width", "320", "--lr", "1e-5"])
+    ck_path = os.path.join(save, "res50", "synthetic", "rfcn_detect_track_1_1_1.pth")
+    ck = torch.load(ck_path, map_location="cpu")
+    assert set(ck) == {"session", "epoch", "model", "optimizer", "pooling_mode", "class_agnostic"}
+    assert ck["epoch"] == 2 and "RFCN_base.RFCN_net.weight" in ck["model"] and "RFCN_net.weight" in ck["model"]
+    out = str(tmp_path / "dets")
+    test_net.main(["--dataset", "synthetic", "--net", "res50", "--cfg", "cfgs/res50.yml", "--cag", "--load_dir", save,
+                   "--checksession", "1", "--checkepoch", "1", "--checkpoint", "1", "--num_pairs", "2", "--height", "224",
+                   "--width", "320", "--out_dir", out])
+    all_boxes = pickle.load(open(os.path.join(out, "detections.pkl"), "rb"))
+    assert len(all_boxes) == 31 and len(all_boxes[1]) == 2
+    n = sum(len(all_boxes[j][i]) for j in range(1, 31) for i in range(2))
+    assert all(np.asarray(all_boxes[j][i]).shape[1] == 5 for j in range(1, 31) for i in range(2) if len(all_boxes[j][i]))
+    assert n <= 200

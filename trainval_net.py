@@ -1,0 +1,148 @@
+#!/usr/bin/env python3
+"""Training driver with the reference's command line (trainval_net.py:35-122) and checkpoint contract
+(trainval_net.py:417-437): same flags and defaults, `cfgs/{net}[_ls].yml` selection, per-dataset `set_cfgs`,
+per-parameter SGD groups, loss = sum of the five means, and `rfcn_detect_track_{session}_{epoch}_{step}.pth`
+files holding {session, epoch, model, optimizer, pooling_mode, class_agnostic}.
+
+What differs: one process per GPU instead of `nn.DataParallel` (`--mGPUs` = launch with torchrun; gradients are
+all-reduced over RCCL, dtt/dist.py); and the ImageNet VID/DET roidb / image-loading stack is out of scope of this
+repo, so batches come from the synthetic generator (`--dataset synthetic`, the
+default) -- real-dataset names are accepted for their cfg side effects but raise when the loader is needed.
+
+    python trainval_net.py --dataset synthetic --net res101 --bs 2 --cag --epochs 1 --iters_per_epoch 20
+    torchrun --nproc-per-node 8 --master-addr 127.0.0.1 trainval_net.py --mGPUs --bs 2 --cag ...
+"""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "pytorch-detect-to-track_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser(description="Train a Detect-to-Track R-FCN network")
+    p.add_argument("--dataset", dest="dataset", default="synthetic", type=str)
+    p.add_argument("--net", dest="net", default="res101", type=str)
+    p.add_argument("--start_epoch", dest="start_epoch", default=1, type=int)
+    p.add_argument("--epochs", dest="max_epochs", default=20, type=int)
+    p.add_argument("--disp_interval", dest="disp_interval", default=100, type=int)
+    p.add_argument("--checkpoint_interval", dest="checkpoint_interval", default=10000, type=int)
+    p.add_argument("--save_dir", dest="save_dir", default="output/models", type=str)
+    p.add_argument("--nw", dest="num_workers", default=0, type=int)
+    p.add_argument("--cuda", dest="cuda", action="store_true")
+    p.add_argument("--ls", dest="large_scale", action="store_true")
+    p.add_argument("--mGPUs", dest="mGPUs", action="store_true")
+    p.add_argument("--bs", dest="batch_size", default=1, type=int)
+    p.add_argument("--cag", dest="class_agnostic", action="store_true")
+    p.add_argument("--use_det", dest="use_det", action="store_true")
+    p.add_argument("--o", dest="optimizer", default="sgd", type=str)
+    p.add_argument("--lr", dest="lr", default=0.001, type=float)
+    p.add_argument("--lr_decay_step", dest="lr_decay_step", default=5, type=int)
+    p.add_argument("--lr_decay_gamma", dest="lr_decay_gamma", default=0.1, type=float)
+    p.add_argument("--s", dest="session", default=1, type=int)
+    p.add_argument("--r", dest="resume", default=False, type=bool)
+    p.add_argument("--checksession", dest="checksession", default=1, type=int)
+    p.add_argument("--checkepoch", dest="checkepoch", default=1, type=int)
+    p.add_argument("--checkpoint", dest="checkpoint", default=0, type=int)
+    p.add_argument("--use_tfboard", dest="use_tfboard", default=False, type=bool)
+    # additions for the synthetic loader
+    p.add_argument("--iters_per_epoch", default=100, type=int)
+    p.add_argument("--height", default=600, type=int)
+    p.add_argument("--width", default=1067, type=int)
+    return p.parse_args(argv)
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    from dtt.config import apply_dataset_defaults, cfg, cfg_from_file
+    from dtt.dist import DataParallelSnippets, make_optimizer, shard_snippets
+    from dtt.synth import build_model, calibrate_batchnorm_, make_batch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    if rank == 0:
+        print("Called with args:")
+        print(args)
+    apply_dataset_defaults("imagenet_vid" if args.dataset == "synthetic" else args.dataset)  # trainval_net.py:162-172
+    cfg_file = os.path.join(ROOT, "cfgs", "{}_ls.yml".format(args.net) if args.large_scale else "{}.yml".format(args.net))
+    cfg_from_file(cfg_file)
+    np.random.seed(cfg.RNG_SEED + rank)  # trainval_net.py:183 (+rank: each process samples its own anchors / RoIs)
+    if args.dataset != "synthetic":
+        raise NotImplementedError("the ImageNet VID/DET roidb + image loading stack is outside this repo's scope; "
+                                  "use --dataset synthetic (see DESIGN.md section 7)")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    layers = {"res50": 50, "res101": 101, "res152": 152}[args.net]
+    model = build_model(layers, class_agnostic=args.class_agnostic, cfg=cfg).to(dev)
+    output_dir = os.path.join(args.save_dir, args.net, args.dataset)
+    os.makedirs(output_dir, exist_ok=True)
+    optimizer = make_optimizer(model, cfg, lr=args.lr, optimizer=args.optimizer)
+    lr = args.lr * (0.1 if args.optimizer == "adam" else 1.0)
+    if args.resume:
+        load_name = os.path.join(output_dir, "rfcn_detect_track_{}_{}_{}.pth".format(args.checksession, args.checkepoch,
+                                                                                     args.checkpoint))
+        ck = torch.load(load_name, map_location=dev)
+        args.session, args.start_epoch = ck["session"], ck["epoch"]
+        model.load_state_dict(ck["model"])
+        optimizer.load_state_dict(ck["optimizer"])
+        lr = optimizer.param_groups[0]["lr"]
+        if "pooling_mode" in ck:
+            cfg.POOLING_MODE = ck["pooling_mode"]
+        if rank == 0:
+            print("loaded checkpoint %s" % load_name)
+    runner = DataParallelSnippets(model, world)
+    # global batch = --bs snippets per process (per-snippet sharding; both frames of a pair stay on one GPU)
+    first = make_batch(args.batch_size, args.height, args.width, seed=1000 + rank, device=dev)
+    calibrate_batchnorm_(model, first[0][:, 0])
+    model.train()
+    for epoch in range(args.start_epoch, args.max_epochs + 1):
+        if epoch % (args.lr_decay_step + 1) == 0:
+            for g in optimizer.param_groups:  # adjust_learning_rate (net_utils.py:63-66)
+                g["lr"] *= args.lr_decay_gamma
+            lr *= args.lr_decay_gamma
+        loss_temp, start = 0.0, time.time()
+        for step in range(args.iters_per_epoch):
+            im, info, gt, nb = make_batch(args.batch_size, args.height, args.width,
+                                          seed=(epoch * 100003 + step) * world + rank, device=dev)
+            runner.zero_grad(set_to_none=True)
+            out = runner(im, info, gt, nb)
+            rpn_cls, rpn_box, rcnn_cls, rcnn_box, trk = out[4], out[5], out[6], out[7], out[9]
+            loss = rpn_cls.mean() + rpn_box.mean() + rcnn_cls.mean() + rcnn_box.mean() + trk.mean()  # :367-368
+            loss.backward()
+            runner.finish_gradients()
+            optimizer.step()
+            loss_temp += float(loss.detach())
+            if (step + 1) % args.disp_interval == 0 and rank == 0:
+                n = args.disp_interval
+                fg = int((out[8] != 0).sum())
+                print("[session %d][epoch %2d][iter %4d] loss: %.4f, lr: %.2e" % (args.session, epoch, step + 1,
+                                                                                   loss_temp / n, lr))
+                print("\t\t\tfg/bg=(%d/%d), time cost: %f" % (fg, out[8].numel() - fg, time.time() - start))
+                print("\t\t\trpn_cls: %.4f, rpn_box: %.4f, rcnn_cls: %.4f, rcnn_box %.4f, tracking_box %.4f" %
+                      (float(rpn_cls.mean()), float(rpn_box.mean()), float(rcnn_cls.mean()), float(rcnn_box.mean()),
+                       float(trk.mean())))
+                loss_temp, start = 0.0, time.time()
+        if rank == 0:
+            save_name = os.path.join(output_dir, "rfcn_detect_track_{}_{}_{}.pth".format(args.session, epoch, step))
+            torch.save({"session": args.session, "epoch": epoch + 1, "model": runner.state_dict(),
+                        "optimizer": optimizer.state_dict(), "pooling_mode": cfg.POOLING_MODE,
+                        "class_agnostic": args.class_agnostic}, save_name)
+            print("save model: {}".format(save_name))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
