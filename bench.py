@@ -210,7 +210,7 @@ def main():
                                                         args.height, args.width, args.batch),
                        "global_batch": args.batch * world, "parallelism": "dp%d (per-snippet sharding%s)" %
                        (world, ", RCCL gradient all-reduce" if args.mode == "train" else ", no collective")},
-            "roofline": {"kernel": "corr_fwd_mfma<5> (conv5 correlation, 2048 ch, d=8)", "bound": "mfma",
+            "roofline": {"kernel": "corr_fwd_glds<5> (conv5 correlation, 2048 ch, d=8; profiling label corr_fwd_mfma)", "bound": "mfma",
                          "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                          "launch_us": round(avg5, 2), "launches_timed": len(conv5),

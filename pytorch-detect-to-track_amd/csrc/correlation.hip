@@ -34,6 +34,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef DTT_CORR_MINW
 #define DTT_CORR_MINW 3
 #endif
+#ifndef DTT_CORR_PF
+#define DTT_CORR_PF 6
+#endif
 constexpr int kKc = DTT_CORR_KC;  // channels per LDS chunk
 constexpr int kTile = 8;      // output tile edge (lattice pixels)
 constexpr int kThreads = 256; // 4 waves, one 4x4 M-block each
@@ -258,6 +261,9 @@ __global__ __launch_bounds__(kThreads, MINW) void corr_fwd_mfma_v4(const float* 
                                                                    const float* __restrict__ in2,
                                                                    float* __restrict__ ws, FastGeom g) {
   using K = Cfg<NBR>;
+#ifdef DTT_CORR_STAMP
+  const unsigned long long stamp0 = __builtin_amdgcn_s_memrealtime();
+#endif
   constexpr int G4 = K::HR / 4;             // float4 groups per halo row
   constexpr int PL4 = K::HR * G4;           // groups per channel plane
   constexpr int N4 = (kKc * PL4 + kThreads - 1) / kThreads;
@@ -420,6 +426,270 @@ __global__ __launch_bounds__(kThreads, MINW) void corr_fwd_mfma_v4(const float* 
   for (int nb = 0; nb < K::NB; ++nb)
 #pragma unroll
     for (int r = 0; r < 4; ++r) w[(nb * 4 + r) * 64 + lane] = acc[nb][r];
+#ifdef DTT_CORR_STAMP  // developer timeline: per-workgroup start / end (100 MHz clock) + HW_ID / XCC_ID after the partials
+  if (tid == 0) {
+    unsigned long long* st = reinterpret_cast<unsigned long long*>(ws + (long)g.ksplit * nbatch * ntiles * 4 * K::NB * 256) +
+                             4 * (long)blockIdx.x;
+    st[0] = stamp0;
+    st[1] = __builtin_amdgcn_s_memrealtime();
+    st[2] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));
+    st[3] = (__builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11)) & 0xF) | ((unsigned long long)item << 8) | ((unsigned long long)wg_fix << 40);
+  }
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------
+// LDS-DMA variant (stride 1, halo columns 16-byte aligned in the lattice): the staging pass disappears.
+// Every lane moves 16-byte pieces global -> LDS with global_load_lds_dwordx4 (no staging VGPRs, no ds_write,
+// no address / mask VALU in the loop), two LDS buffers, ONE barrier per chunk: the DMA of chunk i+1 runs
+// underneath the MFMA phase of chunk i.  Zero padding moves to the OUTPUT side: every accumulator element
+// belongs to exactly one (p, q) pixel pair, so pieces that fall outside the image are simply loaded from a
+// clamped in-bounds address (their products are garbage) and corr_fwd_reduce writes 0 for pairs whose p or q
+// lies in the padding.  Pieces are addressed flat in the plane, so a piece straddling the right edge reads
+// the first pixels of the next row / plane (garbage lanes only); the one place where that would leave the
+// tensor (last row of the last plane) is loaded shifted back and rotated in LDS (workgroup-uniform rare path).
+// LDS image = piece-linear (DMA destination is wave base + lane * 16):  [c][HR rows][RS] + pad per plane,
+// frame-t tile [c][8][8] + pad; strides chosen so that both MFMA operand reads stay bank-conflict free.
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+
+__device__ __forceinline__ unsigned lds_byte_addr(const float* p) {
+  return (unsigned)(unsigned long)(const __attribute__((address_space(3))) float*)p;
+}
+template <int OFF>
+__device__ __forceinline__ void lds_read_async(float& dst, unsigned addr) {  // completion is counted by hand below
+  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+template <int N>
+__device__ __forceinline__ void lds_wait(float& v) {  // s_waitcnt tied to the value it releases
+  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v) : "n"(N));
+}
+
+// One MFMA phase over a staged chunk with a hand-counted LDS read-ahead: hipcc sinks every ds_read next to the MFMA
+// that consumes it and waits lgkmcnt(0), exposing the LDS latency on each pair.  Here the B operand of MFMA t is
+// requested PF-1 (or PF) MFMAs early (asm ds_read the compiler does not track), released by a counted s_waitcnt (LDS
+// returns in order: lgkmcnt(n) = "all but the newest n have landed"), and the ring slot of MFMA t-1 is refilled
+// after MFMA t has issued.  sched_barrier pins that order.
+template <class K, int NBR, int PF, int T>
+__device__ __forceinline__ void corr_mfma_steps(f32x4 (&acc)[K::NB], float (&ring)[PF], float (&a)[kKc / 4],
+                                                unsigned baddr) {
+  constexpr int TOT = (kKc / 4) * K::NB;
+  constexpr int kq = T / K::NB, nb = T % K::NB;
+  constexpr int newer = (PF - 2 < TOT - 1 - T) ? PF - 2 : TOT - 1 - T;
+  lds_wait<newer>(ring[T % PF]);
+  acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kq], ring[T % PF], acc[nb], 0, 0, 0);
+  if constexpr (T >= 1 && T - 1 + PF < TOT) {
+    constexpr int u = T - 1 + PF, ukq = u / K::NB, unb = u % K::NB;
+    lds_read_async<(ukq * 4 * K::PS2 + (unb / NBR) * 4 * K::RS + (unb % NBR) * 4) * 4>(ring[u % PF], baddr);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (T + 1 < TOT) corr_mfma_steps<K, NBR, PF, T + 1>(acc, ring, a, baddr);
+}
+template <class K, int NBR, int PF, int T>
+__device__ __forceinline__ void corr_mfma_prime(float (&ring)[PF], unsigned baddr) {
+  constexpr int kq = T / K::NB, nb = T % K::NB;
+  lds_read_async<(kq * 4 * K::PS2 + (nb / NBR) * 4 * K::RS + (nb % NBR) * 4) * 4>(ring[T], baddr);
+  if constexpr (T + 1 < PF) corr_mfma_prime<K, NBR, PF, T + 1>(ring, baddr);
+}
+
+template <int NBR>
+struct GCfg {
+  static constexpr int HR = 4 + 4 * NBR;                                        // halo rows = cols
+  static constexpr int G4 = HR / 4;                                             // real pieces per halo row
+  static constexpr int RS = (HR % 32 == 8 || HR % 32 == 24) ? HR : HR + 4;      // row stride (floats)
+  static constexpr int R4 = RS / 4;                                             // pieces per row incl. pad
+  static constexpr int PS2 = HR * RS + (RS == HR ? 4 : 16);                     // plane stride: 4 mod 8 / 16 mod 32
+  static constexpr int PP2 = PS2 / 4;                                           // pieces per halo plane
+  static constexpr int PS1 = kTile * kTile + 4, PP1 = PS1 / 4;                  // frame-t plane
+  static constexpr int A0 = kKc * PS2;                                          // float offset of the frame-t planes
+  static constexpr int NP = kKc * (PP2 + PP1);                                  // pieces per buffer
+  static constexpr int NI = (NP + kThreads - 1) / kThreads;                     // DMA instructions per thread
+  static constexpr int BUF = NP * 4;                                            // floats per buffer
+  static constexpr int NB = NBR * NBR;
+  static constexpr size_t LDS = 2 * (size_t)BUF * sizeof(float);
+};
+
+template <int NBR, int MINW>
+__global__ __launch_bounds__(kThreads, MINW) void corr_fwd_glds(const float* __restrict__ in1,
+                                                                const float* __restrict__ in2,
+                                                                float* __restrict__ ws, FastGeom g) {
+  using K = GCfg<NBR>;
+#ifdef DTT_CORR_STAMP
+  const unsigned long long stamp0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int ntiles = g.tiles_x * g.tiles_y;
+  const int item = dtt_xcd_remap(blockIdx.x, gridDim.x);
+  const int tile = item % ntiles;
+  const int ks = (item / ntiles) % g.ksplit, n = item / (ntiles * g.ksplit);
+  const int nbatch = gridDim.x / (ntiles * g.ksplit);
+  const int ty0 = (tile / g.tiles_x) * kTile, tx0 = (tile % g.tiles_x) * kTile;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int my = wave >> 1, mx = wave & 1;
+  const int plane = g.H * g.W;
+  const int c_begin = ks * g.c_per_split;
+  const int c_end = min(g.C, c_begin + g.c_per_split);
+  const int nch = (c_end - c_begin) / kKc;
+
+  // piece p of a buffer -> source: which frame, channel in chunk, in-plane flat offset, overflow past the plane end
+  auto describe = [&](int p, bool& is_a, int& cc, int& off, int& over) {
+    is_a = p >= kKc * K::PP2;
+    int gy, start;
+    bool real;
+    if (!is_a) {
+      cc = p / K::PP2;
+      const int r = p - cc * K::PP2, hr = r / K::R4, q = r - hr * K::R4;
+      real = hr < K::HR && q < K::G4;
+      gy = g.origin + ty0 - g.R + hr;
+      start = g.origin + tx0 - g.R + 4 * q;
+    } else {
+      const int pa = p - kKc * K::PP2;
+      cc = pa / K::PP1;
+      const int r = pa - cc * K::PP1, py = r >> 1, q = r & 1;
+      real = r < 2 * kTile;
+      gy = g.origin + ty0 + py;
+      start = g.origin + tx0 + 4 * q;
+    }
+    const bool valid = real && gy >= 0 && gy < g.H && start >= 0 && start < g.W;  // holds at least one in-image pixel
+    const int gyc = min(max(gy, 0), g.H - 1);
+    off = real ? gyc * g.W + start : 0;
+    if (!valid) off = min(max(off, 0), plane - 4);
+    over = valid ? max(off + 4 - plane, 0) : 0;
+  };
+  const float* src[K::NI];
+#pragma unroll
+  for (int i = 0; i < K::NI; ++i) {
+    const int p = min(i * kThreads + tid, K::NP - 1);
+    bool is_a;
+    int cc, off, over;
+    describe(p, is_a, cc, off, over);
+    src[i] = (is_a ? in1 : in2) + ((long)n * g.C + c_begin + cc) * plane + off;
+  }
+  const long chunk_stride = (long)kKc * plane;
+  // the only pieces that could read past the end of the tensor: last image, last channel, bottom-right straddle
+  const bool tail_wg = n == nbatch - 1 && c_end == g.C;
+
+  auto issue = [&](float* buf, bool last_chunk) {
+#pragma unroll
+    for (int i = 0; i < K::NI; ++i) {
+      const int p = i * kThreads + tid;
+      const float* sp = src[i];
+      if (tail_wg && last_chunk) {  // workgroup-uniform, once per launch for 1 / (ksplit * batch) of the workgroups
+        bool is_a;
+        int cc, off, over;
+        describe(min(p, K::NP - 1), is_a, cc, off, over);
+        if (cc == kKc - 1) sp -= over;
+      }
+      lds_void_t* dst = (lds_void_t*)(buf + (i * kThreads + wave * 64) * 4);
+      if (i * kThreads + kThreads <= K::NP || p < K::NP)
+        __builtin_amdgcn_global_load_lds((glb_void_t*)sp, dst, 16, 0, 0);
+      src[i] += chunk_stride;
+    }
+  };
+  auto fix_tail = [&](float* buf) {  // rotate the shifted pieces of the last plane into place
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < K::NI; ++i) {
+      const int p = i * kThreads + tid;
+      bool is_a;
+      int cc, off, over;
+      describe(min(p, K::NP - 1), is_a, cc, off, over);
+      if (p < K::NP && cc == kKc - 1 && over > 0) {
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = buf[4 * p + j];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (j + over < 4) buf[4 * p + j] = v[j + over];
+      }
+    }
+  };
+
+  // a wave whose whole 4x4 pixel block lies beyond the output (right / bottom overhang of the tiling) only helps staging
+  const bool wave_live = ty0 + my * 4 < g.oh && tx0 + mx * 4 < g.ow;
+  const int kq_lane = lane >> 4;
+  const int ij = lane & 15;
+  const int a_off = K::A0 + kq_lane * K::PS1 + (my * 4 + (ij >> 2)) * kTile + mx * 4 + (ij & 3);
+  const int b_off = kq_lane * K::PS2 + (my * 4 + (ij >> 2)) * K::RS + mx * 4 + (ij & 3);
+
+  f32x4 acc[K::NB];
+#pragma unroll
+  for (int i = 0; i < K::NB; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const unsigned lds0 = lds_byte_addr(lds);
+#ifdef DTT_CORR_CPHASE   // compiler-scheduled operand reads (experiment)
+  auto mfma_phase = [&](const float* buf) {
+    constexpr int TOT = (kKc / 4) * K::NB;
+    float a = buf[a_off];
+#pragma unroll
+    for (int t = 0; t < TOT; ++t) {
+      const int kq = t / K::NB, nb = t - kq * K::NB;
+      const float b = buf[kq * 4 * K::PS2 + b_off + (nb / NBR) * 4 * K::RS + (nb % NBR) * 4];
+      acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[nb], 0, 0, 0);
+      if (nb == K::NB - 1 && kq + 1 < kKc / 4) a = buf[(kq + 1) * 4 * K::PS1 + a_off];
+    }
+  };
+  (void)lds0;
+#else
+  auto mfma_phase = [&](const float* buf) {
+    constexpr int PF = DTT_CORR_PF;
+    static_assert(PF >= 3 && PF <= 14 && (kKc / 4) * K::NB >= PF, "read-ahead ring");
+    const unsigned base = lds0 + (unsigned)((buf - lds) * sizeof(float));
+    const unsigned baddr = base + b_off * 4, aaddr = base + a_off * 4;
+    float ring[PF], a[kKc / 4];
+    lds_read_async<0>(a[0], aaddr);
+    if constexpr (kKc / 4 > 1) lds_read_async<4 * K::PS1 * 4>(a[1], aaddr);
+    static_assert(kKc / 4 <= 2, "A operand prefetch covers two k-quads");
+    corr_mfma_prime<K, NBR, PF, 0>(ring, baddr);
+    lds_wait<PF>(a[0]);
+    if constexpr (kKc / 4 > 1) lds_wait<PF>(a[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    corr_mfma_steps<K, NBR, PF, 0>(acc, ring, a, baddr);
+  };
+#endif
+  // chunk ci lives in buffer ci & 1.  Top of a step: my DMA pieces have landed (vmcnt) and, past the barrier,
+  // everybody's have -- and everybody is done reading the other buffer, which the next DMA may now overwrite.
+  auto step = [&](float* cur, float* nxt, int ci) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tail_wg && ci == nch - 1) fix_tail(cur);
+#if DTT_CORR_ABLATE != 11 && DTT_CORR_ABLATE != 13 && DTT_CORR_ABLATE != 15   // 11: no barriers, 12: no DMA, 13: neither (timing experiments only)
+    __syncthreads();
+#endif
+#if DTT_CORR_ABLATE != 12 && DTT_CORR_ABLATE != 13 && DTT_CORR_ABLATE != 15
+    if (ci + 1 < nch) issue(nxt, ci + 1 == nch - 1);
+#endif
+    if (wave_live) mfma_phase(cur);
+  };
+  float* buf0 = lds;
+  float* buf1 = lds + K::BUF;
+  issue(buf0, nch == 1);
+  for (int ci = 0; ci < nch; ci += 2) {
+    step(buf0, buf1, ci);
+    if (ci + 1 < nch) step(buf1, buf0, ci + 1);
+  }
+
+  float* w = ws + ((((long)ks * nbatch + n) * ntiles + tile) * 4 + wave) * (long)(K::NB * 256);
+#ifdef DTT_CORR_STAMP
+  const unsigned long long stamp1 = __builtin_amdgcn_s_memrealtime();
+#endif
+#if DTT_CORR_ABLATE == 14 || DTT_CORR_ABLATE == 15   // 14: no partials store; 15: nor barriers / DMA
+  if (g.C < 0)
+#endif
+#pragma unroll
+  for (int nb = 0; nb < K::NB; ++nb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) w[(nb * 4 + r) * 64 + lane] = acc[nb][r];
+#ifdef DTT_CORR_STAMP
+  if (tid == 0) {
+    unsigned long long* st = reinterpret_cast<unsigned long long*>(ws + (long)g.ksplit * nbatch * ntiles * 4 * K::NB * 256) +
+                             4 * (long)blockIdx.x;
+    st[0] = stamp0;
+    st[1] = __builtin_amdgcn_s_memrealtime();
+    st[2] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));
+    st[3] = (__builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11)) & 0xF) | ((unsigned long long)item << 8) | ((stamp1 - stamp0) << 40);
+  }
+#endif
 }
 
 // grid: (tiles * 4 waves, NBR block rows, batch).  One workgroup sums the channel slices of one N-block row
@@ -463,7 +733,11 @@ __global__ __launch_bounds__(kThreads) void corr_fwd_reduce(const float* __restr
     if (y >= g.oh || x >= g.ow) continue;
     const int hc = ti + ix;
     const int lane = iy * 16 + (hr & 3) * 4 + (hc & 3);
-    o[((long)(tj * g.D + ti) * g.oh + y) * g.ow + x] = frag[((hc >> 2) * 4 + ix) * 64 + lane] / nelems;
+    // zero padding, applied on the output side (the LDS-DMA kernel stages unmasked pixels)
+    const int py = g.origin + y * g.s, px = g.origin + x * g.s;
+    const int qy = py + (tj - g.R) * g.s, qx = px + (ti - g.R) * g.s;
+    const bool in_image = py >= 0 && py < g.H && px >= 0 && px < g.W && qy >= 0 && qy < g.H && qx >= 0 && qx < g.W;
+    o[((long)(tj * g.D + ti) * g.oh + y) * g.ow + x] = in_image ? frag[((hc >> 2) * 4 + ix) * 64 + lane] / nelems : 0.f;
   }
 }
 
@@ -828,6 +1102,21 @@ int launch_fast(float* output, long out_batch_stride, const float* in1, const fl
   dtt_prof_begin("corr_fwd_mfma", stream);
   bool use_v4 = false;
   if constexpr (VEC4) use_v4 = g.s == 1 && g.C % kKc == 0 && g.W >= 4;
+#ifndef DTT_CORR_NO_GLDS
+  if (g.s == 1 && g.C % kKc == 0 && g.W >= 4 && (((g.origin - g.R) % 4) + 4) % 4 == 0) {
+    using G = GCfg<NBR>;
+    static bool gattr = false;
+    if (!gattr) {
+      hipError_t e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(corr_fwd_glds<NBR, MINW>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
+      DTT_REQUIRE(e3 == hipSuccess, "correlation: cannot raise dynamic LDS limit (LDS-DMA kernel)");
+      gattr = true;
+    }
+    hipLaunchKernelGGL((corr_fwd_glds<NBR, MINW>), dim3(ntiles * g.ksplit * batch), dim3(kThreads), G::LDS, stream,
+                       in1, in2, static_cast<float*>(workspace), g);
+    use_v4 = true;  // launched
+  } else
+#endif
   if constexpr (VEC4) {
     if (use_v4)
       hipLaunchKernelGGL((corr_fwd_mfma_v4<NBR, MINW>), dim3(ntiles * g.ksplit * batch), dim3(kThreads), K::LDS, stream,

@@ -138,6 +138,12 @@ CORR_CASES = [
     (1, 33, 21, 17, 3, 1, 3, 1, 1),     # R = 3 (padded up to the R <= 4 instantiation)
     (1, 16, 16, 16, 6, 1, 4, 1, 1),     # pad > displacement
     (1, 8, 12, 13, 4, 3, 4, 1, 2),      # kernel_size 3, stride2 != stride1 -> generic path
+    (1, 16, 13, 19, 4, 1, 4, 1, 1),     # LDS-DMA kernel, R = 4
+    (1, 8, 9, 12, 16, 1, 16, 1, 1),     # LDS-DMA kernel, R = 16, one chunk
+    (2, 16, 16, 16, 8, 1, 4, 1, 1),     # LDS-DMA kernel, pad > displacement (output pixels inside the padding)
+    (1, 8, 5, 4, 8, 1, 8, 1, 1),        # LDS-DMA kernel, map narrower than one piece row
+    (1, 24, 38, 67, 8, 1, 8, 1, 1),     # LDS-DMA kernel, the 600 px map, odd number of chunks
+    (3, 8, 8, 8, 8, 1, 8, 1, 1),        # LDS-DMA kernel, single chunk, batch 3
 ]
 
 

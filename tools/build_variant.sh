@@ -1,0 +1,8 @@
+#!/bin/bash
+# Developer tool: build a variant of libdtt_hip.so with extra -D flags into tools/_variants/<name>.so
+#   tools/build_variant.sh stamp "-DDTT_CORR_STAMP"
+set -e
+cd "$(dirname "$0")/../pytorch-detect-to-track_amd/csrc"
+mkdir -p ../../tools/_variants
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math \
+  -I../../include $2 -shared -o ../../tools/_variants/$1.so common.hip correlation.hip
