@@ -128,7 +128,9 @@ def main():
     calibrate_batchnorm_(model, im[:, 0])
     if args.mode == "train":
         from dtt.dist import DataParallelSnippets, make_optimizer
+        from dtt.fuse import fuse_for_training
         model.train()
+        fuse_for_training(model)  # frozen BatchNorm folded out of the activation path (same gradients for the weights)
         runner = DataParallelSnippets(model, world)
         opt = make_optimizer(model, cfg, lr=1e-4)
 

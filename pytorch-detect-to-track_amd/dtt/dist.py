@@ -146,4 +146,45 @@ def make_optimizer(model, cfg, lr=None, optimizer="sgd"):
         for g in groups:
             g["lr"] *= 0.1
         return torch.optim.Adam(groups)
-    return torch.optim.SGD(groups, momentum=T.MOMENTUM)
+    return GroupedSGD(groups, momentum=T.MOMENTUM)
+
+
+class GroupedSGD(torch.optim.SGD):
+    """torch.optim.SGD semantics and state_dict layout (one param group per parameter, as the reference builds them),
+    but `step()` batches all parameters that share (lr, weight_decay, momentum) into the same multi-tensor launches:
+    ~10 kernels per step instead of three per parameter (~950 for ResNet-101)."""
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        buckets = {}
+        for g in self.param_groups:
+            if g.get("nesterov") or g.get("dampening", 0) != 0 or g.get("maximize"):
+                return super().step()  # not used by the D&T recipe
+            key = (float(g["lr"]), float(g["weight_decay"]), float(g["momentum"]))
+            for p in g["params"]:
+                if p.grad is not None:
+                    buckets.setdefault(key, []).append(p)
+        for (lr, wd, mom), ps in buckets.items():
+            grads = [p.grad for p in ps]
+            if wd != 0:
+                grads = torch._foreach_add(grads, ps, alpha=wd)
+            if mom != 0:
+                have, fresh = [], []
+                for p, g in zip(ps, grads):
+                    st = self.state[p]
+                    if st.get("momentum_buffer") is None:
+                        st["momentum_buffer"] = torch.clone(g).detach()  # first step: buf = g
+                        fresh.append(p)
+                    else:
+                        have.append((st["momentum_buffer"], g))
+                if have:
+                    bufs = [b for b, _ in have]
+                    torch._foreach_mul_(bufs, mom)
+                    torch._foreach_add_(bufs, [g for _, g in have])
+                grads = [self.state[p]["momentum_buffer"] for p in ps]
+            torch._foreach_add_(ps, grads, alpha=-lr)
+        return loss

@@ -96,6 +96,103 @@ class FusedTrunk:
         return feats[1], feats[2], feats[3], top
 
 
+# ------------------------------------------------------------------------------------------------ training
+class _BiasActFn(torch.autograd.Function):
+    """y = relu(x + bias[c] (+ residual)) written over x (a fresh convolution output); bias is a frozen-BatchNorm
+    constant.  Backward is one threshold pass; the saved tensor is the output the next convolution keeps anyway."""
+
+    @staticmethod
+    def forward(ctx, x, bias, residual):
+        bias_act_(x, bias, residual, relu=True)
+        ctx.mark_dirty(x)
+        ctx.save_for_backward(x)
+        ctx.has_res = residual is not None
+        return x
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        gi = torch.ops.aten.threshold_backward(g.contiguous(), y, 0)
+        return gi, None, (gi if ctx.has_res else None)
+
+
+class FusedTrainTrunk:
+    """Training-time trunk with the frozen BatchNorm folded out of the activation path.
+
+    The reference trains with every BatchNorm frozen (eval mode, no gradients: resnet.py:290-295, 325-343), so
+    `bn(conv(x; w))` is `conv(x; w * s) + t` with constants s, t.  The trainable weights stay the parameters w
+    (autograd sees the product w * s, checkpoints are unchanged); what disappears are the BatchNorm forward pass,
+    its backward scale pass, the separate ReLU and the residual add over every activation tensor: one in-place HIP
+    pass forward, one threshold pass backward.  Blocks without trainable parameters (conv1 + the FIXED_BLOCKS
+    stages) run under no_grad on cached folded weights.
+    """
+
+    def __init__(self, model):
+        b = model.RFCN_base
+        self.model = model
+        self.pool = b[3]
+        self.stem = _FusedConv(b[0], b[1])
+        self.frozen, self.live = [], []
+        for idx in (4, 5, 6, 7):
+            blocks = list(b[idx])
+            if any(p.requires_grad for p in b[idx].parameters()):
+                self.live.append(blocks)
+            else:
+                assert not self.live, "a frozen stage after a trainable one is not supported"
+                self.frozen.append([_FusedBottleneck(blk) for blk in blocks])
+        self.n_frozen = len(self.frozen)
+        # constants of the trainable blocks: per conv the scale s (C,1,1,1) and shift t
+        self.convs, self.scales, self.shifts = [], [], []
+        for blocks in self.live:
+            for blk in blocks:
+                pairs = [(blk.conv1, blk.bn1), (blk.conv2, blk.bn2), (blk.conv3, blk.bn3)]
+                if blk.downsample is not None:
+                    pairs.append((blk.downsample[0], blk.downsample[1]))
+                for conv, bn in pairs:
+                    sc = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).detach()
+                    self.convs.append(conv)
+                    self.scales.append(sc.view(-1, 1, 1, 1).contiguous())
+                    self.shifts.append((bn.bias - bn.running_mean * sc).detach().contiguous())
+
+    @staticmethod
+    def run_block(blk, x, w, t):
+        """One bottleneck on folded weights w = [w1*s1, w2*s2, w3*s3 (, wd*sd)] and shifts t."""
+        kw = lambda c: dict(stride=c.stride, padding=c.padding, dilation=c.dilation)
+        out = _BiasActFn.apply(F.conv2d(x, w[0], None, **kw(blk.conv1)), t[0], None)
+        out = _BiasActFn.apply(F.conv2d(out, w[1], None, **kw(blk.conv2)), t[1], None)
+        out = F.conv2d(out, w[2], None, **kw(blk.conv3))
+        if blk.downsample is not None:
+            res = F.conv2d(x, w[3], None, **kw(blk.downsample[0]))
+            return _BiasActFn.apply(out, t[2] + t[3], res)
+        return _BiasActFn.apply(out, t[2], x)
+
+    def __call__(self, x):
+        with torch.no_grad():
+            x = self.pool(bias_act_(self.stem.conv(x), self.stem.b))
+            feats = []
+            for stage in self.frozen:
+                for blk in stage:
+                    x = blk(x)
+                feats.append(x)
+        ws = torch._foreach_mul([c.weight for c in self.convs], self.scales)  # all folded weights in a few launches
+        k = 0
+        for blocks in self.live:
+            for blk in blocks:
+                n = 4 if blk.downsample is not None else 3
+                x = self.run_block(blk, x, ws[k:k + n], self.shifts[k:k + n])
+                k += n
+            feats.append(x)
+        top = F.relu(self.model.RFCN_net(feats[3]), inplace=True)
+        return feats[1], feats[2], feats[3], top
+
+
+def fuse_for_training(model):
+    """Build the training-time fused trunk from the model's current (frozen) BatchNorm statistics; call again after
+    loading a checkpoint."""
+    model._fused_train_trunk = FusedTrainTrunk(model)
+    return model
+
+
 def fuse_for_inference(model):
     """Build the fused trunk from the model's current weights (call again after loading a checkpoint)."""
     model._fused_trunk = FusedTrunk(model)
@@ -104,4 +201,5 @@ def fuse_for_inference(model):
 
 def unfuse(model):
     model._fused_trunk = None
+    model._fused_train_trunk = None
     return model

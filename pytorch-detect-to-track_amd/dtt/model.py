@@ -374,6 +374,9 @@ class resnet(_RFCN):
         fused = getattr(self, "_fused_trunk", None)
         if fused is not None and not self.training and not torch.is_grad_enabled() and x.is_cuda:
             return fused(x)  # dtt.fuse: BatchNorm folded, bias + residual + ReLU in one HIP pass
+        fused_train = getattr(self, "_fused_train_trunk", None)
+        if fused_train is not None and self.training and torch.is_grad_enabled() and x.is_cuda:
+            return fused_train(x)
         b = self.RFCN_base
         x = b[3](b[2](b[1](b[0](x))))
         conv3 = b[5](b[4](x))

@@ -156,3 +156,74 @@ def test_drivers_round_trip_checkpoint(tmp_path):
     n = sum(len(all_boxes[j][i]) for j in range(1, 31) for i in range(2))
     assert all(np.asarray(all_boxes[j][i]).shape[1] == 5 for j in range(1, 31) for i in range(2) if len(all_boxes[j][i]))
     assert n <= 200
+
+
+def test_fused_training_trunk_matches_reference_graph():
+    """dtt.fuse.FusedTrainTrunk (frozen BatchNorm folded out of the activation path, fused bias/residual/ReLU with a
+    one-pass backward) against the module graph.  Block by block (same input, same upstream gradient) outputs, input
+    gradients and weight gradients agree to fp32 rounding; through the whole random-init trunk the two graphs drift
+    apart by ReLU-mask flips, so that comparison is a loose sanity bound."""
+    from dtt.config import cfg
+    from dtt.fuse import FusedTrainTrunk, fuse_for_training, unfuse
+    from dtt.synth import build_model, calibrate_batchnorm_, make_batch
+    dev = torch.device("cuda:0")
+    model = build_model(50, cfg=cfg).to(dev)
+    im, _, _, _ = make_batch(1, 160, 224, seed=11, device=dev)
+    x = im[:, 0].contiguous()
+    calibrate_batchnorm_(model, x)
+    model.train()
+    torch.manual_seed(0)
+    ft = FusedTrainTrunk(model)
+    k = 0
+    checked = 0
+    for blocks in ft.live:
+        for blk in blocks:
+            n = 4 if blk.downsample is not None else 3
+            cin = blk.conv1.in_channels
+            xin = torch.relu(torch.randn(2, cin, 20, 28, device=dev))
+            outs = []
+            for fused in (False, True):
+                blk.zero_grad(set_to_none=True)
+                xi = xin.clone().requires_grad_(True)
+                if fused:
+                    ws = [c.weight * sc for c, sc in zip(ft.convs[k:k + n], ft.scales[k:k + n])]
+                    y = ft.run_block(blk, xi, ws, ft.shifts[k:k + n])
+                else:
+                    y = blk(xi)
+                if not outs:
+                    probe = torch.randn_like(y)
+                (y * probe).sum().backward()
+                outs.append((y.detach().clone(), xi.grad.clone(), [c.weight.grad.clone() for c in ft.convs[k:k + n]]))
+            (y0, gx0, gw0), (y1, gx1, gw1) = outs
+            # forward to fp32 rounding; gradients to the accuracy of MIOpen's Winograd backward kernels (the two graphs
+            # hand them differently scaled weights), far below what a wrong mask / missing residual term would give
+            close = lambda a, b, tol: float((a - b).norm()) <= tol * max(1e-12, float(a.norm()))
+            assert close(y0, y1, 2e-5) and close(gx0, gx1, 5e-3), (k, float((y0 - y1).norm() / y0.norm()), float((gx0 - gx1).norm() / gx0.norm()))
+            for a, b in zip(gw0, gw1):
+                assert close(a, b, 5e-3), (k, float((a - b).norm() / a.norm()))
+            k += n
+            checked += 1
+    assert checked == 13  # layer2..layer4 of ResNet-50
+
+    probes = None
+
+    def run():
+        nonlocal probes
+        model.zero_grad(set_to_none=True)
+        feats = model._im_to_head(x)
+        if probes is None:
+            probes = [torch.randn_like(f) for f in feats]
+        sum((f * p).sum() for f, p in zip(feats, probes)).backward()
+        grads = {n: p.grad.clone() for n, p in model.RFCN_base.named_parameters() if p.grad is not None}
+        return [f.detach().clone() for f in feats], grads
+
+    unfuse(model)
+    f_ref, g_ref = run()
+    fuse_for_training(model)
+    f_fus, g_fus = run()
+    unfuse(model)
+    for a, b in zip(f_ref, f_fus):
+        assert float((a - b).norm()) <= 2e-2 * float(a.norm())
+    assert set(g_ref) == set(g_fus) and len(g_ref) > 30
+    for n in g_ref:
+        assert float((g_ref[n] - g_fus[n]).norm()) <= 0.1 * float(g_ref[n].norm()), n

@@ -137,3 +137,37 @@ def test_target_layers_match_reference_golden():
     out = _TrackingProposalTargetLayer(31, cfg=cfg)(gt, nb)
     for name, t in zip(("rois", "labels", "targets", "inside", "outside"), out):
         np.testing.assert_allclose(t.numpy(), g["tt/" + name], rtol=1e-5, atol=1e-5, err_msg="tt/" + name)
+
+
+def test_grouped_sgd_matches_torch_sgd():
+    """dtt.dist.GroupedSGD: same updates and the same state_dict layout as torch.optim.SGD with one group per
+    parameter (the layout the reference's checkpoints hold, trainval_net.py:280-294)."""
+    import torch
+    from dtt.dist import GroupedSGD
+    torch.manual_seed(0)
+    shapes = [(4, 3), (4,), (5, 4), (5,), (2, 5)]
+    def make():
+        torch.manual_seed(1)
+        ps = [torch.nn.Parameter(torch.randn(*s)) for s in shapes]
+        groups = [{"params": [p], "lr": 0.02 if p.dim() == 1 else 0.01, "weight_decay": 0.0 if p.dim() == 1 else 1e-2} for p in ps]
+        return ps, groups
+    pa, ga = make()
+    pb, gb = make()
+    oa, ob = torch.optim.SGD(ga, momentum=0.9), GroupedSGD(gb, momentum=0.9)
+    for step in range(4):
+        torch.manual_seed(10 + step)
+        for x, y in zip(pa, pb):
+            g = torch.randn_like(x)
+            x.grad, y.grad = g.clone(), g.clone()
+        if step == 2:
+            pa[1].grad = None; pb[1].grad = None  # a parameter without gradient is skipped
+        oa.step(); ob.step()
+    for x, y in zip(pa, pb):
+        assert torch.allclose(x, y, rtol=1e-6, atol=1e-7)
+    sa, sb = oa.state_dict(), ob.state_dict()
+    assert [g["params"] for g in sa["param_groups"]] == [g["params"] for g in sb["param_groups"]]
+    assert set(sa["state"]) == set(sb["state"])
+    for k in sa["state"]:
+        assert torch.allclose(sa["state"][k]["momentum_buffer"], sb["state"][k]["momentum_buffer"], rtol=1e-6, atol=1e-7)
+    ob2 = GroupedSGD(make()[1], momentum=0.9)
+    ob2.load_state_dict(sa)  # a torch.optim.SGD checkpoint loads

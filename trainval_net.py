@@ -106,6 +106,8 @@ def main(argv=None):
     first = make_batch(args.batch_size, args.height, args.width, seed=1000 + rank, device=dev)
     calibrate_batchnorm_(model, first[0][:, 0])
     model.train()
+    from dtt.fuse import fuse_for_training
+    fuse_for_training(model)
     for epoch in range(args.start_epoch, args.max_epochs + 1):
         if epoch % (args.lr_decay_step + 1) == 0:
             for g in optimizer.param_groups:  # adjust_learning_rate (net_utils.py:63-66)
