@@ -60,16 +60,46 @@ __global__ void at_init(int* __restrict__ gt_max_bits, int n, int* __restrict__ 
   if (i < ncounts) counts[i] = 0;
 }
 
+// Per-GT maximum over the inside anchors.  IoUs >= 0 order like their bit patterns, so the maximum is an integer
+// max: reduced across the wave by shuffles, across the workgroup through LDS, and only then one atomic per
+// (workgroup, gt) reaches memory -- the per-anchor atomics of a direct translation all hit the same B*G words.
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
 __global__ __launch_bounds__(kThreads) void at_gt_max(const float* __restrict__ gt_boxes, const float* __restrict__ base,
                                                       AtGeom g, int* __restrict__ gt_max_bits) {
+  constexpr int kNone = (int)0xBF800000;  // -1.0f
+  __shared__ int wmax[kThreads / 64][32];
   const int t = blockIdx.x * kThreads + threadIdx.x, b = blockIdx.y;
-  if (t >= g.n) return;
-  float x1, y1, x2, y2;
-  anchor_of(base, g, t, x1, y1, x2, y2);
-  if (!inside(g, x1, y1, x2, y2)) return;
-  for (int j = 0; j < g.G; ++j) {
-    const float ov = overlap(x1, y1, x2, y2, gt_boxes + ((long)b * g.G + j) * 5);
-    if (ov >= 0.f) atomicMax(&gt_max_bits[b * g.G + j], __float_as_int(ov + 0.f));
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float x1 = 0.f, y1 = 0.f, x2 = 0.f, y2 = 0.f;
+  bool live = t < g.n;
+  if (live) {
+    anchor_of(base, g, t, x1, y1, x2, y2);
+    live = inside(g, x1, y1, x2, y2);
+  }
+  for (int j0 = 0; j0 < g.G; j0 += 32) {
+    const int nj = min(32, g.G - j0);
+    for (int j = 0; j < nj; ++j) {
+      int v = kNone;
+      if (live) {
+        const float ov = overlap(x1, y1, x2, y2, gt_boxes + ((long)b * g.G + j0 + j) * 5);
+        if (ov >= 0.f) v = __float_as_int(ov + 0.f);
+      }
+      v = wave_max_i32(v);
+      if (lane == 0) wmax[wave][j] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < nj) {
+      int v = wmax[0][threadIdx.x];
+#pragma unroll
+      for (int w = 1; w < kThreads / 64; ++w) v = max(v, wmax[w][threadIdx.x]);
+      if (v != kNone) atomicMax(&gt_max_bits[b * g.G + j0 + threadIdx.x], v);
+    }
+    __syncthreads();
   }
 }
 
@@ -78,29 +108,35 @@ __global__ __launch_bounds__(kThreads) void at_assign(const float* __restrict__ 
                                                       float pos_thr, int clobber, int* __restrict__ labels,
                                                       int* __restrict__ argmax_gt, int* __restrict__ counts) {
   const int t = blockIdx.x * kThreads + threadIdx.x, b = blockIdx.y;
-  if (t >= g.n) return;
-  float x1, y1, x2, y2;
-  anchor_of(base, g, t, x1, y1, x2, y2);
+  float x1 = 0.f, y1 = 0.f, x2 = 0.f, y2 = 0.f;
   int label = -1, amax = 0;
-  if (inside(g, x1, y1, x2, y2)) {
-    float best = -INFINITY;
-    bool is_gt_best = false;
-    for (int j = 0; j < g.G; ++j) {
-      const float ov = overlap(x1, y1, x2, y2, gt_boxes + ((long)b * g.G + j) * 5);
-      if (ov > best) { best = ov; amax = j; }  // first maximum, as torch.max(dim)
-      float gm = __int_as_float(gt_max_bits[b * g.G + j]);
-      if (gm == 0.f) gm = 1e-5f;                // anchor_target_layer.py:104
-      if (ov == gm) is_gt_best = true;          // anchor_target_layer.py:105
+  bool live = t < g.n;
+  if (live) {
+    anchor_of(base, g, t, x1, y1, x2, y2);
+    if (inside(g, x1, y1, x2, y2)) {
+      float best = -INFINITY;
+      bool is_gt_best = false;
+      for (int j = 0; j < g.G; ++j) {
+        const float ov = overlap(x1, y1, x2, y2, gt_boxes + ((long)b * g.G + j) * 5);
+        if (ov > best) { best = ov; amax = j; }  // first maximum, as torch.max(dim)
+        float gm = __int_as_float(gt_max_bits[b * g.G + j]);
+        if (gm == 0.f) gm = 1e-5f;                // anchor_target_layer.py:104
+        if (ov == gm) is_gt_best = true;          // anchor_target_layer.py:105
+      }
+      if (!clobber && best < neg_thr) label = 0;
+      if (is_gt_best) label = 1;
+      if (best >= pos_thr) label = 1;
+      if (clobber && best < neg_thr) label = 0;
     }
-    if (!clobber && best < neg_thr) label = 0;
-    if (is_gt_best) label = 1;
-    if (best >= pos_thr) label = 1;
-    if (clobber && best < neg_thr) label = 0;
-    if (label == 1) atomicAdd(&counts[b * 2 + 0], 1);
-    if (label == 0) atomicAdd(&counts[b * 2 + 1], 1);
+    labels[(long)b * g.n + t] = label;
+    argmax_gt[(long)b * g.n + t] = amax;
   }
-  labels[(long)b * g.n + t] = label;
-  argmax_gt[(long)b * g.n + t] = amax;
+  // fg / bg counts: one atomic per wave, not per anchor
+  const unsigned long long fg = __ballot(live && label == 1), bg = __ballot(live && label == 0);
+  if ((threadIdx.x & 63) == 0) {
+    if (fg) atomicAdd(&counts[b * 2 + 0], __popcll(fg));
+    if (bg) atomicAdd(&counts[b * 2 + 1], __popcll(bg));
+  }
 }
 
 __global__ void at_disable(int* __restrict__ labels, const int* __restrict__ disable,
