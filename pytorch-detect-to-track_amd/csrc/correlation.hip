@@ -501,8 +501,9 @@ struct GCfg {
   static constexpr int PS2 = HR * RS + (RS == HR ? 4 : 16);                     // plane stride: 4 mod 8 / 16 mod 32
   static constexpr int PP2 = PS2 / 4;                                           // pieces per halo plane
   static constexpr int PS1 = kTile * kTile + 4, PP1 = PS1 / 4;                  // frame-t plane
-  static constexpr int A0 = kKc * PS2;                                          // float offset of the frame-t planes
-  static constexpr int NP = kKc * (PP2 + PP1);                                  // pieces per buffer
+  static constexpr int HSLOTS = (kKc * PP2 + 63) / 64;                          // wave slots of the halo planes (+ pad):
+  static constexpr int A0 = HSLOTS * 64 * 4;                                    // the frame-t planes start on a slot boundary
+  static constexpr int NP = HSLOTS * 64 + kKc * PP1;                            // pieces per buffer
   static constexpr int NI = (NP + kThreads - 1) / kThreads;                     // DMA instructions per thread
   static constexpr int BUF = NP * 4;                                            // floats per buffer
   static constexpr int NB = NBR * NBR;
@@ -534,17 +535,17 @@ __global__ __launch_bounds__(kThreads, MINW) void corr_fwd_glds(const float* __r
 
   // piece p of a buffer -> source: which frame, channel in chunk, in-plane flat offset, overflow past the plane end
   auto describe = [&](int p, bool& is_a, int& cc, int& off, int& over) {
-    is_a = p >= kKc * K::PP2;
+    is_a = p >= K::HSLOTS * 64;
     int gy, start;
     bool real;
     if (!is_a) {
-      cc = p / K::PP2;
+      cc = min(p / K::PP2, kKc - 1);
       const int r = p - cc * K::PP2, hr = r / K::R4, q = r - hr * K::R4;
-      real = hr < K::HR && q < K::G4;
+      real = p < kKc * K::PP2 && hr < K::HR && q < K::G4;
       gy = g.origin + ty0 - g.R + hr;
       start = g.origin + tx0 - g.R + 4 * q;
     } else {
-      const int pa = p - kKc * K::PP2;
+      const int pa = p - K::HSLOTS * 64;
       cc = pa / K::PP1;
       const int r = pa - cc * K::PP1, py = r >> 1, q = r & 1;
       real = r < 2 * kTile;
@@ -557,16 +558,21 @@ __global__ __launch_bounds__(kThreads, MINW) void corr_fwd_glds(const float* __r
     if (!valid) off = min(max(off, 0), plane - 4);
     over = valid ? max(off + 4 - plane, 0) : 0;
   };
-  const float* src[K::NI];
+  // Source of piece i of this thread = wave-uniform base (frame, image, first channel of the chunk: SGPRs, advanced once
+  // per chunk) + a per-lane 32-bit offset that never changes: the DMA instructions take the SGPR-base form and the loop
+  // carries no per-lane address arithmetic.
+  unsigned soff[K::NI];
 #pragma unroll
   for (int i = 0; i < K::NI; ++i) {
     const int p = min(i * kThreads + tid, K::NP - 1);
     bool is_a;
     int cc, off, over;
     describe(p, is_a, cc, off, over);
-    src[i] = (is_a ? in1 : in2) + ((long)n * g.C + c_begin + cc) * plane + off;
+    soff[i] = (unsigned)(cc * plane + off) * 4u;
   }
   const long chunk_stride = (long)kKc * plane;
+  const float* base2 = in2 + ((long)n * g.C + c_begin) * plane;
+  const float* base1 = in1 + ((long)n * g.C + c_begin) * plane;
   // the only pieces that could read past the end of the tensor: last image, last channel, bottom-right straddle
   const bool tail_wg = n == nbatch - 1 && c_end == g.C;
 
@@ -574,18 +580,21 @@ __global__ __launch_bounds__(kThreads, MINW) void corr_fwd_glds(const float* __r
 #pragma unroll
     for (int i = 0; i < K::NI; ++i) {
       const int p = i * kThreads + tid;
-      const float* sp = src[i];
+      unsigned o = soff[i];
       if (tail_wg && last_chunk) {  // workgroup-uniform, once per launch for 1 / (ksplit * batch) of the workgroups
         bool is_a;
         int cc, off, over;
         describe(min(p, K::NP - 1), is_a, cc, off, over);
-        if (cc == kKc - 1) sp -= over;
+        if (cc == kKc - 1) o -= 4u * (unsigned)over;
       }
+      const bool slot_is_a = i * 4 + wave >= K::HSLOTS;  // wave-uniform
+      const char* sbase = reinterpret_cast<const char*>(slot_is_a ? base1 : base2);
       lds_void_t* dst = (lds_void_t*)(buf + (i * kThreads + wave * 64) * 4);
       if (i * kThreads + kThreads <= K::NP || p < K::NP)
-        __builtin_amdgcn_global_load_lds((glb_void_t*)sp, dst, 16, 0, 0);
-      src[i] += chunk_stride;
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(sbase + o), dst, 16, 0, 0);
     }
+    base1 += chunk_stride;
+    base2 += chunk_stride;
   };
   auto fix_tail = [&](float* buf) {  // rotate the shifted pieces of the last plane into place
     __syncthreads();
