@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--width", type=int, default=1067)
     ap.add_argument("--layers", type=int, default=101)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--nchw-trunk", action="store_true", help="inference: keep the fused trunk in NCHW (A/B against channels-last)")
     return ap.parse_args()
 
 
@@ -144,7 +145,7 @@ def main():
     else:
         model.eval()
         from dtt.fuse import fuse_for_inference
-        fuse_for_inference(model)  # frozen BatchNorm folded into the convolutions, fused bias/residual/ReLU epilogue
+        fuse_for_inference(model, channels_last=not args.nchw_trunk)  # frozen BatchNorm folded into the convolutions, fused bias/residual/ReLU epilogue
 
         def step():
             with torch.no_grad():

@@ -237,6 +237,10 @@ int dtt_class_nms(const float* scores, const float* boxes, int images, int num_r
  */
 int dtt_bias_act_inplace(float* x, const float* bias, const float* residual, int batch, int channels,
                          int hw, int relu, void* stream);
+/* Same epilogue for the channels-last trunk: x (rows, channels) row-major, bias along the fastest dimension.
+ * channels % 4 == 0; x, bias and residual 16-byte aligned; residual may be NULL. */
+int dtt_bias_act_nhwc_inplace(float* x, const float* bias, const float* residual, long rows, int channels,
+                              int relu, void* stream);
 
 #ifdef __cplusplus
 }

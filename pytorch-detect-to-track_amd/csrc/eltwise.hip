@@ -54,7 +54,49 @@ __global__ __launch_bounds__(kThreads) void bias_act_kernel(float* __restrict__ 
   }
 }
 
+// Row-major (rows, channels) variant for the channels-last trunk: the bias index is the fastest dimension.
+template <bool RELU, bool RES>
+__global__ __launch_bounds__(kThreads) void bias_act_rows_kernel(float* __restrict__ x, const float* __restrict__ bias,
+                                                                 const float* __restrict__ res, long n4, int c4) {
+  const long stride = (long)gridDim.x * kThreads;
+  for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < n4; i += stride) {
+    const float4 b = reinterpret_cast<const float4*>(bias)[i % c4];
+    float4 v = reinterpret_cast<float4*>(x)[i];
+    v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+    if (RES) {
+      const float4 r = reinterpret_cast<const float4*>(res)[i];
+      v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+    }
+    if (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    reinterpret_cast<float4*>(x)[i] = v;
+  }
+}
+
 }  // namespace
+
+extern "C" int dtt_bias_act_nhwc_inplace(float* x, const float* bias, const float* residual, long rows, int channels,
+                                         int relu, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  DTT_REQUIRE(x && bias, "bias_act_nhwc: null pointer");
+  DTT_REQUIRE(rows > 0 && channels > 0 && channels % 4 == 0, "bias_act_nhwc: channels must be a positive multiple of 4");
+  DTT_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(residual)) & 15) == 0,
+              "bias_act_nhwc: pointers must be 16-byte aligned");
+  const long n4 = rows * (channels / 4);
+  long blocks = (n4 + kThreads * 4 - 1) / (kThreads * 4);
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  if (blocks < 1) blocks = 1;
+  const dim3 grid((unsigned)blocks);
+  const int c4 = channels / 4;
+  if (residual) {
+    if (relu) hipLaunchKernelGGL((bias_act_rows_kernel<true, true>), grid, dim3(kThreads), 0, stream, x, bias, residual, n4, c4);
+    else hipLaunchKernelGGL((bias_act_rows_kernel<false, true>), grid, dim3(kThreads), 0, stream, x, bias, residual, n4, c4);
+  } else {
+    if (relu) hipLaunchKernelGGL((bias_act_rows_kernel<true, false>), grid, dim3(kThreads), 0, stream, x, bias, residual, n4, c4);
+    else hipLaunchKernelGGL((bias_act_rows_kernel<false, false>), grid, dim3(kThreads), 0, stream, x, bias, residual, n4, c4);
+  }
+  DTT_CHECK_LAUNCH("bias_act_rows_kernel");
+  return 1;
+}
 
 extern "C" int dtt_bias_act_inplace(float* x, const float* bias, const float* residual, int batch, int channels,
                                     int hw, int relu, void* stream_) {

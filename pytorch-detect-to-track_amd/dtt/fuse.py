@@ -193,9 +193,105 @@ def fuse_for_training(model):
     return model
 
 
-def fuse_for_inference(model):
+# ------------------------------------------------------------------------------------------------ channels-last inference
+def bias_act_nhwc_(y2d, bias, relu=True):
+    """In place on a (rows, C) row-major view: y = act(y + bias[None, :])."""
+    L = _lib.lib()
+    with torch.cuda.device(y2d.device):
+        check(L.dtt_bias_act_nhwc_inplace(ptr(y2d), ptr(bias), None, y2d.shape[0], y2d.shape[1], int(relu),
+                                          stream_ptr(y2d.device)), "bias_act_nhwc")
+    return y2d
+
+
+def _rows(x):
+    """(N,C,H,W) channels-last tensor -> its (N*H*W, C) row-major view."""
+    return x.permute(0, 2, 3, 1).reshape(-1, x.shape[1])
+
+
+def _from_rows(y2d, n, h, w):
+    return y2d.view(n, h, w, y2d.shape[1]).permute(0, 3, 1, 2)
+
+
+class _NhwcConv:
+    """One folded convolution for the channels-last trunk: 1x1 stride-1 layers are plain GEMMs over the (pixels, C)
+    view (hipBLASLt, bias + ReLU in the GEMM epilogue); everything else is MIOpen's NHWC kernel + the fused pass."""
+
+    def __init__(self, conv, bn=None, extra_bias=None):
+        base = _FusedConv(conv, bn)
+        self.b = base.b if extra_bias is None else (base.b + extra_bias).contiguous()
+        self.kw = base.kw
+        self.is_gemm = conv.kernel_size == (1, 1) and conv.stride == (1, 1)
+        if self.is_gemm:
+            self.wt = base.w.view(base.w.shape[0], base.w.shape[1]).t().contiguous()   # (Cin, Cout)
+        else:
+            self.w = base.w.contiguous(memory_format=torch.channels_last)
+
+    def raw(self, x):
+        """Convolution without bias; x and the result are channels-last."""
+        if self.is_gemm:
+            n, _, h, w = x.shape
+            return _from_rows(torch.mm(_rows(x), self.wt), n, h, w)
+        return F.conv2d(x, self.w, None, **self.kw)
+
+    def act(self, x):
+        """relu(conv(x) + b)."""
+        if self.is_gemm:
+            n, _, h, w = x.shape
+            return _from_rows(torch._addmm_activation(self.b, _rows(x), self.wt), n, h, w)
+        y = F.conv2d(x, self.w, None, **self.kw)
+        bias_act_nhwc_(_rows(y), self.b)
+        return y
+
+
+class _NhwcBottleneck:
+    def __init__(self, blk):
+        self.c1, self.c2 = _NhwcConv(blk.conv1, blk.bn1), _NhwcConv(blk.conv2, blk.bn2)
+        self.down = _NhwcConv(blk.downsample[0], blk.downsample[1]) if blk.downsample is not None else None
+        # both shifts of the block's last step land in the single final pass
+        self.c3 = _NhwcConv(blk.conv3, blk.bn3, extra_bias=self.down.b if self.down is not None else None)
+
+    def __call__(self, x):
+        h = self.c2.act(self.c1.act(x))
+        n, _, hh, ww = h.shape
+        if self.down is None:
+            # residual rides in as the GEMM's C operand; in place over the block input, which nothing reads afterwards
+            # (stage outputs only ever feed downsample blocks)
+            y = _rows(x).addmm_(_rows(h), self.c3.wt)
+        else:
+            y = _rows(self.down.raw(x)).addmm_(_rows(h), self.c3.wt)
+        bias_act_nhwc_(y, self.c3.b)
+        return _from_rows(y, n, hh, ww)
+
+
+class FusedTrunkNHWC:
+    """Inference trunk in channels-last layout.  Same folded weights as FusedTrunk; the 1x1 convolutions (two thirds
+    of the layers) become GEMMs whose epilogue already applies bias + ReLU, the residual add is the GEMM's beta * C
+    term, and MIOpen's NHWC 3x3 kernels need no layout transposes around them.  The four feature maps the D&T ops
+    consume are returned NCHW-contiguous (one transpose each)."""
+
+    def __init__(self, model):
+        b = model.RFCN_base
+        self.stem = _NhwcConv(b[0], b[1])
+        self.pool = b[3]
+        self.stages = [[_NhwcBottleneck(blk) for blk in b[i]] for i in (4, 5, 6, 7)]
+        self.top = _NhwcConv(b[8])
+
+    @torch.no_grad()
+    def __call__(self, x):
+        x = x.contiguous(memory_format=torch.channels_last)
+        x = self.pool(self.stem.act(x))
+        feats = []
+        for stage in self.stages:
+            for blk in stage:
+                x = blk(x)
+            feats.append(x)
+        top = self.top.act(feats[3])
+        return feats[1].contiguous(), feats[2].contiguous(), feats[3].contiguous(), top.contiguous()
+
+
+def fuse_for_inference(model, channels_last=True):
     """Build the fused trunk from the model's current weights (call again after loading a checkpoint)."""
-    model._fused_trunk = FusedTrunk(model)
+    model._fused_trunk = FusedTrunkNHWC(model) if channels_last else FusedTrunk(model)
     return model
 
 

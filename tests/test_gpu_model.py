@@ -123,14 +123,24 @@ def test_fused_inference_trunk_matches_reference_graph():
     im, _, _, _ = make_batch(2, 224, 320, seed=9, device=dev)
     calibrate_batchnorm_(model, im[:, 0])
     x = im[:, 0].contiguous()
+    from dtt.fuse import bias_act_nhwc_
+    for rows, ch in ((7, 4), (1000, 64), (38 * 67 * 2, 1024)):
+        y = torch.from_numpy(rng.normal(size=(rows, ch)).astype(np.float32)).to(dev)
+        b = torch.from_numpy(rng.normal(size=ch).astype(np.float32)).to(dev)
+        for relu in (True, False):
+            ref = y + b
+            ref = torch.relu(ref) if relu else ref
+            assert torch.equal(bias_act_nhwc_(y.clone(), b, relu), ref), (rows, ch, relu)
     with torch.no_grad():
         ref = model._im_to_head(x)
-        fuse_for_inference(model)
-        got = model._im_to_head(x)
-        unfuse(model)
-    for a, b in zip(got, ref):
-        scale = float(b.abs().max())
-        assert float((a - b).abs().max()) < 2e-4 * max(1.0, scale)
+        for channels_last in (False, True):   # NCHW fused trunk and the channels-last / GEMM-epilogue trunk
+            fuse_for_inference(model, channels_last=channels_last)
+            got = model._im_to_head(x)
+            unfuse(model)
+            for a, b in zip(got, ref):
+                assert a.is_contiguous() and a.shape == b.shape
+                scale = float(b.abs().max())
+                assert float((a - b).abs().max()) < 2e-4 * max(1.0, scale), channels_last
 
 
 def test_drivers_round_trip_checkpoint(tmp_path):
