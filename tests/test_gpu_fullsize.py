@@ -1,0 +1,198 @@
+"""The hot-path ops at BASELINE.json's full sizes (600 x 1067 -> 38 x 67 stride-16 maps, 2048 / 1024 / 512 channels,
+d = 8, 6000 / 12000 pre-NMS boxes, 7x7x31 position-sensitive maps), where the scalar oracle would take minutes.
+Checked through size-independent properties that pin the result without it:
+
+  * correlation forward: every output is one dot product -> a few thousand entries recomputed in float64; the
+    zero-displacement channel against an elementwise product; bilinearity; the swap identity
+    corr(a, b)[d, p] = corr(b, a)[-d, p + d];
+  * correlation backward: the op is bilinear, so <corr(u, x2), g> = <u, grad1(g)> and <corr(x1, v), g> = <v, grad2(g)>
+    for arbitrary u, v (adjoint identity);
+  * greedy NMS: the keep list is the unique set with (i) no kept pair above the threshold and (ii) every suppressed
+    box overlapped above the threshold by an earlier kept one -- both verified on the full IoU matrix; idempotence;
+  * PSRoI pooling: constant maps pool to the constant, linearity in the features, adjoint identity for the backward,
+    and a float64 recomputation of sampled bins.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    from dtt import _lib
+    _lib.lib()
+    return torch.device("cuda:0")
+
+
+def _feat(g, shape, dev):
+    return torch.relu(torch.randn(*shape, generator=g, device=dev))
+
+
+CORR_FULL = [(2, 2048, 38, 67, 8, 1, 8, 1, 1),    # conv5
+             (2, 1024, 38, 67, 8, 1, 8, 1, 1),    # conv4
+             (2, 512, 75, 134, 8, 1, 8, 2, 2),    # conv3 (stride 2)
+             (4, 2048, 38, 67, 8, 1, 8, 1, 1)]    # both legs' worth of images in one call
+
+
+@pytest.mark.parametrize("case", CORR_FULL)
+def test_correlation_forward_full_size_properties(dev, case):
+    from dtt.ops import Correlation
+    B, C, H, W, pad, k, d, s1, s2 = case
+    g = torch.Generator(device=dev).manual_seed(sum(case))
+    x1, x2, y1 = _feat(g, (B, C, H, W), dev), _feat(g, (B, C, H, W), dev), _feat(g, (B, C, H, W), dev)
+    corr = Correlation(pad, k, d, s1, s2)
+    out = corr(x1, x2)
+    R = d // s2
+    D = 2 * R + 1
+    oh, ow = out.shape[2], out.shape[3]
+    assert out.shape == (B, D * D, oh, ow) and torch.isfinite(out).all()
+    # (1) sampled entries in float64 (including image corners / borders and out-of-image displacements)
+    rs = np.random.RandomState(1)
+    n = 3000
+    bb, tj, ti = rs.randint(0, B, n), rs.randint(0, D, n), rs.randint(0, D, n)
+    yy, xx = rs.randint(0, oh, n), rs.randint(0, ow, n)
+    yy[:200] = rs.choice([0, 1, oh - 2, oh - 1], 200); xx[:200] = rs.choice([0, 1, ow - 2, ow - 1], 200)
+    x1d, x2d = x1.double(), x2.double()
+    py, px = yy * s1 + d - pad, xx * s1 + d - pad          # centre pixel of output (yy, xx) in unpadded coordinates
+    qy, qx = py + (tj - R) * s2, px + (ti - R) * s2
+    inside = (qy >= 0) & (qy < H) & (qx >= 0) & (qx < W) & (py >= 0) & (py < H) & (px >= 0) & (px < W)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    a = x1d[t(bb), :, t(np.clip(py, 0, H - 1)), t(np.clip(px, 0, W - 1))]
+    b = x2d[t(bb), :, t(np.clip(qy, 0, H - 1)), t(np.clip(qx, 0, W - 1))]
+    want = (a * b).sum(1) / C * t(inside.astype(np.float64))
+    got = out[t(bb), t(tj * D + ti), t(yy), t(xx)].double()
+    assert float((got - want).abs().max()) <= 1e-4          # north-star tolerance
+    assert inside.sum() > n // 2 and (~inside).sum() > 50
+    # (2) zero displacement = mean over channels of the elementwise product on the stride lattice
+    c0 = (x1d * x2d).mean(1)[:, d - pad::s1, d - pad::s1][:, :oh, :ow]
+    assert float((out[:, R * D + R].double() - c0).abs().max()) <= 1e-4
+    # (3) bilinearity in the first argument
+    lin = corr(2.5 * x1 + y1, x2)
+    assert float((lin - (2.5 * out + corr(y1, x2))).abs().max()) <= 2e-4
+    # (4) swap identity on the pixels where both sides are defined (stride-1 lattices)
+    if s1 == 1 and s2 == 1 and pad == d:
+        sw = corr(x2, x1)
+        for (dy, dx) in ((-8, 3), (5, -7), (0, 8), (-1, -1)):
+            ch, chs = (dy + R) * D + (dx + R), (-dy + R) * D + (-dx + R)
+            ys = slice(max(0, -dy), min(oh, oh - dy)); xs = slice(max(0, -dx), min(ow, ow - dx))
+            yt = slice(max(0, dy), min(oh, oh + dy)); xt = slice(max(0, dx), min(ow, ow + dx))
+            assert float((out[:, ch, ys, xs] - sw[:, chs, yt, xt]).abs().max()) <= 1e-5
+
+
+@pytest.mark.parametrize("case", CORR_FULL[:3])
+def test_correlation_backward_full_size_adjoint(dev, case):
+    from dtt.ops import Correlation
+    B, C, H, W, pad, k, d, s1, s2 = case
+    g = torch.Generator(device=dev).manual_seed(7 + sum(case))
+    x1 = _feat(g, (B, C, H, W), dev).requires_grad_(True)
+    x2 = _feat(g, (B, C, H, W), dev).requires_grad_(True)
+    corr = Correlation(pad, k, d, s1, s2)
+    out = corr(x1, x2)
+    go = torch.randn(out.shape, generator=g, device=dev)
+    out.backward(go)
+    u, v = _feat(g, (B, C, H, W), dev), _feat(g, (B, C, H, W), dev)
+    with torch.no_grad():
+        lhs1 = float((corr(u, x2.detach()).double() * go.double()).sum())
+        rhs1 = float((u.double() * x1.grad.double()).sum())
+        lhs2 = float((corr(x1.detach(), v).double() * go.double()).sum())
+        rhs2 = float((v.double() * x2.grad.double()).sum())
+    assert abs(lhs1 - rhs1) <= 1e-4 * max(1.0, abs(lhs1)), (lhs1, rhs1)
+    assert abs(lhs2 - rhs2) <= 1e-4 * max(1.0, abs(lhs2)), (lhs2, rhs2)
+    # sampled gradient entries in float64: dL/dx1[b,c,p] = (1/C) sum_d go[b,d,p] * x2[b,c,p+d]
+    rs = np.random.RandomState(3)
+    R, D = d // s2, 2 * (d // s2) + 1
+    oh, ow = out.shape[2], out.shape[3]
+    for _ in range(40):
+        b, c, y, x = rs.randint(B), rs.randint(C), rs.randint(oh), rs.randint(ow)
+        py, px = y * s1 + d - pad, x * s1 + d - pad
+        acc = 0.0
+        win = torch.zeros(D, D, dtype=torch.float64, device=dev)
+        y0, y1_ = max(0, py - R * s2), min(H - 1, py + R * s2)
+        ys = [(py + (j - R) * s2) for j in range(D)]
+        xs = [(px + (i - R) * s2) for i in range(D)]
+        for j, qy in enumerate(ys):
+            for i, qx in enumerate(xs):
+                if 0 <= qy < H and 0 <= qx < W:
+                    win[j, i] = x2[b, c, qy, qx].double()
+        want = float((go[b, :, y, x].double().view(D, D) * win).sum().item() / C)
+        assert abs(float(x1.grad[b, c, py, px]) - want) <= 1e-5 * max(1.0, abs(want))
+
+
+@pytest.mark.parametrize("n,thresh,seed", [(6000, 0.7, 0), (12000, 0.7, 1), (12000, 0.3, 2), (20000, 0.5, 3)])
+def test_nms_full_size_certificate(dev, n, thresh, seed):
+    from dtt.ops import nms
+    rs = np.random.RandomState(seed)
+    centers = rs.uniform(0, 1000, size=(n // 20, 2))
+    c = centers[rs.randint(0, len(centers), size=n)] + rs.normal(0, 12, size=(n, 2))
+    wh = rs.uniform(16, 200, size=(n, 2))
+    scores = np.sort(rs.uniform(0, 1, size=n))[::-1]
+    dets = torch.from_numpy(np.concatenate([c - wh / 2, c + wh / 2, scores[:, None]], 1).astype(np.float32)).to(dev)
+    keep = nms(dets, thresh).view(-1).long()
+    assert keep.numel() > 0 and bool((keep[1:] > keep[:-1]).all())      # sorted, unique (input is score-sorted)
+    # IoU exactly as the reference kernel computes it (nms_cuda_kernel.cu:31-42), float32, +1 widths
+    bx = dets[:, :4]
+    area = (bx[:, 2] - bx[:, 0] + 1) * (bx[:, 3] - bx[:, 1] + 1)
+    kept = torch.zeros(n, dtype=torch.bool, device=dev); kept[keep] = True
+    kb = bx[keep]
+    ka = area[keep]
+    covered = torch.zeros(n, dtype=torch.bool, device=dev)
+    worst_kept = 0.0
+    for s in range(0, n, 2048):                                          # row blocks of the (n x |keep|) IoU matrix
+        q = bx[s:s + 2048]
+        w = (torch.min(q[:, None, 2], kb[None, :, 2]) - torch.max(q[:, None, 0], kb[None, :, 0]) + 1).clamp(min=0)
+        h = (torch.min(q[:, None, 3], kb[None, :, 3]) - torch.max(q[:, None, 1], kb[None, :, 1]) + 1).clamp(min=0)
+        inter = w * h
+        iou = inter / (area[s:s + 2048, None] + ka[None, :] - inter)
+        earlier = keep[None, :] < torch.arange(s, min(n, s + 2048), device=dev)[:, None]
+        hit = ((iou > thresh) & earlier).any(1)
+        covered[s:s + 2048] = hit
+    assert not bool((covered & kept).any()), "a kept box is suppressed by an earlier kept box"
+    assert bool((covered | kept).all()), "a dropped box has no earlier kept box above the threshold"
+    again = nms(dets[keep].contiguous(), thresh).view(-1).long()        # idempotence
+    assert again.numel() == keep.numel() and bool((again == torch.arange(keep.numel(), device=dev)).all())
+
+
+def test_psroi_full_size_properties(dev):
+    from dtt.ops import _PSRoIPooling
+    B, od, gsz, H, W = 4, 31, 7, 38, 67
+    C = od * gsz * gsz
+    g = torch.Generator(device=dev).manual_seed(5)
+    rs = np.random.RandomState(5)
+    R = 1200
+    x1 = rs.uniform(-30, 1040, R); y1 = rs.uniform(-30, 580, R)
+    w = rs.uniform(8, 700, R); h = rs.uniform(8, 500, R)
+    rois = torch.from_numpy(np.stack([rs.randint(0, B, R), x1, y1, x1 + w, y1 + h], 1).astype(np.float32)).to(dev)
+    pool = _PSRoIPooling(gsz, gsz, 1 / 16.0, gsz, od)
+    f = torch.randn(B, C, H, W, generator=g, device=dev).requires_grad_(True)
+    out = pool(f, rois)
+    assert out.shape == (R, od, gsz, gsz)
+    # constant maps pool to the constant wherever the bin is not empty, and to 0 where it is
+    const = pool(torch.full((B, C, H, W), 3.25, device=dev), rois)
+    assert bool(((const == 3.25) | (const == 0)).all()) and float((const == 3.25).float().mean()) > 0.5
+    # linearity
+    f2 = torch.randn(B, C, H, W, generator=g, device=dev)
+    assert float((pool(1.5 * f.detach() + f2, rois) - (1.5 * out.detach() + pool(f2, rois))).abs().max()) <= 1e-4
+    # adjoint identity for the backward
+    go = torch.randn(out.shape, generator=g, device=dev)
+    out.backward(go)
+    lhs = float((pool(f2, rois).double() * go.double()).sum())
+    rhs = float((f2.double() * f.grad.double()).sum())
+    assert abs(lhs - rhs) <= 1e-4 * max(1.0, abs(lhs)), (lhs, rhs)
+    # sampled bins recomputed in float64 with the reference's bin arithmetic (psroi_pooling_kernel.cu:15-80)
+    fd = f.detach().double().cpu().numpy(); rn = rois.cpu().numpy(); on = out.detach().cpu().numpy()
+    r32 = np.float32
+    for _ in range(300):
+        n, ct, ph, pw = rs.randint(R), rs.randint(od), rs.randint(gsz), rs.randint(gsz)
+        b = int(rn[n, 0])
+        sw, sh = r32(np.round(rn[n, 1])) * r32(0.0625), r32(np.round(rn[n, 2])) * r32(0.0625)
+        ew, eh = r32(np.round(rn[n, 3]) + 1.0) * r32(0.0625), r32(np.round(rn[n, 4]) + 1.0) * r32(0.0625)
+        rw, rh = max(r32(ew - sw), 0.1), max(r32(eh - sh), 0.1)
+        bh, bw = r32(rh / r32(gsz)), r32(rw / r32(gsz))
+        hs = int(min(max(np.floor(r32(r32(ph) * bh + sh)), 0), H)); he = int(min(max(np.ceil(r32(r32(ph + 1) * bh + sh)), 0), H))
+        ws = int(min(max(np.floor(r32(r32(pw) * bw + sw)), 0), W)); we = int(min(max(np.ceil(r32(r32(pw + 1) * bw + sw)), 0), W))
+        c = (ct * gsz + ph) * gsz + pw
+        want = 0.0 if (he <= hs or we <= ws) else fd[b, c, hs:he, ws:we].mean()
+        assert abs(on[n, ct, ph, pw] - want) <= 1e-5 * max(1.0, abs(want)), (n, ct, ph, pw)
