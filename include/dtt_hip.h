@@ -242,6 +242,13 @@ int dtt_bias_act_inplace(float* x, const float* bias, const float* residual, int
 int dtt_bias_act_nhwc_inplace(float* x, const float* bias, const float* residual, long rows, int channels,
                               int relu, void* stream);
 
+/* Row-major GEMM with the bottleneck epilogue: out (rows, n) = act(a (rows, k) * w (k, n) + bias[n] (+ residual
+ * (rows, n))); residual may be NULL and may alias out.  A library GEMM (hipBLASLt) -- the entry point exists for the
+ * epilogue: frozen-BatchNorm shift + `out += residual` + ReLU of faster_rcnn/resnet.py:100-107 in the GEMM itself.
+ * workspace: caller-owned scratch for the library (32 MiB is plenty); plans are cached per shape. */
+int dtt_gemm_bias_act(float* out, const float* a, const float* w, const float* bias, const float* residual,
+                      long rows, int k, int n, int relu, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

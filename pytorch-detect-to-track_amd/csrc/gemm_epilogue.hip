@@ -1,0 +1,81 @@
+// Row-major GEMM with the whole bottleneck epilogue in the GEMM: out = act(a * w + bias[n] (+ residual)).
+//
+// The 1x1 convolutions of the channels-last trunk are plain library GEMMs over the (pixels, channels) view
+// (hipBLASLt; a hand-written kernel would have to beat Tensile's fp32 MFMA tiles to earn its place).  What this
+// entry point adds over calling the library through PyTorch is the epilogue the reference's blocks need and
+// PyTorch does not expose: frozen-BatchNorm shift + residual add (the GEMM's beta * C operand, C == D allowed)
+// + ReLU in one pass (faster_rcnn/resnet.py:100-107 `out = bn3(conv3(out)); out += residual; out = relu(out)`).
+// Row-major operands are handed to the column-major library transposed: out^T (n x rows) = w^T (n x k) * a^T
+// (k x rows), so the per-channel bias runs along the library's M dimension, where its bias epilogue lives.
+#include "common.h"
+#include <hipblaslt/hipblaslt.h>
+#include <map>
+#include <mutex>
+#include <tuple>
+
+namespace {
+
+struct Plan {
+  hipblasLtMatmulDesc_t desc = nullptr;
+  hipblasLtMatrixLayout_t la = nullptr, lb = nullptr, lc = nullptr;
+  hipblasLtMatmulHeuristicResult_t heur;
+  bool ok = false;
+};
+
+std::mutex g_mu;
+std::map<int, hipblasLtHandle_t> g_handles;                                     // per device
+std::map<std::tuple<int, long, int, int, int, int>, Plan> g_plans;              // (device, rows, k, n, relu, residual)
+
+}  // namespace
+
+extern "C" int dtt_gemm_bias_act(float* out, const float* a, const float* w, const float* bias,
+                                 const float* residual, long rows, int k, int n, int relu, void* workspace,
+                                 size_t workspace_bytes, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  DTT_REQUIRE(out && a && w && bias, "gemm_bias_act: null pointer");
+  DTT_REQUIRE(rows > 0 && k > 0 && n > 0, "gemm_bias_act: bad shape");
+  int dev = 0;
+  DTT_REQUIRE(hipGetDevice(&dev) == hipSuccess, "gemm_bias_act: hipGetDevice failed");
+  std::lock_guard<std::mutex> lock(g_mu);
+  hipblasLtHandle_t& handle = g_handles[dev];
+  if (!handle) DTT_REQUIRE(hipblasLtCreate(&handle) == HIPBLAS_STATUS_SUCCESS, "gemm_bias_act: hipblasLtCreate failed");
+  Plan& p = g_plans[std::make_tuple(dev, rows, k, n, relu, residual ? 1 : 0)];
+  if (!p.ok) {
+    DTT_REQUIRE(hipblasLtMatmulDescCreate(&p.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F) == HIPBLAS_STATUS_SUCCESS,
+                "gemm_bias_act: desc");
+    const hipblasOperation_t op = HIPBLAS_OP_N;
+    hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSA, &op, sizeof(op));
+    hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSB, &op, sizeof(op));
+    const hipblasLtEpilogue_t epi = relu ? HIPBLASLT_EPILOGUE_RELU_BIAS : HIPBLASLT_EPILOGUE_BIAS;
+    DTT_REQUIRE(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_EPILOGUE, &epi, sizeof(epi)) ==
+                    HIPBLAS_STATUS_SUCCESS, "gemm_bias_act: epilogue attribute");
+    // column-major views: A = w^T (n x k, ld n), B = a^T (k x rows, ld k), C = D = out^T (n x rows, ld n)
+    DTT_REQUIRE(hipblasLtMatrixLayoutCreate(&p.la, HIP_R_32F, n, k, n) == HIPBLAS_STATUS_SUCCESS &&
+                    hipblasLtMatrixLayoutCreate(&p.lb, HIP_R_32F, k, rows, k) == HIPBLAS_STATUS_SUCCESS &&
+                    hipblasLtMatrixLayoutCreate(&p.lc, HIP_R_32F, n, rows, n) == HIPBLAS_STATUS_SUCCESS,
+                "gemm_bias_act: layouts");
+    // the bias pointer takes part in kernel selection on some versions: set it before asking
+    hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias));
+    hipblasLtMatmulPreference_t pref;
+    DTT_REQUIRE(hipblasLtMatmulPreferenceCreate(&pref) == HIPBLAS_STATUS_SUCCESS, "gemm_bias_act: preference");
+    const uint64_t ws = workspace ? workspace_bytes : 0;
+    hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &ws, sizeof(ws));
+    int found = 0;
+    const hipblasStatus_t st = hipblasLtMatmulAlgoGetHeuristic(handle, p.desc, p.la, p.lb, p.lc, p.lc, pref, 1,
+                                                               &p.heur, &found);
+    hipblasLtMatmulPreferenceDestroy(pref);
+    DTT_REQUIRE(st == HIPBLAS_STATUS_SUCCESS && found > 0, "gemm_bias_act: no hipBLASLt kernel for %ld x %d x %d", rows,
+                k, n);
+    p.ok = true;
+  }
+  DTT_REQUIRE(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias)) ==
+                  HIPBLAS_STATUS_SUCCESS, "gemm_bias_act: bias pointer");
+  DTT_REQUIRE(p.heur.workspaceSize <= (workspace ? workspace_bytes : 0), "gemm_bias_act: workspace too small (%zu < %zu)",
+              workspace ? workspace_bytes : (size_t)0, (size_t)p.heur.workspaceSize);
+  const float alpha = 1.f, beta = residual ? 1.f : 0.f;
+  const float* c = residual ? residual : out;
+  const hipblasStatus_t st = hipblasLtMatmul(handle, p.desc, &alpha, w, p.la, a, p.lb, &beta, c, p.lc, out, p.lc,
+                                             &p.heur.algo, workspace, workspace ? workspace_bytes : 0, stream);
+  DTT_REQUIRE(st == HIPBLAS_STATUS_SUCCESS, "gemm_bias_act: hipblasLtMatmul failed (%d)", (int)st);
+  return 1;
+}

@@ -203,6 +203,25 @@ def bias_act_nhwc_(y2d, bias, relu=True):
     return y2d
 
 
+_GEMM_WS = {}
+
+
+def gemm_bias_act_(out2d, a2d, wt, bias, residual2d=None, relu=True):
+    """out2d (rows, n) = act(a2d (rows, k) @ wt (k, n) + bias (+ residual2d)); residual2d may be out2d itself.
+    One hipBLASLt launch (dtt_gemm_bias_act): bias, residual add and ReLU live in the GEMM epilogue."""
+    assert out2d.is_contiguous() and a2d.is_contiguous() and wt.is_contiguous() and out2d.dtype == torch.float32
+    dev = out2d.device
+    ws = _GEMM_WS.get(dev)
+    if ws is None:
+        ws = _GEMM_WS[dev] = torch.empty(32 << 20, dtype=torch.uint8, device=dev)
+    L = _lib.lib()
+    with torch.cuda.device(dev):
+        check(L.dtt_gemm_bias_act(ptr(out2d), ptr(a2d), ptr(wt), ptr(bias), ptr(residual2d) if residual2d is not None else None,
+                                  a2d.shape[0], a2d.shape[1], wt.shape[1], int(relu), ptr(ws), ws.numel(),
+                                  stream_ptr(dev)), "gemm_bias_act")
+    return out2d
+
+
 def _rows(x):
     """(N,C,H,W) channels-last tensor -> its (N*H*W, C) row-major view."""
     return x.permute(0, 2, 3, 1).reshape(-1, x.shape[1])
@@ -253,13 +272,11 @@ class _NhwcBottleneck:
     def __call__(self, x):
         h = self.c2.act(self.c1.act(x))
         n, _, hh, ww = h.shape
-        if self.down is None:
-            # residual rides in as the GEMM's C operand; in place over the block input, which nothing reads afterwards
-            # (stage outputs only ever feed downsample blocks)
-            y = _rows(x).addmm_(_rows(h), self.c3.wt)
-        else:
-            y = _rows(self.down.raw(x)).addmm_(_rows(h), self.c3.wt)
-        bias_act_nhwc_(y, self.c3.b)
+        # relu(conv3(h) + shift + shortcut) in ONE GEMM: the shortcut rides in as the C operand and is overwritten in
+        # place -- for identity shortcuts that is the block input, which nothing reads afterwards (stage outputs only
+        # ever feed downsample blocks, which write into their own projection buffer)
+        res = _rows(x) if self.down is None else _rows(self.down.raw(x))
+        y = gemm_bias_act_(res, _rows(h), self.c3.wt, self.c3.b, residual2d=res, relu=True)
         return _from_rows(y, n, hh, ww)
 
 

@@ -131,6 +131,20 @@ def test_fused_inference_trunk_matches_reference_graph():
             ref = y + b
             ref = torch.relu(ref) if relu else ref
             assert torch.equal(bias_act_nhwc_(y.clone(), b, relu), ref), (rows, ch, relu)
+    from dtt.fuse import gemm_bias_act_
+    for rows, k, n in ((33, 8, 12), (10184, 256, 1024), (2000, 512, 2048)):
+        a = torch.from_numpy(rng.normal(size=(rows, k)).astype(np.float32)).to(dev)
+        w = torch.from_numpy((rng.normal(size=(k, n)) / np.sqrt(k)).astype(np.float32)).to(dev)
+        b = torch.from_numpy(rng.normal(size=n).astype(np.float32)).to(dev)
+        r = torch.from_numpy(rng.normal(size=(rows, n)).astype(np.float32)).to(dev)
+        want = (a.double() @ w.double() + b.double())
+        for res in (None, r):
+            for relu in (True, False):
+                ref = want + (res.double() if res is not None else 0)
+                ref = torch.relu(ref) if relu else ref
+                out = res.clone() if res is not None else torch.empty(rows, n, device=dev)
+                got = gemm_bias_act_(out, a, w, b, residual2d=out if res is not None else None, relu=relu)  # in place over the residual
+                assert float((got.double() - ref).abs().max()) <= 1e-4, (rows, k, n, res is not None, relu)
     with torch.no_grad():
         ref = model._im_to_head(x)
         for channels_last in (False, True):   # NCHW fused trunk and the channels-last / GEMM-epilogue trunk
