@@ -249,6 +249,22 @@ int dtt_bias_act_nhwc_inplace(float* x, const float* bias, const float* residual
 int dtt_gemm_bias_act(float* out, const float* a, const float* w, const float* bias, const float* residual,
                       long rows, int k, int n, int relu, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---------------------------------------------------------------- zero-jump Viterbi tube linking
+ * Replaces VideoPostProcessor._make_tubes / _zero_jump_link / _score_of_edge (lib/model/utils/tracking_utils.py:
+ * 86-124, 127-264, 268-290) for `problems` independent (video, class) problems of `frames` frames each, in three
+ * launches: per-frame NMS in the given priority order (first max_per_image <= 32 survivors), tracklet-link masks, and
+ * all K = min_t n_t Viterbi paths per problem.  T = frames - 1 frames take part (the last one only closes the last
+ * pair).  dets (problems, frames, max_dets <= 1024, det_stride >= 5) rows [x1,y1,x2,y2,score,...], n (problems,
+ * frames) row counts; trk (problems, frames, 2, max_tracklets <= 512, 4) or NULL, m (problems, frames) tracklet
+ * counts (-1 = the frame has none).  Outputs: kept_boxes (problems, T, 32, 4), kept_scores (problems, T, 32), kept_n
+ * (problems, T), path_idx (problems, 32, T) box index per frame, path_total (problems, 32) = best score / frames,
+ * n_paths (problems) -- 0 when a frame has no detection (the reference raises).  Ties: lowest index. */
+size_t dtt_tube_link_workspace_bytes(int problems, int frames);
+int dtt_tube_link(const float* dets, int det_stride, const int* n, const float* trk, const int* m, int problems,
+                  int frames, int max_dets, int max_tracklets, int max_per_image, float nms_thresh, float* kept_boxes,
+                  float* kept_scores, int* kept_n, int* path_idx, float* path_total, int* n_paths, void* workspace,
+                  size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
