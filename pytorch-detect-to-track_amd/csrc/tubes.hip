@@ -154,23 +154,29 @@ __global__ __launch_bounds__(64) void tube_viterbi_kernel(const float* __restric
   for (int k = 0; k < K; ++k) {
     // ---- forward pass, t = T-2 .. 0: D[t][a] = max_b ((s[t][a] + s[t+1][b]) (+1) + D[t+1][b]) over alive b (:207-218)
     float D = 0.f;                                        // data_scores[T-1] = 0
+    // rows are fetched one step ahead of their use: the recursion is a chain of dependent steps, so an exposed global
+    // load per step would be its whole cost
+    float sb = (lane < kMaxK && T >= 2) ? S[(T - 1) * kMaxK + lane] : 0.f;      // scores of frame t + 1
+    float sa = (lane < kMaxK && T >= 2) ? S[(T - 2) * kMaxK + lane] : 0.f;      // scores of frame t
+    unsigned bn = (lane < kMaxK && T >= 2) ? Bn[(T - 2) * kMaxK + lane] : 0u;
     for (int t = T - 2; t >= 0; --t) {
-      const float sa = lane < kMaxK ? S[t * kMaxK + lane] : 0.f;
-      const float sb = lane < kMaxK ? S[(t + 1) * kMaxK + lane] : 0.f;
-      const unsigned bn = lane < kMaxK ? Bn[t * kMaxK + lane] : 0u;
-      unsigned al = alive[t + 1];
+      const int tp = max(t - 1, 0);
+      const float sa_pref = lane < kMaxK ? S[tp * kMaxK + lane] : 0.f;
+      const unsigned bn_pref = lane < kMaxK ? Bn[tp * kMaxK + lane] : 0u;
+      unsigned al = __builtin_amdgcn_readfirstlane(alive[t + 1]);   // wave-uniform: the loop runs on the scalar unit
       float best = -INFINITY;
       int arg = 0;
       while (al) {
         const int b = __builtin_ctz(al);
         al &= al - 1;
-        float e = sa + __shfl(sb, b, 64);
+        float e = sa + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sb), b));
         if ((bn >> b) & 1u) e += 1.0f;
-        e = e + __shfl(D, b, 64);
+        e = e + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(D), b));
         if (e > best) { best = e; arg = b; }               // first maximum wins
       }
       if (lane < kMaxK) back[t * kMaxK + lane] = (unsigned char)arg;
       D = best;
+      sb = sa; sa = sa_pref; bn = bn_pref;
     }
     // ---- start box: highest D[0] among the alive boxes of frame 0, lowest index among equals (:222-223)
     const unsigned a0 = alive[0];
