@@ -86,6 +86,10 @@ cfg = AttrDict({
     "FEAT_STRIDE": [16],                         # (*)
     "CUDA": False,
     "CROP_RESIZE_WITH_MAX_POOL": True,
+    # not in the reference's config: its _RFCN hard-codes max_displacement = 8 (rfcn.py:58-60).  BASELINE.json's
+    # config 5 asks for d = 16; set via `--set CORR_MAX_DISPLACEMENT 16` (changes corr_bbox_net's input width, so
+    # checkpoints are only interchangeable at the default)
+    "CORR_MAX_DISPLACEMENT": 8,
 })
 
 

@@ -169,9 +169,10 @@ class _RFCN(nn.Module):
         nn.init.normal_(self.RFCN_cls_net.weight, 0.0, 0.01)
         self.RFCN_bbox_net = nn.Conv2d(512, 4 * self.n_reg_classes * 7 * 7, [1, 1], padding=0, stride=1)
         nn.init.normal_(self.RFCN_bbox_net.weight, 0.0, 0.01)
-        self.conv3_corr_layer = Correlation(pad_size=8, kernel_size=1, max_displacement=8, stride1=2, stride2=2)
-        self.conv4_corr_layer = Correlation(pad_size=8, kernel_size=1, max_displacement=8, stride1=1, stride2=1)
-        self.conv5_corr_layer = Correlation(pad_size=8, kernel_size=1, max_displacement=8, stride1=1, stride2=1)
+        d = int(getattr(c, "CORR_MAX_DISPLACEMENT", 8))  # 8 in the reference (rfcn.py:58-60); 16 = BASELINE config 5
+        self.conv3_corr_layer = Correlation(pad_size=d, kernel_size=1, max_displacement=d, stride1=2, stride2=2)
+        self.conv4_corr_layer = Correlation(pad_size=d, kernel_size=1, max_displacement=d, stride1=1, stride2=1)
+        self.conv5_corr_layer = Correlation(pad_size=d, kernel_size=1, max_displacement=d, stride1=1, stride2=1)
         self.RFCN_cls_score = nn.AvgPool2d((7, 7), stride=(7, 7))
         self.RFCN_bbox_pred = nn.AvgPool2d((7, 7), stride=(7, 7))
         self.RFCN_tracking_pred = nn.AvgPool2d((7, 7), stride=(7, 7))
@@ -355,7 +356,9 @@ class resnet(_RFCN):
             sd = torch.load(self.model_rfcn_path, map_location="cpu")["model"]
             own = self.state_dict()
             self.load_state_dict({k: v for k, v in sd.items() if k in own}, strict=False)
-        tracking_in = 2 * 4 * self.n_reg_classes * 49 + 81 + 289 + 289  # 1051 when class agnostic (resnet.py:311)
+        d = int(getattr(self._cfg, "CORR_MAX_DISPLACEMENT", 8))
+        d3, d45 = (2 * (d // 2) + 1) ** 2, (2 * d + 1) ** 2
+        tracking_in = 2 * 4 * self.n_reg_classes * 49 + d3 + 2 * d45  # 392 + 81 + 289 + 289 = 1051 (resnet.py:311)
         self.corr_bbox_net = nn.Conv2d(tracking_in, 4 * self.n_reg_classes * 7 * 7, [1, 1], padding=0, stride=1)
         nn.init.normal_(self.corr_bbox_net.weight, 0.0, 0.01)
 

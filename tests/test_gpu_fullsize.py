@@ -34,7 +34,9 @@ def _feat(g, shape, dev):
 CORR_FULL = [(2, 2048, 38, 67, 8, 1, 8, 1, 1),    # conv5
              (2, 1024, 38, 67, 8, 1, 8, 1, 1),    # conv4
              (2, 512, 75, 134, 8, 1, 8, 2, 2),    # conv3 (stride 2)
-             (4, 2048, 38, 67, 8, 1, 8, 1, 1)]    # both legs' worth of images in one call
+             (4, 2048, 38, 67, 8, 1, 8, 1, 1),    # both legs' worth of images in one call
+             (1, 2048, 36, 63, 16, 1, 16, 1, 1),  # config 5 (563 x 1000, d = 16): conv5, 33 x 33 displacements
+             (1, 512, 71, 125, 16, 1, 16, 2, 2)]  # config 5 conv3 (stride 2, R = 8)
 
 
 @pytest.mark.parametrize("case", CORR_FULL)
@@ -75,14 +77,14 @@ def test_correlation_forward_full_size_properties(dev, case):
     # (4) swap identity on the pixels where both sides are defined (stride-1 lattices)
     if s1 == 1 and s2 == 1 and pad == d:
         sw = corr(x2, x1)
-        for (dy, dx) in ((-8, 3), (5, -7), (0, 8), (-1, -1)):
+        for (dy, dx) in ((-R, 3), (5, -7), (0, R), (-1, -1)):
             ch, chs = (dy + R) * D + (dx + R), (-dy + R) * D + (-dx + R)
             ys = slice(max(0, -dy), min(oh, oh - dy)); xs = slice(max(0, -dx), min(ow, ow - dx))
             yt = slice(max(0, dy), min(oh, oh + dy)); xt = slice(max(0, dx), min(ow, ow + dx))
             assert float((out[:, ch, ys, xs] - sw[:, chs, yt, xt]).abs().max()) <= 1e-5
 
 
-@pytest.mark.parametrize("case", CORR_FULL[:3])
+@pytest.mark.parametrize("case", CORR_FULL[:3] + CORR_FULL[4:])
 def test_correlation_backward_full_size_adjoint(dev, case):
     from dtt.ops import Correlation
     B, C, H, W, pad, k, d, s1, s2 = case

@@ -251,3 +251,23 @@ def test_fused_training_trunk_matches_reference_graph():
     assert set(g_ref) == set(g_fus) and len(g_ref) > 30
     for n in g_ref:
         assert float((g_ref[n] - g_fus[n]).norm()) <= 0.1 * float(g_ref[n].norm()), n
+
+
+def test_config5_displacement_16_forward():
+    """BASELINE.json config 5's correlation window (d = 16: 33 x 33 displacements at conv4 / conv5, 17 x 17 at conv3) as
+    an explicit option; the tracking head widens to 2859 input channels."""
+    import copy
+    from dtt.config import cfg
+    from dtt.fuse import fuse_for_inference
+    from dtt.synth import build_model, calibrate_batchnorm_, make_batch
+    c = copy.deepcopy(cfg)
+    c.CORR_MAX_DISPLACEMENT = 16
+    dev = torch.device("cuda:0")
+    model = build_model(50, class_agnostic=True, cfg=c).to(dev).eval()
+    assert model.corr_bbox_net.in_channels == 2 * 4 * 49 + 17 * 17 + 2 * 33 * 33 == 2859
+    im, info, gt, nb = make_batch(1, 288, 400, seed=21, device=dev)
+    calibrate_batchnorm_(model, im[:, 0])
+    fuse_for_inference(model)
+    with torch.no_grad():
+        rois, cls_prob, bbox_pred, tracking_pred = model(im, info, gt, nb)[:4]
+    assert tracking_pred.shape == (rois.shape[1] * rois.shape[2], 4) and torch.isfinite(tracking_pred).all()
