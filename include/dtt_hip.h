@@ -99,6 +99,13 @@ int dtt_psroi_pool_vote_forward(const float* bottom_data, float spatial_scale, i
                                 int pooled_height, int pooled_width, const float* bottom_rois,
                                 int group_size, int output_dim, float* top_data,
                                 float* vote_out, void* stream);
+/* Vote only (what the R-FCN heads consume at inference): the pooled bins never take the reference layout -- they go
+ * to `scratch` (channels * num_rois floats, channel-major: coalesced stores and coalesced vote reads) and only
+ * vote_out (num_rois, output_dim) is defined on return.  Same bin arithmetic, summation order and division as the
+ * two-step path, so vote_out is bit-identical to dtt_psroi_pool_vote_forward's. */
+int dtt_psroi_vote_forward(const float* bottom_data, float spatial_scale, int batch_size, int num_rois, int height,
+                           int width, int channels, int pooled_height, int pooled_width, const float* bottom_rois,
+                           int group_size, int output_dim, float* scratch, float* vote_out, void* stream);
 
 /* ---------------------------------------------------------------- NMS
  * Replaces nms_cuda_compute (nms/src/nms_cuda_kernel.cu:87-161).  boxes: (boxes_num, boxes_dim>=4)

@@ -43,8 +43,42 @@ __device__ __forceinline__ Bin psroi_bin(const float* __restrict__ roi, float sp
 }
 
 constexpr int kThreads = 256;
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+#ifndef DTT_PSROI_ABLATE
+#define DTT_PSROI_ABLATE 0   // developer timing experiments: 1 = staging only, 2 = no plane staging, 3 = no bin geometry
+#endif
 
-// grid (channels, batch).  LDS: height*width floats.
+// Stage one contiguous plane (hw floats at 4-byte alignment) into LDS.  All of a thread's 16-byte loads are issued
+// before the first LDS write: a plain `plane[i] = src[i]` loop waits out one global-load latency per element
+// (10 per thread at 38 x 67), which is what used to bound the whole kernel.
+__device__ __forceinline__ void stage_plane(float* __restrict__ plane, const float* __restrict__ src, int hw) {
+  const int hw4 = hw >> 2;
+  constexpr int U = 4;
+  const int nt = (int)blockDim.x;
+  for (int base = 0; base < hw4; base += nt * U) {
+    f32x4_t v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int idx = base + u * nt + (int)threadIdx.x;
+      if (idx < hw4) __builtin_memcpy(&v[u], src + 4 * idx, 16);   // global_load_dwordx4 at 4-byte alignment
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int idx = base + u * nt + (int)threadIdx.x;
+      if (idx < hw4) *reinterpret_cast<f32x4_t*>(plane + 4 * idx) = v[u];
+    }
+  }
+  const int t = (hw4 << 2) + (int)threadIdx.x;
+  if (t < hw) plane[t] = src[t];
+}
+#ifndef DTT_PSROI_CT
+#define DTT_PSROI_CT 1   // class planes per workgroup in the forward (measured: 1 > 2 > 4 at the D&T shapes)
+#endif
+
+// grid (channels, batch).  LDS: height*width floats.  TR: write the bins channel-major, top[c][roi] -- every store
+// instruction covers consecutive RoIs of one plane (coalesced) instead of one dword per 6 KB; only the fused vote
+// reads that layout.
+template <bool TR>
 __global__ __launch_bounds__(kThreads) void psroi_fwd_plane(
     const float* __restrict__ bottom_data, float spatial_scale, int num_rois, int height, int width, int channels,
     int pooled_height, int pooled_width, const float* __restrict__ bottom_rois, int group_size, int output_dim,
@@ -55,19 +89,74 @@ __global__ __launch_bounds__(kThreads) void psroi_fwd_plane(
   if (gw >= pooled_width || gh >= pooled_height || ctop >= output_dim) return;  // channel feeds no bin
   const int hw = height * width;
   const float* src = bottom_data + ((long)b * channels + c) * hw;
-  for (int i = threadIdx.x; i < hw; i += kThreads) plane[i] = src[i];
+#if DTT_PSROI_ABLATE != 2
+  stage_plane(plane, src, hw);
+#endif
+  __syncthreads();
+#if DTT_PSROI_ABLATE == 1
+  if (num_rois > 0) return;
+#endif
+  for (int n = threadIdx.x; n < num_rois; n += blockDim.x) {
+    const float* roi = bottom_rois + (long)n * 5;
+    if ((int)roi[0] != b) continue;
+#if DTT_PSROI_ABLATE == 3
+    Bin bin; bin.hstart = (int)roi[2] & 15; bin.hend = bin.hstart + 2; bin.wstart = (int)roi[1] & 31; bin.wend = bin.wstart + 3; bin.empty = false;
+#else
+    const Bin bin = psroi_bin(roi, spatial_scale, gh, gw, pooled_height, pooled_width, height, width);
+#endif
+    float out_sum = 0;
+    for (int h = bin.hstart; h < bin.hend; ++h)
+      for (int w = bin.wstart; w < bin.wend; ++w) out_sum += plane[h * width + w];
+    const float bin_area = (float)((bin.hend - bin.hstart) * (bin.wend - bin.wstart));
+    const long index = TR ? (long)c * num_rois + n : (((long)n * output_dim + ctop) * pooled_height + gh) * pooled_width + gw;
+    top_data[index] = bin.empty ? 0.f : out_sum / bin_area;
+    if (!TR && mapping_channel) mapping_channel[index] = c;
+  }
+}
+
+// Several class planes per workgroup: one workgroup owns one bin position (gh, gw) of CT consecutive output
+// classes, so the bin geometry of a RoI (four double-precision roundings, two divisions -- the bulk of the
+// arithmetic) and its RoI row are computed / read once for CT planes instead of once per plane.
+// grid (group_size^2 * ceil(output_dim / CT), batch).  LDS: CT * height * width floats.
+template <int CT>
+__global__ __launch_bounds__(kThreads) void psroi_fwd_planes(
+    const float* __restrict__ bottom_data, float spatial_scale, int num_rois, int height, int width, int channels,
+    int pooled_height, int pooled_width, const float* __restrict__ bottom_rois, int group_size, int output_dim,
+    float* __restrict__ top_data, int* __restrict__ mapping_channel) {
+  extern __shared__ __attribute__((aligned(16))) float plane[];
+  const int gg = group_size * group_size;
+  const int pos = blockIdx.x % gg, ctop0 = (blockIdx.x / gg) * CT, b = blockIdx.y;
+  const int gw = pos % group_size, gh = pos / group_size;
+  if (gw >= pooled_width || gh >= pooled_height) return;  // position feeds no bin
+  const int hw = height * width;
+  const int nct = min(CT, output_dim - ctop0);
+  for (int ct = 0; ct < nct; ++ct) {
+    const int c = (ctop0 + ct) * gg + pos;
+    stage_plane(plane + ct * hw, bottom_data + ((long)b * channels + c) * hw, hw);   // ct * hw * 4 B keeps 16-byte LDS alignment only for hw % 4 == 0
+  }
   __syncthreads();
   for (int n = threadIdx.x; n < num_rois; n += kThreads) {
     const float* roi = bottom_rois + (long)n * 5;
     if ((int)roi[0] != b) continue;
     const Bin bin = psroi_bin(roi, spatial_scale, gh, gw, pooled_height, pooled_width, height, width);
-    float out_sum = 0;
+    float out_sum[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) out_sum[ct] = 0.f;
     for (int h = bin.hstart; h < bin.hend; ++h)
-      for (int w = bin.wstart; w < bin.wend; ++w) out_sum += plane[h * width + w];
+      for (int w = bin.wstart; w < bin.wend; ++w) {
+        const int o = h * width + w;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) out_sum[ct] += plane[(ct < nct ? ct : 0) * hw + o];   // same (h, w) order per plane
+      }
     const float bin_area = (float)((bin.hend - bin.hstart) * (bin.wend - bin.wstart));
-    const long index = (((long)n * output_dim + ctop) * pooled_height + gh) * pooled_width + gw;
-    top_data[index] = bin.empty ? 0.f : out_sum / bin_area;
-    if (mapping_channel) mapping_channel[index] = c;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      if (ct < nct) {
+        const long index = (((long)n * output_dim + ctop0 + ct) * pooled_height + gh) * pooled_width + gw;
+        top_data[index] = bin.empty ? 0.f : out_sum[ct] / bin_area;
+        if (mapping_channel) mapping_channel[index] = (ctop0 + ct) * gg + pos;
+      }
+    }
   }
 }
 
@@ -159,8 +248,38 @@ __global__ void psroi_vote(const float* __restrict__ top_data, long n_out, int b
   vote[i] = s / (float)bins;
 }
 
+// The same vote over the channel-major scratch of psroi_fwd_plane<true>: thread = (ctop, roi) with the RoI fastest, so
+// the 49 reads of a wave are 49 coalesced rows.  Same summation order (ph, pw row-major) and the same division.
+__global__ void psroi_vote_tr(const float* __restrict__ top_t, int num_rois, int output_dim, int group_size,
+                              int pooled_height, int pooled_width, float* __restrict__ vote) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)num_rois * output_dim) return;
+  const int n = (int)(i % num_rois), ctop = (int)(i / num_rois);
+  float s = 0.f;
+  if (pooled_height == 7 && pooled_width == 7 && group_size == 7) {   // the R-FCN shape: 49 independent coalesced loads
+    const float* p = top_t + (long)ctop * 49 * num_rois + n;
+    float v[49];
+#pragma unroll
+    for (int k = 0; k < 49; ++k) v[k] = p[(long)k * num_rois];
+#pragma unroll
+    for (int k = 0; k < 49; ++k) s += v[k];
+  } else {
+    for (int ph = 0; ph < pooled_height; ++ph)
+      for (int pw = 0; pw < pooled_width; ++pw)
+        s += top_t[(long)((ctop * group_size + ph) * group_size + pw) * num_rois + n];
+  }
+  vote[(long)n * output_dim + ctop] = s / (float)(pooled_height * pooled_width);
+}
+
+size_t fwd_plane_lds(int height, int width, int num_rois) {
+  (void)num_rois;
+  return (((size_t)height * width + 3) & ~(size_t)3) * sizeof(float);
+}
+
+int fwd_plane_threads(int, int) { return kThreads; }
+
 bool plane_path_ok(int height, int width, int pooled_height, int pooled_width, int group_size) {
-  return (size_t)height * width * sizeof(float) <= 144 * 1024 && pooled_height <= group_size &&
+  return (size_t)height * width * sizeof(float) <= 120 * 1024 && pooled_height <= group_size &&
          pooled_width <= group_size;
 }
 
@@ -194,11 +313,20 @@ extern "C" int dtt_psroi_pool_forward(const float* bottom_data, float spatial_sc
   DTT_REQUIRE(bottom_data && bottom_rois && top_data, "psroi forward: null pointer");
   if (plane_path_ok(height, width, pooled_height, pooled_width, group_size)) {
     const size_t lds = (size_t)height * width * sizeof(float);
-    if (!raise_lds(reinterpret_cast<const void*>(psroi_fwd_plane), lds)) return 0;
+    constexpr int CT = DTT_PSROI_CT;
     dtt_prof_begin("psroi_fwd_plane", stream);
-    hipLaunchKernelGGL(psroi_fwd_plane, dim3(channels, batch_size), dim3(kThreads), lds, stream, bottom_data,
-                       spatial_scale, num_rois, height, width, channels, pooled_height, pooled_width, bottom_rois,
-                       group_size, output_dim, top_data, mapping_channel);
+    if (CT > 1 && output_dim >= CT && lds * CT <= 64 * 1024) {
+      const int groups = (output_dim + CT - 1) / CT;
+      hipLaunchKernelGGL((psroi_fwd_planes<CT>), dim3(group_size * group_size * groups, batch_size), dim3(kThreads), lds * CT,
+                         stream, bottom_data, spatial_scale, num_rois, height, width, channels, pooled_height, pooled_width,
+                         bottom_rois, group_size, output_dim, top_data, mapping_channel);
+    } else {
+      const size_t lds1 = fwd_plane_lds(height, width, num_rois);
+      if (!raise_lds(reinterpret_cast<const void*>(psroi_fwd_plane<false>), lds1)) return 0;
+      hipLaunchKernelGGL(psroi_fwd_plane<false>, dim3(channels, batch_size), dim3(fwd_plane_threads(num_rois, batch_size)), lds1, stream, bottom_data,
+                         spatial_scale, num_rois, height, width, channels, pooled_height, pooled_width, bottom_rois,
+                         group_size, output_dim, top_data, mapping_channel);
+    }
     dtt_prof_end("psroi_fwd_plane", stream);
   } else {
     const long n = (long)num_rois * output_dim * pooled_height * pooled_width;
@@ -224,6 +352,34 @@ extern "C" int dtt_psroi_pool_vote_forward(const float* bottom_data, float spati
   hipLaunchKernelGGL(psroi_vote, dim3(dtt_cdiv(n_out, 256)), dim3(256), 0, static_cast<hipStream_t>(stream_),
                      top_data, n_out, pooled_height * pooled_width, vote_out);
   DTT_CHECK_LAUNCH("psroi vote");
+  return 1;
+}
+
+extern "C" int dtt_psroi_vote_forward(const float* bottom_data, float spatial_scale, int batch_size, int num_rois,
+                                      int height, int width, int channels, int pooled_height, int pooled_width,
+                                      const float* bottom_rois, int group_size, int output_dim, float* scratch,
+                                      float* vote_out, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (!check_common(batch_size, num_rois, height, width, channels, pooled_height, pooled_width, group_size, output_dim))
+    return 0;
+  if (num_rois == 0) return 1;
+  DTT_REQUIRE(bottom_data && bottom_rois && scratch && vote_out, "psroi vote: null pointer");
+  if (!plane_path_ok(height, width, pooled_height, pooled_width, group_size))   // planes too large for LDS: two-step path
+    return dtt_psroi_pool_vote_forward(bottom_data, spatial_scale, batch_size, num_rois, height, width, channels,
+                                       pooled_height, pooled_width, bottom_rois, group_size, output_dim, scratch,
+                                       vote_out, stream_);
+  const size_t lds = fwd_plane_lds(height, width, num_rois);
+  if (!raise_lds(reinterpret_cast<const void*>(psroi_fwd_plane<true>), lds)) return 0;
+  dtt_prof_begin("psroi_fwd_plane", stream);
+  hipLaunchKernelGGL(psroi_fwd_plane<true>, dim3(channels, batch_size), dim3(fwd_plane_threads(num_rois, batch_size)), lds, stream, bottom_data,
+                     spatial_scale, num_rois, height, width, channels, pooled_height, pooled_width, bottom_rois,
+                     group_size, output_dim, scratch, nullptr);
+  dtt_prof_end("psroi_fwd_plane", stream);
+  DTT_CHECK_LAUNCH("psroi forward (channel-major)");
+  const long n_out = (long)num_rois * output_dim;
+  hipLaunchKernelGGL(psroi_vote_tr, dim3(dtt_cdiv(n_out, 256)), dim3(256), 0, stream, scratch, num_rois, output_dim,
+                     group_size, pooled_height, pooled_width, vote_out);
+  DTT_CHECK_LAUNCH("psroi vote (channel-major)");
   return 1;
 }
 

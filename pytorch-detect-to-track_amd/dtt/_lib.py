@@ -32,6 +32,7 @@ SIGNATURES = {
     "dtt_psroi_pool_forward": (_I, [_P, _F, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P, _P, _P]),
     "dtt_psroi_pool_backward": (_I, [_P, _P, _I, _I, _F, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     "dtt_psroi_pool_vote_forward": (_I, [_P, _F, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P, _P, _P]),
+    "dtt_psroi_vote_forward": (_I, [_P, _F, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P, _P, _P]),
     "dtt_nms_workspace_bytes": (_Z, [_I]),
     "dtt_nms": (_I, [_P, _P, _P, _I, _I, _F, _I, _P, _Z, _P]),
     "dtt_roi_align_forward": (_I, [_P, _F, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P]),

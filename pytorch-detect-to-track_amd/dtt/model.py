@@ -21,7 +21,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .config import cfg as _global_cfg
-from .ops import Correlation, _PSRoIPooling, correlation_forward_into, correlation_output_shape, psroi_pool_vote
+from .ops import Correlation, _PSRoIPooling, correlation_forward_into, correlation_output_shape, psroi_pool_vote, psroi_vote
 from .rpn import _AnchorTargetLayer, _ProposalLayer
 from .targets import _ProposalTargetLayer, _TrackingProposalTargetLayer
 
@@ -181,8 +181,8 @@ class _RFCN(nn.Module):
     def _pool_vote(self, pool, vote, feat, rois):
         if torch.is_grad_enabled() and feat.requires_grad:
             return vote(pool(feat, rois)).squeeze(3).squeeze(2)
-        return psroi_pool_vote(feat, rois, pool.pooled_height, pool.pooled_width, pool.spatial_scale,
-                               pool.group_size, pool.output_dim)[1]
+        return psroi_vote(feat, rois, pool.pooled_height, pool.pooled_width, pool.spatial_scale, pool.group_size,
+                          pool.output_dim)
 
     def _tracking_features(self, rfcn_bbox, conv3, conv4, conv5):
         """cat([bbox_t, bbox_t+tau, corr3, corr4, corr5], 1) (rfcn.py:166-174).  Without autograd the

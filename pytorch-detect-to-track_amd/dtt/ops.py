@@ -189,6 +189,23 @@ def psroi_pool_vote(features, rois, pooled_height, pooled_width, spatial_scale, 
     return pooled, vote
 
 
+def psroi_vote(features, rois, pooled_height, pooled_width, spatial_scale, group_size, output_dim):
+    """Inference-only: the (R, od) vote of `psroi_pool_vote` without materialising the pooled tensor in the reference
+    layout (the bins live in a channel-major scratch buffer; bit-identical vote)."""
+    require_gpu(features, rois)
+    require_f32_contig("features", features)
+    _check_rois(rois)
+    B, C, H, W = features.shape
+    R = rois.size(0)
+    scratch = torch.empty(max(C * R, 1), dtype=torch.float32, device=features.device)
+    vote = torch.empty((R, output_dim), dtype=torch.float32, device=features.device)
+    with torch.cuda.device(features.device):
+        check(_lib.lib().dtt_psroi_vote_forward(ptr(features), spatial_scale, B, R, H, W, C, pooled_height, pooled_width,
+                                                ptr(rois), group_size, output_dim, ptr(scratch), ptr(vote),
+                                                stream_ptr(features.device)), "psroi vote")
+    return vote
+
+
 # -------------------------------------------------------------------------------------------- NMS
 def nms(dets, thresh, force_cpu=False, max_keep=0):
     """nms/nms_wrapper.py:11-18: dets (N, 5) [x1,y1,x2,y2,score] sorted by descending score ->

@@ -122,6 +122,12 @@ def test_psroi_vote_and_empty(dev):
     pooled, vote = psroi_pool_vote(cu(feat, dev), cu(rois, dev), 7, 7, 1 / 16.0, 7, 4)
     np.testing.assert_array_equal(pooled.cpu().numpy(), ref)
     np.testing.assert_allclose(vote.cpu().numpy(), ref.reshape(50, 4, 49).mean(2), rtol=1e-5, atol=1e-6)
+    from dtt.ops import psroi_vote
+    assert torch.equal(psroi_vote(cu(feat, dev), cu(rois, dev), 7, 7, 1 / 16.0, 7, 4), vote)   # channel-major scratch path
+    big = rng.normal(size=(4, 31 * 49, 38, 67)).astype(np.float32)
+    brois = random_rois(rng, 1200, 4, 600, 1067)
+    v1 = psroi_pool_vote(cu(big, dev), cu(brois, dev), 7, 7, 1 / 16.0, 7, 31)[1]
+    assert torch.equal(psroi_vote(cu(big, dev), cu(brois, dev), 7, 7, 1 / 16.0, 7, 31), v1)
     out = _PSRoIPooling(7, 7, 1 / 16.0, 7, 4)(cu(feat, dev), torch.zeros((0, 5), device=dev))
     assert tuple(out.shape) == (0, 4, 7, 7)
     with pytest.raises(ValueError):

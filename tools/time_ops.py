@@ -59,6 +59,8 @@ pc, pl = _PSRoIPooling(7, 7, 1 / 16.0, 7, 31), _PSRoIPooling(7, 7, 1 / 16.0, 7, 
 timeit("psroi cls 1519ch R=%d" % r.size(0), lambda: pc(cls, r), bytes_=B * (15.47e6 + 1.82e6))
 timeit("psroi loc 196ch", lambda: pl(loc, r), bytes_=B * (2.0e6 + 0.235e6))
 timeit("psroi cls + vote", lambda: psroi_pool_vote(cls, r, 7, 7, 1 / 16.0, 7, 31), bytes_=B * (15.47e6 + 1.82e6))
+from dtt.ops import psroi_vote
+timeit("psroi cls vote (channel-major)", lambda: psroi_vote(cls, r, 7, 7, 1 / 16.0, 7, 31), bytes_=B * (15.47e6 + 1.82e6))
 clsg = cls.clone().requires_grad_(True)
 out = pc(clsg, r)
 go = torch.randn_like(out)
