@@ -223,6 +223,18 @@ class _RFCN(nn.Module):
         # result is the same, with half the launches and better-filled kernels.
         flat = im_data.view(n_legs * B, *im_data.shape[2:])
         c3, c4, c5, top = self._im_to_head(flat)
+        side = None
+        if not self.training and top.is_cuda and not torch.is_grad_enabled():
+            # The proposal chain (RPN convs, select/sort, NMS) is a handful of single-workgroup-per-image kernels that
+            # leave the GPU idle; it runs on a side stream underneath the head convolutions and the correlations,
+            # which do not depend on it.
+            cur = torch.cuda.current_stream(dev)
+            side = getattr(self, "_side_stream", None)
+            if side is None or side.device != dev:
+                side = self._side_stream = torch.cuda.Stream(device=dev)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                all_rois, _, _ = self.RFCN_rpn(top, im_info.view(n_legs * B, -1), None, None)
         cls_maps = self.RFCN_cls_net(top)
         bbox_maps = self.RFCN_bbox_net(top)
         leg = lambda t, i: t[i * B:(i + 1) * B]
@@ -233,9 +245,15 @@ class _RFCN(nn.Module):
         rois, rois_label = [], []
         rpn_loss_cls, rpn_loss_bbox, cls_prob, bbox_pred = [], [], [], []
         loss_cls, loss_bbox = [], []
+        tracking_reg = None
         if not self.training:
             # inference: RPN, proposal layer and PSRoI pooling also run once for all n_legs*B images
-            all_rois, _, _ = self.RFCN_rpn(top, im_info.view(n_legs * B, -1), None, None)
+            if side is not None:
+                tracking_reg = self.corr_bbox_net(self._tracking_features(rfcn_bbox, conv3, conv4, conv5))
+                torch.cuda.current_stream(dev).wait_stream(side)
+                all_rois.record_stream(torch.cuda.current_stream(dev))
+            else:
+                all_rois, _, _ = self.RFCN_rpn(top, im_info.view(n_legs * B, -1), None, None)
             R = all_rois.size(1)
             flat_rois = all_rois.view(-1, 5)
             score = self._pool_vote(self.RFCN_psroi_cls_pool, self.RFCN_cls_score, cls_maps, flat_rois)
@@ -273,8 +291,8 @@ class _RFCN(nn.Module):
             cls_prob.append(prob.view(B, leg_rois.size(1), -1))
             bbox_pred.append(pred.view(B, leg_rois.size(1), -1))
 
-        tracking_feat = self._tracking_features(rfcn_bbox, conv3, conv4, conv5)
-        tracking_reg = self.corr_bbox_net(tracking_feat)
+        if tracking_reg is None:
+            tracking_reg = self.corr_bbox_net(self._tracking_features(rfcn_bbox, conv3, conv4, conv5))
         if self.training:
             trk_rois, trk_label, trk_target, trk_in, trk_out = self.RFCN_tracking_proposal_target(gt_boxes, num_boxes)
             trk_target = trk_target.view(-1, trk_target.size(2))
