@@ -119,15 +119,21 @@ class _RPN(nn.Module):
         s = x.size()
         return x.view(s[0], int(d), int(float(s[1] * s[2]) / float(d)), s[3])
 
-    def forward(self, base_feat, im_info, gt_boxes, num_boxes):
-        B = base_feat.size(0)
+    def head(self, base_feat):
+        """The convolutional part: (cls_score, cls_score_r, cls_prob, bbox_pred)."""
         conv1 = F.relu(self.RPN_Conv(base_feat), inplace=True)
         cls_score = self.RPN_cls_score(conv1)
         cls_score_r = self.reshape(cls_score, 2)
         cls_prob = self.reshape(F.softmax(cls_score_r, dim=1), self.nc_score_out)
-        bbox_pred = self.RPN_bbox_pred(conv1)
-        key = "TRAIN" if self.training else "TEST"
-        rois = self.RPN_proposal((cls_prob.detach(), bbox_pred.detach(), im_info, key))
+        return cls_score, cls_score_r, cls_prob, self.RPN_bbox_pred(conv1)
+
+    def proposals(self, cls_prob, bbox_pred, im_info):
+        return self.RPN_proposal((cls_prob.detach(), bbox_pred.detach(), im_info, "TRAIN" if self.training else "TEST"))
+
+    def forward(self, base_feat, im_info, gt_boxes, num_boxes):
+        B = base_feat.size(0)
+        cls_score, cls_score_r, cls_prob, bbox_pred = self.head(base_feat)
+        rois = self.proposals(cls_prob, bbox_pred, im_info)
         self.rpn_loss_cls = 0
         self.rpn_loss_box = 0
         if self.training:
@@ -225,16 +231,19 @@ class _RFCN(nn.Module):
         c3, c4, c5, top = self._im_to_head(flat)
         side = None
         if not self.training and top.is_cuda and not torch.is_grad_enabled():
-            # The proposal chain (RPN convs, select/sort, NMS) is a handful of single-workgroup-per-image kernels that
-            # leave the GPU idle; it runs on a side stream underneath the head convolutions and the correlations,
-            # which do not depend on it.
+            # The proposal layer (select / sort, NMS mask + sweep) is a handful of single-workgroup-per-image kernels
+            # that leave all but a few CUs idle; it runs on a side stream underneath the head convolutions and the
+            # correlations, which do not depend on it.  (The RPN's own convolutions stay on the main stream: sharing
+            # the CUs with them slowed the correlation kernels by 15 %.)
             cur = torch.cuda.current_stream(dev)
             side = getattr(self, "_side_stream", None)
             if side is None or side.device != dev:
                 side = self._side_stream = torch.cuda.Stream(device=dev)
+            _, _, rpn_prob, rpn_bbox = self.RFCN_rpn.head(top)
             side.wait_stream(cur)
             with torch.cuda.stream(side):
-                all_rois, _, _ = self.RFCN_rpn(top, im_info.view(n_legs * B, -1), None, None)
+                all_rois = self.RFCN_rpn.proposals(rpn_prob, rpn_bbox, im_info.view(n_legs * B, -1))
+            rpn_prob.record_stream(side); rpn_bbox.record_stream(side)
         cls_maps = self.RFCN_cls_net(top)
         bbox_maps = self.RFCN_bbox_net(top)
         leg = lambda t, i: t[i * B:(i + 1) * B]
