@@ -71,9 +71,6 @@ __device__ __forceinline__ void stage_plane(float* __restrict__ plane, const flo
   const int t = (hw4 << 2) + (int)threadIdx.x;
   if (t < hw) plane[t] = src[t];
 }
-#ifndef DTT_PSROI_CT
-#define DTT_PSROI_CT 1   // class planes per workgroup in the forward (measured: 1 > 2 > 4 at the D&T shapes)
-#endif
 
 // grid (channels, batch).  LDS: height*width floats.  TR: write the bins channel-major, top[c][roi] -- every store
 // instruction covers consecutive RoIs of one plane (coalesced) instead of one dword per 6 KB; only the fused vote
@@ -111,52 +108,6 @@ __global__ __launch_bounds__(kThreads) void psroi_fwd_plane(
     const long index = TR ? (long)c * num_rois + n : (((long)n * output_dim + ctop) * pooled_height + gh) * pooled_width + gw;
     top_data[index] = bin.empty ? 0.f : out_sum / bin_area;
     if (!TR && mapping_channel) mapping_channel[index] = c;
-  }
-}
-
-// Several class planes per workgroup: one workgroup owns one bin position (gh, gw) of CT consecutive output
-// classes, so the bin geometry of a RoI (four double-precision roundings, two divisions -- the bulk of the
-// arithmetic) and its RoI row are computed / read once for CT planes instead of once per plane.
-// grid (group_size^2 * ceil(output_dim / CT), batch).  LDS: CT * height * width floats.
-template <int CT>
-__global__ __launch_bounds__(kThreads) void psroi_fwd_planes(
-    const float* __restrict__ bottom_data, float spatial_scale, int num_rois, int height, int width, int channels,
-    int pooled_height, int pooled_width, const float* __restrict__ bottom_rois, int group_size, int output_dim,
-    float* __restrict__ top_data, int* __restrict__ mapping_channel) {
-  extern __shared__ __attribute__((aligned(16))) float plane[];
-  const int gg = group_size * group_size;
-  const int pos = blockIdx.x % gg, ctop0 = (blockIdx.x / gg) * CT, b = blockIdx.y;
-  const int gw = pos % group_size, gh = pos / group_size;
-  if (gw >= pooled_width || gh >= pooled_height) return;  // position feeds no bin
-  const int hw = height * width;
-  const int nct = min(CT, output_dim - ctop0);
-  for (int ct = 0; ct < nct; ++ct) {
-    const int c = (ctop0 + ct) * gg + pos;
-    stage_plane(plane + ct * hw, bottom_data + ((long)b * channels + c) * hw, hw);   // ct * hw * 4 B keeps 16-byte LDS alignment only for hw % 4 == 0
-  }
-  __syncthreads();
-  for (int n = threadIdx.x; n < num_rois; n += kThreads) {
-    const float* roi = bottom_rois + (long)n * 5;
-    if ((int)roi[0] != b) continue;
-    const Bin bin = psroi_bin(roi, spatial_scale, gh, gw, pooled_height, pooled_width, height, width);
-    float out_sum[CT];
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct) out_sum[ct] = 0.f;
-    for (int h = bin.hstart; h < bin.hend; ++h)
-      for (int w = bin.wstart; w < bin.wend; ++w) {
-        const int o = h * width + w;
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) out_sum[ct] += plane[(ct < nct ? ct : 0) * hw + o];   // same (h, w) order per plane
-      }
-    const float bin_area = (float)((bin.hend - bin.hstart) * (bin.wend - bin.wstart));
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {
-      if (ct < nct) {
-        const long index = (((long)n * output_dim + ctop0 + ct) * pooled_height + gh) * pooled_width + gw;
-        top_data[index] = bin.empty ? 0.f : out_sum[ct] / bin_area;
-        if (mapping_channel) mapping_channel[index] = (ctop0 + ct) * gg + pos;
-      }
-    }
   }
 }
 
@@ -276,8 +227,6 @@ size_t fwd_plane_lds(int height, int width, int num_rois) {
   return (((size_t)height * width + 3) & ~(size_t)3) * sizeof(float);
 }
 
-int fwd_plane_threads(int, int) { return kThreads; }
-
 bool plane_path_ok(int height, int width, int pooled_height, int pooled_width, int group_size) {
   return (size_t)height * width * sizeof(float) <= 120 * 1024 && pooled_height <= group_size &&
          pooled_width <= group_size;
@@ -312,21 +261,12 @@ extern "C" int dtt_psroi_pool_forward(const float* bottom_data, float spatial_sc
   if (num_rois == 0) return 1;
   DTT_REQUIRE(bottom_data && bottom_rois && top_data, "psroi forward: null pointer");
   if (plane_path_ok(height, width, pooled_height, pooled_width, group_size)) {
-    const size_t lds = (size_t)height * width * sizeof(float);
-    constexpr int CT = DTT_PSROI_CT;
+    const size_t lds = fwd_plane_lds(height, width, num_rois);
+    if (!raise_lds(reinterpret_cast<const void*>(psroi_fwd_plane<false>), lds)) return 0;
     dtt_prof_begin("psroi_fwd_plane", stream);
-    if (CT > 1 && output_dim >= CT && lds * CT <= 64 * 1024) {
-      const int groups = (output_dim + CT - 1) / CT;
-      hipLaunchKernelGGL((psroi_fwd_planes<CT>), dim3(group_size * group_size * groups, batch_size), dim3(kThreads), lds * CT,
-                         stream, bottom_data, spatial_scale, num_rois, height, width, channels, pooled_height, pooled_width,
-                         bottom_rois, group_size, output_dim, top_data, mapping_channel);
-    } else {
-      const size_t lds1 = fwd_plane_lds(height, width, num_rois);
-      if (!raise_lds(reinterpret_cast<const void*>(psroi_fwd_plane<false>), lds1)) return 0;
-      hipLaunchKernelGGL(psroi_fwd_plane<false>, dim3(channels, batch_size), dim3(fwd_plane_threads(num_rois, batch_size)), lds1, stream, bottom_data,
-                         spatial_scale, num_rois, height, width, channels, pooled_height, pooled_width, bottom_rois,
-                         group_size, output_dim, top_data, mapping_channel);
-    }
+    hipLaunchKernelGGL(psroi_fwd_plane<false>, dim3(channels, batch_size), dim3(kThreads), lds, stream, bottom_data,
+                       spatial_scale, num_rois, height, width, channels, pooled_height, pooled_width, bottom_rois,
+                       group_size, output_dim, top_data, mapping_channel);
     dtt_prof_end("psroi_fwd_plane", stream);
   } else {
     const long n = (long)num_rois * output_dim * pooled_height * pooled_width;
@@ -371,7 +311,7 @@ extern "C" int dtt_psroi_vote_forward(const float* bottom_data, float spatial_sc
   const size_t lds = fwd_plane_lds(height, width, num_rois);
   if (!raise_lds(reinterpret_cast<const void*>(psroi_fwd_plane<true>), lds)) return 0;
   dtt_prof_begin("psroi_fwd_plane", stream);
-  hipLaunchKernelGGL(psroi_fwd_plane<true>, dim3(channels, batch_size), dim3(fwd_plane_threads(num_rois, batch_size)), lds, stream, bottom_data,
+  hipLaunchKernelGGL(psroi_fwd_plane<true>, dim3(channels, batch_size), dim3(kThreads), lds, stream, bottom_data,
                      spatial_scale, num_rois, height, width, channels, pooled_height, pooled_width, bottom_rois,
                      group_size, output_dim, scratch, nullptr);
   dtt_prof_end("psroi_fwd_plane", stream);
