@@ -86,6 +86,19 @@ __global__ __launch_bounds__(kThreads) void psroi_fwd_plane(
   if (gw >= pooled_width || gh >= pooled_height || ctop >= output_dim) return;  // channel feeds no bin
   const int hw = height * width;
   const float* src = bottom_data + ((long)b * channels + c) * hw;
+  // RoI rows for the first kPre rounds of the loop are requested BEFORE the plane is staged and consumed after the
+  // barrier: a wave's critical path is then one global round trip (plane and RoI rows together), not one for the
+  // plane, one for the batch index and one for the coordinates of every round -- and with ~1.5 workgroup waves per
+  // launch the kernel's duration is a small multiple of exactly that path.
+  constexpr int kPre = 5;   // 1280 RoIs: the inference shape is 4 images x 300
+  float pre[kPre][5];
+#pragma unroll
+  for (int it = 0; it < kPre; ++it) {
+    const int n = (int)threadIdx.x + it * kThreads;
+    const float* roi = bottom_rois + (long)min(n, num_rois - 1) * 5;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) pre[it][q] = roi[q];
+  }
 #if DTT_PSROI_ABLATE != 2
   stage_plane(plane, src, hw);
 #endif
@@ -93,14 +106,8 @@ __global__ __launch_bounds__(kThreads) void psroi_fwd_plane(
 #if DTT_PSROI_ABLATE == 1
   if (num_rois > 0) return;
 #endif
-  for (int n = threadIdx.x; n < num_rois; n += blockDim.x) {
-    const float* roi = bottom_rois + (long)n * 5;
-    if ((int)roi[0] != b) continue;
-#if DTT_PSROI_ABLATE == 3
-    Bin bin; bin.hstart = (int)roi[2] & 15; bin.hend = bin.hstart + 2; bin.wstart = (int)roi[1] & 31; bin.wend = bin.wstart + 3; bin.empty = false;
-#else
+  auto pool = [&](const float* roi, int n) {
     const Bin bin = psroi_bin(roi, spatial_scale, gh, gw, pooled_height, pooled_width, height, width);
-#endif
     float out_sum = 0;
     for (int h = bin.hstart; h < bin.hend; ++h)
       for (int w = bin.wstart; w < bin.wend; ++w) out_sum += plane[h * width + w];
@@ -108,6 +115,16 @@ __global__ __launch_bounds__(kThreads) void psroi_fwd_plane(
     const long index = TR ? (long)c * num_rois + n : (((long)n * output_dim + ctop) * pooled_height + gh) * pooled_width + gw;
     top_data[index] = bin.empty ? 0.f : out_sum / bin_area;
     if (!TR && mapping_channel) mapping_channel[index] = c;
+  };
+#pragma unroll
+  for (int it = 0; it < kPre; ++it) {
+    const int n = (int)threadIdx.x + it * kThreads;
+    if (n < num_rois && (int)pre[it][0] == b) pool(pre[it], n);
+  }
+  for (int n = (int)threadIdx.x + kPre * kThreads; n < num_rois; n += kThreads) {
+    const float* roi = bottom_rois + (long)n * 5;
+    if ((int)roi[0] != b) continue;
+    pool(roi, n);
   }
 }
 
