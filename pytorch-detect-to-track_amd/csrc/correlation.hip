@@ -37,7 +37,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef DTT_CORR_PF
 #define DTT_CORR_PF 6
 #endif
-constexpr int kKc = DTT_CORR_KC;  // channels per LDS chunk
+constexpr int kKc = DTT_CORR_KC;  // channels per LDS chunk (register-staged kernels)
+#ifndef DTT_CORR_GKC
+#define DTT_CORR_GKC 8
+#endif
+constexpr int kGKc = DTT_CORR_GKC;  // channels per LDS chunk of the LDS-DMA kernel (4 wins a back-to-back micro-benchmark by 10 %, 8 wins inside the pipeline by 2 %)
 constexpr int kTile = 8;      // output tile edge (lattice pixels)
 constexpr int kThreads = 256; // 4 waves, one 4x4 M-block each
 constexpr int kPS1 = 68;      // frame-t plane stride (64 px, +4: second k pair lands on the other banks)
@@ -471,9 +475,9 @@ __device__ __forceinline__ void lds_wait(float& v) {  // s_waitcnt tied to the v
 // returns in order: lgkmcnt(n) = "all but the newest n have landed"), and the ring slot of MFMA t-1 is refilled
 // after MFMA t has issued.  sched_barrier pins that order.
 template <class K, int NBR, int PF, int T>
-__device__ __forceinline__ void corr_mfma_steps(f32x4 (&acc)[K::NB], float (&ring)[PF], float (&a)[kKc / 4],
+__device__ __forceinline__ void corr_mfma_steps(f32x4 (&acc)[K::NB], float (&ring)[PF], float (&a)[kGKc / 4],
                                                 unsigned baddr) {
-  constexpr int TOT = (kKc / 4) * K::NB;
+  constexpr int TOT = (kGKc / 4) * K::NB;
   constexpr int kq = T / K::NB, nb = T % K::NB;
   constexpr int newer = (PF - 2 < TOT - 1 - T) ? PF - 2 : TOT - 1 - T;
   lds_wait<newer>(ring[T % PF]);
@@ -501,9 +505,9 @@ struct GCfg {
   static constexpr int PS2 = HR * RS + (RS == HR ? 4 : 16);                     // plane stride: 4 mod 8 / 16 mod 32
   static constexpr int PP2 = PS2 / 4;                                           // pieces per halo plane
   static constexpr int PS1 = kTile * kTile + 4, PP1 = PS1 / 4;                  // frame-t plane
-  static constexpr int HSLOTS = (kKc * PP2 + 63) / 64;                          // wave slots of the halo planes (+ pad):
+  static constexpr int HSLOTS = (kGKc * PP2 + 63) / 64;                          // wave slots of the halo planes (+ pad):
   static constexpr int A0 = HSLOTS * 64 * 4;                                    // the frame-t planes start on a slot boundary
-  static constexpr int NP = HSLOTS * 64 + kKc * PP1;                            // pieces per buffer
+  static constexpr int NP = HSLOTS * 64 + kGKc * PP1;                            // pieces per buffer
   static constexpr int NI = (NP + kThreads - 1) / kThreads;                     // DMA instructions per thread
   static constexpr int BUF = NP * 4;                                            // floats per buffer
   static constexpr int NB = NBR * NBR;
@@ -531,7 +535,7 @@ __global__ __launch_bounds__(kThreads, MINW) void corr_fwd_glds(const float* __r
   const int plane = g.H * g.W;
   const int c_begin = ks * g.c_per_split;
   const int c_end = min(g.C, c_begin + g.c_per_split);
-  const int nch = (c_end - c_begin) / kKc;
+  const int nch = (c_end - c_begin) / kGKc;
 
   // piece p of a buffer -> source: which frame, channel in chunk, in-plane flat offset, overflow past the plane end
   auto describe = [&](int p, bool& is_a, int& cc, int& off, int& over) {
@@ -539,9 +543,9 @@ __global__ __launch_bounds__(kThreads, MINW) void corr_fwd_glds(const float* __r
     int gy, start;
     bool real;
     if (!is_a) {
-      cc = min(p / K::PP2, kKc - 1);
+      cc = min(p / K::PP2, kGKc - 1);
       const int r = p - cc * K::PP2, hr = r / K::R4, q = r - hr * K::R4;
-      real = p < kKc * K::PP2 && hr < K::HR && q < K::G4;
+      real = p < kGKc * K::PP2 && hr < K::HR && q < K::G4;
       gy = g.origin + ty0 - g.R + hr;
       start = g.origin + tx0 - g.R + 4 * q;
     } else {
@@ -570,7 +574,7 @@ __global__ __launch_bounds__(kThreads, MINW) void corr_fwd_glds(const float* __r
     describe(p, is_a, cc, off, over);
     soff[i] = (unsigned)(cc * plane + off) * 4u;
   }
-  const long chunk_stride = (long)kKc * plane;
+  const long chunk_stride = (long)kGKc * plane;
   const float* base2 = in2 + ((long)n * g.C + c_begin) * plane;
   const float* base1 = in1 + ((long)n * g.C + c_begin) * plane;
   // the only pieces that could read past the end of the tensor: last image, last channel, bottom-right straddle
@@ -585,7 +589,7 @@ __global__ __launch_bounds__(kThreads, MINW) void corr_fwd_glds(const float* __r
         bool is_a;
         int cc, off, over;
         describe(min(p, K::NP - 1), is_a, cc, off, over);
-        if (cc == kKc - 1) o -= 4u * (unsigned)over;
+        if (cc == kGKc - 1) o -= 4u * (unsigned)over;
       }
       const bool slot_is_a = i * 4 + wave >= K::HSLOTS;  // wave-uniform
       const char* sbase = reinterpret_cast<const char*>(slot_is_a ? base1 : base2);
@@ -604,7 +608,7 @@ __global__ __launch_bounds__(kThreads, MINW) void corr_fwd_glds(const float* __r
       bool is_a;
       int cc, off, over;
       describe(min(p, K::NP - 1), is_a, cc, off, over);
-      if (p < K::NP && cc == kKc - 1 && over > 0) {
+      if (p < K::NP && cc == kGKc - 1 && over > 0) {
         float v[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = buf[4 * p + j];
@@ -629,30 +633,30 @@ __global__ __launch_bounds__(kThreads, MINW) void corr_fwd_glds(const float* __r
   const unsigned lds0 = lds_byte_addr(lds);
 #ifdef DTT_CORR_CPHASE   // compiler-scheduled operand reads (experiment)
   auto mfma_phase = [&](const float* buf) {
-    constexpr int TOT = (kKc / 4) * K::NB;
+    constexpr int TOT = (kGKc / 4) * K::NB;
     float a = buf[a_off];
 #pragma unroll
     for (int t = 0; t < TOT; ++t) {
       const int kq = t / K::NB, nb = t - kq * K::NB;
       const float b = buf[kq * 4 * K::PS2 + b_off + (nb / NBR) * 4 * K::RS + (nb % NBR) * 4];
       acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[nb], 0, 0, 0);
-      if (nb == K::NB - 1 && kq + 1 < kKc / 4) a = buf[(kq + 1) * 4 * K::PS1 + a_off];
+      if (nb == K::NB - 1 && kq + 1 < kGKc / 4) a = buf[(kq + 1) * 4 * K::PS1 + a_off];
     }
   };
   (void)lds0;
 #else
   auto mfma_phase = [&](const float* buf) {
     constexpr int PF = DTT_CORR_PF;
-    static_assert(PF >= 3 && PF <= 14 && (kKc / 4) * K::NB >= PF, "read-ahead ring");
+    static_assert(PF >= 3 && PF <= 14 && (kGKc / 4) * K::NB >= PF, "read-ahead ring");
     const unsigned base = lds0 + (unsigned)((buf - lds) * sizeof(float));
     const unsigned baddr = base + b_off * 4, aaddr = base + a_off * 4;
-    float ring[PF], a[kKc / 4];
+    float ring[PF], a[kGKc / 4];
     lds_read_async<0>(a[0], aaddr);
-    if constexpr (kKc / 4 > 1) lds_read_async<4 * K::PS1 * 4>(a[1], aaddr);
-    static_assert(kKc / 4 <= 2, "A operand prefetch covers two k-quads");
+    if constexpr (kGKc / 4 > 1) lds_read_async<4 * K::PS1 * 4>(a[1], aaddr);
+    static_assert(kGKc / 4 <= 2, "A operand prefetch covers two k-quads");
     corr_mfma_prime<K, NBR, PF, 0>(ring, baddr);
     lds_wait<PF>(a[0]);
-    if constexpr (kKc / 4 > 1) lds_wait<PF>(a[1]);
+    if constexpr (kGKc / 4 > 1) lds_wait<PF>(a[1]);
     __builtin_amdgcn_sched_barrier(0);
     corr_mfma_steps<K, NBR, PF, 0>(acc, ring, a, baddr);
   };
@@ -1112,7 +1116,7 @@ int launch_fast(float* output, long out_batch_stride, const float* in1, const fl
   bool use_v4 = false;
   if constexpr (VEC4) use_v4 = g.s == 1 && g.C % kKc == 0 && g.W >= 4;
 #ifndef DTT_CORR_NO_GLDS
-  if (g.s == 1 && g.C % kKc == 0 && g.W >= 4 && (((g.origin - g.R) % 4) + 4) % 4 == 0) {
+  if (g.s == 1 && g.C % kGKc == 0 && g.c_per_split % kGKc == 0 && g.W >= 4 && (((g.origin - g.R) % 4) + 4) % 4 == 0) {
     using G = GCfg<NBR>;
     static bool gattr = false;
     if (!gattr) {

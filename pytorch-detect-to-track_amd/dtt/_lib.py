@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 PKG_ROOT = os.path.dirname(_HERE)
-LIB_PATH = os.path.join(PKG_ROOT, "lib", "libdtt_hip.so")
+LIB_PATH = os.environ.get("DTT_HIP_LIBRARY") or os.path.join(PKG_ROOT, "lib", "libdtt_hip.so")   # env override: developer A/B builds
 CSRC = os.path.join(PKG_ROOT, "csrc")
 
 _P = ctypes.c_void_p
