@@ -131,7 +131,7 @@ def main():
         from dtt.dist import DataParallelSnippets, make_optimizer
         from dtt.fuse import fuse_for_training
         model.train()
-        fuse_for_training(model)  # frozen BatchNorm folded out of the activation path (same gradients for the weights)
+        fuse_for_training(model, channels_last=not args.nchw_trunk)  # frozen BatchNorm folded out of the activation path (same gradients for the weights)
         runner = DataParallelSnippets(model, world)
         opt = make_optimizer(model, cfg, lr=1e-4)
 

@@ -103,7 +103,15 @@ class _BiasActFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, bias, residual):
-        bias_act_(x, bias, residual, relu=True)
+        if x.dim() == 4 and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last):
+            # channels-last trunk: same pass over the (pixels, C) rows
+            res = None
+            if residual is not None:
+                res = _rows(residual if residual.is_contiguous(memory_format=torch.channels_last)
+                            else residual.contiguous(memory_format=torch.channels_last))
+            bias_act_nhwc_(_rows(x), bias, relu=True, residual2d=res)
+        else:
+            bias_act_(x, bias, residual, relu=True)
         ctx.mark_dirty(x)
         ctx.save_for_backward(x)
         ctx.has_res = residual is not None
@@ -112,7 +120,9 @@ class _BiasActFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (y,) = ctx.saved_tensors
-        gi = torch.ops.aten.threshold_backward(g.contiguous(), y, 0)
+        if not g.is_contiguous() and not g.is_contiguous(memory_format=torch.channels_last):
+            g = g.contiguous()
+        gi = torch.ops.aten.threshold_backward(g, y, 0)
         return gi, None, (gi if ctx.has_res else None)
 
 
@@ -127,9 +137,10 @@ class FusedTrainTrunk:
     stages) run under no_grad on cached folded weights.
     """
 
-    def __init__(self, model):
+    def __init__(self, model, channels_last=False):
         b = model.RFCN_base
         self.model = model
+        self.channels_last = channels_last
         self.pool = b[3]
         self.stem = _FusedConv(b[0], b[1])
         self.frozen, self.live = [], []
@@ -175,6 +186,10 @@ class FusedTrainTrunk:
                     x = blk(x)
                 feats.append(x)
         ws = torch._foreach_mul([c.weight for c in self.convs], self.scales)  # all folded weights in a few launches
+        if self.channels_last:
+            # MIOpen's fp32 backward kernels are NHWC implicit GEMMs; feeding them NCHW costs a transpose on each side
+            x = x.contiguous(memory_format=torch.channels_last)
+            ws = [w.contiguous(memory_format=torch.channels_last) for w in ws]
         k = 0
         for blocks in self.live:
             for blk in blocks:
@@ -183,23 +198,25 @@ class FusedTrainTrunk:
                 k += n
             feats.append(x)
         top = F.relu(self.model.RFCN_net(feats[3]), inplace=True)
+        if self.channels_last:
+            return feats[1].contiguous(), feats[2].contiguous(), feats[3].contiguous(), top.contiguous()
         return feats[1], feats[2], feats[3], top
 
 
-def fuse_for_training(model):
+def fuse_for_training(model, channels_last=False):
     """Build the training-time fused trunk from the model's current (frozen) BatchNorm statistics; call again after
     loading a checkpoint."""
-    model._fused_train_trunk = FusedTrainTrunk(model)
+    model._fused_train_trunk = FusedTrainTrunk(model, channels_last=channels_last)
     return model
 
 
 # ------------------------------------------------------------------------------------------------ channels-last inference
-def bias_act_nhwc_(y2d, bias, relu=True):
-    """In place on a (rows, C) row-major view: y = act(y + bias[None, :])."""
+def bias_act_nhwc_(y2d, bias, relu=True, residual2d=None):
+    """In place on a (rows, C) row-major view: y = act(y + bias[None, :] (+ residual))."""
     L = _lib.lib()
     with torch.cuda.device(y2d.device):
-        check(L.dtt_bias_act_nhwc_inplace(ptr(y2d), ptr(bias), None, y2d.shape[0], y2d.shape[1], int(relu),
-                                          stream_ptr(y2d.device)), "bias_act_nhwc")
+        check(L.dtt_bias_act_nhwc_inplace(ptr(y2d), ptr(bias), ptr(residual2d) if residual2d is not None else None,
+                                          y2d.shape[0], y2d.shape[1], int(relu), stream_ptr(y2d.device)), "bias_act_nhwc")
     return y2d
 
 

@@ -206,19 +206,26 @@ def test_fused_training_trunk_matches_reference_graph():
             cin = blk.conv1.in_channels
             xin = torch.relu(torch.randn(2, cin, 20, 28, device=dev))
             outs = []
-            for fused in (False, True):
+            for fused in (False, True, "channels_last"):
                 blk.zero_grad(set_to_none=True)
                 xi = xin.clone().requires_grad_(True)
                 if fused:
                     ws = [c.weight * sc for c, sc in zip(ft.convs[k:k + n], ft.scales[k:k + n])]
-                    y = ft.run_block(blk, xi, ws, ft.shifts[k:k + n])
+                    xf = xi
+                    if fused == "channels_last":   # the layout the training step runs in
+                        ws = [w.contiguous(memory_format=torch.channels_last) for w in ws]
+                        xf = xi.contiguous(memory_format=torch.channels_last)
+                    y = ft.run_block(blk, xf, ws, ft.shifts[k:k + n])
                 else:
                     y = blk(xi)
                 if not outs:
                     probe = torch.randn_like(y)
                 (y * probe).sum().backward()
                 outs.append((y.detach().clone(), xi.grad.clone(), [c.weight.grad.clone() for c in ft.convs[k:k + n]]))
-            (y0, gx0, gw0), (y1, gx1, gw1) = outs
+            (y0, gx0, gw0), (y1, gx1, gw1), (y2, gx2, gw2) = outs
+            assert float((y0 - y2).norm()) <= 2e-5 * float(y0.norm()) and float((gx0 - gx2).norm()) <= 5e-3 * float(gx0.norm())
+            for a, b in zip(gw0, gw2):
+                assert float((a - b).norm()) <= 5e-3 * max(1e-12, float(a.norm())), k
             # forward to fp32 rounding; gradients to the accuracy of MIOpen's Winograd backward kernels (the two graphs
             # hand them differently scaled weights), far below what a wrong mask / missing residual term would give
             close = lambda a, b, tol: float((a - b).norm()) <= tol * max(1e-12, float(a.norm()))
@@ -243,14 +250,16 @@ def test_fused_training_trunk_matches_reference_graph():
 
     unfuse(model)
     f_ref, g_ref = run()
-    fuse_for_training(model)
-    f_fus, g_fus = run()
-    unfuse(model)
-    for a, b in zip(f_ref, f_fus):
-        assert float((a - b).norm()) <= 2e-2 * float(a.norm())
-    assert set(g_ref) == set(g_fus) and len(g_ref) > 30
-    for n in g_ref:
-        assert float((g_ref[n] - g_fus[n]).norm()) <= 0.1 * float(g_ref[n].norm()), n
+    for channels_last in (False, True):
+        fuse_for_training(model, channels_last=channels_last)
+        f_fus, g_fus = run()
+        unfuse(model)
+        for a, b in zip(f_ref, f_fus):
+            assert a.shape == b.shape and b.is_contiguous()
+            assert float((a - b).norm()) <= 2e-2 * float(a.norm())
+        assert set(g_ref) == set(g_fus) and len(g_ref) > 30
+        for n in g_ref:
+            assert float((g_ref[n] - g_fus[n]).norm()) <= 0.1 * float(g_ref[n].norm()), (n, channels_last)
 
 
 def test_config5_displacement_16_forward():

@@ -107,7 +107,7 @@ def main(argv=None):
     calibrate_batchnorm_(model, first[0][:, 0])
     model.train()
     from dtt.fuse import fuse_for_training
-    fuse_for_training(model)
+    fuse_for_training(model, channels_last=True)
     for epoch in range(args.start_epoch, args.max_epochs + 1):
         if epoch % (args.lr_decay_step + 1) == 0:
             for g in optimizer.param_groups:  # adjust_learning_rate (net_utils.py:63-66)
