@@ -116,3 +116,80 @@ def make_tubes(dets, n, trk=None, m=None, max_per_image=25, nms_thresh=0.3):
         if trk is not None and m[f] >= 0:
             tracked[f] = (np.asarray(trk[f, 0, :m[f]], f32), np.asarray(trk[f, 1, :m[f]], f32))
     return zero_jump_link(boxes, scores, tracked)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Front end of VideoPostProcessor: tracking_utils.py:19-52 (__init__), 320-386 (_process_frame_pairs), 294-318
+# (_keep_top_k) and 54-84 (build_class_paths).  Pinned by the "video/*" entries of tests/golden/tubes.npz.
+def process_frame_pairs(pred_boxes, scores, pred_trk_boxes, max_per_image=400):
+    """tracking_utils.py:320-386.  pred_boxes (P,2,R,>=4), scores (P,2,R,C), pred_trk_boxes (P,R,4).
+    Returns aboxes[c][f] (list of (n,6) arrays or None), tracks[f] = (boxes_t, boxes_t+1) or None."""
+    P, _, R, C = scores.shape
+    F = P + 1
+    aboxes = [[None] * F for _ in range(C)]
+    tracks = [None] * F
+    for i_pair in range(P - 1):                                        # sic: the last pair is never read (:322)
+        s0 = scores[i_pair, 0]
+        tracklets = np.nonzero(s0[:, 1:].max(axis=1) > f32(0.01))[0]   # :325-326
+        if tracklets.size:
+            tracks[i_pair] = (pred_boxes[i_pair, 0][tracklets][:, :4].astype(f32), pred_trk_boxes[i_pair][tracklets].astype(f32))
+        for i_leg in range(2):
+            f = i_pair + i_leg
+            boxes, sc = pred_boxes[i_pair, i_leg], scores[i_pair, i_leg]
+            for c in range(1, C):
+                order = np.argsort(-sc[:, c], kind="stable")[:max_per_image]          # CONF_THRESH starts at -inf: all rows
+                entry = np.concatenate([boxes[order][:, :4], sc[order, c][:, None], sc[order, 0][:, None]], 1).astype(f32)
+                aboxes[c][f] = entry if aboxes[c][f] is None else np.concatenate([aboxes[c][f], entry], 0)
+    return aboxes, tracks
+
+
+def keep_top_k(frames, top_k):
+    """tracking_utils.py:294-318 for one class: threshold = the (top_k + 1)-th best score of the whole video; frames
+    keep their rows >= threshold (a frame with none keeps everything).  The reference indexes scores[min(n, top_k)],
+    which is out of range unless the class has MORE than top_k detections -- reproduced as IndexError."""
+    lst = [b for b in frames if b is not None]
+    if not lst:
+        return frames, None
+    allsc = np.sort(np.concatenate(lst, 0)[:, 4])[::-1]
+    if min(allsc.size, top_k) >= allsc.size:
+        raise IndexError("index %d is out of bounds for dimension 0 with size %d" % (min(allsc.size, top_k), allsc.size))
+    thresh = allsc[min(allsc.size, top_k)]
+    out = []
+    for b in frames:
+        if b is not None and len(b):
+            keep = np.nonzero(b[:, 4] >= thresh)[0]
+            out.append(b[keep] if keep.size else b)
+        else:
+            out.append(b)
+    return out, thresh
+
+
+def build_class_paths(pred_boxes, scores, pred_trk_boxes, max_per_image=25):
+    """VideoPostProcessor(pred_boxes, scores, pred_trk_boxes, classes).build_class_paths(): dict class -> paths dict."""
+    P, _, R, C = scores.shape
+    F = P + 1
+    aboxes, tracks = process_frame_pairs(pred_boxes, scores, pred_trk_boxes)
+    paths, thresh = {}, np.full(C, -np.inf, f32)
+    for c in range(1, C):
+        aboxes[c], t = keep_top_k(aboxes[c], 160 * F)
+        if t is not None:
+            thresh[c] = t
+    for c in range(1, C):
+        frames = [f for f in range(F) if aboxes[c][f] is not None and len(aboxes[c][f])]
+        if not frames:
+            continue
+        fb = [aboxes[c][f] for f in frames]
+        nmax = max(len(b) for b in fb)
+        dets = np.zeros((len(fb), nmax, 6), f32)
+        n = np.zeros(len(fb), np.int32)
+        for i, b in enumerate(fb):
+            dets[i, :len(b)], n[i] = b, len(b)
+        mmax = max([len(tracks[f][0]) for f in frames if tracks[f] is not None] + [1])
+        trk = np.zeros((len(fb), 2, mmax, 4), f32)
+        m = np.full(len(fb), -1, np.int32)
+        for i, f in enumerate(frames):
+            if tracks[f] is not None:
+                m[i] = len(tracks[f][0])
+                trk[i, 0, :m[i]], trk[i, 1, :m[i]] = tracks[f]
+        paths[c] = make_tubes(dets, n, trk, m, max_per_image=max_per_image)
+    return paths, aboxes, thresh

@@ -104,3 +104,111 @@ def make_tubes(frame_dets, tracks=None, max_per_image=25, nms_thresh=0.3):
         empty = (kn[0] == 0).nonzero().view(-1)
         raise RuntimeError("ERROR: Found empty box at %d" % (int(empty[0]) if empty.numel() else -1))   # :166-169
     return paths_from_link(kb[0], ks[0], pidx[0], ptot[0], k_paths)
+
+
+class VideoPostProcessor:
+    """Device counterpart of the reference's `VideoPostProcessor` (tracking_utils.py:18-386): same constructor
+    arguments, `build_class_paths()` returns the per-class path dicts (index 0 = background = None).
+
+    Everything stays on the GPU as padded tensors: the per-pair / per-leg / per-class Python loops of
+    `_process_frame_pairs` become one batched sort + gather, `_keep_top_k` one sort per class, and all classes are
+    linked by a single `link_tubes` call.  One host read (the per-frame detection counts) decides which frames take
+    part, as the reference's `nonempty_frames` does."""
+
+    def __init__(self, pred_boxes, scores, pred_trk_boxes, classes, max_per_image=400):
+        _lib.require_gpu(pred_boxes, scores, pred_trk_boxes)
+        self.pred_boxes, self.scores, self.pred_trk_boxes = pred_boxes, scores, pred_trk_boxes
+        self.classes = classes
+        self.num_classes = len(classes)
+        self.num_frames = pred_boxes.size(0) + 1
+        self.max_per_image = max_per_image
+        self.max_per_set = 160 * self.num_frames
+        self._paths = np.ndarray((self.num_classes,), dtype=object)
+        self._process_frame_pairs()
+        self._keep_top_k()
+
+    # tracking_utils.py:320-386, all pairs / legs / classes at once
+    def _process_frame_pairs(self):
+        P, _, R, C = self.scores.shape
+        F, Pm, dev = self.num_frames, self.scores.size(0) - 1, self.scores.device
+        k = min(R, self.max_per_image)
+        S = self.scores[:Pm]                                                    # (Pm, 2, R, C)   (the last pair is never read)
+        cls_scores = S[..., 1:].permute(0, 1, 3, 2)                             # (Pm, 2, C-1, R)
+        vals, order = torch.sort(cls_scores, dim=-1, descending=True, stable=True)
+        vals, order = vals[..., :k], order[..., :k]
+        boxes = self.pred_boxes[:Pm, :, :, :4]                                  # class agnostic (:356-357)
+        gidx = order.unsqueeze(-1).expand(-1, -1, -1, -1, 4)
+        b = torch.gather(boxes.unsqueeze(2).expand(-1, -1, C - 1, -1, -1), 3, gidx)
+        bg = torch.gather(S[..., 0].unsqueeze(2).expand(-1, -1, C - 1, -1), 3, order)
+        entry = torch.cat([b, vals.unsqueeze(-1), bg.unsqueeze(-1)], dim=-1)    # (Pm, 2, C-1, k, 6)
+        # frame f = [leg 1 of pair f-1, leg 0 of pair f] in that order (pairs are visited in order, leg 0 first)
+        dets = torch.zeros(C - 1, F, 2 * k, 6, device=dev)
+        n = torch.zeros(C - 1, F, dtype=torch.int32, device=dev)
+        if Pm > 0:
+            leg0 = entry[:, 0].permute(1, 0, 2, 3)                              # (C-1, Pm, k, 6) -> frames 0..Pm-1
+            leg1 = entry[:, 1].permute(1, 0, 2, 3)                              #                 -> frames 1..Pm
+            dets[:, 1:Pm + 1, :k] = leg1
+            dets[:, 0, :k] = leg0[:, 0]
+            dets[:, 1:Pm, k:2 * k] = leg0[:, 1:]
+            n[:, 0] = k
+            n[:, 1:Pm] = 2 * k
+            n[:, Pm] = k
+        self._dets, self._n = dets, n
+        # tracklets: RoIs of leg 0 whose best foreground score exceeds 0.01 (:324-345), in RoI order
+        tmask = S[:, 0, :, 1:].max(dim=2).values > 0.01 if Pm > 0 else torch.zeros(0, R, dtype=torch.bool, device=dev)
+        _, torder = torch.sort(tmask.to(torch.int8), dim=1, descending=True, stable=True)
+        trk = torch.zeros(F, 2, R, 4, device=dev)
+        m = torch.full((F,), -1, dtype=torch.int32, device=dev)
+        if Pm > 0:
+            ti = torder.unsqueeze(-1).expand(-1, -1, 4)
+            trk[:Pm, 0] = torch.gather(self.pred_boxes[:Pm, 0, :, :4], 1, ti)
+            trk[:Pm, 1] = torch.gather(self.pred_trk_boxes[:Pm], 1, ti)
+            cnt = tmask.sum(dim=1).to(torch.int32)
+            m[:Pm] = torch.where(cnt > 0, cnt, torch.full_like(cnt, -1))
+        self._trk, self._m = trk, m
+
+    # tracking_utils.py:294-318 for every class
+    def _keep_top_k(self):
+        C1, F, N2, _ = self._dets.shape
+        dev = self._dets.device
+        valid = torch.arange(N2, device=dev)[None, None, :] < self._n[:, :, None]
+        sc = torch.where(valid, self._dets[..., 4], torch.full_like(self._dets[..., 4], float("-inf")))
+        total = int(self._n[0].sum()) if C1 else 0                              # same count for every class
+        top_k = self.max_per_set
+        if C1 and min(total, top_k) >= total:
+            raise IndexError("index %d is out of bounds for dimension 0 with size %d" % (min(total, top_k), total))  # :312
+        flat, _ = torch.sort(sc.reshape(C1, -1), dim=1, descending=True)
+        thresh = flat[:, min(total, top_k)] if C1 else flat.new_zeros(0)
+        self.CONF_THRESH = torch.cat([thresh.new_full((1,), float("-inf")), thresh])
+        keep = valid & (sc >= thresh[:, None, None])
+        none_kept = keep.sum(dim=2, keepdim=True) == 0
+        keep = torch.where(none_kept, valid, keep)                              # `if keep.numel()==0: continue` (:318)
+        _, order = torch.sort(keep.to(torch.int8), dim=2, descending=True, stable=True)
+        self._dets = torch.gather(self._dets, 2, order.unsqueeze(-1).expand(-1, -1, -1, 6)).contiguous()
+        self._n = keep.sum(dim=2).to(torch.int32)
+
+    # tracking_utils.py:54-84
+    def build_class_paths(self, max_per_image=25, nms_thresh=0.3):
+        C1, F = self._n.shape
+        n_host = self._n.cpu().numpy()
+        groups = {}
+        for c in range(C1):                                                     # classes sharing the same non-empty frames
+            frames = tuple(int(f) for f in np.nonzero(n_host[c] > 0)[0])
+            if len(frames) >= 2:
+                groups.setdefault(frames, []).append(c)
+            elif len(frames) == 1:
+                raise RuntimeError("class %d has detections in a single frame" % (c + 1))
+        for frames, cls in groups.items():
+            fi = torch.tensor(frames, device=self._dets.device)
+            ci = torch.tensor(cls, device=self._dets.device)
+            dets = self._dets[ci][:, fi].contiguous()
+            n = self._n[ci][:, fi].contiguous()
+            trk = self._trk[fi].unsqueeze(0).expand(len(cls), -1, -1, -1, -1).contiguous()
+            m = self._m[fi].unsqueeze(0).expand(len(cls), -1).contiguous()
+            kb, ks, kn, pidx, ptot, npaths = link_tubes(dets, n, trk, m, max_per_image, nms_thresh)
+            npaths = npaths.cpu().tolist()
+            for j, c in enumerate(cls):
+                if npaths[j] == 0:
+                    raise RuntimeError("ERROR: Found empty box")                 # :166-169
+                self._paths[c + 1] = paths_from_link(kb[j], ks[j], pidx[j], ptot[j], npaths[j])
+        return self._paths

@@ -154,6 +154,30 @@ def main():
         for k in ("total_score", "boxes", "idx", "smooth_scores", "scores"):
             out[name + "/" + k] = paths[k].detach().cpu().numpy()
         print(name, {k: tuple(paths[k].shape) for k in paths})
+    # ---- the whole VideoPostProcessor: __init__ (_process_frame_pairs, _keep_top_k) + build_class_paths
+    rng = np.random.RandomState(11)
+    P, R, NC, nobj = 6, 300, 5, 14
+    classes = ["bg"] + ["c%d" % i for i in range(1, NC)]
+    cent = rng.uniform(60, 900, (nobj, 2)); size = rng.uniform(40, 200, (nobj, 2)); ocls = rng.randint(1, NC, nobj)
+    pb = np.zeros((P, 2, R, 4), np.float32); sc = np.zeros((P, 2, R, NC), np.float32); trk = np.zeros((P, R, 4), np.float32)
+    for p in range(P):
+        for l in range(2):
+            which = rng.randint(0, nobj, R)
+            c = cent[which] + 5.0 * (p + l) + rng.normal(0, 6, (R, 2)); wh = size[which] * rng.uniform(0.8, 1.2, (R, 2))
+            pb[p, l] = np.concatenate([c - wh / 2, c + wh / 2], 1)
+            logits = rng.normal(0, 1.0, (R, NC)); logits[np.arange(R), ocls[which]] += rng.uniform(0, 4, R)
+            e = np.exp(logits); sc[p, l] = (e / e.sum(1, keepdims=True)).astype(np.float32)
+        trk[p] = pb[p, 0] + 5.0 + rng.normal(0, 3, (R, 4))
+    sc[2, 0, :, 1:] *= 0.005            # a frame without tracklets (every class score <= 0.01)
+    vp = mod.VideoPostProcessor(torch.from_numpy(pb), torch.from_numpy(sc), torch.from_numpy(trk), classes)
+    paths = vp.build_class_paths()
+    out["video/pred_boxes"], out["video/scores"], out["video/pred_trk_boxes"] = pb, sc, trk
+    out["video/conf_thresh"] = vp.CONF_THRESH.numpy()
+    for c in range(1, NC):
+        out["video/n_kept_c%d" % c] = np.array([0 if b is None else b.shape[0] for b in vp._aboxes[c]], np.int32)
+        for k in ("total_score", "boxes", "idx", "smooth_scores", "scores"):
+            out["video/c%d/%s" % (c, k)] = paths[c][k].detach().cpu().numpy()
+        print("video class", c, {k: tuple(paths[c][k].shape) for k in paths[c]}, out["video/n_kept_c%d" % c])
     np.savez_compressed(os.path.join(HERE, "tubes.npz"), **out)
 
 

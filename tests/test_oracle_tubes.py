@@ -8,7 +8,7 @@ import pytest
 from oracle import tubes_oracle as to
 
 G = np.load(os.path.join(os.path.dirname(__file__), "golden", "tubes.npz"))
-CASES = sorted({k.split("/")[0] for k in G.files})
+CASES = sorted({k.split("/")[0] for k in G.files} - {"video"})
 
 
 @pytest.mark.parametrize("case", CASES)
@@ -39,3 +39,24 @@ def test_filter2d_reflect101():
     got = to.filter2d_reflect101(v)
     assert abs(got[0] - want[0]) < 1e-6 and abs(got[1] - want[1]) < 1e-6
     assert to.filter2d_reflect101(np.array([3.0], np.float32))[0] == 3.0
+
+
+def test_video_post_processor_oracle_matches_reference():
+    """The whole VideoPostProcessor flow (frame-pair bookkeeping, dynamic class thresholds, tracklet selection, class
+    paths) restated in oracle/tubes_oracle.py against the reference object run on the same predictions."""
+    paths, aboxes, thresh = to.build_class_paths(G["video/pred_boxes"], G["video/scores"], G["video/pred_trk_boxes"])
+    np.testing.assert_allclose(thresh, G["video/conf_thresh"], rtol=0, atol=0)
+    C = G["video/scores"].shape[3]
+    for c in range(1, C):
+        kept = np.array([0 if b is None else len(b) for b in aboxes[c]], np.int32)
+        np.testing.assert_array_equal(kept, G["video/n_kept_c%d" % c])
+        np.testing.assert_array_equal(paths[c]["idx"], G["video/c%d/idx" % c])
+        np.testing.assert_array_equal(paths[c]["boxes"], G["video/c%d/boxes" % c])
+        for k in ("total_score", "scores", "smooth_scores"):
+            np.testing.assert_allclose(paths[c][k], G["video/c%d/%s" % (c, k)], rtol=0, atol=1e-6)
+
+
+def test_keep_top_k_reproduces_the_reference_index_error():
+    frames = [np.array([[0, 0, 5, 5, 0.5, 0.5]], np.float32)] * 3
+    with pytest.raises(IndexError):
+        to.keep_top_k(frames, 160 * 3)
