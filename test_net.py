@@ -41,6 +41,8 @@ def parse_args(argv=None):
     p.add_argument("--height", default=600, type=int)
     p.add_argument("--width", default=1067, type=int)
     p.add_argument("--out_dir", default="output/detections", type=str)
+    p.add_argument("--link_tubes", action="store_true",
+                   help="treat the pairs as consecutive frame pairs of one video and link class tubes (demo.py:432-489)")
     return p.parse_args(argv)
 
 
@@ -81,6 +83,7 @@ def main(argv=None):
     n_classes = model.n_classes
     all_boxes = [[[] for _ in range(args.num_pairs)] for _ in range(n_classes)]
     det_time = nms_time = 0.0
+    vid_boxes, vid_scores, vid_trk = [], [], []
     for i in range(args.num_pairs):
         im, info, gt, nb = make_batch(args.batch_size, args.height, args.width, seed=10 + i, device=dev)
         torch.cuda.synchronize()
@@ -88,6 +91,12 @@ def main(argv=None):
         with torch.no_grad():
             rois, cls_prob, bbox_pred, tracking_pred = model(im, info, gt, nb)[:4]
             boxes = decode_detections(rois[0], bbox_pred[0], info[:, 0], cfg, args.class_agnostic)   # leg 0 (:277)
+            if args.link_tubes:   # demo.py:432-473: both legs' boxes / scores and the tracked boxes of snippet 0
+                legs = [decode_detections(rois[l], bbox_pred[l], info[:, l], cfg, args.class_agnostic)[0] for l in range(2)]
+                vid_boxes.append(torch.stack(legs, 0))
+                vid_scores.append(torch.stack([cls_prob[0][0], cls_prob[1][0]], 0))
+                R = rois.size(2)
+                vid_trk.append(decode_detections(rois[0][:1], tracking_pred.view(-1, R, 4)[:1], info[:, 0][:1], cfg, True)[0])
         torch.cuda.synchronize()
         t1 = time.time()
         dets, counts = class_nms(cls_prob[0], boxes, thresh, cfg.TEST.NMS, max_per_image, args.class_agnostic)
@@ -99,6 +108,21 @@ def main(argv=None):
         nms_time += t2 - t1
         sys.stdout.write("im_detect: {:d}/{:d} {:.3f}s {:.3f}s   \r".format(i + 1, args.num_pairs, t1 - t0, t2 - t1))
         sys.stdout.flush()
+    if args.link_tubes:
+        from dtt.tubes import VideoPostProcessor
+        torch.cuda.synchronize()
+        t0 = time.time()
+        vp = VideoPostProcessor(torch.stack(vid_boxes, 0), torch.stack(vid_scores, 0), torch.stack(vid_trk, 0),
+                                ["__background__"] + ["class_%d" % j for j in range(1, n_classes)])
+        paths = vp.build_class_paths()
+        torch.cuda.synchronize()
+        n_tubes = [0 if p is None else int(p["idx"].shape[0]) for p in paths]
+        print("\ntube linking: %d classes, %d frames, %d tubes in %.1f ms" %
+              (n_classes - 1, vp.num_frames, sum(n_tubes), (time.time() - t0) * 1e3))
+        os.makedirs(args.out_dir, exist_ok=True)
+        with open(os.path.join(args.out_dir, "tubes.pkl"), "wb") as f:
+            pickle.dump([None if p is None else {k: v.cpu().numpy() for k, v in p.items()} for p in paths], f,
+                        pickle.HIGHEST_PROTOCOL)
     os.makedirs(args.out_dir, exist_ok=True)
     with open(os.path.join(args.out_dir, "detections.pkl"), "wb") as f:
         pickle.dump(all_boxes, f, pickle.HIGHEST_PROTOCOL)

@@ -85,7 +85,7 @@ def test_training_step_runs_and_produces_finite_gradients():
         loss.backward()
         runner.finish_gradients()
         opt.step()
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
     assert all(np.isfinite(losses)), losses
     rois, cls_prob, bbox_pred, tracking_pred = out[:4]
     N = cfg.TRAIN.BATCH_SIZE
@@ -172,6 +172,14 @@ def test_drivers_round_trip_checkpoint(tmp_path):
     assert set(ck) == {"session", "epoch", "model", "optimizer", "pooling_mode", "class_agnostic"}
     assert ck["epoch"] == 2 and "RFCN_base.RFCN_net.weight" in ck["model"] and "RFCN_net.weight" in ck["model"]
     out = str(tmp_path / "dets")
+    test_net.main(["--dataset", "synthetic", "--net", "res50", "--cfg", "cfgs/res50.yml", "--cag", "--load_dir", save,
+                   "--checksession", "1", "--checkepoch", "1", "--checkpoint", "1", "--num_pairs", "2", "--height", "224",
+                   "--width", "320", "--out_dir", out])
+    test_net.main(["--dataset", "synthetic", "--net", "res50", "--cfg", "cfgs/res50.yml", "--cag", "--load_dir", save,
+                   "--checksession", "1", "--checkepoch", "1", "--checkpoint", "1", "--num_pairs", "4", "--height", "224",
+                   "--width", "320", "--out_dir", out, "--link_tubes"])
+    tubes = pickle.load(open(os.path.join(out, "tubes.pkl"), "rb"))
+    assert len(tubes) == 31 and tubes[0] is None and all(t["idx"].shape[1] == 3 for t in tubes[1:])   # 5 frames -> 3 linked
     test_net.main(["--dataset", "synthetic", "--net", "res50", "--cfg", "cfgs/res50.yml", "--cag", "--load_dir", save,
                    "--checksession", "1", "--checkepoch", "1", "--checkpoint", "1", "--num_pairs", "2", "--height", "224",
                    "--width", "320", "--out_dir", out])

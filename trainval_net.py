@@ -132,8 +132,8 @@ def main(argv=None):
                                                                                    loss_temp / n, lr))
                 print("\t\t\tfg/bg=(%d/%d), time cost: %f" % (fg, out[8].numel() - fg, time.time() - start))
                 print("\t\t\trpn_cls: %.4f, rpn_box: %.4f, rcnn_cls: %.4f, rcnn_box %.4f, tracking_box %.4f" %
-                      (float(rpn_cls.mean()), float(rpn_box.mean()), float(rcnn_cls.mean()), float(rcnn_box.mean()),
-                       float(trk.mean())))
+                      (float(rpn_cls.mean().detach()), float(rpn_box.mean().detach()), float(rcnn_cls.mean().detach()), float(rcnn_box.mean().detach()),
+                       float(trk.mean().detach())))
                 loss_temp, start = 0.0, time.time()
         if rank == 0:
             save_name = os.path.join(output_dir, "rfcn_detect_track_{}_{}_{}.pth".format(args.session, epoch, step))
