@@ -198,3 +198,21 @@ def test_psroi_full_size_properties(dev):
         c = (ct * gsz + ph) * gsz + pw
         want = 0.0 if (he <= hs or we <= ws) else fd[b, c, hs:he, ws:we].mean()
         assert abs(on[n, ct, ph, pw] - want) <= 1e-5 * max(1.0, abs(want)), (n, ct, ph, pw)
+
+
+def test_correlation_race_screen(dev):
+    """The forward is deterministic (fixed-order split-K reduction), so any run-to-run difference is a synchronisation bug
+    in the LDS-DMA pipeline (DMA landing vs operand reads vs buffer reuse).  Repeated under traffic from a second stream."""
+    from dtt.ops import Correlation
+    side = torch.cuda.Stream()
+    junk = torch.randn(32 << 20, device=dev)
+    for (B, C, H, W, d) in [(2, 2048, 38, 67, 8), (1, 2048, 36, 63, 16), (3, 64, 38, 67, 8)]:
+        g = torch.Generator(device=dev).manual_seed(C + d)
+        x1, x2 = _feat(g, (B, C, H, W), dev), _feat(g, (B, C, H, W), dev)
+        corr = Correlation(d, 1, d, 1, 1)
+        ref = corr(x1, x2).clone()
+        for _ in range(60):
+            with torch.cuda.stream(side):
+                junk.mul_(1.0001)
+            assert torch.equal(corr(x1, x2), ref)
+    torch.cuda.synchronize()
