@@ -216,3 +216,56 @@ def test_correlation_race_screen(dev):
                 junk.mul_(1.0001)
             assert torch.equal(corr(x1, x2), ref)
     torch.cuda.synchronize()
+
+
+def _cfg5_rois(rs, R, B, im_h, im_w):
+    x1 = rs.uniform(-20, im_w - 30, R); y1 = rs.uniform(-20, im_h - 30, R)
+    w = rs.uniform(4, im_w * 0.8, R); h = rs.uniform(4, im_h * 0.8, R)
+    return np.stack([rs.randint(0, B, R), x1, y1, x1 + w, y1 + h], 1).astype(np.float32)
+
+
+def test_roi_align_pool_crop_config5_size_vs_oracle(dev):
+    """The legacy-head RoI ops at BASELINE config 5's shape (512-channel 36 x 63 map of a 563 x 1000 frame, 300 RoIs per
+    image): the scalar C oracle still finishes in seconds here (OpenMP), so the forwards are compared bit for bit and the
+    backwards through the oracle and the adjoint identity."""
+    from oracle import oracle_lib as O
+    from dtt.ops import RoIAlign, RoIAlignAvg, RoIPoolFunction, _RoICrop
+    rs = np.random.RandomState(9)
+    B, C, H, W, R = 2, 512, 36, 63, 600
+    feat = rs.normal(size=(B, C, H, W)).astype(np.float32)
+    rois = _cfg5_rois(rs, R, B, 563, 1000)
+    ft = torch.from_numpy(feat).to(dev).requires_grad_(True)
+    rt = torch.from_numpy(rois).to(dev)
+    # RoI Align (8 x 8 samples, then the 2 x 2 / stride-1 average of RoIAlignAvg)
+    ref8 = O.roi_align_forward(feat, rois, 8, 8, 1 / 16.0)
+    out = RoIAlign(8, 8, 1 / 16.0)(ft, rt)
+    np.testing.assert_array_equal(out.detach().cpu().numpy(), ref8)
+    go = torch.randn(out.shape, device=dev)
+    out.backward(go)
+    v = torch.randn(B, C, H, W, device=dev)
+    with torch.no_grad():
+        lhs = float((RoIAlign(8, 8, 1 / 16.0)(v, rt).double() * go.double()).sum())
+        rhs = float((v.double() * ft.grad.double()).sum())
+        avg = RoIAlignAvg(7, 7, 1 / 16.0)(ft.detach(), rt)
+    assert abs(lhs - rhs) <= 1e-4 * max(1.0, abs(lhs)), (lhs, rhs)
+    np.testing.assert_allclose(avg.cpu().numpy(), torch.nn.functional.avg_pool2d(torch.from_numpy(ref8), 2, 1).numpy(),
+                               rtol=1e-6, atol=1e-6)
+    # RoI max pooling: values and argmax exact, backward = scatter through argmax
+    ref, ref_arg = O.roi_pool_forward(feat, rois, 7, 7, 1 / 16.0)
+    ft2 = torch.from_numpy(feat).to(dev).requires_grad_(True)
+    out2, arg = RoIPoolFunction.apply(ft2, rt, 7, 7, 1 / 16.0)
+    np.testing.assert_array_equal(out2.detach().cpu().numpy(), ref)
+    np.testing.assert_array_equal(arg.cpu().numpy(), ref_arg)
+    go2 = torch.randn(out2.shape, device=dev)
+    out2.backward(go2)
+    gref = O.roi_pool_backward(go2.cpu().numpy(), rois, ref_arg, feat.shape, 7, 7, 1 / 16.0)
+    np.testing.assert_allclose(ft2.grad.cpu().numpy(), gref, rtol=1e-5, atol=1e-5)
+    # RoI crop (bilinear grid sampler, 14 x 14 grids as with CROP_RESIZE_WITH_MAX_POOL)
+    grid = rs.uniform(-1.2, 1.2, size=(64, 14, 14, 2)).astype(np.float32)
+    img = feat[:1].repeat(64, 0)[:, :128].copy()
+    it = torch.from_numpy(img).to(dev).requires_grad_(True)
+    oc = _RoICrop()(it, torch.from_numpy(grid).to(dev))
+    np.testing.assert_array_equal(oc.detach().cpu().numpy(), O.roi_crop_forward(img, grid))
+    go3 = torch.randn(oc.shape, device=dev)
+    oc.backward(go3)
+    np.testing.assert_allclose(it.grad.cpu().numpy(), O.roi_crop_backward(img, grid, go3.cpu().numpy()), rtol=1e-5, atol=1e-5)
