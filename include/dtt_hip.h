@@ -132,6 +132,12 @@ int dtt_nms(int* keep_out, int* num_out, const float* boxes, int boxes_num, int 
 int dtt_roi_align_forward(const float* bottom_data, float spatial_scale, int num_rois, int height,
                           int width, int channels, int aligned_height, int aligned_width,
                           const float* bottom_rois, float* top_data, int pool_mode, void* stream);
+/* Same result (bit-identical), map-stationary: needs the batch size (the reference launcher does not carry it), keeps
+ * kAlignCB channel planes of one image in LDS and computes each output bin's geometry once for all of them.  Falls
+ * back to the kernel above when the planes do not fit LDS.  RoIs with a batch index outside [0, batch_size) are skipped. */
+int dtt_roi_align_forward_planes(const float* bottom_data, float spatial_scale, int batch_size, int num_rois,
+                                 int height, int width, int channels, int aligned_height, int aligned_width,
+                                 const float* bottom_rois, float* top_data, int pool_mode, void* stream);
 int dtt_roi_align_backward(const float* top_diff, float spatial_scale, int batch_size,
                            int num_rois, int height, int width, int channels, int aligned_height,
                            int aligned_width, const float* bottom_rois, float* bottom_diff,

@@ -69,6 +69,107 @@ __global__ __launch_bounds__(kThreads) void roi_align_fwd(long nthreads, const f
   }
 }
 
+// Map-stationary RoI Align: one workgroup owns CB channel planes of one image in LDS and walks that image's RoIs.
+// The thread-per-output kernel above recomputes the RoI geometry (double-precision divisions) for every sample of
+// every channel and gathers its 16 taps from L2; here the geometry and the bilinear weights of an output bin are
+// computed once and reused for the CB planes, and the taps come from LDS.  Per-sample arithmetic and the 2x2 pooling
+// order are the same expressions as align_sample / roi_align_fwd, so results are bit-identical.
+// grid (channels / CB, batch).  LDS: CB planes | RoI list (indices) -- staged in chunks of kAlignChunk RoIs.
+constexpr int kAlignCB = 4;
+constexpr int kAlignChunk = 1024;
+constexpr int kAlignThreads = 1024;   // 4 waves per SIMD: the double-precision tap arithmetic is a long dependent chain
+
+struct AxisTap { int start; float ratio; bool valid; };
+
+__device__ __forceinline__ AxisTap align_axis(float coord, int extent) {
+  AxisTap t;
+  t.valid = !(coord < 0 || coord >= extent);
+  t.start = (int)fminf(floorf(coord), (float)(extent - 2));
+  t.ratio = coord - (float)t.start;
+  return t;
+}
+
+__global__ __launch_bounds__(kAlignThreads) void roi_align_planes(const float* __restrict__ bottom_data, float spatial_scale,
+                                                             int num_rois, int height, int width, int channels, int oh,
+                                                             int ow, const float* __restrict__ bottom_rois,
+                                                             float* __restrict__ top_data, int pool_mode) {
+  extern __shared__ __attribute__((aligned(16))) float smem_f[];
+  const int hw = height * width;
+  float* planes = smem_f;                                        // [kAlignCB][hw]
+  int* list = reinterpret_cast<int*>(smem_f + kAlignCB * hw);    // [kAlignChunk]
+  __shared__ int list_n;
+  const int c0 = blockIdx.x * kAlignCB, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+  const int ncb = min(kAlignCB, channels - c0);
+  for (int cb = 0; cb < ncb; ++cb) {
+    const float* src = bottom_data + ((long)b * channels + c0 + cb) * hw;
+    for (int i = tid; i < hw; i += kAlignThreads) planes[cb * hw + i] = src[i];
+  }
+  const int ah = pool_mode == 0 ? oh : oh + 1, aw = pool_mode == 0 ? ow : ow + 1;   // sample grid
+  const int bins = oh * ow;
+  for (int r0 = 0; r0 < num_rois; r0 += kAlignChunk) {
+    __syncthreads();
+    if (tid == 0) list_n = 0;
+    __syncthreads();
+    // this image's RoIs of the chunk, in order (ballot compaction, one LDS atomic per wave)
+    for (int i0 = 0; i0 < kAlignChunk; i0 += kAlignThreads) {
+      const int n = r0 + i0 + tid;
+      const bool mine = n < num_rois && bottom_rois[(long)n * 5] == (float)b;
+      const unsigned long long mk = __ballot(mine);
+      if (mk) {
+        int base = 0;
+        const int leader = __builtin_ctzll(mk);
+        if (lane == leader) base = atomicAdd(&list_n, __builtin_popcountll(mk));
+        base = __builtin_amdgcn_readlane(base, leader);
+        if (mine) list[base + __builtin_popcountll(mk & ((1ULL << lane) - 1ULL))] = n;
+      }
+    }
+    __syncthreads();
+    const int total = list_n * bins;
+    for (int idx = tid; idx < total; idx += kAlignThreads) {
+      const int n = list[idx / bins], bin = idx % bins;
+      const int ph = bin / ow, pw = bin - ph * ow;
+      const float* roi = bottom_rois + (long)n * 5;
+      // roi_align_kernel.cu:33-46, once per output bin
+      const float roi_start_w = roi[1] * spatial_scale;
+      const float roi_start_h = roi[2] * spatial_scale;
+      const float roi_end_w = roi[3] * spatial_scale;
+      const float roi_end_h = roi[4] * spatial_scale;
+      const float roi_width = fmaxf((float)((double)(roi_end_w - roi_start_w) + 1.), 0.f);
+      const float roi_height = fmaxf((float)((double)(roi_end_h - roi_start_h) + 1.), 0.f);
+      const float bin_size_h = (float)((double)roi_height / (ah - 1.));
+      const float bin_size_w = (float)((double)roi_width / (aw - 1.));
+      const int ns = pool_mode == 0 ? 1 : 2;
+      AxisTap th[2], tw[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        th[i] = align_axis((float)(ph + i) * bin_size_h + roi_start_h, height);
+        tw[i] = align_axis((float)(pw + i) * bin_size_w + roi_start_w, width);
+      }
+      for (int cb = 0; cb < ncb; ++cb) {
+        const float* pl = planes + cb * hw;
+        float s[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            if (i < ns && j < ns && th[i].valid && tw[j].valid) {
+              const int ul = th[i].start * width + tw[j].start;
+              const float hr = th[i].ratio, wr = tw[j].ratio;
+              const double v = (double)pl[ul] * (1. - hr) * (1. - wr) + (double)pl[ul + 1] * (1. - hr) * wr +
+                               (double)pl[ul + width] * hr * (1. - wr) + (double)pl[ul + width + 1] * hr * wr;
+              s[i][j] = (float)v;
+            }
+          }
+        float v;
+        if (pool_mode == 0) v = s[0][0];
+        else if (pool_mode == 1) v = (((s[0][0] + s[0][1]) + s[1][0]) + s[1][1]) / 4.f;
+        else v = fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[1][0], s[1][1]));
+        top_data[(((long)n * channels + c0 + cb) * oh + ph) * ow + pw] = v;
+      }
+    }
+  }
+}
+
 // roi_align_kernel.cu:94-143
 __global__ __launch_bounds__(kThreads) void roi_align_bwd(long nthreads, const float* __restrict__ top_diff,
                                                           float spatial_scale, int height, int width, int channels,
@@ -281,6 +382,35 @@ extern "C" int dtt_roi_align_forward(const float* bottom_data, float spatial_sca
                      bottom_data, spatial_scale, height, width, channels, aligned_height, aligned_width, bottom_rois,
                      top_data, pool_mode);
   DTT_CHECK_LAUNCH("roi_align_fwd");
+  return 1;
+}
+
+extern "C" int dtt_roi_align_forward_planes(const float* bottom_data, float spatial_scale, int batch_size, int num_rois,
+                                            int height, int width, int channels, int aligned_height,
+                                            int aligned_width, const float* bottom_rois, float* top_data,
+                                            int pool_mode, void* stream) {
+  DTT_REQUIRE(batch_size > 0, "roi_align forward: bad batch size");
+  DTT_REQUIRE(num_rois >= 0 && height > 1 && width > 1 && channels > 0, "roi_align forward: bad shape");
+  DTT_REQUIRE(pool_mode >= 0 && pool_mode <= 2, "roi_align forward: pool_mode must be 0, 1 or 2");
+  DTT_REQUIRE(aligned_height > (pool_mode == 0 ? 1 : 0) && aligned_width > (pool_mode == 0 ? 1 : 0),
+              "roi_align forward: aligned size too small");
+  if ((long)num_rois * channels * aligned_height * aligned_width == 0) return 1;
+  DTT_REQUIRE(bottom_data && bottom_rois && top_data, "roi_align forward: null pointer");
+  const size_t lds = ((size_t)kAlignCB * height * width + kAlignChunk) * sizeof(float);
+  if (lds > 150 * 1024)   // planes do not fit LDS: thread-per-output path
+    return dtt_roi_align_forward(bottom_data, spatial_scale, num_rois, height, width, channels, aligned_height,
+                                 aligned_width, bottom_rois, top_data, pool_mode, stream);
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(roi_align_planes),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);  // + static list_n
+    DTT_REQUIRE(e == hipSuccess, "roi_align: cannot raise dynamic LDS limit");
+    attr = true;
+  }
+  hipLaunchKernelGGL(roi_align_planes, dim3((channels + kAlignCB - 1) / kAlignCB, batch_size), dim3(kAlignThreads), lds,
+                     static_cast<hipStream_t>(stream), bottom_data, spatial_scale, num_rois, height, width, channels,
+                     aligned_height, aligned_width, bottom_rois, top_data, pool_mode);
+  DTT_CHECK_LAUNCH("roi_align_planes");
   return 1;
 }
 

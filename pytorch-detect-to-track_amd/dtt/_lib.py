@@ -36,6 +36,7 @@ SIGNATURES = {
     "dtt_nms_workspace_bytes": (_Z, [_I]),
     "dtt_nms": (_I, [_P, _P, _P, _I, _I, _F, _I, _P, _Z, _P]),
     "dtt_roi_align_forward": (_I, [_P, _F, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P]),
+    "dtt_roi_align_forward_planes": (_I, [_P, _F, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P]),
     "dtt_roi_align_backward": (_I, [_P, _F, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     "dtt_roi_pool_forward": (_I, [_P, _F, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "dtt_roi_pool_backward": (_I, [_P, _F, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),

@@ -241,7 +241,7 @@ class RoIAlignFunction(Function):
         R = rois.size(0)
         out = torch.empty((R, C, aligned_height, aligned_width), dtype=torch.float32, device=features.device)
         with torch.cuda.device(features.device):
-            check(_lib.lib().dtt_roi_align_forward(ptr(features), spatial_scale, R, H, W, C, aligned_height,
+            check(_lib.lib().dtt_roi_align_forward_planes(ptr(features), spatial_scale, B, R, H, W, C, aligned_height,
                                                    aligned_width, ptr(rois), ptr(out), 0,
                                                    stream_ptr(features.device)), "roi_align forward")
         ctx.save_for_backward(rois)
@@ -270,8 +270,8 @@ def _roi_align_pooled(features, rois, h, w, scale, mode):
     B, C, H, W = features.shape
     out = torch.empty((rois.size(0), C, h, w), dtype=torch.float32, device=features.device)
     with torch.cuda.device(features.device):
-        check(_lib.lib().dtt_roi_align_forward(ptr(features), scale, rois.size(0), H, W, C, h, w, ptr(rois),
-                                               ptr(out), mode, stream_ptr(features.device)), "roi_align forward")
+        check(_lib.lib().dtt_roi_align_forward_planes(ptr(features), scale, B, rois.size(0), H, W, C, h, w, ptr(rois),
+                                                      ptr(out), mode, stream_ptr(features.device)), "roi_align forward")
     return out
 
 

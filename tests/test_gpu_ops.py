@@ -222,6 +222,13 @@ def test_roi_align(dev):
     np.testing.assert_allclose(avg2.detach().cpu().numpy(), avg.numpy(), rtol=1e-6, atol=1e-6)
     avg2.sum().backward()
     assert torch.isfinite(ft2.grad).all()
+    # a map too large for the LDS-resident kernel takes the thread-per-output path: same results
+    big = rng.normal(size=(1, 3, 120, 130)).astype(np.float32)
+    brois = random_rois(rng, 30, 1, 120 * 16, 130 * 16)
+    outb = RoIAlign(8, 8, 1 / 16.0)(cu(big, dev), cu(brois, dev))
+    np.testing.assert_array_equal(outb.cpu().numpy(), O.roi_align_forward(big, brois, 8, 8, 1 / 16.0))
+    avgb = RoIAlignAvg(7, 7, 1 / 16.0)(cu(big, dev), cu(brois, dev)).cpu()
+    np.testing.assert_allclose(avgb.numpy(), torch.nn.functional.avg_pool2d(outb.cpu(), 2, 1).numpy(), rtol=1e-6, atol=1e-6)
 
 
 def test_roi_pool(dev):
