@@ -9,9 +9,8 @@
 // matrix product:   out[p, q] = sum_c f1[c, p] * f2[c, q]   for |q - p| <= R on the stride lattice,
 // computed with exact-f32 MFMA (v_mfma_f32_16x16x4_f32 is bitwise an fmaf chain, so no precision is
 // traded).  One workgroup = one 8x8 tile of output pixels x one channel slice:
-//   * NCHW is read directly with W-contiguous loads; zero padding is applied by predication
-//     (no repack, no scratch fills);
-//   * per 16-channel chunk the 8x8 frame-t tile and the (8+2R)^2 frame-(t+tau) halo are staged in LDS
+//   * NCHW is read directly (no repack, no scratch fills);
+//   * per 8-channel chunk the 8x8 frame-t tile and the (8+2R)^2 frame-(t+tau) halo are staged in LDS
 //     as [c][row][col] with row / plane strides chosen so both MFMA operand reads are conflict free;
 //   * each of the 4 waves owns a 4x4 block of frame-t pixels (MFMA rows) and multiplies it against the
 //     (4+2R)^2 halo it needs, cut into 4x4 pixel blocks (MFMA columns): 72 % of the MFMA work lands
@@ -19,6 +18,15 @@
 //   * accumulators stay in registers for the whole channel loop; partial sums of the channel slices go
 //     to a workspace in fragment order (coalesced) and a small reduce kernel sums the slices in a fixed
 //     order, divides by C and scatters into NCHW -- deterministic, no atomics.
+// Kernels, fastest first (all produce the same partials layout):
+//   corr_fwd_glds     stride 1, 16-byte aligned halo columns: LDS-DMA staging (global_load_lds_dwordx4), double
+//                     buffered, zero padding applied by the reduce kernel -- the D&T conv4 / conv5 path;
+//   corr_fwd_mfma_v4  stride 1 otherwise: 16-byte register staging, padding by masks at the LDS write;
+//   corr_fwd_mfma     any stride (conv3): scalar register staging, software-pipelined;
+//   corr_fwd_generic  kernel_size > 1 or stride1 != stride2: wave per output pixel.
+// Backward: corr_bwd_mfma (band in registers, other frame streamed through LDS), corr_bwd_simple fallback.
+// DTT_CORR_ABLATE / DTT_CORR_STAMP / DTT_CORR_CPHASE are developer builds for tools/corr_tune.py (timing
+// experiments and the per-workgroup timeline); they never ship in libdtt_hip.so.
 #include "common.h"
 
 namespace {
@@ -68,7 +76,7 @@ struct Cfg {
 };
 
 // grid: tiles * ksplit * batch (1-D).  ws layout: [ksplit][batch][tile][wave][nb][reg][lane].
-// Software pipeline per 16-channel chunk: the global loads of chunk i+1 are issued (unconditionally, to
+// Software pipeline per channel chunk: the global loads of chunk i+1 are issued (unconditionally, to
 // clamped addresses) before the MFMA phase of chunk i and land in registers while the matrix pipe works;
 // they are written to LDS after the phase's barrier.
 template <int NBR, bool PIPE, int MINW>
