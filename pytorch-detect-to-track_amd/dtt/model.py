@@ -255,10 +255,12 @@ class _RFCN(nn.Module):
         rpn_loss_cls, rpn_loss_bbox, cls_prob, bbox_pred = [], [], [], []
         loss_cls, loss_bbox = [], []
         tracking_reg = None
+        single_frame = n_legs == 1   # BASELINE configs 1-2: plain R-FCN on one frame, no tracking branch
         if not self.training:
             # inference: RPN, proposal layer and PSRoI pooling also run once for all n_legs*B images
             if side is not None:
-                tracking_reg = self.corr_bbox_net(self._tracking_features(rfcn_bbox, conv3, conv4, conv5))
+                if not single_frame:
+                    tracking_reg = self.corr_bbox_net(self._tracking_features(rfcn_bbox, conv3, conv4, conv5))
                 torch.cuda.current_stream(dev).wait_stream(side)
                 all_rois.record_stream(torch.cuda.current_stream(dev))
             else:
@@ -300,6 +302,14 @@ class _RFCN(nn.Module):
             cls_prob.append(prob.view(B, leg_rois.size(1), -1))
             bbox_pred.append(pred.view(B, leg_rois.size(1), -1))
 
+        if single_frame:
+            zero = torch.zeros(1, device=dev)
+            rois = torch.stack(rois, 0)
+            if rois_label:
+                rois_label = torch.stack(rois_label, 0).view(n_legs, B, -1)
+            return (rois, torch.stack(cls_prob, 0), torch.stack(bbox_pred, 0), torch.zeros(0, 4, device=dev),
+                    torch.stack(rpn_loss_cls, 0), torch.stack(rpn_loss_bbox, 0), torch.stack(loss_cls, 0),
+                    torch.stack(loss_bbox, 0), rois_label, zero)
         if tracking_reg is None:
             tracking_reg = self.corr_bbox_net(self._tracking_features(rfcn_bbox, conv3, conv4, conv5))
         if self.training:
