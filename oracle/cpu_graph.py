@@ -53,6 +53,9 @@ def rfcn_forward_test(model, im_data, im_info, cfg):
         s = F.avg_pool2d(_t(pc), (7, 7), stride=(7, 7)).squeeze(3).squeeze(2)
         cls_prob.append(F.softmax(s, dim=1).view(B, r.shape[1], -1))
         bbox_pred.append(F.avg_pool2d(_t(pl), (7, 7), stride=(7, 7)).squeeze(3).squeeze(2).view(B, r.shape[1], -1))
+    if n_legs == 1:   # single-frame R-FCN (BASELINE configs 1-2): no tracking branch
+        return dict(rois=_t(np.stack(rois, 0)), cls_prob=torch.stack(cls_prob, 0), bbox_pred=torch.stack(bbox_pred, 0),
+                    tracking_pred=torch.zeros(0, 4))
     feats = list(bbox_maps)
     for (f, pad, k, d, s1, s2) in ((conv3, 8, 1, 8, 2, 2), (conv4, 8, 1, 8, 1, 1), (conv5, 8, 1, 8, 1, 1)):
         feats.append(_t(O.correlation_forward(f[0].numpy(), f[1].numpy(), pad, k, d, s1, s2)))

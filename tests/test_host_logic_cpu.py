@@ -171,3 +171,23 @@ def test_grouped_sgd_matches_torch_sgd():
         assert torch.allclose(sa["state"][k]["momentum_buffer"], sb["state"][k]["momentum_buffer"], rtol=1e-6, atol=1e-7)
     ob2 = GroupedSGD(make()[1], momentum=0.9)
     ob2.load_state_dict(sa)  # a torch.optim.SGD checkpoint loads
+
+
+def test_config1_single_frame_res50_cpu_graph():
+    """BASELINE configs[0]: single-frame R-FCN Res-50 on one 300 px image, CPU only -- the plumbing (model graph with the
+    reference's module names, cfg surface, anchors / proposal / PSRoI through the oracle) end to end without a GPU."""
+    import torch
+    from dtt.config import cfg
+    from dtt.synth import build_model, calibrate_batchnorm_, make_batch
+    from oracle import cpu_graph
+    torch.set_num_threads(min(8, torch.get_num_threads()))
+    model = build_model(50, class_agnostic=True, cfg=cfg).eval()
+    im, info, _, _ = make_batch(1, 300, 500, seed=5)
+    calibrate_batchnorm_(model, im[:, 0])
+    out = cpu_graph.rfcn_forward_test(model, im[:, :1].contiguous(), info[:, :1].contiguous(), cfg)
+    R = cfg.TEST.RPN_POST_NMS_TOP_N
+    assert tuple(out["rois"].shape) == (1, 1, R, 5) and tuple(out["cls_prob"].shape) == (1, 1, R, 31)
+    assert tuple(out["bbox_pred"].shape) == (1, 1, R, 4) and out["tracking_pred"].shape == (0, 4)
+    assert torch.isfinite(out["cls_prob"]).all() and abs(float(out["cls_prob"].sum(-1).mean()) - 1.0) < 1e-5
+    r = out["rois"][0, 0]
+    assert float(r[:, 1].min()) >= 0 and float(r[:, 3].max()) <= 499 and float(r[:, 4].max()) <= 299
