@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--width", type=int, default=1067)
     ap.add_argument("--layers", type=int, default=101)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--disp", type=int, default=8, help="correlation max displacement (8 = reference; 16 = BASELINE config 5)")
     ap.add_argument("--nchw-trunk", action="store_true", help="inference: keep the fused trunk in NCHW (A/B against channels-last)")
     return ap.parse_args()
 
@@ -122,6 +123,7 @@ def main():
     from dtt.config import apply_dataset_defaults, cfg
     from dtt.synth import build_model, calibrate_batchnorm_, make_batch
     apply_dataset_defaults("imagenet_vid")
+    cfg.CORR_MAX_DISPLACEMENT = args.disp
     torch.backends.cudnn.benchmark = True
 
     model = build_model(args.layers, cfg=cfg).to(dev)
@@ -181,8 +183,9 @@ def main():
         avg5 = sum(conv5) / max(len(conv5), 1)
         B = args.batch
         H16, W16 = -(-args.height // 16), -(-args.width // 16)
-        flops = 2.0 * 2048 * 289 * H16 * W16 * B           # 2*C*D^2*oH*oW per frame pair
-        bytes_ = (2 * 2048 * H16 * W16 * 4 + 289 * H16 * W16 * 4) * B
+        D2 = (2 * args.disp + 1) ** 2
+        flops = 2.0 * 2048 * D2 * H16 * W16 * B            # 2*C*D^2*oH*oW per frame pair
+        bytes_ = (2 * 2048 * H16 * W16 * 4 + D2 * H16 * W16 * 4) * B
         achieved = flops / (avg5 * 1e-6) / 1e12 if avg5 > 0 else 0.0
         # HBM bytes per launch come from a separate rocprofv3 --pmc pass (profiles/r01_pmc_conv5.json); only quoted
         # when this run has the shape that pass was taken on
@@ -207,13 +210,13 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "Res-%d D&T siamese 2-frame %s step, %dx%d, correlation d=8 + PSRoI, bs=%d per GPU "
+            "config": {"workload": "Res-%d D&T siamese 2-frame %s step, %dx%d, correlation d=%d + PSRoI, bs=%d per GPU "
                                    "(BASELINE.json configs[2]); random-init weights, BN statistics calibrated on the "
                                    "synthetic input" % (args.layers, "inference" if args.mode == "infer" else "training",
-                                                        args.height, args.width, args.batch),
+                                                        args.height, args.width, args.disp, args.batch),
                        "global_batch": args.batch * world, "parallelism": "dp%d (per-snippet sharding%s)" %
                        (world, ", RCCL gradient all-reduce" if args.mode == "train" else ", no collective")},
-            "roofline": {"kernel": "corr_fwd_glds<5> (conv5 correlation, 2048 ch, d=8; profiling label corr_fwd_mfma)", "bound": "mfma",
+            "roofline": {"kernel": "%s (conv5 correlation, 2048 ch, d=%d; profiling label corr_fwd_mfma)" % ("corr_fwd_glds<5>" if args.disp <= 8 else "corr_fwd_mfma<9>", args.disp), "bound": "mfma",
                          "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                          "launch_us": round(avg5, 2), "launches_timed": len(conv5),

@@ -1124,7 +1124,9 @@ int launch_fast(float* output, long out_batch_stride, const float* in1, const fl
   bool use_v4 = false;
   if constexpr (VEC4) use_v4 = g.s == 1 && g.C % kKc == 0 && g.W >= 4;
 #ifndef DTT_CORR_NO_GLDS
-  if (g.s == 1 && g.C % kGKc == 0 && g.c_per_split % kGKc == 0 && g.W >= 4 && (((g.origin - g.R) % 4) + 4) % 4 == 0) {
+  // (R <= 8 only: with the 81 accumulators of the R <= 16 instantiation the LDS-DMA kernel spills and runs 3x slower
+  // than the register-staged one)
+  if (NBR <= 5 && g.s == 1 && g.C % kGKc == 0 && g.c_per_split % kGKc == 0 && g.W >= 4 && (((g.origin - g.R) % 4) + 4) % 4 == 0) {
     using G = GCfg<NBR>;
     static bool gattr = false;
     if (!gattr) {

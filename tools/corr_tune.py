@@ -4,16 +4,17 @@ import ctypes, glob, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 import torch
 dev = torch.device("cuda:0")
-B, C, H, W = int(os.environ.get("B", 2)), int(os.environ.get("C", 2048)), 38, 67
+B, C, H, W = int(os.environ.get("B", 2)), int(os.environ.get("C", 2048)), int(os.environ.get("H", 38)), int(os.environ.get("W", 67))
+DISP = int(os.environ.get("D", 8)); OC = (2 * DISP + 1) ** 2
 x1 = torch.relu(torch.randn(B, C, H, W, device=dev)); x2 = torch.relu(torch.randn(B, C, H, W, device=dev))
 if os.environ.get("ZERO"): x1.zero_(); x2.zero_()
-out = torch.empty(B, 289, H, W, device=dev)
+out = torch.empty(B, OC, H, W, device=dev)
 P, I, L, Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_size_t
 for so in sorted(glob.glob(os.path.join(ROOT, "tools", "_variants", "*.so"))):
     lib = ctypes.CDLL(so)
     lib.dtt_correlation_forward_workspace_bytes.restype = Z
     lib.dtt_correlation_forward.argtypes = [P, I, I, I, I, L, P, I, I, I, P, P, Z, I, I, I, I, I, I, P]
-    n = lib.dtt_correlation_forward_workspace_bytes(B, C, H, W, 8, 1, 8, 1, 1)
+    n = lib.dtt_correlation_forward_workspace_bytes(B, C, H, W, DISP, 1, DISP, 1, 1)
     ws = torch.zeros(n + (1 << 20), dtype=torch.uint8, device=dev)
     lib.dtt_profile_attach.argtypes = [ctypes.c_char_p, P, P, I]
     N = 30
@@ -22,8 +23,8 @@ for so in sorted(glob.glob(os.path.join(ROOT, "tools", "_variants", "*.so"))):
     torch.cuda.synchronize()
     ab = (P * N)(*[e.cuda_event for e in evb]); ae = (P * N)(*[e.cuda_event for e in eve])
     def run():
-        ok = lib.dtt_correlation_forward(P(out.data_ptr()), B, 289, H, W, 289 * H * W, P(x1.data_ptr()), C, H, W, P(x2.data_ptr()),
-                                         P(ws.data_ptr()), n, 8, 1, 8, 1, 1, 1, P(torch.cuda.current_stream().cuda_stream))
+        ok = lib.dtt_correlation_forward(P(out.data_ptr()), B, OC, H, W, OC * H * W, P(x1.data_ptr()), C, H, W, P(x2.data_ptr()),
+                                         P(ws.data_ptr()), n, DISP, 1, DISP, 1, 1, 1, P(torch.cuda.current_stream().cuda_stream))
         assert ok == 1
     for _ in range(5): run()
     torch.cuda.synchronize()
