@@ -322,13 +322,16 @@ __global__ __launch_bounds__(kThreads, MINW) void corr_fwd_mfma_v4(const float* 
   int goff1, loff1, dl1;
   unsigned vb1;
   {
+    // 16 float4 groups per channel: with kKc = 8 only threads 0..127 own a group of the frame-t tile.  (The others used
+    // to stage channels kKc..15 -- past the chunk, and past the end of the tensor on its last chunk: tools/fuzz_ops.py.)
     const int cc = tid >> 4, r = tid & 15, py = r >> 1, q = r & 1;
-    const bool live = (ty0 + py) < g.oh;
-    describe(cc, g.origin + ty0 + py, g.origin + tx0 + 4 * q, live, goff1, vb1, dl1);
+    const bool in_chunk = cc < kKc;
+    const bool live = in_chunk && (ty0 + py) < g.oh;
+    describe(in_chunk ? cc : 0, g.origin + ty0 + py, g.origin + tx0 + 4 * q, live, goff1, vb1, dl1);
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       if (tx0 + 4 * q + j >= g.ow) vb1 &= ~(1u << j);
-    loff1 = cc * kPS1 + py * kTile + 4 * q;
+    loff1 = in_chunk ? cc * kPS1 + py * kTile + 4 * q : kKc * kPS1;   // idle threads: spare slot behind the tile
     fix |= dl1 != 0;
   }
   const bool wg_fix = __syncthreads_or(fix);
@@ -980,6 +983,8 @@ __global__ __launch_bounds__(kThreads, MINW) void corr_bwd_mfma(const float* __r
   const int wy = g.origin + (ty0 + my * 4 + tyi) * g.s, wx = g.origin + (tx0 + mx * 4 + txi) * g.s;
   const bool w_ok = wy >= 0 && wy < g.H && wx >= 0 && wx < g.W;
 
+  if (c_begin >= c_end) return;   // more channel groups than 16-channel chunks (small C): nothing to do, and no staging --
+                                  // the prologue below would read past the end of the tensor (found by tools/fuzz_ops.py)
   if (vec4) { stage_vec(c_begin, true, true); } else { stage_scalar(c_begin); }
   __syncthreads();
   for (int c0 = c_begin; c0 < c_end; c0 += KB) {
