@@ -16,3 +16,10 @@ def test_random_shape_sweep(seed):
     assert torch.cuda.is_available()
     import fuzz_ops
     assert fuzz_ops.run(N=120, seed=seed) == (0, 0, 0)
+
+
+def test_random_shape_sweep_remaining_ops():
+    """Proposal layer (incl. heavy score ties), anchor-target layer, RoI Align / Pool / Crop, per-class NMS and tube
+    linking on random shapes against the oracle."""
+    import fuzz_ops
+    assert not any(fuzz_ops.run_more(N=40, seed=5).values())

@@ -68,6 +68,114 @@ def run(N=150, seed=0):
     return bad, badp, badn
 
 
+def run_more(N=60, seed=0):
+    """Second sweep: proposal layer, anchor-target layer, RoI Align / Pool / Crop, per-class NMS, tube linking.
+    Returns a dict op -> number of mismatching cases."""
+    from oracle import rpn_oracle as ro
+    from oracle import tubes_oracle as to
+    from dtt.ops import RoIAlign, RoIAlignAvg, RoIPoolFunction, _RoICrop
+    from dtt.postprocess import class_nms, to_all_boxes
+    from dtt.rpn import anchor_target_forward, generate_anchors, proposal_forward
+    from dtt.tubes import make_tubes
+    dev = torch.device("cuda:0")
+    rs = np.random.RandomState(seed)
+    bad = dict(proposal=0, anchor_target=0, roi_align=0, roi_pool=0, roi_crop=0, class_nms=0, tubes=0)
+    cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    for it in range(N):
+        # ---- proposal layer
+        scales = (4, 8, 16, 32) if rs.rand() < 0.7 else (8, 16, 32)
+        base = generate_anchors(scales=scales); A = base.shape[0]
+        B = rs.randint(1, 4); H = rs.randint(1, 40); W = rs.randint(1, 70)
+        pre = int(rs.choice([100, 300, 6000, 12000])); post = int(rs.choice([20, 300, 2000])); thr = float(rs.choice([0.5, 0.7]))
+        logits = rs.normal(0, 2, size=(B, 2, A * H, W)).astype(np.float32)
+        prob = torch.softmax(torch.from_numpy(logits), 1).view(B, 2 * A, H, W).numpy()
+        if rs.rand() < 0.3:
+            prob = (np.round(prob * 16) / 16).astype(np.float32)          # many exact score ties
+        bbox = rs.normal(0, 0.5, size=(B, 4 * A, H, W)).astype(np.float32)
+        info = np.tile(np.array([[H * 16.0, W * 16.0, 1.0]], dtype=np.float32), (B, 1)); info[-1, :2] -= rs.randint(0, 9)
+        ref, nref = ro.proposal_layer(prob, bbox, info, base, 16, pre, post, thr, O.nms)
+        rois, num = proposal_forward(cu(prob), cu(bbox), cu(info), torch.from_numpy(base).float(), 16, pre, post, thr)
+        if not (np.array_equal(num.cpu().numpy(), nref) and np.array_equal(rois.cpu().numpy(), ref)):
+            bad["proposal"] += 1; print("PROPOSAL MISMATCH", (B, A, H, W, pre, post, thr), flush=True)
+        # ---- anchor-target layer
+        G_ = rs.randint(1, 31)
+        gt = np.zeros((B, G_, 5), np.float32)
+        for b in range(B):
+            k = rs.randint(1, G_ + 1)
+            xy = rs.uniform(0, [W * 16 * 0.8 + 1, H * 16 * 0.8 + 1], size=(k, 2)); wh = rs.uniform(8, [W * 8 + 9, H * 8 + 9], size=(k, 2))
+            gt[b, :k, :2] = xy; gt[b, :k, 2:4] = xy + wh; gt[b, :k, 4] = rs.randint(1, 31, k)
+        np.random.seed(100 + it)
+        try:
+            aref = ro.anchor_target_layer(gt, info, base, H, W, 16)
+        except ValueError:          # no anchor inside the image (tiny maps): the reference fails the same way
+            aref = None
+        if aref is not None:
+            np.random.seed(100 + it)
+            agot = anchor_target_forward(cu(gt), torch.from_numpy(info), torch.from_numpy(base).float(), H, W, 16)
+            if not all(np.array_equal(a.cpu().numpy(), b) for a, b in zip(agot, aref)):
+                bad["anchor_target"] += 1; print("ANCHOR TARGET MISMATCH", (B, A, H, W, G_), flush=True)
+        # ---- RoI ops
+        C = rs.randint(1, 20); Hh = rs.randint(2, 40); Ww = rs.randint(2, 60); R = rs.randint(1, 200)
+        feat = rs.normal(size=(B, C, Hh, Ww)).astype(np.float32)
+        x1 = rs.uniform(-40, Ww * 16, R); y1 = rs.uniform(-40, Hh * 16, R)
+        rr = np.stack([rs.randint(0, B, R), x1, y1, x1 + rs.uniform(-10, Ww * 14, R), y1 + rs.uniform(-10, Hh * 14, R)], 1).astype(np.float32)
+        if not np.array_equal(RoIAlign(8, 8, 1 / 16.0)(cu(feat), cu(rr)).cpu().numpy(), O.roi_align_forward(feat, rr, 8, 8, 1 / 16.0)):
+            bad["roi_align"] += 1; print("ROI ALIGN MISMATCH", (B, C, Hh, Ww, R), flush=True)
+        a7 = RoIAlignAvg(7, 7, 1 / 16.0)(cu(feat), cu(rr)).cpu()
+        if not np.allclose(a7.numpy(), torch.nn.functional.avg_pool2d(torch.from_numpy(O.roi_align_forward(feat, rr, 8, 8, 1 / 16.0)), 2, 1).numpy(), rtol=1e-6, atol=1e-6):
+            bad["roi_align"] += 1; print("ROI ALIGN AVG MISMATCH", (B, C, Hh, Ww, R), flush=True)
+        pref, parg = O.roi_pool_forward(feat, rr, 7, 7, 1 / 16.0)
+        pout, pa = RoIPoolFunction.apply(cu(feat), cu(rr), 7, 7, 1 / 16.0)
+        if not (np.array_equal(pout.cpu().numpy(), pref) and np.array_equal(pa.cpu().numpy(), parg)):
+            bad["roi_pool"] += 1; print("ROI POOL MISMATCH", (B, C, Hh, Ww, R), flush=True)
+        Gs = int(rs.choice([7, 14])); nro = rs.randint(1, 5)
+        grid = rs.uniform(-1.4, 1.4, size=(B * nro, Gs, Gs, 2)).astype(np.float32)
+        if not np.array_equal(_RoICrop()(cu(feat), cu(grid)).cpu().numpy(), O.roi_crop_forward(feat, grid)):
+            bad["roi_crop"] += 1; print("ROI CROP MISMATCH", (B, C, Hh, Ww, nro, Gs), flush=True)
+        # ---- per-class NMS
+        Rn = rs.randint(1, 400); ncls = rs.randint(2, 32); agn = bool(rs.rand() < 0.6); mpi = int(rs.choice([0, 5, 100]))
+        sc = rs.dirichlet(np.ones(ncls) * 0.3, size=(B, Rn)).astype(np.float32)
+        ctr = rs.uniform(50, 400, size=(B, Rn, 2)); whh = rs.uniform(20, 200, size=(B, Rn, 2))
+        bb = np.concatenate([ctr - whh / 2, ctr + whh / 2], 2).astype(np.float32)
+        boxes = bb if agn else (bb[:, :, None, :] + rs.normal(0, 3, size=(B, Rn, ncls, 4))).reshape(B, Rn, 4 * ncls).astype(np.float32)
+        dets, counts = class_nms(cu(sc), cu(boxes), 0.05, 0.3, mpi, agn)
+        got = to_all_boxes(dets, counts)
+        okc = True
+        for i in range(B):
+            refc = ro.class_nms(sc[i], boxes[i], O.nms, 0.05, 0.3, mpi, agn)
+            okc &= all(np.array_equal(got[i][j], refc[j]) for j in range(ncls))
+        if not okc:
+            bad["class_nms"] += 1; print("CLASS NMS MISMATCH", (B, Rn, ncls, agn, mpi), flush=True)
+        # ---- tube linking
+        F_ = rs.randint(2, 25); M = int(rs.choice([0, 5, 60]))
+        dets_l, trk_l = [], []
+        cen = rs.uniform(40, 500, size=(60, 2)); siz = rs.uniform(30, 140, size=(60, 2))
+        for f in range(F_):
+            k = rs.randint(1, 40)
+            c = cen[:k] + 3.0 * f + rs.normal(0, 3, size=(k, 2)); wh2 = siz[:k] + rs.normal(0, 3, size=(k, 2))
+            b2 = np.concatenate([c - wh2 / 2, c + wh2 / 2], 1); s2 = np.sort(rs.uniform(0.02, 1, k))[::-1]
+            dets_l.append(np.concatenate([b2, s2[:, None], 1 - s2[:, None]], 1).astype(np.float32))
+            if M and rs.rand() < 0.85:
+                pk = rs.randint(0, k, M); t0 = np.concatenate([c[pk] - wh2[pk] / 2, c[pk] + wh2[pk] / 2], 1) + rs.normal(0, 4, size=(M, 4))
+                trk_l.append((t0.astype(np.float32), (t0 + 3).astype(np.float32)))
+            else:
+                trk_l.append(None)
+        nmx = max(len(d) for d in dets_l)
+        Dp = np.zeros((F_, nmx, 6), np.float32); npd = np.array([len(d) for d in dets_l], np.int32)
+        Tp = np.zeros((F_, 2, max(M, 1), 4), np.float32); mp = np.full(F_, -1, np.int32)
+        for f in range(F_):
+            Dp[f, :npd[f]] = dets_l[f]
+            if trk_l[f] is not None:
+                Tp[f, 0], Tp[f, 1] = trk_l[f]; mp[f] = M
+        want = to.make_tubes(Dp, npd, Tp if M else None, mp)
+        gott = make_tubes([cu(d) for d in dets_l], None if not M else [None if t is None else (cu(t[0]), cu(t[1])) for t in trk_l])
+        if not (np.array_equal(gott["idx"].cpu().numpy(), want["idx"]) and np.array_equal(gott["boxes"].cpu().numpy(), want["boxes"])):
+            bad["tubes"] += 1; print("TUBES MISMATCH", (F_, M), flush=True)
+    print("second sweep (%d rounds):" % N, bad, flush=True)
+    return bad
+
+
 if __name__ == "__main__":
     b = run(int(os.environ.get("N", 150)), int(os.environ.get("SEED", 0)))
-    sys.exit(1 if any(b) else 0)
+    m = run_more(int(os.environ.get("N2", 60)), int(os.environ.get("SEED", 0)))
+    sys.exit(1 if (any(b) or any(m.values())) else 0)
