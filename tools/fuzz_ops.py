@@ -47,9 +47,13 @@ def run(N=150, seed=0):
         feat = rs.normal(size=(B, od * gs * gs, H, W)).astype(np.float32)
         x1 = rs.uniform(-30, W * 16, R); y1 = rs.uniform(-30, H * 16, R)
         rois = np.stack([rs.randint(0, B, R), x1, y1, x1 + rs.uniform(0, W * 12, R), y1 + rs.uniform(0, H * 12, R)], 1).astype(np.float32)
-        ref, _ = O.psroi_pool_forward(feat, rois, gs, gs, 1 / 16.0, gs, od)
-        out = _PSRoIPooling(gs, gs, 1 / 16.0, gs, od)(torch.from_numpy(feat).to(dev), torch.from_numpy(rois).to(dev))
-        if not np.array_equal(out.cpu().numpy(), ref):
+        ref, refmap = O.psroi_pool_forward(feat, rois, gs, gs, 1 / 16.0, gs, od)
+        ft = torch.from_numpy(feat).to(dev).requires_grad_(True)
+        out = _PSRoIPooling(gs, gs, 1 / 16.0, gs, od)(ft, torch.from_numpy(rois).to(dev))
+        gop = rs.normal(size=ref.shape).astype(np.float32)
+        out.backward(torch.from_numpy(gop).to(dev))
+        gref = O.psroi_pool_backward(gop, rois, feat.shape, gs, gs, 1 / 16.0, gs, od, refmap)
+        if not np.array_equal(out.detach().cpu().numpy(), ref) or float(np.abs(ft.grad.cpu().numpy() - gref).max()) > 1e-4:
             badp += 1
             print("PSROI MISMATCH", (B, od, gs, H, W, R), flush=True)
     print("psroi: %d cases, %d bad" % (N // 3, badp), flush=True)
@@ -119,18 +123,33 @@ def run_more(N=60, seed=0):
         feat = rs.normal(size=(B, C, Hh, Ww)).astype(np.float32)
         x1 = rs.uniform(-40, Ww * 16, R); y1 = rs.uniform(-40, Hh * 16, R)
         rr = np.stack([rs.randint(0, B, R), x1, y1, x1 + rs.uniform(-10, Ww * 14, R), y1 + rs.uniform(-10, Hh * 14, R)], 1).astype(np.float32)
-        if not np.array_equal(RoIAlign(8, 8, 1 / 16.0)(cu(feat), cu(rr)).cpu().numpy(), O.roi_align_forward(feat, rr, 8, 8, 1 / 16.0)):
+        fa = cu(feat).requires_grad_(True)
+        oa = RoIAlign(8, 8, 1 / 16.0)(fa, cu(rr))
+        ga = rs.normal(size=tuple(oa.shape)).astype(np.float32)
+        oa.backward(cu(ga))
+        if not np.array_equal(oa.detach().cpu().numpy(), O.roi_align_forward(feat, rr, 8, 8, 1 / 16.0)) or \
+                float(np.abs(fa.grad.cpu().numpy() - O.roi_align_backward(ga, rr, feat.shape, 8, 8, 1 / 16.0)).max()) > 1e-4:
             bad["roi_align"] += 1; print("ROI ALIGN MISMATCH", (B, C, Hh, Ww, R), flush=True)
         a7 = RoIAlignAvg(7, 7, 1 / 16.0)(cu(feat), cu(rr)).cpu()
         if not np.allclose(a7.numpy(), torch.nn.functional.avg_pool2d(torch.from_numpy(O.roi_align_forward(feat, rr, 8, 8, 1 / 16.0)), 2, 1).numpy(), rtol=1e-6, atol=1e-6):
             bad["roi_align"] += 1; print("ROI ALIGN AVG MISMATCH", (B, C, Hh, Ww, R), flush=True)
         pref, parg = O.roi_pool_forward(feat, rr, 7, 7, 1 / 16.0)
-        pout, pa = RoIPoolFunction.apply(cu(feat), cu(rr), 7, 7, 1 / 16.0)
-        if not (np.array_equal(pout.cpu().numpy(), pref) and np.array_equal(pa.cpu().numpy(), parg)):
+        fp = cu(feat).requires_grad_(True)
+        pout, pa = RoIPoolFunction.apply(fp, cu(rr), 7, 7, 1 / 16.0)
+        gp = rs.normal(size=pref.shape).astype(np.float32)
+        pout.backward(cu(gp))
+        if not (np.array_equal(pout.detach().cpu().numpy(), pref) and np.array_equal(pa.cpu().numpy(), parg)) or \
+                float(np.abs(fp.grad.cpu().numpy() - O.roi_pool_backward(gp, rr, parg, feat.shape, 7, 7, 1 / 16.0)).max()) > 1e-4:
             bad["roi_pool"] += 1; print("ROI POOL MISMATCH", (B, C, Hh, Ww, R), flush=True)
         Gs = int(rs.choice([7, 14])); nro = rs.randint(1, 5)
         grid = rs.uniform(-1.4, 1.4, size=(B * nro, Gs, Gs, 2)).astype(np.float32)
-        if not np.array_equal(_RoICrop()(cu(feat), cu(grid)).cpu().numpy(), O.roi_crop_forward(feat, grid)):
+        imgc = np.repeat(feat, nro, axis=0)                            # one image per grid, as the op expects
+        fc = cu(imgc).requires_grad_(True)
+        oc_ = _RoICrop()(fc, cu(grid))
+        gc = rs.normal(size=tuple(oc_.shape)).astype(np.float32)
+        oc_.backward(cu(gc))
+        if not np.array_equal(oc_.detach().cpu().numpy(), O.roi_crop_forward(imgc, grid)) or \
+                float(np.abs(fc.grad.cpu().numpy() - O.roi_crop_backward(imgc, grid, gc)).max()) > 1e-4:
             bad["roi_crop"] += 1; print("ROI CROP MISMATCH", (B, C, Hh, Ww, nro, Gs), flush=True)
         # ---- per-class NMS
         Rn = rs.randint(1, 400); ncls = rs.randint(2, 32); agn = bool(rs.rand() < 0.6); mpi = int(rs.choice([0, 5, 100]))
