@@ -82,6 +82,20 @@ class KernelTimer:
     def durations_us(self, used):
         return [self.begin[i].elapsed_time(self.end[i]) * 1e3 for i in range(used)]
 
+    @staticmethod
+    def event_pair_overhead_us(device, n=50):
+        """What an empty begin/end event bracket measures on this stream (subtract from a bracketed kernel to compare
+        with rocprofv3's kernel durations; `launch_us` itself is reported raw, i.e. conservatively)."""
+        s = torch.cuda.current_stream(device)
+        b = [torch.cuda.Event(enable_timing=True) for _ in range(n)]
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(n)]
+        for i in range(n):
+            b[i].record(s)
+            e[i].record(s)
+        torch.cuda.synchronize(device)
+        d = sorted(b[i].elapsed_time(e[i]) * 1e3 for i in range(n))
+        return d[n // 2]
+
 
 def cpu_baseline(args, cfg):
     """One frame pair through the CPU graph (stock PyTorch convs + oracle ops) on the host cores."""
@@ -220,6 +234,7 @@ def main():
                          "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                          "launch_us": round(avg5, 2), "launches_timed": len(conv5),
+                         "event_bracket_overhead_us": round(KernelTimer.event_pair_overhead_us(dev), 2),
                          "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": bytes_,
                          "hbm_view": {"achieved_GBs": round(bytes_ / (avg5 * 1e-6) / 1e9, 1) if avg5 > 0 else 0.0,
                                       "peak_GBs": HBM_PEAK_GBS}},
