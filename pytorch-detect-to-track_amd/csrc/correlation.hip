@@ -63,6 +63,9 @@ struct FastGeom {
   int D;                // 2R + 1
   int tiles_x, tiles_y; // output tiles
   int ksplit, c_per_split;
+  // window decomposition (LDS-DMA kernel + reduce only): this launch computes the (2R+1)^2 sub-window centred at
+  // displacement (qy, qx) of a larger (2*Rfull+1)^2 window; plain launches have qy = qx = 0, Rfull = R, Dfull = D
+  int qy, qx, Rfull, Dfull;
 };
 
 template <int NBR>
@@ -557,8 +560,8 @@ __global__ __launch_bounds__(kThreads, MINW) void corr_fwd_glds(const float* __r
       cc = min(p / K::PP2, kGKc - 1);
       const int r = p - cc * K::PP2, hr = r / K::R4, q = r - hr * K::R4;
       real = p < kGKc * K::PP2 && hr < K::HR && q < K::G4;
-      gy = g.origin + ty0 - g.R + hr;
-      start = g.origin + tx0 - g.R + 4 * q;
+      gy = g.origin + ty0 - g.R + hr + g.qy;
+      start = g.origin + tx0 - g.R + 4 * q + g.qx;
     } else {
       const int pa = p - K::HSLOTS * 64;
       cc = pa / K::PP1;
@@ -759,9 +762,10 @@ __global__ __launch_bounds__(kThreads) void corr_fwd_reduce(const float* __restr
     const int lane = iy * 16 + (hr & 3) * 4 + (hc & 3);
     // zero padding, applied on the output side (the LDS-DMA kernel stages unmasked pixels)
     const int py = g.origin + y * g.s, px = g.origin + x * g.s;
-    const int qy = py + (tj - g.R) * g.s, qx = px + (ti - g.R) * g.s;
+    const int tjg = tj + g.qy + g.Rfull - g.R, tig = ti + g.qx + g.Rfull - g.R;   // index in the full window
+    const int qy = py + (tjg - g.Rfull) * g.s, qx = px + (tig - g.Rfull) * g.s;
     const bool in_image = py >= 0 && py < g.H && px >= 0 && px < g.W && qy >= 0 && qy < g.H && qx >= 0 && qx < g.W;
-    o[((long)(tj * g.D + ti) * g.oh + y) * g.ow + x] = in_image ? frag[((hc >> 2) * 4 + ix) * 64 + lane] / nelems : 0.f;
+    o[((long)(tjg * g.Dfull + tig) * g.oh + y) * g.ow + x] = in_image ? frag[((hc >> 2) * 4 + ix) * 64 + lane] / nelems : 0.f;
   }
 }
 
@@ -1076,6 +1080,7 @@ FastGeom make_geom(int batch, int C, int H, int W, int oc, int oh, int ow, int p
   g.origin = maxd - pad;
   g.R = maxd / s;
   g.D = 2 * g.R + 1;
+  g.qy = g.qx = 0; g.Rfull = g.R; g.Dfull = g.D;
   g.tiles_x = (ow + kTile - 1) / kTile;
   g.tiles_y = (oh + kTile - 1) / kTile;
   // Channel slices: about 3 workgroups per CU (more only inflates the split-K partials), and slices x batch a
@@ -1126,8 +1131,7 @@ int launch_fast(float* output, long out_batch_stride, const float* in1, const fl
   }
   const int ntiles = g.tiles_x * g.tiles_y;
   dtt_prof_begin("corr_fwd_mfma", stream);
-  bool use_v4 = false;
-  if constexpr (VEC4) use_v4 = g.s == 1 && g.C % kKc == 0 && g.W >= 4;
+  bool launched = false;
 #ifndef DTT_CORR_NO_GLDS
   // (R <= 8 only: with the 81 accumulators of the R <= 16 instantiation the LDS-DMA kernel spills and runs 3x slower
   // than the register-staged one)
@@ -1142,17 +1146,22 @@ int launch_fast(float* output, long out_batch_stride, const float* in1, const fl
     }
     hipLaunchKernelGGL((corr_fwd_glds<NBR, MINW>), dim3(ntiles * g.ksplit * batch), dim3(kThreads), G::LDS, stream,
                        in1, in2, static_cast<float*>(workspace), g);
-    use_v4 = true;  // launched
-  } else
+    launched = true;
+  }
 #endif
-  if constexpr (VEC4) {
-    if (use_v4)
-      hipLaunchKernelGGL((corr_fwd_mfma_v4<NBR, MINW>), dim3(ntiles * g.ksplit * batch), dim3(kThreads), K::LDS, stream,
+  if (!launched) {
+    DTT_REQUIRE(g.qy == 0 && g.qx == 0, "correlation: window decomposition needs the LDS-DMA kernel");
+    if constexpr (VEC4) {
+      if (g.s == 1 && g.C % kKc == 0 && g.W >= 4) {
+        hipLaunchKernelGGL((corr_fwd_mfma_v4<NBR, MINW>), dim3(ntiles * g.ksplit * batch), dim3(kThreads), K::LDS, stream,
+                           in1, in2, static_cast<float*>(workspace), g);
+        launched = true;
+      }
+    }
+    if (!launched)
+      hipLaunchKernelGGL((corr_fwd_mfma<NBR, PIPE, MINW>), dim3(ntiles * g.ksplit * batch), dim3(kThreads), K::LDS, stream,
                          in1, in2, static_cast<float*>(workspace), g);
   }
-  if (!use_v4)
-    hipLaunchKernelGGL((corr_fwd_mfma<NBR, PIPE, MINW>), dim3(ntiles * g.ksplit * batch), dim3(kThreads), K::LDS, stream,
-                       in1, in2, static_cast<float*>(workspace), g);
   dtt_prof_end("corr_fwd_mfma", stream);
   DTT_CHECK_LAUNCH("corr_fwd_mfma");
   dtt_prof_begin("corr_fwd_reduce", stream);
@@ -1215,6 +1224,29 @@ extern "C" int dtt_correlation_forward(float* output, int ob, int oc, int oh, in
     const FastGeom g = make_geom(ob, ic, ih, iw, oc, oh, ow, pad_size, max_displacement, stride1);
     if (nbr == 3) return launch_fast<3, true, DTT_CORR_MINW, true>(output, out_batch_stride, input1, input2, workspace, workspace_bytes, g, ob, stream);
     if (nbr == 5) return launch_fast<5, true, DTT_CORR_MINW, true>(output, out_batch_stride, input1, input2, workspace, workspace_bytes, g, ob, stream);
+#ifndef DTT_CORR_NO_QUADRANTS
+    // 8 < R <= 16 (BASELINE config 5: d = 16): the 81-accumulator instantiation runs one wave per SIMD.  The window is
+    // instead covered by four (2*8+1)^2 sub-windows centred at (+-(R-8), +-(R-8)) -- the same arithmetic per output, so
+    // the overlapping rows / columns are simply written twice with identical values -- each one a launch of the R <= 8
+    // LDS-DMA kernel on frame t+tau shifted by the centre.  Needs 16-byte aligned halo columns: R a multiple of 4.
+    if (g.s == 1 && g.R % 4 == 0 && ic % kGKc == 0 && iw >= 4 && (((g.origin - 8) % 4) + 4) % 4 == 0) {
+      FastGeom q = g;
+      q.R = 8; q.D = 17;
+      q.Rfull = g.R; q.Dfull = g.D;
+      const int c = g.R - 8;
+      for (int sy = -1; sy <= 1; sy += 2)
+        for (int sx = -1; sx <= 1; sx += 2) {
+          q.qy = sy * c; q.qx = sx * c;
+#ifdef DTT_CORR_QDEBUG
+          q.qy = DTT_CORR_QDEBUG_Y; q.qx = DTT_CORR_QDEBUG_X;   // one fixed window (debug)
+#endif
+          if (!launch_fast<5, true, DTT_CORR_MINW, true>(output, out_batch_stride, input1, input2, workspace, workspace_bytes,
+                                                         q, ob, stream))
+            return 0;
+        }
+      return 1;
+    }
+#endif
     return launch_fast<9, false, 1, false>(output, out_batch_stride, input1, input2, workspace, workspace_bytes, g, ob, stream);
   }
   hipLaunchKernelGGL(corr_fwd_generic, dim3(ow, oh, ob), dim3(64), 0, stream, input1, input2, output,

@@ -150,6 +150,8 @@ CORR_CASES = [
     (1, 8, 5, 4, 8, 1, 8, 1, 1),        # LDS-DMA kernel, map narrower than one piece row
     (1, 24, 38, 67, 8, 1, 8, 1, 1),     # LDS-DMA kernel, the 600 px map, odd number of chunks
     (3, 8, 8, 8, 8, 1, 8, 1, 1),        # LDS-DMA kernel, single chunk, batch 3
+    (2, 16, 20, 30, 12, 1, 12, 1, 1),   # R = 12: four R = 8 sub-windows of the LDS-DMA kernel
+    (1, 24, 37, 50, 16, 1, 16, 1, 1),   # R = 16 the same way, three chunks
 ]
 
 
