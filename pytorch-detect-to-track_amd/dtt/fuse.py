@@ -259,6 +259,7 @@ class _NhwcConv:
         self.is_gemm = conv.kernel_size == (1, 1) and conv.stride == (1, 1)
         if self.is_gemm:
             self.wt = base.w.view(base.w.shape[0], base.w.shape[1]).t().contiguous()   # (Cin, Cout)
+            self.zero_b = torch.zeros_like(self.b)
         else:
             self.w = base.w.contiguous(memory_format=torch.channels_last)
 
@@ -266,14 +267,18 @@ class _NhwcConv:
         """Convolution without bias; x and the result are channels-last."""
         if self.is_gemm:
             n, _, h, w = x.shape
-            return _from_rows(torch.mm(_rows(x), self.wt), n, h, w)
+            a = _rows(x)
+            out = torch.empty((a.shape[0], self.wt.shape[1]), dtype=a.dtype, device=a.device)
+            return _from_rows(gemm_bias_act_(out, a, self.wt, self.zero_b, relu=False), n, h, w)
         return F.conv2d(x, self.w, None, **self.kw)
 
     def act(self, x):
         """relu(conv(x) + b)."""
         if self.is_gemm:
             n, _, h, w = x.shape
-            return _from_rows(torch._addmm_activation(self.b, _rows(x), self.wt), n, h, w)
+            a = _rows(x)
+            out = torch.empty((a.shape[0], self.wt.shape[1]), dtype=a.dtype, device=a.device)
+            return _from_rows(gemm_bias_act_(out, a, self.wt, self.b), n, h, w)
         y = F.conv2d(x, self.w, None, **self.kw)
         bias_act_nhwc_(_rows(y), self.b)
         return y

@@ -402,3 +402,36 @@ class _RoICrop(nn.Module):
 
     def forward(self, input1, input2):
         return RoICropFunction.apply(input1, input2)
+
+
+def affine_grid_gen(rois, input_size, grid_size):
+    """Sampling grids for the 'crop' pooling mode (net_utils.py:143-165, `_affine_grid_gen`).
+
+    rois (R,5) rows [batch, x1, y1, x2, y2] in image pixels; input_size = (H, W) of the stride-16 feature map.
+    Returns (R, grid_size, grid_size, 2) holding (x, y) in the [-1, 1] corner-aligned convention of the torch 0.3
+    `F.affine_grid` the reference calls: x = theta00 * u + theta02, y = theta11 * v + theta12 with u, v =
+    linspace(-1, 1, grid_size).  Written out directly so the result does not depend on the align_corners default.
+    """
+    rois = rois.detach()
+    height, width = int(input_size[0]), int(input_size[1])
+    x1, y1, x2, y2 = (rois[:, k] / 16.0 for k in (1, 2, 3, 4))
+    sx, tx = (x2 - x1) / (width - 1), (x1 + x2 - width + 1) / (width - 1)
+    sy, ty = (y2 - y1) / (height - 1), (y1 + y2 - height + 1) / (height - 1)
+    lin = torch.linspace(-1.0, 1.0, grid_size, device=rois.device, dtype=rois.dtype) if grid_size > 1 else \
+        torch.full((1,), -1.0, device=rois.device, dtype=rois.dtype)
+    gx = sx[:, None, None] * lin[None, None, :] + tx[:, None, None]
+    gy = sy[:, None, None] * lin[None, :, None] + ty[:, None, None]
+    return torch.stack([gx.expand(-1, grid_size, grid_size), gy.expand(-1, grid_size, grid_size)], 3).contiguous()
+
+
+def roi_crop_pool(base_feat, rois, pooling_size, max_pool=True):
+    """The 'crop' branch of the detector's RoI pooling (faster_rcnn.py:73-80): affine grids from the RoIs, (x, y)
+    swapped to the (y, x) order `_RoICrop` samples with, bilinear crop on the HIP kernel, optional 2x2 max pool
+    (cfg.CROP_RESIZE_WITH_MAX_POOL, grid_size = 2 * POOLING_SIZE)."""
+    grid_size = pooling_size * 2 if max_pool else pooling_size
+    grid_xy = affine_grid_gen(rois.view(-1, 5), base_feat.shape[2:], grid_size)
+    grid_yx = torch.stack([grid_xy[..., 1], grid_xy[..., 0]], 3).contiguous()
+    pooled = RoICropFunction.apply(base_feat, grid_yx.detach())
+    if max_pool:
+        pooled = torch.nn.functional.max_pool2d(pooled, 2, 2)
+    return pooled

@@ -266,6 +266,34 @@ def test_roi_crop(dev):
     np.testing.assert_allclose(it.grad.cpu().numpy(), O.roi_crop_backward(img, grid, gout), rtol=1e-5, atol=1e-5)
 
 
+def test_roi_crop_pool_matches_grid_sample(dev):
+    """faster_rcnn.py:73-80 ('crop' pooling mode): grids from RoIs -> bilinear crop -> 2x2 max pool."""
+    import torch.nn.functional as F
+    from dtt.ops import affine_grid_gen, roi_crop_pool
+    rng = np.random.RandomState(16)
+    B, C, H, W, RPI, P = 2, 12, 19, 31, 6, 7
+    feat = rng.normal(size=(B, C, H, W)).astype(np.float32)
+    x1 = rng.uniform(0, 300, B * RPI); y1 = rng.uniform(0, 200, B * RPI)
+    rois = np.stack([np.repeat(np.arange(B), RPI), x1, y1, x1 + rng.uniform(8, 180, B * RPI),
+                     y1 + rng.uniform(8, 90, B * RPI)], 1).astype(np.float32)
+    for max_pool in (True, False):
+        ft = cu(feat, dev).requires_grad_(True)
+        out = roi_crop_pool(ft, cu(rois, dev).view(B, RPI, 5), P, max_pool)
+        G = 2 * P if max_pool else P
+        grid = affine_grid_gen(torch.from_numpy(rois), (H, W), G)
+        x = torch.from_numpy(feat).requires_grad_(True)
+        ref = F.grid_sample(x.repeat_interleave(RPI, 0), grid, mode="bilinear", padding_mode="zeros",
+                            align_corners=True)
+        if max_pool:
+            ref = F.max_pool2d(ref, 2, 2)
+        assert tuple(out.shape) == (B * RPI, C, P, P)
+        np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), atol=1e-4)
+        gout = rng.normal(size=tuple(out.shape)).astype(np.float32)
+        out.backward(cu(gout, dev))
+        ref.backward(torch.from_numpy(gout))
+        np.testing.assert_allclose(ft.grad.cpu().numpy(), x.grad.numpy(), atol=1e-4)
+
+
 # ------------------------------------------------------------------------------------ proposal layer
 def _proposal_inputs(rng, B, A, H, W):
     logits = rng.normal(0, 2, size=(B, 2, A * H, W)).astype(np.float32)

@@ -191,3 +191,26 @@ def test_config1_single_frame_res50_cpu_graph():
     assert torch.isfinite(out["cls_prob"]).all() and abs(float(out["cls_prob"].sum(-1).mean()) - 1.0) < 1e-5
     r = out["rois"][0, 0]
     assert float(r[:, 1].min()) >= 0 and float(r[:, 3].max()) <= 499 and float(r[:, 4].max()) <= 299
+
+
+def test_affine_grid_gen_matches_corner_aligned_affine_grid():
+    """net_utils.py:143-165: theta from rois / 16, then torch 0.3's affine_grid (corner aligned linspace(-1, 1))."""
+    import torch.nn.functional as F
+    from dtt.ops import affine_grid_gen
+    rng = np.random.RandomState(4)
+    R, H, W, G = 9, 19, 31, 14
+    x1 = rng.uniform(0, 300, R); y1 = rng.uniform(0, 200, R)
+    rois = np.stack([rng.randint(0, 2, R), x1, y1, x1 + rng.uniform(1, 180, R), y1 + rng.uniform(1, 90, R)], 1)
+    rois = torch.from_numpy(rois.astype(np.float32))
+    grid = affine_grid_gen(rois, (H, W), G)
+    b = rois[:, 1:] / 16.0
+    zero = torch.zeros(R)
+    theta = torch.stack([(b[:, 2] - b[:, 0]) / (W - 1), zero, (b[:, 0] + b[:, 2] - W + 1) / (W - 1),
+                         zero, (b[:, 3] - b[:, 1]) / (H - 1), (b[:, 1] + b[:, 3] - H + 1) / (H - 1)], 1).view(-1, 2, 3)
+    ref = F.affine_grid(theta, (R, 1, G, G), align_corners=True)
+    assert grid.shape == (R, G, G, 2)
+    np.testing.assert_allclose(grid.numpy(), ref.numpy(), atol=1e-6)
+    # the four grid corners land on the RoI corners of the feature map: pixel = (g + 1) / 2 * (size - 1)
+    px = (grid[:, 0, :, 0] + 1) / 2 * (W - 1)
+    np.testing.assert_allclose(px[:, 0].numpy(), b[:, 0].numpy(), atol=1e-4)
+    np.testing.assert_allclose(px[:, -1].numpy(), b[:, 2].numpy(), atol=1e-4)
