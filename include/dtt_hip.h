@@ -255,6 +255,11 @@ int dtt_bias_act_inplace(float* x, const float* bias, const float* residual, int
 int dtt_bias_act_nhwc_inplace(float* x, const float* bias, const float* residual, long rows, int channels,
                               int relu, void* stream);
 
+/* Batched 2-D transpose: in (batch, rows, cols) row-major -> out (batch, cols, rows).  The layout change between
+ * the channels-last trunk and the NCHW maps the operators above read (NHWC -> NCHW: rows = H*W, cols = C), which the
+ * reference never needs because its trunk is NCHW throughout (faster_rcnn/resnet.py:325-343).  in != out. */
+int dtt_transpose_batched(const float* in, float* out, int batch, int rows, int cols, void* stream);
+
 /* Row-major GEMM with the bottleneck epilogue: out (rows, n) = act(a (rows, k) * w (k, n) + bias[n] (+ residual
  * (rows, n))); residual may be NULL and may alias out.  A library GEMM (hipBLASLt) -- the entry point exists for the
  * epilogue: frozen-BatchNorm shift + `out += residual` + ReLU of faster_rcnn/resnet.py:100-107 in the GEMM itself.

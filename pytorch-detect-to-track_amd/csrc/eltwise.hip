@@ -72,6 +72,53 @@ __global__ __launch_bounds__(kThreads) void bias_act_rows_kernel(float* __restri
   }
 }
 
+// Batched 2-D transpose in (batch, rows, cols) -> out (batch, cols, rows): the layout change between the
+// channels-last trunk and the NCHW maps the D&T operators read (NHWC -> NCHW: rows = H*W, cols = C; the reverse for
+// gradients).  64 x 64 tile through LDS (stride 65: both phases bank-conflict free), 256-byte row segments on both
+// sides; 16-byte accesses on whichever side has a multiple-of-4 fastest extent.
+constexpr int kTile = 64;
+
+template <bool VR, bool VW>
+__global__ __launch_bounds__(kThreads) void transpose_tiles(const float* __restrict__ in, float* __restrict__ out,
+                                                            int rows, int cols) {
+  __shared__ float tile[kTile][kTile + 1];
+  const int c0 = blockIdx.x * kTile, r0 = blockIdx.y * kTile, tid = threadIdx.x;
+  const float* src = in + (long)blockIdx.z * rows * cols;
+  float* dst = out + (long)blockIdx.z * rows * cols;
+  if (VR) {
+#pragma unroll
+    for (int it = 0; it < kTile * kTile / 4 / kThreads; ++it) {
+      const int idx = it * kThreads + tid, r = idx >> 4, c = (idx & 15) << 2;
+      if (r0 + r < rows && c0 + c < cols) {
+        const float4 v = *reinterpret_cast<const float4*>(src + (long)(r0 + r) * cols + c0 + c);
+        tile[r][c] = v.x; tile[r][c + 1] = v.y; tile[r][c + 2] = v.z; tile[r][c + 3] = v.w;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int it = 0; it < kTile * kTile / kThreads; ++it) {
+      const int idx = it * kThreads + tid, r = idx >> 6, c = idx & 63;
+      if (r0 + r < rows && c0 + c < cols) tile[r][c] = src[(long)(r0 + r) * cols + c0 + c];
+    }
+  }
+  __syncthreads();
+  if (VW) {
+#pragma unroll
+    for (int it = 0; it < kTile * kTile / 4 / kThreads; ++it) {
+      const int idx = it * kThreads + tid, c = idx >> 4, r = (idx & 15) << 2;
+      if (c0 + c < cols && r0 + r < rows)
+        *reinterpret_cast<float4*>(dst + (long)(c0 + c) * rows + r0 + r) =
+            make_float4(tile[r][c], tile[r + 1][c], tile[r + 2][c], tile[r + 3][c]);
+    }
+  } else {
+#pragma unroll
+    for (int it = 0; it < kTile * kTile / kThreads; ++it) {
+      const int idx = it * kThreads + tid, c = idx >> 6, r = idx & 63;
+      if (c0 + c < cols && r0 + r < rows) dst[(long)(c0 + c) * rows + r0 + r] = tile[r][c];
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int dtt_bias_act_nhwc_inplace(float* x, const float* bias, const float* residual, long rows, int channels,
@@ -117,5 +164,22 @@ extern "C" int dtt_bias_act_inplace(float* x, const float* bias, const float* re
     else hipLaunchKernelGGL((bias_act_kernel<false, false>), grid, dim3(kThreads), 0, stream, x, bias, residual, channels, hw);
   }
   DTT_CHECK_LAUNCH("bias_act_kernel");
+  return 1;
+}
+
+extern "C" int dtt_transpose_batched(const float* in, float* out, int batch, int rows, int cols, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  DTT_REQUIRE(in && out, "transpose_batched: null pointer");
+  DTT_REQUIRE(in != out, "transpose_batched: in place is not supported");
+  DTT_REQUIRE(batch > 0 && rows > 0 && cols > 0, "transpose_batched: bad shape");
+  const dim3 grid((cols + kTile - 1) / kTile, (rows + kTile - 1) / kTile, batch);
+  DTT_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "transpose_batched: extent too large");
+  const bool vr = cols % 4 == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0 && ((long)rows * cols) % 4 == 0;
+  const bool vw = rows % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && ((long)rows * cols) % 4 == 0;
+  if (vr && vw) hipLaunchKernelGGL((transpose_tiles<true, true>), grid, dim3(kThreads), 0, stream, in, out, rows, cols);
+  else if (vr) hipLaunchKernelGGL((transpose_tiles<true, false>), grid, dim3(kThreads), 0, stream, in, out, rows, cols);
+  else if (vw) hipLaunchKernelGGL((transpose_tiles<false, true>), grid, dim3(kThreads), 0, stream, in, out, rows, cols);
+  else hipLaunchKernelGGL((transpose_tiles<false, false>), grid, dim3(kThreads), 0, stream, in, out, rows, cols);
+  DTT_CHECK_LAUNCH("transpose_tiles");
   return 1;
 }

@@ -199,7 +199,7 @@ class FusedTrainTrunk:
             feats.append(x)
         top = F.relu(self.model.RFCN_net(feats[3]), inplace=True)
         if self.channels_last:
-            return feats[1].contiguous(), feats[2].contiguous(), feats[3].contiguous(), top.contiguous()
+            return _to_nchw(feats[1]), _to_nchw(feats[2]), _to_nchw(feats[3]), _to_nchw(top)
         return feats[1], feats[2], feats[3], top
 
 
@@ -237,6 +237,48 @@ def gemm_bias_act_(out2d, a2d, wt, bias, residual2d=None, relu=True):
                                   a2d.shape[0], a2d.shape[1], wt.shape[1], int(relu), ptr(ws), ws.numel(),
                                   stream_ptr(dev)), "gemm_bias_act")
     return out2d
+
+
+def _transpose_batched(src, dst, batch, rows, cols):
+    with torch.cuda.device(src.device):
+        check(_lib.lib().dtt_transpose_batched(ptr(src), ptr(dst), batch, rows, cols, stream_ptr(src.device)),
+              "transpose_batched")
+    return dst
+
+
+def nhwc_to_nchw(x):
+    """Channels-last (N,C,H,W)-shaped tensor -> NCHW-contiguous copy, by the tiled HIP transpose (torch's strided
+    copy kernel moves these maps at 1.4 TB/s)."""
+    n, c, h, w = x.shape
+    assert x.dtype == torch.float32 and x.is_contiguous(memory_format=torch.channels_last)
+    return _transpose_batched(x, torch.empty((n, c, h, w), dtype=x.dtype, device=x.device), n, h * w, c)
+
+
+def nchw_to_nhwc(x):
+    """NCHW-contiguous tensor -> channels-last tensor of the same logical shape."""
+    n, c, h, w = x.shape
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    out = torch.empty((n, c, h, w), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    return _transpose_batched(x, out, n, c, h * w)
+
+
+class _ToNCHWFn(torch.autograd.Function):
+    """nhwc_to_nchw with the reverse transpose as its backward (training trunk -> D&T operators)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return nhwc_to_nchw(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return nchw_to_nhwc(g.contiguous())
+
+
+def _to_nchw(x):
+    if x.shape[1] == 1 or x.shape[2] * x.shape[3] == 1 or not x.is_contiguous(memory_format=torch.channels_last) \
+            or x.is_contiguous():
+        return x.contiguous()
+    return _ToNCHWFn.apply(x) if x.requires_grad else nhwc_to_nchw(x)
 
 
 def _rows(x):
@@ -325,7 +367,7 @@ class FusedTrunkNHWC:
                 x = blk(x)
             feats.append(x)
         top = self.top.act(feats[3])
-        return feats[1].contiguous(), feats[2].contiguous(), feats[3].contiguous(), top.contiguous()
+        return _to_nchw(feats[1]), _to_nchw(feats[2]), _to_nchw(feats[3]), _to_nchw(top)
 
 
 def fuse_for_inference(model, channels_last=True):

@@ -294,6 +294,25 @@ def test_roi_crop_pool_matches_grid_sample(dev):
         np.testing.assert_allclose(ft.grad.cpu().numpy(), x.grad.numpy(), atol=1e-4)
 
 
+def test_layout_transposes(dev):
+    """dtt_transpose_batched behind nhwc_to_nchw / nchw_to_nhwc: exact copies, all four vector / scalar variants."""
+    from dtt.fuse import _ToNCHWFn, nchw_to_nhwc, nhwc_to_nchw
+    g = torch.Generator().manual_seed(5)
+    for (n, c, h, w) in [(2, 64, 38, 67), (1, 130, 5, 7), (3, 4, 1, 9), (2, 7, 8, 8), (1, 3, 13, 11), (2, 256, 2, 2)]:
+        x = torch.randn(n, c, h, w, generator=g).to(dev)
+        xl = x.contiguous(memory_format=torch.channels_last)
+        if c > 1 and h * w > 1:
+            y = nhwc_to_nchw(xl)
+            assert y.is_contiguous() and torch.equal(y, x)
+        z = nchw_to_nhwc(x)
+        assert z.is_contiguous(memory_format=torch.channels_last) and torch.equal(z, x)
+    xl = torch.randn(2, 32, 9, 10, generator=g).to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = _ToNCHWFn.apply(xl)
+    gy = torch.randn(2, 32, 9, 10, generator=g).to(dev)
+    y.backward(gy)
+    assert torch.equal(xl.grad, gy)
+
+
 # ------------------------------------------------------------------------------------ proposal layer
 def _proposal_inputs(rng, B, A, H, W):
     logits = rng.normal(0, 2, size=(B, 2, A * H, W)).astype(np.float32)
