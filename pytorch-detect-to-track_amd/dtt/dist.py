@@ -5,8 +5,8 @@ Replaces the reference's single-process `nn.DataParallel` (trainval_net.py:310-3
 replica (identical after the one broadcast at construction), runs its shard of video snippets -- both frames
 of a pair always stay on one GPU, exactly as DataParallel's dim-0 scatter did -- and the only collective is a
 bucketed gradient all-reduce that overlaps with the rest of backward:
-  * trainable gradients are views into a few flat fp32 buckets (default 32 MiB: on 8 GPUs a ring all-reduce
-    is bound by one xGMI link (~153 GB/s), so a 32 MiB bucket costs ~0.4 ms -- large enough to amortise the
+  * trainable gradients are gathered into a few flat fp32 buckets (one multi-tensor copy each; default 32 MiB:
+    on 8 GPUs a ring all-reduce is bound by one xGMI link (~153 GB/s), so a 32 MiB bucket costs ~0.4 ms -- large enough to amortise the
     launch, small enough that the first bucket is on the wire while layer3/layer2 are still in backward);
   * buckets are filled in reverse registration order (the order autograd produces gradients) and each one
     is all-reduced asynchronously as soon as its last gradient has been accumulated;
@@ -19,6 +19,16 @@ import torch.distributed as dist
 from torch import nn
 
 
+def _bucket_view(flat, off, p):
+    """Slice of a flat bucket shaped and laid out like p (channels-last parameters get a channels-last view, so
+    gradient accumulation and the multi-tensor optimizer never mix layouts)."""
+    piece = flat[off:off + p.numel()]
+    if p.dim() == 4 and not p.is_contiguous() and p.is_contiguous(memory_format=torch.channels_last):
+        n, c, h, w = p.shape
+        return piece.view(n, h, w, c).permute(0, 3, 1, 2)
+    return piece.view_as(p)
+
+
 class DataParallelSnippets(nn.Module):
     def __init__(self, module, world_size=None, bucket_bytes=32 << 20, process_group=None):
         super().__init__()
@@ -27,6 +37,7 @@ class DataParallelSnippets(nn.Module):
         self.world = world_size if world_size is not None else (dist.get_world_size() if dist.is_initialized() else 1)
         self._handles = []
         self._buckets = []
+        self._views = []
         self._pending = {}
         if self.world > 1:
             self._sync_initial_state()
@@ -62,42 +73,68 @@ class DataParallelSnippets(nn.Module):
             groups.append(cur)
         for bi, grp in enumerate(groups):
             flat = torch.zeros(sum(p.numel() for p in grp), dtype=grp[0].dtype, device=grp[0].device)
-            off = 0
             for p in grp:
-                p.grad = flat[off:off + p.numel()].view_as(p)  # gradients accumulate straight into the bucket
-                off += p.numel()
+                p.grad = None
                 p.register_post_accumulate_grad_hook(self._make_hook(bi))
             self._buckets.append((flat, grp))
+            self._views.append(None)
         self._reset_pending()
 
     def _reset_pending(self):
         self._pending = {bi: len(grp) for bi, (_, grp) in enumerate(self._buckets)}
 
+    def _bucket_views(self, bi):
+        """Per-parameter views into bucket bi, laid out like the parameters (rebuilt if a layout changed)."""
+        flat, grp = self._buckets[bi]
+        cached = self._views[bi]
+        if cached is None or any(v.stride() != p.stride() for v, p in zip(cached, grp)):
+            cached, off = [], 0
+            for p in grp:
+                cached.append(_bucket_view(flat, off, p))
+                off += p.numel()
+            self._views[bi] = cached
+        return cached
+
+    def _fill_and_reduce(self, bi):
+        """Gather the bucket's gradients (autograd hands each one over as a fresh tensor: no zeroing pass, no add
+        per parameter) with one multi-tensor copy, re-point .grad at the bucket and put it on the wire."""
+        flat, grp = self._buckets[bi]
+        views = self._bucket_views(bi)
+        dst, src = [], []
+        for p, v in zip(grp, views):
+            if p.grad is None:
+                v.zero_()  # unused this step
+            elif p.grad.data_ptr() != v.data_ptr():
+                dst.append(v)
+                src.append(p.grad)
+            p.grad = v
+        if dst:
+            torch._foreach_copy_(dst, src)
+        self._handles.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
     def _make_hook(self, bucket_index):
         def hook(param):
             self._pending[bucket_index] -= 1
             if self._pending[bucket_index] == 0:
-                flat, grp = self._buckets[bucket_index]
-                # a parameter whose .grad was re-pointed (e.g. by zero_grad(set_to_none=True)) is copied back in
-                off = 0
-                for p in grp:
-                    view = flat[off:off + p.numel()].view_as(p)
-                    if p.grad is not None and p.grad.data_ptr() != view.data_ptr():
-                        view.copy_(p.grad)
-                        p.grad = view
-                    off += p.numel()
-                self._handles.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                self._fill_and_reduce(bucket_index)
         return hook
 
     # ------------------------------------------------------------------ step API
     def forward(self, *args, **kwargs):
         return self.module(*args, **kwargs)
 
-    def zero_grad(self, set_to_none=False):
-        for flat, _ in self._buckets:
-            flat.zero_()
+    def zero_grad(self, set_to_none=True):
+        """Drop the gradients (default) so that backward hands fresh tensors over instead of running one add per
+        parameter; set_to_none=False keeps the tensors and zeroes them."""
         if self.world == 1:
             self.module.zero_grad(set_to_none=set_to_none)
+            return
+        for flat, grp in self._buckets:
+            if set_to_none:
+                for p in grp:
+                    p.grad = None
+            else:
+                flat.zero_()
 
     def finish_gradients(self):
         """Wait for the in-flight bucket all-reduces and average.  Parameters that received no gradient this
@@ -106,8 +143,7 @@ class DataParallelSnippets(nn.Module):
             return
         for bi, left in self._pending.items():
             if left > 0:
-                self._handles.append(dist.all_reduce(self._buckets[bi][0], op=dist.ReduceOp.SUM, group=self.group,
-                                                     async_op=True))
+                self._fill_and_reduce(bi)
         for h in self._handles:
             h.wait()
         self._handles = []
@@ -149,6 +185,19 @@ def make_optimizer(model, cfg, lr=None, optimizer="sgd"):
     return GroupedSGD(groups, momentum=T.MOMENTUM)
 
 
+def _grad_like_param(p):
+    """p.grad with exactly p's strides.  The multi-tensor kernels take their fast path only when every (param, grad,
+    buffer) triple has identical strides; MIOpen returns 1x1 filter gradients with channels-last flavoured strides
+    on size-1 dimensions (same memory, different stride tuple), which would silently send the whole list down the
+    one-kernel-per-tensor path."""
+    g = p.grad
+    if g.stride() == p.stride():
+        return g
+    if all(sz == 1 or a == b for sz, a, b in zip(p.shape, g.stride(), p.stride())):
+        return g.as_strided(p.shape, p.stride(), g.storage_offset())  # same memory order: a relabelling
+    return torch.empty_like(p).copy_(g)
+
+
 class GroupedSGD(torch.optim.SGD):
     """torch.optim.SGD semantics and state_dict layout (one param group per parameter, as the reference builds them),
     but `step()` batches all parameters that share (lr, weight_decay, momentum) into the same multi-tensor launches:
@@ -169,7 +218,7 @@ class GroupedSGD(torch.optim.SGD):
                 if p.grad is not None:
                     buckets.setdefault(key, []).append(p)
         for (lr, wd, mom), ps in buckets.items():
-            grads = [p.grad for p in ps]
+            grads = [_grad_like_param(p) for p in ps]
             if wd != 0:
                 grads = torch._foreach_add(grads, ps, alpha=wd)
             if mom != 0:

@@ -126,6 +126,26 @@ class _BiasActFn(torch.autograd.Function):
         return gi, None, (gi if ctx.has_res else None)
 
 
+class _FoldScalesFn(torch.autograd.Function):
+    """(w_1 .. w_n, s_1 .. s_n) -> (w_1 * s_1, .. , w_n * s_n) with multi-tensor launches in both directions; the
+    scales are frozen-BatchNorm constants (no gradient)."""
+
+    @staticmethod
+    def forward(ctx, *tensors):
+        n = len(tensors) // 2
+        ctx.scales = tensors[n:]
+        return tuple(torch._foreach_mul(list(tensors[:n]), list(tensors[n:])))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        n = len(grads)
+        if all(g is not None for g in grads):
+            out = torch._foreach_mul(list(grads), list(ctx.scales))
+        else:
+            out = [None if g is None else g * s for g, s in zip(grads, ctx.scales)]
+        return tuple(out) + (None,) * n
+
+
 class FusedTrainTrunk:
     """Training-time trunk with the frozen BatchNorm folded out of the activation path.
 
@@ -164,6 +184,15 @@ class FusedTrainTrunk:
                     self.convs.append(conv)
                     self.scales.append(sc.view(-1, 1, 1, 1).contiguous())
                     self.shifts.append((bn.bias - bn.running_mean * sc).detach().contiguous())
+        if channels_last:
+            # keep the trainable filters themselves in channels-last memory (values, names and checkpoints are
+            # unchanged): no per-step layout copy of every weight and of every weight gradient
+            for conv in self.convs:
+                w = conv.weight
+                if not w.is_contiguous(memory_format=torch.channels_last):
+                    w.data = w.data.contiguous(memory_format=torch.channels_last)
+                    if w.grad is not None:
+                        w.grad = None
 
     @staticmethod
     def run_block(blk, x, w, t):
@@ -185,11 +214,11 @@ class FusedTrainTrunk:
                 for blk in stage:
                     x = blk(x)
                 feats.append(x)
-        ws = torch._foreach_mul([c.weight for c in self.convs], self.scales)  # all folded weights in a few launches
+        # all folded weights in a few launches, forward and backward (the parameters already have the trunk's layout)
+        ws = _FoldScalesFn.apply(*[c.weight for c in self.convs], *self.scales)
         if self.channels_last:
             # MIOpen's fp32 backward kernels are NHWC implicit GEMMs; feeding them NCHW costs a transpose on each side
             x = x.contiguous(memory_format=torch.channels_last)
-            ws = [w.contiguous(memory_format=torch.channels_last) for w in ws]
         k = 0
         for blocks in self.live:
             for blk in blocks:

@@ -53,10 +53,11 @@ def _worker(rank, world, port, q):
         loss = dp(data[mine]).sum() / 6.0 * world   # per-rank mean convention: sum/N_global * world -> avg over ranks
         loss.backward()
         dp.finish_gradients()
-        grads.append({n: p.grad.clone() for n, p in model.named_parameters() if p.requires_grad and p.grad is not None})
-    w0 = {n: p.detach().clone() for n, p in model.named_parameters()}
+        grads.append({n: p.grad.clone().numpy() for n, p in model.named_parameters()
+                      if p.requires_grad and p.grad is not None})
+    w0 = {n: p.detach().clone().numpy() for n, p in model.named_parameters()}
     if rank == 0:
-        q.put((w0, grads))
+        q.put((w0, grads))  # numpy: pickled by value (tensors travel as fds that die with this process)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -69,6 +70,8 @@ def test_two_rank_gradients_match_single_process():
     for p in procs:
         p.start()
     w0, grads = q.get()
+    w0 = {n: torch.from_numpy(v) for n, v in w0.items()}
+    grads = [{n: torch.from_numpy(v) for n, v in g.items()} for g in grads]
     for p in procs:
         p.join(60)
         assert p.exitcode == 0

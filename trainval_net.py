@@ -101,13 +101,13 @@ def main(argv=None):
             cfg.POOLING_MODE = ck["pooling_mode"]
         if rank == 0:
             print("loaded checkpoint %s" % load_name)
-    runner = DataParallelSnippets(model, world)
     # global batch = --bs snippets per process (per-snippet sharding; both frames of a pair stay on one GPU)
     first = make_batch(args.batch_size, args.height, args.width, seed=1000 + rank, device=dev)
     calibrate_batchnorm_(model, first[0][:, 0])
     model.train()
     from dtt.fuse import fuse_for_training
-    fuse_for_training(model, channels_last=True)
+    fuse_for_training(model, channels_last=True)  # also moves the trainable filters to channels-last memory ...
+    runner = DataParallelSnippets(model, world)   # ... so the gradient buckets are laid out after it
     for epoch in range(args.start_epoch, args.max_epochs + 1):
         if epoch % (args.lr_decay_step + 1) == 0:
             for g in optimizer.param_groups:  # adjust_learning_rate (net_utils.py:63-66)
