@@ -5,17 +5,26 @@
  * product (pytorch-detect-to-track_amd/) never links, imports or falls back to it.
  *
  * Every function follows one reference kernel line by line (paths relative to the reference's
- * lib/model/).  The reference's CUDA sources cannot be compiled or run in this environment (no
- * nvcc / CUDA device, TH/THC headers gone from torch>=1.0, torch.utils.ffi removed) and the
- * reference ships no tests, golden vectors or known-answer files for any of these ops, so
+ * lib/model/).
  *
- *     ***  PARITY UNPINNED for the ops in this file  ***
+ *     ***  PARITY PINNED against the reference's own kernels  ***
  *
- * by anything the reference itself provides.  What pins them instead: independent second
- * formulations in PyTorch (tests/test_oracle_*.py: shifted-product correlation, python-loop
- * pooling, F.grid_sample for RoI crop / RoI align, O(N^2) greedy NMS) and float64 autograd for the
- * backwards.  The RPN-side pieces that CAN be imported from the reference are pinned by golden
- * fixtures (tests/golden/, oracle/rpn_oracle.py).
+ * The reference ships no tests, golden vectors or known-answer files for these ops, and its TH/THC
+ * cffi shims cannot be built (no TH.h / THC.h, torch.utils.ffi removed).  Its six kernel translation
+ * units, however, are self-contained CUDA with plain extern "C" launchers: oracle/build_ref.sh puts
+ * them through ROCm's hipify-perl + hipcc (sources read where they lie under /root/reference, nothing
+ * copied or hand-written) into oracle/_ref/libdtt_ref_kernels.so, and
+ *   - tests/test_gpu_ref_kernels.py runs those kernels on the MI355X beside this file and beside the
+ *     product: forwards, channel / argmax maps and keep lists agree with this restatement BIT FOR
+ *     BIT (gradients, which the reference accumulates with float atomics, to 1e-5);
+ *   - tests/golden/ref_kernels.npz holds their outputs on seeded inputs, so the CPU-only suite
+ *     (tests/test_oracle_ref_golden.py) checks the same thing without a GPU.
+ * (That comparison found one mis-restated promotion here -- RoI align's `data * h_ratio` is a float
+ * product in C++, not a double one -- which the independent PyTorch checks below were too coarse to
+ * see.)  Independent second formulations remain as a cross-check (tests/test_oracle_ops.py:
+ * shifted-product correlation, python-loop pooling, F.grid_sample for RoI crop / RoI align, O(N^2)
+ * greedy NMS, float64 autograd for the backwards).  The RPN-side Python is pinned by executing the
+ * reference modules themselves (tests/golden/, oracle/rpn_oracle.py).
  *
  * Floating point: compile with -ffp-contract=off -fno-fast-math.  nvcc's default -fmad=true may have
  * contracted some mul+add pairs in the reference build; no such contraction is assumed here (the
@@ -433,10 +442,15 @@ int oracle_roi_align_forward(const float* bottom_data, float spatial_scale, int 
       float w_ratio = w - (float)(wstart);
       long upleft = img_start + ((long)c * height + hstart) * width + wstart;
       long upright = upleft + 1, downleft = upleft + width, downright = downleft + 1;
+      /* .cu:65-68, C++ promotion as written: `data * (1. - h_ratio)` is a double product, but `data * h_ratio` is
+       * float * float and is ROUNDED TO FLOAT before it meets a double (term 3) or not at all (term 4, all float).
+       * Pinned against the reference kernel itself (oracle/_ref, tests/test_gpu_ref_kernels.py). */
+      float dl_h = bottom_data[downleft] * h_ratio;
+      float dr_hw = (bottom_data[downright] * h_ratio) * w_ratio;
       double v = (double)bottom_data[upleft] * (1. - h_ratio) * (1. - w_ratio) +
                  (double)bottom_data[upright] * (1. - h_ratio) * w_ratio +
-                 (double)bottom_data[downleft] * h_ratio * (1. - w_ratio) +
-                 (double)bottom_data[downright] * h_ratio * w_ratio;
+                 (double)dl_h * (1. - w_ratio) +
+                 (double)dr_hw;
       top_data[index] = (float)v;
     }
   }
@@ -478,8 +492,9 @@ int oracle_roi_align_backward(const float* top_diff, float spatial_scale, int ba
       double g = (double)top_diff[index];
       bottom_diff[upleft] += (float)(g * (1. - h_ratio) * (1 - w_ratio));
       bottom_diff[upright] += (float)(g * (1. - h_ratio) * w_ratio);
-      bottom_diff[downleft] += (float)(g * h_ratio * (1 - w_ratio));
-      bottom_diff[downright] += (float)(g * h_ratio * w_ratio);
+      /* .cu:140-141: float * float * float -- no double operand in these two */
+      bottom_diff[downleft] += (top_diff[index] * h_ratio) * (1 - w_ratio);
+      bottom_diff[downright] += (top_diff[index] * h_ratio) * w_ratio;
     }
   }
   return 1;

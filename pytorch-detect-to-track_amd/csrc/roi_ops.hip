@@ -37,10 +37,13 @@ __device__ __forceinline__ float align_sample(const float* __restrict__ bottom_d
   const float h_ratio = h - (float)(hstart);
   const float w_ratio = w - (float)(wstart);
   const long upleft = img_start + ((long)c * height + hstart) * width + wstart;
+  // C++ promotion exactly as roi_align_kernel.cu:65-68 writes it: `data * (1. - h_ratio)` is a double product, `data *
+  // h_ratio` is float * float (rounded to float); checked bit for bit against the reference kernel (oracle/_ref)
+  const float dl_h = bottom_data[upleft + width] * h_ratio;
+  const float dr_hw = (bottom_data[upleft + width + 1] * h_ratio) * w_ratio;
   const double v = (double)bottom_data[upleft] * (1. - h_ratio) * (1. - w_ratio) +
-                   (double)bottom_data[upleft + 1] * (1. - h_ratio) * w_ratio +
-                   (double)bottom_data[upleft + width] * h_ratio * (1. - w_ratio) +
-                   (double)bottom_data[upleft + width + 1] * h_ratio * w_ratio;
+                   (double)bottom_data[upleft + 1] * (1. - h_ratio) * w_ratio + (double)dl_h * (1. - w_ratio) +
+                   (double)dr_hw;
   return (float)v;
 }
 
@@ -155,8 +158,10 @@ __global__ __launch_bounds__(kAlignThreads) void roi_align_planes(const float* _
             if (i < ns && j < ns && th[i].valid && tw[j].valid) {
               const int ul = th[i].start * width + tw[j].start;
               const float hr = th[i].ratio, wr = tw[j].ratio;
+              const float dl_h = pl[ul + width] * hr;  // float products, as in align_value()
+              const float dr_hw = (pl[ul + width + 1] * hr) * wr;
               const double v = (double)pl[ul] * (1. - hr) * (1. - wr) + (double)pl[ul + 1] * (1. - hr) * wr +
-                               (double)pl[ul + width] * hr * (1. - wr) + (double)pl[ul + width + 1] * hr * wr;
+                               (double)dl_h * (1. - wr) + (double)dr_hw;
               s[i][j] = (float)v;
             }
           }
@@ -202,8 +207,9 @@ __global__ __launch_bounds__(kThreads) void roi_align_bwd(long nthreads, const f
     const double g = (double)top_diff[index];
     atomicAdd(bottom_diff + upleft, (float)(g * (1. - h_ratio) * (1 - w_ratio)));
     atomicAdd(bottom_diff + upleft + 1, (float)(g * (1. - h_ratio) * w_ratio));
-    atomicAdd(bottom_diff + upleft + width, (float)(g * h_ratio * (1 - w_ratio)));
-    atomicAdd(bottom_diff + upleft + width + 1, (float)(g * h_ratio * w_ratio));
+    // roi_align_kernel.cu:140-141: float * float * float, no double operand in these two
+    atomicAdd(bottom_diff + upleft + width, (top_diff[index] * h_ratio) * (1 - w_ratio));
+    atomicAdd(bottom_diff + upleft + width + 1, (top_diff[index] * h_ratio) * w_ratio);
   }
 }
 
