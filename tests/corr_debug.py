@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Developer tool: locate forward-correlation mismatches against the oracle for one case."""
+"""Test-side developer script (it uses the oracle, so it lives under tests/): locate forward-correlation mismatches against the oracle for one case."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "pytorch-detect-to-track_amd")]

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Developer tool: randomized shape sweep of the hot-path ops against the oracle (GPU box).  Complements the fixed cases
+"""Test helper (also runnable on its own on the GPU box): randomized shape sweep of the hot-path ops against the oracle (GPU box).  Complements the fixed cases
 of tests/test_gpu_ops.py: map sizes around tile / piece boundaries, channel counts around chunk boundaries, batch 1-3."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -198,3 +198,56 @@ if __name__ == "__main__":
     b = run(int(os.environ.get("N", 150)), int(os.environ.get("SEED", 0)))
     m = run_more(int(os.environ.get("N2", 60)), int(os.environ.get("SEED", 0)))
     sys.exit(1 if (any(b) or any(m.values())) else 0)
+
+
+def run_ref(N=60, seed=0):
+    """Random shapes, CPU oracle against the REFERENCE's own kernels (oracle/_ref, see oracle/build_ref.sh): forwards, index
+    maps and keep lists bit for bit.  Returns a dict of mismatch counts per op; {} when oracle/_ref is not built."""
+    from oracle import ref_kernels as RK
+    if not RK.available():
+        return {}
+    rs = np.random.RandomState(seed)
+    bad = dict(correlation=0, psroi=0, roi_align=0, roi_pool=0, roi_crop=0, nms=0)
+    for it in range(N):
+        B = rs.randint(1, 3); C = int(rs.choice([1, 7, 16, 33, 64, 100])); H = rs.randint(2, 30); W = rs.randint(2, 40)
+        d = int(rs.choice([1, 2, 4, 8])); s2 = int(rs.choice([1, 1, 2])); s1 = int(rs.choice([1, 1, 2]))
+        k = int(rs.choice([1, 1, 1, 3])); pad = d + (k - 1) // 2 if rs.rand() < 0.7 else rs.randint(0, d + 3)
+        try:
+            O.correlation_output_shape(C, H, W, pad, k, d, s1, s2)
+        except ValueError:
+            continue
+        x1 = rs.normal(size=(B, C, H, W)).astype(np.float32); x2 = rs.normal(size=(B, C, H, W)).astype(np.float32)
+        if not np.array_equal(O.correlation_forward(x1, x2, pad, k, d, s1, s2), RK.correlation_forward(x1, x2, pad, k, d, s1, s2)):
+            bad["correlation"] += 1
+            print("REF CORR MISMATCH", (B, C, H, W, pad, k, d, s1, s2), flush=True)
+    for it in range(N // 2):
+        B = rs.randint(1, 4); od = rs.randint(1, 6); gs = int(rs.choice([1, 3, 7])); H = rs.randint(3, 45); W = rs.randint(3, 70)
+        R = rs.randint(1, 200); scale = float(rs.choice([1 / 16.0, 1 / 8.0, 0.1]))
+        x1 = rs.uniform(-30, W / scale, R); y1 = rs.uniform(-30, H / scale, R)
+        rois = np.stack([rs.randint(0, B, R), x1, y1, x1 + rs.uniform(0, W / scale * 0.8, R), y1 + rs.uniform(0, H / scale * 0.8, R)],
+                        1).astype(np.float32)
+        if rs.rand() < 0.3:
+            rois[:, 1:] = np.round(rois[:, 1:])
+        feat = rs.normal(size=(B, od * gs * gs, H, W)).astype(np.float32)
+        a, am = O.psroi_pool_forward(feat, rois, gs, gs, scale, gs, od); b, bm = RK.psroi_pool_forward(feat, rois, gs, gs, scale, gs, od)
+        if not (np.array_equal(a, b) and np.array_equal(am, bm)):
+            bad["psroi"] += 1; print("REF PSROI MISMATCH", (B, od, gs, H, W, R, scale), flush=True)
+        C = rs.randint(1, 9); feat = rs.normal(size=(B, C, H, W)).astype(np.float32); p = int(rs.choice([2, 7, 14]))
+        if not np.array_equal(O.roi_align_forward(feat, rois, p, p, scale), RK.roi_align_forward(feat, rois, p, p, scale)):
+            bad["roi_align"] += 1; print("REF ROI ALIGN MISMATCH", (B, C, H, W, R, p, scale), flush=True)
+        a, aa = O.roi_pool_forward(feat, rois, p, p, scale); b, ba = RK.roi_pool_forward(feat, rois, p, p, scale)
+        if not (np.array_equal(a, b) and np.array_equal(aa, ba)):
+            bad["roi_pool"] += 1; print("REF ROI POOL MISMATCH", (B, C, H, W, R, p, scale), flush=True)
+        grid = rs.uniform(-1.4, 1.4, size=(B * rs.randint(1, 5), p, p, 2)).astype(np.float32)
+        if not np.array_equal(O.roi_crop_forward(feat, grid), RK.roi_crop_forward(feat, grid)):
+            bad["roi_crop"] += 1; print("REF ROI CROP MISMATCH", (B, C, H, W, grid.shape), flush=True)
+    for it in range(N // 2):
+        n = rs.randint(1, 2500); thr = float(rs.choice([0.3, 0.5, 0.7]))
+        c = rs.uniform(0, 300, size=(n, 2)); wh = rs.uniform(5, 150, size=(n, 2))
+        dets = np.concatenate([c - wh / 2, c + wh / 2, np.sort(rs.uniform(0, 1, n))[::-1][:, None]], 1).astype(np.float32)
+        if rs.rand() < 0.4:
+            dets[:, :4] = np.round(dets[:, :4])
+        if not np.array_equal(O.nms(dets, thr).reshape(-1), RK.nms(dets, thr)):
+            bad["nms"] += 1; print("REF NMS MISMATCH", n, thr, flush=True)
+    print("oracle vs reference kernels:", bad, flush=True)
+    return bad

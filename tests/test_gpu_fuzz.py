@@ -1,13 +1,12 @@
 """Randomized shape sweep of correlation (forward + backward), PSRoI pooling and NMS against the oracle: map sizes around
 tile / piece boundaries, channel counts around chunk boundaries, strides, pad != displacement, integer boxes.  The sweep
-(tools/fuzz_ops.py) found two out-of-bounds reads in this round that the fixed cases did not reach."""
+(tests/fuzz_ops.py) found two out-of-bounds reads in this round that the fixed cases did not reach."""
 import os
 import sys
 
 import pytest
 
 pytestmark = pytest.mark.gpu
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
 
 
 @pytest.mark.parametrize("seed", [0, 11])
@@ -23,3 +22,12 @@ def test_random_shape_sweep_remaining_ops():
     linking on random shapes against the oracle."""
     import fuzz_ops
     assert not any(fuzz_ops.run_more(N=40, seed=5).values())
+
+
+def test_oracle_against_reference_kernels_on_random_shapes():
+    """The CPU oracle against the reference's own kernels (oracle/_ref) over random geometries: bit for bit."""
+    import fuzz_ops
+    from oracle import ref_kernels as RK
+    if not RK.available():
+        pytest.skip("oracle/_ref not built (oracle/build_ref.sh needs /root/reference + hipify-perl)")
+    assert not any(fuzz_ops.run_ref(N=60, seed=3).values())

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Developer tool: time tube linking at a production-like size (30 classes x 300 frames, 300 detections and 300
+"""Test-side developer script (it uses the oracle, so it lives under tests/): time tube linking at a production-like size (30 classes x 300 frames, 300 detections and 300
 tracklets per frame) on the GPU, and the numpy oracle on one class for scale."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
