@@ -272,11 +272,19 @@ class _RFCN(nn.Module):
             pred = self._pool_vote(self.RFCN_psroi_loc_pool, self.RFCN_bbox_pred, bbox_maps, flat_rois)
             pred = pred.view(n_legs, B, R, -1)
             leg_rois = all_rois.view(n_legs, B, R, 5).clone()
-            leg_rois[..., 0] -= torch.arange(n_legs, device=dev, dtype=leg_rois.dtype).view(n_legs, 1, 1) * B
-            zero = torch.zeros(1, device=dev)
-            for i in range(n_legs):
-                rois.append(leg_rois[i]); cls_prob.append(prob[i]); bbox_pred.append(pred[i])
-                rpn_loss_cls.append(zero); rpn_loss_bbox.append(zero); loss_cls.append(zero); loss_bbox.append(zero)
+            for i in range(1, n_legs):
+                leg_rois[i, :, :, 0] -= i * B  # batch index within the leg
+            # everything is already laid out (n_legs, B, R, .): hand the tensors over instead of re-stacking slices
+            zeros = torch.zeros(n_legs, 1, device=dev)
+            zero = zeros[0]
+            tracking_pred = torch.zeros(0, 4, device=dev)
+            if not single_frame:
+                if tracking_reg is None:
+                    tracking_reg = self.corr_bbox_net(self._tracking_features(rfcn_bbox, conv3, conv4, conv5))
+                # tracking RoIs = frame-t RoIs (rfcn.py:192)
+                tracking_pred = self._pool_vote(self.RFCN_psroi_loc_pool, self.RFCN_tracking_pred, tracking_reg,
+                                                leg_rois[0].view(-1, 5))
+            return leg_rois, prob, pred, tracking_pred, zeros, zeros, zeros, zeros, [], zero
         for i in range(n_legs if self.training else 0):
             # training keeps the reference's per-leg order: anchor-target and RoI sampling draw from numpy's RNG
             top_i, cls_map, bbox_map = leg(top, i), leg(cls_maps, i), rfcn_bbox[i]
