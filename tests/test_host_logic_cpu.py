@@ -173,6 +173,49 @@ def test_grouped_sgd_matches_torch_sgd():
     ob2.load_state_dict(sa)  # a torch.optim.SGD checkpoint loads
 
 
+def test_grouped_sgd_with_channels_last_parameters_and_relabelled_gradients():
+    """Filters kept in channels-last memory (dtt.fuse.FusedTrainTrunk) and gradients whose stride tuple differs from
+    the parameter's -- on size-1 dimensions only (what MIOpen returns for 1x1 filters) or genuinely (another layout) --
+    must give torch.optim.SGD's updates; momentum buffers take the parameter's layout."""
+    import torch
+    from dtt.dist import GroupedSGD, _bucket_view, _grad_like_param
+    shapes = [(8, 4, 1, 1), (6, 5, 3, 3), (6,), (7, 6, 3, 3)]
+    def make(channels_last):
+        torch.manual_seed(3)
+        ps = []
+        for s in shapes:
+            w = torch.randn(*s)
+            if channels_last and len(s) == 4:
+                w = w.contiguous(memory_format=torch.channels_last)
+            ps.append(torch.nn.Parameter(w))
+        return ps, [{"params": [p], "lr": 0.01, "weight_decay": 5e-4} for p in ps]
+    pa, ga = make(False)
+    pb, gb = make(True)
+    oa, ob = torch.optim.SGD(ga, momentum=0.9), GroupedSGD(gb, momentum=0.9)
+    for step in range(3):
+        torch.manual_seed(20 + step)
+        for i, (x, y) in enumerate(zip(pa, pb)):
+            g = torch.randn_like(x)
+            x.grad = g.clone()
+            if i == 0:    # 1x1 filter: same memory, channels-last flavoured stride tuple
+                y.grad = g.clone().as_strided(g.shape, (4, 1, 4, 4))
+            elif i == 1:  # gradient in the other layout
+                y.grad = g.clone().contiguous()
+            else:
+                y.grad = g.clone().contiguous(memory_format=torch.channels_last) if g.dim() == 4 else g.clone()
+            assert _grad_like_param(y).stride() == y.stride() and torch.equal(_grad_like_param(y), g)
+        oa.step(); ob.step()
+    for x, y in zip(pa, pb):
+        assert torch.allclose(x, y, rtol=1e-6, atol=1e-7)
+        assert ob.state[y]["momentum_buffer"].stride() == y.stride()
+    # bucket views follow the parameter's layout
+    flat = torch.zeros(sum(p.numel() for p in pb))
+    v = _bucket_view(flat, pb[0].numel(), pb[1])
+    assert v.shape == pb[1].shape and v.stride() == pb[1].stride()
+    v.copy_(pb[1].detach())
+    assert torch.equal(v, pb[1].detach())
+
+
 def test_config1_single_frame_res50_cpu_graph():
     """BASELINE configs[0]: single-frame R-FCN Res-50 on one 300 px image, CPU only -- the plumbing (model graph with the
     reference's module names, cfg surface, anchors / proposal / PSRoI through the oracle) end to end without a GPU."""
