@@ -3,9 +3,9 @@
 Only tests/, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this
 module; the product package never does.
 
-Unlike the CUDA ops (oracle/dtt_oracle.c, "parity unpinned"), these pieces ARE pinned: the reference
-modules they restate can be imported in the build container, and tests/golden/make_golden.py runs
-them there to produce the fixtures in tests/golden/*.npz that tests/test_oracle_rpn.py checks this
+Pinned by executing the reference itself (the CUDA ops of oracle/dtt_oracle.c are pinned against the
+reference's own kernels, oracle/build_ref.sh): the reference modules restated here can be imported in the
+build container, and tests/golden/make_golden.py runs them there to produce the fixtures in tests/golden/*.npz that tests/test_oracle_rpn.py checks this
 file against.
 
 Declared semantics where the reference leans on unspecified library behaviour:

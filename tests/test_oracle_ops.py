@@ -1,7 +1,8 @@
-"""The C oracle (oracle/dtt_oracle.c) against INDEPENDENT formulations -- the reference ships no tests or
-golden vectors for its CUDA ops ("parity unpinned"), so these second formulations are what pins the
-restatement: shifted-product correlation + float64 autograd, brute-force pooling, O(N^2) greedy NMS,
-F.grid_sample for the bilinear ops.  CPU only."""
+"""The C oracle (oracle/dtt_oracle.c) against INDEPENDENT formulations: shifted-product correlation + float64
+autograd, brute-force pooling, O(N^2) greedy NMS, F.grid_sample for the bilinear ops.  CPU only.  (The reference
+ships no tests or golden vectors for its CUDA ops; the oracle is pinned bit for bit against the reference's own
+kernels in tests/test_oracle_ref_golden.py / tests/test_gpu_ref_kernels.py -- these second formulations are the
+cross-check that does not depend on the reference at all.)"""
 import numpy as np
 import pytest
 import torch
