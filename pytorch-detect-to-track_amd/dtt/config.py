@@ -73,7 +73,7 @@ cfg = AttrDict({
     "RNG_SEED": 3,                               # (*) seeds numpy for the anchor / RoI subsampling
     "EPS": 1e-14,
     "ROOT_DIR": _ROOT,
-    "DATA_DIR": os.path.join(_ROOT, "data"),
+    "DATA_DIR": os.environ.get("DTT_DATA_DIR") or os.path.join(_ROOT, "data"),   # devkits live in DATA_DIR/ILSVRC
     "MATLAB": "matlab",
     "EXP_DIR": "default",
     "USE_GPU_NMS": True,

@@ -4,7 +4,9 @@
 weights when the file does not exist and `--dataset synthetic`), runs the D&T forward on frame pairs, decodes the
 boxes (test_net.py:239-266) and applies the per-class NMS + top-100 cut (test_net.py:274-301) -- the latter as
 ONE device launch per pair instead of 30 NMS round trips.  Writes `detections.pkl` with the reference's
-`all_boxes[class][pair]` layout.  The ImageNet VID imdb / evaluator is out of scope (synthetic pairs only).
+`all_boxes[class][pair]` layout.  `--dataset imagenet_vid` reads the VID test split of an ILSVRC devkit under
+cfg.DATA_DIR/ILSVRC (dtt/data) and finishes with the VOC-style mAP (imagenet_detect.py:263-318); `--dataset synthetic`
+(the default: no dataset ships with this repo) runs seeded synthetic pairs.
 """
 import argparse
 import os
@@ -59,9 +61,21 @@ def main(argv=None):
     cfg_from_file(cfg_file)
     if args.set_cfgs:
         cfg_from_list(args.set_cfgs)
-    if args.dataset != "synthetic":
-        raise NotImplementedError("the ImageNet VID imdb / evaluator is outside this repo's scope; use --dataset synthetic")
     np.random.seed(cfg.RNG_SEED)
+    imdb = pairs = data_iter = None
+    if args.dataset != "synthetic":
+        # test_net.py:131-144: imagenet_vid_test pairs through the test-mode loader, one pair per step
+        from dtt.data import combined_roidb, roibatchLoader
+        if args.dataset not in ("imagenet_vid", "imagenet_vid+imagenet_det"):
+            raise KeyError("Unknown dataset: {}".format(args.dataset))
+        cfg.TRAIN.USE_FLIPPED = False
+        imdb, pairs, ratio_list, ratio_index = combined_roidb("imagenet_vid_test", False)
+        imdb.competition_mode(on=True)
+        print("{:d} roidb frame pairs".format(len(pairs)))
+        loader = torch.utils.data.DataLoader(roibatchLoader(pairs, ratio_list, ratio_index, 1, imdb.num_classes,
+                                                            training=False), batch_size=1, shuffle=False, num_workers=0)
+        data_iter = iter(loader)
+        args.num_pairs, args.batch_size = len(pairs), 1
     dev = torch.device("cuda:0")
     layers = {"res50": 50, "res101": 101, "res152": 152}[args.net]
     model = build_model(layers, class_agnostic=args.class_agnostic, cfg=cfg).to(dev)
@@ -85,7 +99,10 @@ def main(argv=None):
     det_time = nms_time = 0.0
     vid_boxes, vid_scores, vid_trk = [], [], []
     for i in range(args.num_pairs):
-        im, info, gt, nb = make_batch(args.batch_size, args.height, args.width, seed=10 + i, device=dev)
+        if data_iter is not None:
+            im, info, gt, nb = (t.to(dev) for t in next(data_iter))
+        else:
+            im, info, gt, nb = make_batch(args.batch_size, args.height, args.width, seed=10 + i, device=dev)
         torch.cuda.synchronize()
         t0 = time.time()
         with torch.no_grad():
@@ -128,6 +145,12 @@ def main(argv=None):
         pickle.dump(all_boxes, f, pickle.HIGHEST_PROTOCOL)
     print("\nmean detect time %.4fs, mean per-class NMS time %.4fs over %d pairs" %
           (det_time / args.num_pairs, nms_time / args.num_pairs, args.num_pairs))
+    if imdb is not None:
+        print("Evaluating detections")  # test_net.py:309-310
+        empty = np.zeros((0, 5), dtype=np.float32)
+        boxes = [[(b if len(b) else empty) for b in per_class] for per_class in all_boxes]
+        aps = imdb.evaluate_detections(boxes, pairs, args.out_dir)
+        return float(np.mean(aps))
 
 
 if __name__ == "__main__":

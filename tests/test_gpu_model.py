@@ -190,6 +190,39 @@ def test_drivers_round_trip_checkpoint(tmp_path):
     assert n <= 200
 
 
+def test_drivers_on_an_ilsvrc_devkit(tmp_path):
+    """The drivers on real-layout data: a synthetic ILSVRC devkit (tests/data_fixture.py) read through dtt.data -- VID
+    training pairs, alternating VID / DET batches, then the VID test split through the test loader and the VOC-style
+    evaluation (random-init weights: the mAP is just a number, the plumbing is what is checked)."""
+    import pickle
+    import data_fixture as fx
+    import test_net
+    import trainval_net
+    from dtt.config import cfg
+    saved = cfg.DATA_DIR
+    cfg.DATA_DIR = str(tmp_path / "data")
+    fx.build_devkit(cfg.DATA_DIR)
+    save = str(tmp_path / "models")
+    try:
+        trainval_net.main(["--dataset", "imagenet_vid", "--net", "res50", "--bs", "2", "--cag", "--epochs", "1",
+                           "--disp_interval", "2", "--save_dir", save, "--lr", "1e-5", "--set", "TRAIN.SCALES", "(96,)"])
+        ck = torch.load(os.path.join(save, "res50", "imagenet_vid", "rfcn_detect_track_1_1_5.pth"), map_location="cpu")
+        assert ck["epoch"] == 2  # 13 training pairs / batch 2 -> 6 steps
+        trainval_net.main(["--dataset", "imagenet_vid+imagenet_det", "--net", "res50", "--bs", "1", "--cag", "--epochs", "1",
+                           "--save_dir", save, "--lr", "1e-5", "--set", "TRAIN.SCALES", "(96,)"])
+        assert os.path.exists(os.path.join(save, "res50", "imagenet_vid+imagenet_det", "rfcn_detect_track_1_1_1.pth"))
+        out = str(tmp_path / "dets")
+        m_ap = test_net.main(["--dataset", "imagenet_vid", "--net", "res50", "--cfg", "cfgs/res50.yml", "--cag",
+                              "--load_dir", save, "--checksession", "1", "--checkepoch", "1", "--checkpoint", "5",
+                              "--out_dir", out, "--set", "TEST.SCALES", "(96,)", "TRAIN.SCALES", "(96,)"])
+        assert 0.0 <= m_ap <= 1.0
+        all_boxes = pickle.load(open(os.path.join(out, "detections.pkl"), "rb"))
+        assert len(all_boxes) == 31 and len(all_boxes[1]) == 3  # three test pairs
+        assert os.path.exists(os.path.join(out, "airplane_pr.pkl"))
+    finally:
+        cfg.DATA_DIR = saved
+
+
 def test_fused_training_trunk_matches_reference_graph():
     """dtt.fuse.FusedTrainTrunk (frozen BatchNorm folded out of the activation path, fused bias/residual/ReLU with a
     one-pass backward) against the module graph.  Block by block (same input, same upstream gradient) outputs, input

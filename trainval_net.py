@@ -5,9 +5,9 @@ per-parameter SGD groups, loss = sum of the five means, and `rfcn_detect_track_{
 files holding {session, epoch, model, optimizer, pooling_mode, class_agnostic}.
 
 What differs: one process per GPU instead of `nn.DataParallel` (`--mGPUs` = launch with torchrun; gradients are
-all-reduced over RCCL, dtt/dist.py); and the ImageNet VID/DET roidb / image-loading stack is out of scope of this
-repo, so batches come from the synthetic generator (`--dataset synthetic`, the
-default) -- real-dataset names are accepted for their cfg side effects but raise when the loader is needed.
+all-reduced over RCCL, dtt/dist.py).  `--dataset imagenet_vid` / `imagenet_vid+imagenet_det` read an ILSVRC devkit under
+cfg.DATA_DIR/ILSVRC through dtt/data (the reference's roidb / loader semantics); `--dataset synthetic` (the default: no
+dataset ships with this repo) draws batches of the same layout from the seeded generator.
 
     python trainval_net.py --dataset synthetic --net res101 --bs 2 --cag --epochs 1 --iters_per_epoch 20
     torchrun --nproc-per-node 8 --master-addr 127.0.0.1 trainval_net.py --mGPUs --bs 2 --cag ...
@@ -57,7 +57,41 @@ def parse_args(argv=None):
     p.add_argument("--iters_per_epoch", default=100, type=int)
     p.add_argument("--height", default=600, type=int)
     p.add_argument("--width", default=1067, type=int)
+    p.add_argument("--set", dest="set_cfgs", default=None, nargs=argparse.REMAINDER,
+                   help="cfg overrides, KEY VALUE pairs (as test_net.py:50-52)")
     return p.parse_args(argv)
+
+
+def _build_loaders(args, cfg, rank, world):
+    """The reference's data path (trainval_net.py:186-238): frame-pair roidb(s), aspect-ratio-grouped loader(s) and the
+    batch-permuting sampler.  With several processes every rank builds the same roidb and reads its own contiguous shard
+    of each permuted epoch (per-snippet sharding, both frames of a pair on one GPU)."""
+    from dtt.data import combined_roidb, roibatchLoader, sampler
+    cfg.TRAIN.USE_FLIPPED = False  # trainval_net.py:191
+    cfg.USE_GPU_NMS = True
+    names = {"imagenet_vid": ["imagenet_vid_train"], "imagenet_vid+imagenet_det": ["imagenet_vid_train", "imagenet_det_train"]}
+    if args.dataset not in names:
+        raise KeyError("Unknown dataset: {} (imagenet_vid, imagenet_vid+imagenet_det or synthetic)".format(args.dataset))
+    loaders = []
+    for k, name in enumerate(names[args.dataset]):
+        imdb, pairs, ratio_list, ratio_index = combined_roidb(name, duplicate_frames=(k == 1))
+        if rank == 0:
+            print("{:d} roidb frame pairs in {}".format(len(pairs), name))
+        ds = roibatchLoader(pairs, ratio_list, ratio_index, args.batch_size * world, imdb.num_classes, training=True)
+        order = sampler(len(pairs), args.batch_size * world)
+
+        class _Shard(torch.utils.data.Sampler):  # rank r takes slots [r*bs, (r+1)*bs) of every global batch
+            def __iter__(self):
+                idx = list(iter(order))
+                full = len(idx) - len(idx) % (args.batch_size * world)
+                g = torch.tensor(idx[:full]).view(-1, world, args.batch_size)[:, rank].reshape(-1)
+                return iter(g.tolist())
+
+            def __len__(self):
+                return (len(pairs) // (args.batch_size * world)) * args.batch_size
+        loaders.append(torch.utils.data.DataLoader(ds, batch_size=args.batch_size, sampler=_Shard(),
+                                                   num_workers=args.num_workers, drop_last=True))
+    return loaders
 
 
 def main(argv=None):
@@ -77,10 +111,13 @@ def main(argv=None):
     apply_dataset_defaults("imagenet_vid" if args.dataset == "synthetic" else args.dataset)  # trainval_net.py:162-172
     cfg_file = os.path.join(ROOT, "cfgs", "{}_ls.yml".format(args.net) if args.large_scale else "{}.yml".format(args.net))
     cfg_from_file(cfg_file)
+    if args.set_cfgs:
+        from dtt.config import cfg_from_list
+        cfg_from_list(args.set_cfgs)
     np.random.seed(cfg.RNG_SEED + rank)  # trainval_net.py:183 (+rank: each process samples its own anchors / RoIs)
+    loaders = None
     if args.dataset != "synthetic":
-        raise NotImplementedError("the ImageNet VID/DET roidb + image loading stack is outside this repo's scope; "
-                                  "use --dataset synthetic (see DESIGN.md section 7)")
+        loaders = _build_loaders(args, cfg, rank, world)  # ImageNet VID (+ DET) under cfg.DATA_DIR/ILSVRC (dtt/data)
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     layers = {"res50": 50, "res101": 101, "res152": 152}[args.net]
@@ -102,7 +139,8 @@ def main(argv=None):
         if rank == 0:
             print("loaded checkpoint %s" % load_name)
     # global batch = --bs snippets per process (per-snippet sharding; both frames of a pair stay on one GPU)
-    first = make_batch(args.batch_size, args.height, args.width, seed=1000 + rank, device=dev)
+    first = (tuple(t.to(dev) for t in next(iter(loaders[0]))) if loaders else
+             make_batch(args.batch_size, args.height, args.width, seed=1000 + rank, device=dev))
     calibrate_batchnorm_(model, first[0][:, 0])
     model.train()
     from dtt.fuse import fuse_for_training
@@ -114,9 +152,14 @@ def main(argv=None):
                 g["lr"] *= args.lr_decay_gamma
             lr *= args.lr_decay_gamma
         loss_temp, start = 0.0, time.time()
-        for step in range(args.iters_per_epoch):
-            im, info, gt, nb = make_batch(args.batch_size, args.height, args.width,
-                                          seed=(epoch * 100003 + step) * world + rank, device=dev)
+        iters = [iter(l) for l in loaders] if loaders else None
+        n_steps = args.iters_per_epoch if not loaders else min(len(l) for l in loaders)
+        for step in range(n_steps):
+            if loaders:  # VID and DET batches alternate when both are given (trainval_net.py:340-347)
+                im, info, gt, nb = (t.to(dev, non_blocking=True) for t in next(iters[step % len(iters)]))
+            else:
+                im, info, gt, nb = make_batch(args.batch_size, args.height, args.width,
+                                              seed=(epoch * 100003 + step) * world + rank, device=dev)
             runner.zero_grad(set_to_none=True)
             out = runner(im, info, gt, nb)
             rpn_cls, rpn_box, rcnn_cls, rcnn_box, trk = out[4], out[5], out[6], out[7], out[9]
