@@ -45,6 +45,8 @@ def parse_args(argv=None):
     p.add_argument("--out_dir", default="output/detections", type=str)
     p.add_argument("--link_tubes", action="store_true",
                    help="treat the pairs as consecutive frame pairs of one video and link class tubes (demo.py:432-489)")
+    p.add_argument("--online_tubes", action="store_true",
+                   help="also run the demo's incremental tube linker + temporal labelling (online_tubes.py) over the pairs")
     return p.parse_args(argv)
 
 
@@ -108,7 +110,7 @@ def main(argv=None):
         with torch.no_grad():
             rois, cls_prob, bbox_pred, tracking_pred = model(im, info, gt, nb)[:4]
             boxes = decode_detections(rois[0], bbox_pred[0], info[:, 0], cfg, args.class_agnostic)   # leg 0 (:277)
-            if args.link_tubes:   # demo.py:432-473: both legs' boxes / scores and the tracked boxes of snippet 0
+            if args.link_tubes or args.online_tubes:   # demo.py:432-473: both legs' boxes / scores and the tracked boxes of snippet 0
                 legs = [decode_detections(rois[l], bbox_pred[l], info[:, l], cfg, args.class_agnostic)[0] for l in range(2)]
                 vid_boxes.append(torch.stack(legs, 0))
                 vid_scores.append(torch.stack([cls_prob[0][0], cls_prob[1][0]], 0))
@@ -139,6 +141,18 @@ def main(argv=None):
         os.makedirs(args.out_dir, exist_ok=True)
         with open(os.path.join(args.out_dir, "tubes.pkl"), "wb") as f:
             pickle.dump([None if p is None else {k: v.cpu().numpy() for k, v in p.items()} for p in paths], f,
+                        pickle.HIGHEST_PROTOCOL)
+    if args.online_tubes:   # demo.py:487-489: incremental linking + temporal labelling of the video demo
+        from dtt.online_tubes import VideoPostProcessor as OnlineVideoPostProcessor
+        t0 = time.time()
+        ovp = OnlineVideoPostProcessor(torch.stack(vid_boxes, 0), torch.stack(vid_scores, 0), torch.stack(vid_trk, 0),
+                                       ["__background__"] + ["class_%d" % j for j in range(1, n_classes)], "video")
+        ovp.class_paths(path_score_thresh=0.5)
+        print("online tube linking: %d tubes above 0.5 in %.1f ms" % (len(ovp.path_boxes), (time.time() - t0) * 1e3))
+        os.makedirs(args.out_dir, exist_ok=True)
+        with open(os.path.join(args.out_dir, "online_tubes.pkl"), "wb") as f:
+            pickle.dump({"labels": ovp.path_labels.numpy(), "starts": ovp.path_starts.numpy(), "ends": ovp.path_ends.numpy(),
+                         "boxes": [b.numpy() for b in ovp.path_boxes], "scores": [x.numpy() for x in ovp.path_scores]}, f,
                         pickle.HIGHEST_PROTOCOL)
     os.makedirs(args.out_dir, exist_ok=True)
     with open(os.path.join(args.out_dir, "detections.pkl"), "wb") as f:

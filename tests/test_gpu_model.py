@@ -177,7 +177,9 @@ def test_drivers_round_trip_checkpoint(tmp_path):
                    "--width", "320", "--out_dir", out])
     test_net.main(["--dataset", "synthetic", "--net", "res50", "--cfg", "cfgs/res50.yml", "--cag", "--load_dir", save,
                    "--checksession", "1", "--checkepoch", "1", "--checkpoint", "1", "--num_pairs", "4", "--height", "224",
-                   "--width", "320", "--out_dir", out, "--link_tubes"])
+                   "--width", "320", "--out_dir", out, "--link_tubes", "--online_tubes"])
+    online = pickle.load(open(os.path.join(out, "online_tubes.pkl"), "rb"))
+    assert set(online) == {"labels", "starts", "ends", "boxes", "scores"} and len(online["boxes"]) == len(online["labels"])
     tubes = pickle.load(open(os.path.join(out, "tubes.pkl"), "rb"))
     assert len(tubes) == 31 and tubes[0] is None and all(t["idx"].shape[1] == 3 for t in tubes[1:])   # 5 frames -> 3 linked
     test_net.main(["--dataset", "synthetic", "--net", "res50", "--cfg", "cfgs/res50.yml", "--cag", "--load_dir", save,

@@ -130,3 +130,25 @@ def test_video_post_processor_vs_reference_golden(dev):
         _check(paths[c], {k: G["video/c%d/%s" % (c, k)] for k in ("idx", "boxes", "total_score", "scores", "smooth_scores")}, 0)
     with pytest.raises(IndexError):                                   # fewer detections than 160 per frame: as the reference
         VideoPostProcessor(pb[:, :, :50], sc[:, :, :50], trk[:, :50], ["bg"] + ["c%d" % i for i in range(1, C)])
+
+
+@pytest.mark.parametrize("case", [0, 1])
+def test_online_tubes_on_device_tensors_match_reference_run(case):
+    """dtt.online_tubes with the detections on the GPU (batched candidate selection on the device, linking on the host)
+    against the goldens of the reference run (tests/golden/make_golden_online_tubes.py)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden_online_tubes as mk
+    from dtt.online_tubes import VideoPostProcessor
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "online_tubes.npz"))
+    tag, seed, kw = mk.CASES[case]
+    boxes, scores = mk.make_video(seed, **kw)
+    dev = torch.device("cuda:0")
+    C = scores.shape[-1]
+    vp = VideoPostProcessor(torch.from_numpy(boxes).to(dev), torch.from_numpy(scores).to(dev), torch.zeros(1),
+                            ["__background__"] + ["class_%d" % j for j in range(1, C)], "vid_" + tag)
+    tubes = vp.class_paths(path_score_thresh=0.5)
+    out = {}
+    mk.flatten(vp, tubes, tag, out)
+    for k in [k for k in gold.files if k.startswith(tag + "_")]:
+        np.testing.assert_allclose(out[k], gold[k], rtol=1e-6, atol=1e-6, err_msg=k)
