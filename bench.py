@@ -127,12 +127,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
+    torch.cuda.set_device(local)  # before the process group exists: RCCL binds its communicator to the current device
+    dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world)
-    assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
 
     from dtt.config import apply_dataset_defaults, cfg
     from dtt.synth import build_model, calibrate_batchnorm_, make_batch
