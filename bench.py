@@ -194,6 +194,20 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    psroi_us = None
+    if rank == 0 and args.mode == "infer":
+        # the class PSRoI pooling of the same step, timed the same way in a few extra (untimed) steps --
+        # the library records one tag at a time.  Three PSRoI launches per step: class scores, boxes, tracking.
+        n_extra = min(args.steps, 10)
+        kp = KernelTimer("psroi_fwd_plane", 3 * n_extra, dev)
+        kp.attach()
+        for _ in range(n_extra):
+            step()
+        torch.cuda.synchronize(dev)
+        d = kp.durations_us(kp.detach())
+        if len(d) >= 3:
+            cls = d[0::3]
+            psroi_us = sum(cls) / len(cls)
     if rank == 0:
         durs = kt.durations_us(used)
         conv5 = [sum(durs[i + 1 + n_sub:i + launches_per_step]) for i in range(0, len(durs) - launches_per_step + 1, launches_per_step)]
@@ -242,6 +256,14 @@ def main():
                          "hbm_view": {"achieved_GBs": round(bytes_ / (avg5 * 1e-6) / 1e9, 1) if avg5 > 0 else 0.0,
                                       "peak_GBs": HBM_PEAK_GBS}},
         }
+        if psroi_us:
+            n_img, od = 2 * args.batch, 31 * 49
+            ps_bytes = n_img * od * H16 * W16 * 4 + n_img * cfg.TEST.RPN_POST_NMS_TOP_N * od * 4   # score maps in, pooled bins out
+            out["secondary"] = {"psroi_cls": {"kernel": "psroi_fwd_plane (R-FCN class scores: %d x %d x %d x %d maps, %d RoIs)" %
+                                              (n_img, od, H16, W16, n_img * cfg.TEST.RPN_POST_NMS_TOP_N), "bound": "hbm",
+                                              "achieved": round(ps_bytes / (psroi_us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                                              "unit": "GB/s", "frac": round(ps_bytes / (psroi_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                              "launch_us": round(psroi_us, 2), "algorithmic_bytes_per_launch": ps_bytes}}
         if world == 1 and not args.no_cpu_baseline and args.mode == "infer":
             out["cpu_baseline"] = cpu_baseline(args, cfg)
         print(json.dumps(out), flush=True)
