@@ -14,6 +14,7 @@
 #include <map>
 #include <mutex>
 #include <tuple>
+#include <utility>
 
 namespace {
 
@@ -120,5 +121,94 @@ extern "C" int dtt_gemm_bias_act(float* out, const float* a, const float* w, con
   const hipblasStatus_t st = hipblasLtMatmul(handle, p.desc, &alpha, w, p.la, a, p.lb, &beta, c, p.lc, out, p.lc,
                                              &p.heur.algo, workspace, workspace ? workspace_bytes : 0, stream);
   DTT_REQUIRE(st == HIPBLAS_STATUS_SUCCESS, "gemm_bias_act: hipblasLtMatmul failed (%d)", (int)st);
+  return 1;
+}
+
+// Strided-batched row-major GEMM without epilogue: out[b] (rows, n) = a[b] (rows, k) * w[b] (k, n), operands packed
+// back to back (the 16 products of a Winograd F(2x2, 3x3) convolution, csrc/winograd.hip).  Same transposed column-major
+// hand-over and the same once-per-shape candidate timing as dtt_gemm_bias_act.
+namespace {
+std::map<std::tuple<int, int, long, int, int>, Plan> g_batched_plans;   // (device, batch, rows, k, n)
+}
+
+extern "C" int dtt_gemm_batched(float* out, const float* a, const float* w, int batch, long rows, int k, int n,
+                                void* workspace, size_t workspace_bytes, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  DTT_REQUIRE(out && a && w, "gemm_batched: null pointer");
+  DTT_REQUIRE(batch > 0 && rows > 0 && k > 0 && n > 0, "gemm_batched: bad shape");
+  int dev = 0;
+  DTT_REQUIRE(hipGetDevice(&dev) == hipSuccess, "gemm_batched: hipGetDevice failed");
+  std::lock_guard<std::mutex> lock(g_mu);
+  hipblasLtHandle_t& handle = g_handles[dev];
+  if (!handle) DTT_REQUIRE(hipblasLtCreate(&handle) == HIPBLAS_STATUS_SUCCESS, "gemm_batched: hipblasLtCreate failed");
+  const uint64_t ws = workspace ? workspace_bytes : 0;
+  const float alpha = 1.f, beta = 0.f;
+  Plan& p = g_batched_plans[std::make_tuple(dev, batch, rows, k, n)];
+  if (!p.ok) {
+    DTT_REQUIRE(hipblasLtMatmulDescCreate(&p.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F) == HIPBLAS_STATUS_SUCCESS,
+                "gemm_batched: desc");
+    const hipblasOperation_t op = HIPBLAS_OP_N;
+    hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSA, &op, sizeof(op));
+    hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSB, &op, sizeof(op));
+    DTT_REQUIRE(hipblasLtMatrixLayoutCreate(&p.la, HIP_R_32F, n, k, n) == HIPBLAS_STATUS_SUCCESS &&
+                    hipblasLtMatrixLayoutCreate(&p.lb, HIP_R_32F, k, rows, k) == HIPBLAS_STATUS_SUCCESS &&
+                    hipblasLtMatrixLayoutCreate(&p.lc, HIP_R_32F, n, rows, n) == HIPBLAS_STATUS_SUCCESS,
+                "gemm_batched: layouts");
+    const int32_t bc = batch;
+    const int64_t sa = (int64_t)k * n, sb = (int64_t)rows * k, sc = (int64_t)rows * n;
+    for (auto lay_stride : {std::make_pair(p.la, sa), std::make_pair(p.lb, sb), std::make_pair(p.lc, sc)}) {
+      DTT_REQUIRE(hipblasLtMatrixLayoutSetAttribute(lay_stride.first, HIPBLASLT_MATRIX_LAYOUT_BATCH_COUNT, &bc, sizeof(bc)) ==
+                          HIPBLAS_STATUS_SUCCESS &&
+                      hipblasLtMatrixLayoutSetAttribute(lay_stride.first, HIPBLASLT_MATRIX_LAYOUT_STRIDED_BATCH_OFFSET,
+                                                        &lay_stride.second, sizeof(lay_stride.second)) == HIPBLAS_STATUS_SUCCESS,
+                  "gemm_batched: batch attributes");
+    }
+    hipblasLtMatmulPreference_t pref;
+    DTT_REQUIRE(hipblasLtMatmulPreferenceCreate(&pref) == HIPBLAS_STATUS_SUCCESS, "gemm_batched: preference");
+    hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &ws, sizeof(ws));
+    constexpr int kMaxCand = 48;
+    static hipblasLtMatmulHeuristicResult_t cand[kMaxCand];  // under g_mu
+    int found = 0;
+    const char* tune_env = getenv("DTT_GEMM_AUTOTUNE");
+    const bool tune = !(tune_env && tune_env[0] == '0');
+    const hipblasStatus_t st = hipblasLtMatmulAlgoGetHeuristic(handle, p.desc, p.la, p.lb, p.lc, p.lc, pref,
+                                                               tune ? kMaxCand : 1, cand, &found);
+    hipblasLtMatmulPreferenceDestroy(pref);
+    DTT_REQUIRE(st == HIPBLAS_STATUS_SUCCESS && found > 0, "gemm_batched: no hipBLASLt kernel for %d x %ld x %d x %d", batch,
+                rows, k, n);
+    int best = 0;
+    if (found > 1) {   // out is the scratch: the caller's product is (re)computed right below
+      hipEvent_t e0 = nullptr, e1 = nullptr;
+      if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+        float best_ms = 1e30f;
+        for (int i = 0; i < found; ++i) {
+          if (cand[i].state != HIPBLAS_STATUS_SUCCESS || cand[i].workspaceSize > ws) continue;
+          bool good = true;
+          for (int r = -1; r < 3 && good; ++r) {
+            if (r == 0) (void)hipEventRecord(e0, stream);
+            good = hipblasLtMatmul(handle, p.desc, &alpha, w, p.la, a, p.lb, &beta, out, p.lc, out, p.lc, &cand[i].algo,
+                                   workspace, ws, stream) == HIPBLAS_STATUS_SUCCESS;
+          }
+          float ms = 0.f;
+          if (!good || hipEventRecord(e1, stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
+              hipEventElapsedTime(&ms, e0, e1) != hipSuccess)
+            continue;
+          if (ms < best_ms) { best_ms = ms; best = i; }
+        }
+      }
+      (void)hipGetLastError();
+      if (e0) (void)hipEventDestroy(e0);
+      if (e1) (void)hipEventDestroy(e1);
+      if (getenv("DTT_GEMM_AUTOTUNE_VERBOSE"))
+        fprintf(stderr, "[dtt] batched gemm %d x %ld x %d x %d: %d candidates, picked #%d\n", batch, rows, k, n, found, best);
+    }
+    p.heur = cand[best];
+    p.ok = true;
+  }
+  DTT_REQUIRE(p.heur.workspaceSize <= ws, "gemm_batched: workspace too small (%zu < %zu)", (size_t)ws,
+              (size_t)p.heur.workspaceSize);
+  const hipblasStatus_t st = hipblasLtMatmul(handle, p.desc, &alpha, w, p.la, a, p.lb, &beta, out, p.lc, out, p.lc,
+                                             &p.heur.algo, workspace, ws, stream);
+  DTT_REQUIRE(st == HIPBLAS_STATUS_SUCCESS, "gemm_batched: hipblasLtMatmul failed (%d)", (int)st);
   return 1;
 }

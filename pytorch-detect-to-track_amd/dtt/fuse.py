@@ -8,6 +8,8 @@ still run on MIOpen / rocBLAS; the per-channel bias, the residual add and the Re
 unfused graph.  Weights are not modified: the folded copies live next to the original modules, the state_dict /
 checkpoint layout is untouched, and `unfuse()` (or `.train()`) goes back to the reference graph.
 """
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -319,6 +321,57 @@ def _from_rows(y2d, n, h, w):
     return y2d.view(n, h, w, y2d.shape[1]).permute(0, 3, 1, 2)
 
 
+_WINO_G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]])
+_WINO_BUF = {}
+
+
+def winograd_weights(w):
+    """(K, C, 3, 3) filters -> U (16, C, K) = G g G^T per (k, c), laid out for the 16 row-major GEMMs (computed in
+    float64, stored fp32)."""
+    G = _WINO_G.to(device=w.device, dtype=torch.float64)
+    u = torch.einsum("ia,kcab,jb->ijck", G, w.double(), G)
+    return u.reshape(16, w.shape[1], w.shape[0]).float().contiguous()
+
+
+def winograd_conv3x3_nhwc(x, u, bias, dilation=1, relu=True):
+    """3x3, stride 1, padding == dilation convolution of a channels-last map as Winograd F(2x2, 3x3): input transform
+    (HIP) -> 16 batched GEMMs (hipBLASLt, dtt_gemm_batched) -> output transform + bias (+ ReLU) (HIP)."""
+    assert x.dtype == torch.float32 and x.is_contiguous(memory_format=torch.channels_last)
+    n, c, h, w = x.shape
+    k = u.shape[2]
+    L = _lib.lib()
+    dev = x.device
+    tiles = L.dtt_winograd_tiles(n, h, w, dilation)
+    key = (dev, tiles, c, k)
+    bufs = _WINO_BUF.get(key)
+    if bufs is None:
+        bufs = _WINO_BUF[key] = (torch.empty(16 * tiles * c, device=dev), torch.empty(16 * tiles * k, device=dev))
+    v, m = bufs
+    ws = _GEMM_WS.get(dev)
+    if ws is None:
+        ws = _GEMM_WS[dev] = torch.empty(32 << 20, dtype=torch.uint8, device=dev)
+    y = torch.empty((n, k, h, w), dtype=x.dtype, device=dev, memory_format=torch.channels_last)
+    st = stream_ptr(dev)
+    with torch.cuda.device(dev):
+        check(L.dtt_winograd_input_transform(ptr(x), ptr(v), n, h, w, c, dilation, st), "winograd input transform")
+        check(L.dtt_gemm_batched(ptr(m), ptr(v), ptr(u), 16, tiles, c, k, ptr(ws), ws.numel(), st), "gemm_batched")
+        check(L.dtt_winograd_output_transform(ptr(m), ptr(bias), ptr(y), n, h, w, k, dilation, int(relu), st),
+              "winograd output transform")
+    return y
+
+
+def _time_us(fn, reps=5):
+    fn(); fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / reps
+
+
 class _NhwcConv:
     """One folded convolution for the channels-last trunk: 1x1 stride-1 layers are plain GEMMs over the (pixels, C)
     view (hipBLASLt, bias + ReLU in the GEMM epilogue); everything else is MIOpen's NHWC kernel + the fused pass."""
@@ -328,11 +381,18 @@ class _NhwcConv:
         self.b = base.b if extra_bias is None else (base.b + extra_bias).contiguous()
         self.kw = base.kw
         self.is_gemm = conv.kernel_size == (1, 1) and conv.stride == (1, 1)
+        self.u = None          # Winograd-domain filters, for 3x3 / stride 1 / padding == dilation layers
+        self.use_wino = {}     # per input shape: whether the Winograd path won the timing against MIOpen
         if self.is_gemm:
             self.wt = base.w.view(base.w.shape[0], base.w.shape[1]).t().contiguous()   # (Cin, Cout)
             self.zero_b = torch.zeros_like(self.b)
         else:
             self.w = base.w.contiguous(memory_format=torch.channels_last)
+            if (conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.groups == 1 and
+                    conv.padding == conv.dilation and conv.dilation[0] == conv.dilation[1] and
+                    base.w.shape[0] % 4 == 0 and base.w.shape[1] % 4 == 0 and os.environ.get("DTT_WINOGRAD", "1") != "0"):
+                self.u = winograd_weights(base.w)
+                self.dil = conv.dilation[0]
 
     def raw(self, x):
         """Convolution without bias; x and the result are channels-last."""
@@ -350,6 +410,20 @@ class _NhwcConv:
             a = _rows(x)
             out = torch.empty((a.shape[0], self.wt.shape[1]), dtype=a.dtype, device=a.device)
             return _from_rows(gemm_bias_act_(out, a, self.wt, self.b), n, h, w)
+        if self.u is not None:
+            key = tuple(x.shape)
+            pick = self.use_wino.get(key)
+            if pick is None and 64 * _lib.lib().dtt_winograd_tiles(x.shape[0], x.shape[2], x.shape[3], self.dil) * \
+                    max(x.shape[1], self.u.shape[2]) > (160 << 20):
+                pick = self.use_wino[key] = False   # transform buffers would be out of proportion (few, huge tiles)
+            if pick is None:   # first time at this shape: the faster of the two paths wins (both timed on this input)
+                t_direct = _time_us(lambda: bias_act_nhwc_(_rows(F.conv2d(x, self.w, None, **self.kw)), self.b))
+                t_wino = _time_us(lambda: winograd_conv3x3_nhwc(x, self.u, self.b, self.dil, True))
+                pick = self.use_wino[key] = t_wino < t_direct
+                if os.environ.get("DTT_WINOGRAD_VERBOSE"):
+                    print("[dtt] conv3x3 %s dil %d: direct %.1f us, winograd %.1f us" % (key, self.dil, t_direct, t_wino))
+            if pick:
+                return winograd_conv3x3_nhwc(x, self.u, self.b, self.dil, True)
         y = F.conv2d(x, self.w, None, **self.kw)
         bias_act_nhwc_(_rows(y), self.b)
         return y

@@ -192,6 +192,26 @@ def test_drivers_round_trip_checkpoint(tmp_path):
     assert n <= 200
 
 
+def test_winograd_conv3x3_matches_direct_convolution():
+    """dtt.fuse.winograd_conv3x3_nhwc (HIP transforms + 16 batched library GEMMs) against F.conv2d: dilations 1 / 2 / 3,
+    odd map sizes (partial tiles, uneven parity sub-lattices), bias and ReLU in the output transform."""
+    import torch.nn.functional as F
+    from dtt.fuse import winograd_conv3x3_nhwc, winograd_weights
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(21)
+    for (n, c, k, h, w, d, relu) in [(2, 16, 24, 9, 13, 1, True), (1, 8, 8, 38, 67, 2, True), (3, 12, 4, 7, 10, 3, False),
+                                     (4, 256, 256, 38, 67, 1, True), (1, 4, 4, 1, 1, 1, False), (2, 32, 16, 5, 4, 2, True)]:
+        x = torch.randn(n, c, h, w, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+        wt = (torch.randn(k, c, 3, 3, generator=g) / (3.0 * c ** 0.5)).to(dev)
+        b = torch.randn(k, generator=g).to(dev)
+        ref = F.conv2d(x.double(), wt.double(), b.double(), 1, d, d)
+        ref = torch.relu(ref) if relu else ref
+        out = winograd_conv3x3_nhwc(x, winograd_weights(wt), b, d, relu)
+        assert out.shape == ref.shape and out.is_contiguous(memory_format=torch.channels_last)
+        err = (out.double() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-6)
+        assert err < 2e-5, ((n, c, k, h, w, d), err)
+
+
 def test_drivers_on_an_ilsvrc_devkit(tmp_path):
     """The drivers on real-layout data: a synthetic ILSVRC devkit (tests/data_fixture.py) read through dtt.data -- VID
     training pairs, alternating VID / DET batches, then the VID test split through the test loader and the VOC-style
