@@ -459,6 +459,10 @@ class FusedTrunkNHWC:
         self.pool = b[3]
         self.stages = [[_NhwcBottleneck(blk) for blk in b[i]] for i in (4, 5, 6, 7)]
         self.top = _NhwcConv(b[8])
+        # the RPN's 3x3 convolution + ReLU (rpn.py:60-61) reads the same channels-last map: computed here, where it can
+        # take the Winograd path, and handed to _RPN.head() through `rpn_conv1`
+        self.rpn_conv = _NhwcConv(model.RFCN_rpn.RPN_Conv)
+        self.rpn_conv1 = None
 
     @torch.no_grad()
     def __call__(self, x):
@@ -470,6 +474,7 @@ class FusedTrunkNHWC:
                 x = blk(x)
             feats.append(x)
         top = self.top.act(feats[3])
+        self.rpn_conv1 = _to_nchw(self.rpn_conv.act(top))
         return _to_nchw(feats[1]), _to_nchw(feats[2]), _to_nchw(feats[3]), _to_nchw(top)
 
 

@@ -119,9 +119,11 @@ class _RPN(nn.Module):
         s = x.size()
         return x.view(s[0], int(d), int(float(s[1] * s[2]) / float(d)), s[3])
 
-    def head(self, base_feat):
-        """The convolutional part: (cls_score, cls_score_r, cls_prob, bbox_pred)."""
-        conv1 = F.relu(self.RPN_Conv(base_feat), inplace=True)
+    def head(self, base_feat, conv1=None):
+        """The convolutional part: (cls_score, cls_score_r, cls_prob, bbox_pred).  conv1: relu(RPN_Conv(base_feat)) when
+        the fused trunk has already computed it (dtt.fuse.FusedTrunkNHWC)."""
+        if conv1 is None:
+            conv1 = F.relu(self.RPN_Conv(base_feat), inplace=True)
         cls_score = self.RPN_cls_score(conv1)
         cls_score_r = self.reshape(cls_score, 2)
         cls_prob = self.reshape(F.softmax(cls_score_r, dim=1), self.nc_score_out)
@@ -239,7 +241,11 @@ class _RFCN(nn.Module):
             side = getattr(self, "_side_stream", None)
             if side is None or side.device != dev:
                 side = self._side_stream = torch.cuda.Stream(device=dev)
-            _, _, rpn_prob, rpn_bbox = self.RFCN_rpn.head(top)
+            fused = getattr(self, "_fused_trunk", None)
+            conv1 = getattr(fused, "rpn_conv1", None)   # set by the channels-last fused trunk during _im_to_head above
+            if conv1 is not None:
+                fused.rpn_conv1 = None
+            _, _, rpn_prob, rpn_bbox = self.RFCN_rpn.head(top, conv1)
             side.wait_stream(cur)
             with torch.cuda.stream(side):
                 all_rois = self.RFCN_rpn.proposals(rpn_prob, rpn_bbox, im_info.view(n_legs * B, -1))
