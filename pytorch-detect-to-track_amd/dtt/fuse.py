@@ -414,7 +414,7 @@ class _NhwcConv:
             key = tuple(x.shape)
             pick = self.use_wino.get(key)
             if pick is None and 64 * _lib.lib().dtt_winograd_tiles(x.shape[0], x.shape[2], x.shape[3], self.dil) * \
-                    max(x.shape[1], self.u.shape[2]) > (160 << 20):
+                    max(x.shape[1], self.u.shape[2]) > (1 << 30):
                 pick = self.use_wino[key] = False   # transform buffers would be out of proportion (few, huge tiles)
             if pick is None:   # first time at this shape: the faster of the two paths wins (both timed on this input)
                 t_direct = _time_us(lambda: bias_act_nhwc_(_rows(F.conv2d(x, self.w, None, **self.kw)), self.b))
