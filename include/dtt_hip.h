@@ -256,21 +256,22 @@ int dtt_bias_act_nhwc_inplace(float* x, const float* bias, const float* residual
                               int relu, void* stream);
 
 /* Strided-batched row-major GEMM: out[b] (rows, n) = a[b] (rows, k) * w[b] (k, n) for b < batch, operands packed back to
- * back.  Library GEMM (hipBLASLt, candidates timed once per shape); no reference counterpart -- it carries the 16 products
+ * back.  Library GEMM (hipBLASLt, candidates timed once per shape); no reference counterpart -- it carries the 16 / 36 products
  * of the Winograd form of the trunk's 3x3 convolutions (faster_rcnn/resnet.py:76-78 `conv3x3`). */
 int dtt_gemm_batched(float* out, const float* a, const float* w, int batch, long rows, int k, int n, void* workspace,
                      size_t workspace_bytes, void* stream);
 
-/* Winograd F(2x2, 3x3) transforms for a 3x3, stride-1, padding == dilation convolution on channels-last maps
- * (faster_rcnn/resnet.py:76-78, 307 in the reference are plain nn.Conv2d calls).  tiles = dtt_winograd_tiles(images,
- * height, width, dilation).  Input: x (images, height, width, channels) -> v[16][tiles][channels].  Output:
- * m[16][tiles][channels] -> y (images, height, width, channels) = A^T m A + bias[c], ReLU if relu != 0.
- * channels % 4 == 0.  The 16 products m[i] = v[i] * u[i] in between are dtt_gemm_batched's. */
-long dtt_winograd_tiles(int images, int height, int width, int dilation);
+/* Winograd transforms for a 3x3, stride-1, padding == dilation convolution on channels-last maps (the reference's
+ * faster_rcnn/resnet.py:76-78, 307 are plain nn.Conv2d calls).  m = 2: F(2x2, 3x3), 16 products; m = 4: F(4x4, 3x3), 36
+ * products.  tiles = dtt_winograd_tiles(images, height, width, dilation, m); t2 = (m + 2)^2.
+ * Input: x (images, height, width, channels) -> v[t2][tiles][channels].  Output: mm[t2][tiles][channels] -> y (images,
+ * height, width, channels) = A^T mm A + bias[c], ReLU if relu != 0.  channels % 4 == 0.  The products mm[i] = v[i] * u[i]
+ * in between are dtt_gemm_batched's. */
+long dtt_winograd_tiles(int images, int height, int width, int dilation, int m);
 int dtt_winograd_input_transform(const float* x, float* v, int images, int height, int width, int channels, int dilation,
-                                 void* stream);
-int dtt_winograd_output_transform(const float* m, const float* bias, float* y, int images, int height, int width,
-                                  int channels, int dilation, int relu, void* stream);
+                                 int m, void* stream);
+int dtt_winograd_output_transform(const float* mm, const float* bias, float* y, int images, int height, int width,
+                                  int channels, int dilation, int m, int relu, void* stream);
 
 /* Batched 2-D transpose: in (batch, rows, cols) row-major -> out (batch, cols, rows).  The layout change between
  * the channels-last trunk and the NCHW maps the operators above read (NHWC -> NCHW: rows = H*W, cols = C), which the

@@ -51,9 +51,9 @@ SIGNATURES = {
     "dtt_bias_act_nhwc_inplace": (_I, [_P, _P, _P, _L, _I, _I, _P]),
     "dtt_transpose_batched": (_I, [_P, _P, _I, _I, _I, _P]),
     "dtt_gemm_batched": (_I, [_P, _P, _P, _I, _L, _I, _I, _P, _Z, _P]),
-    "dtt_winograd_tiles": (_L, [_I, _I, _I, _I]),
-    "dtt_winograd_input_transform": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
-    "dtt_winograd_output_transform": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "dtt_winograd_tiles": (_L, [_I, _I, _I, _I, _I]),
+    "dtt_winograd_input_transform": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "dtt_winograd_output_transform": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "dtt_gemm_bias_act": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _P, _Z, _P]),
     "dtt_tube_link_workspace_bytes": (_Z, [_I, _I]),
     "dtt_tube_link": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),

@@ -321,41 +321,45 @@ def _from_rows(y2d, n, h, w):
     return y2d.view(n, h, w, y2d.shape[1]).permute(0, 3, 1, 2)
 
 
-_WINO_G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]])
+_WINO_G = {2: torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64),
+           4: torch.tensor([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6],
+                            [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]], dtype=torch.float64)}
 _WINO_BUF = {}
 
 
-def winograd_weights(w):
-    """(K, C, 3, 3) filters -> U (16, C, K) = G g G^T per (k, c), laid out for the 16 row-major GEMMs (computed in
-    float64, stored fp32)."""
-    G = _WINO_G.to(device=w.device, dtype=torch.float64)
+def winograd_weights(w, m=2):
+    """(K, C, 3, 3) filters -> U ((m+2)^2, C, K) = G g G^T per (k, c), laid out for the row-major batched GEMMs
+    (computed in float64, stored fp32).  m = 2: F(2x2, 3x3); m = 4: F(4x4, 3x3), points 0, +-1, +-2, infinity."""
+    G = _WINO_G[m].to(device=w.device)
     u = torch.einsum("ia,kcab,jb->ijck", G, w.double(), G)
-    return u.reshape(16, w.shape[1], w.shape[0]).float().contiguous()
+    return u.reshape((m + 2) ** 2, w.shape[1], w.shape[0]).float().contiguous()
 
 
-def winograd_conv3x3_nhwc(x, u, bias, dilation=1, relu=True):
-    """3x3, stride 1, padding == dilation convolution of a channels-last map as Winograd F(2x2, 3x3): input transform
-    (HIP) -> 16 batched GEMMs (hipBLASLt, dtt_gemm_batched) -> output transform + bias (+ ReLU) (HIP)."""
+def winograd_conv3x3_nhwc(x, u, bias, dilation=1, relu=True, m=2):
+    """3x3, stride 1, padding == dilation convolution of a channels-last map in Winograd form: input transform (HIP) ->
+    (m+2)^2 batched GEMMs (hipBLASLt, dtt_gemm_batched) -> output transform + bias (+ ReLU) (HIP)."""
     assert x.dtype == torch.float32 and x.is_contiguous(memory_format=torch.channels_last)
     n, c, h, w = x.shape
     k = u.shape[2]
+    t2 = (m + 2) ** 2
+    assert u.shape[0] == t2 and u.shape[1] == c
     L = _lib.lib()
     dev = x.device
-    tiles = L.dtt_winograd_tiles(n, h, w, dilation)
-    key = (dev, tiles, c, k)
+    tiles = L.dtt_winograd_tiles(n, h, w, dilation, m)
+    key = (dev, t2 * tiles, c, k)
     bufs = _WINO_BUF.get(key)
     if bufs is None:
-        bufs = _WINO_BUF[key] = (torch.empty(16 * tiles * c, device=dev), torch.empty(16 * tiles * k, device=dev))
-    v, m = bufs
+        bufs = _WINO_BUF[key] = (torch.empty(t2 * tiles * c, device=dev), torch.empty(t2 * tiles * k, device=dev))
+    v, mm = bufs
     ws = _GEMM_WS.get(dev)
     if ws is None:
         ws = _GEMM_WS[dev] = torch.empty(32 << 20, dtype=torch.uint8, device=dev)
     y = torch.empty((n, k, h, w), dtype=x.dtype, device=dev, memory_format=torch.channels_last)
     st = stream_ptr(dev)
     with torch.cuda.device(dev):
-        check(L.dtt_winograd_input_transform(ptr(x), ptr(v), n, h, w, c, dilation, st), "winograd input transform")
-        check(L.dtt_gemm_batched(ptr(m), ptr(v), ptr(u), 16, tiles, c, k, ptr(ws), ws.numel(), st), "gemm_batched")
-        check(L.dtt_winograd_output_transform(ptr(m), ptr(bias), ptr(y), n, h, w, k, dilation, int(relu), st),
+        check(L.dtt_winograd_input_transform(ptr(x), ptr(v), n, h, w, c, dilation, m, st), "winograd input transform")
+        check(L.dtt_gemm_batched(ptr(mm), ptr(v), ptr(u), t2, tiles, c, k, ptr(ws), ws.numel(), st), "gemm_batched")
+        check(L.dtt_winograd_output_transform(ptr(mm), ptr(bias), ptr(y), n, h, w, k, dilation, m, int(relu), st),
               "winograd output transform")
     return y
 
@@ -381,8 +385,8 @@ class _NhwcConv:
         self.b = base.b if extra_bias is None else (base.b + extra_bias).contiguous()
         self.kw = base.kw
         self.is_gemm = conv.kernel_size == (1, 1) and conv.stride == (1, 1)
-        self.u = None          # Winograd-domain filters, for 3x3 / stride 1 / padding == dilation layers
-        self.use_wino = {}     # per input shape: whether the Winograd path won the timing against MIOpen
+        self.u = None          # Winograd-domain filters {m: U}, for 3x3 / stride 1 / padding == dilation layers
+        self.pick = {}         # per input shape: 0 = MIOpen, 2 / 4 = the Winograd variant that won the timing
         if self.is_gemm:
             self.wt = base.w.view(base.w.shape[0], base.w.shape[1]).t().contiguous()   # (Cin, Cout)
             self.zero_b = torch.zeros_like(self.b)
@@ -391,7 +395,8 @@ class _NhwcConv:
             if (conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.groups == 1 and
                     conv.padding == conv.dilation and conv.dilation[0] == conv.dilation[1] and
                     base.w.shape[0] % 4 == 0 and base.w.shape[1] % 4 == 0 and os.environ.get("DTT_WINOGRAD", "1") != "0"):
-                self.u = winograd_weights(base.w)
+                variants = (2, 4) if os.environ.get("DTT_WINOGRAD_F4", "1") != "0" else (2,)
+                self.u = {m: winograd_weights(base.w, m) for m in variants}
                 self.dil = conv.dilation[0]
 
     def raw(self, x):
@@ -412,18 +417,22 @@ class _NhwcConv:
             return _from_rows(gemm_bias_act_(out, a, self.wt, self.b), n, h, w)
         if self.u is not None:
             key = tuple(x.shape)
-            pick = self.use_wino.get(key)
-            if pick is None and 64 * _lib.lib().dtt_winograd_tiles(x.shape[0], x.shape[2], x.shape[3], self.dil) * \
-                    max(x.shape[1], self.u.shape[2]) > (1 << 30):
-                pick = self.use_wino[key] = False   # transform buffers would be out of proportion (few, huge tiles)
-            if pick is None:   # first time at this shape: the faster of the two paths wins (both timed on this input)
-                t_direct = _time_us(lambda: bias_act_nhwc_(_rows(F.conv2d(x, self.w, None, **self.kw)), self.b))
-                t_wino = _time_us(lambda: winograd_conv3x3_nhwc(x, self.u, self.b, self.dil, True))
-                pick = self.use_wino[key] = t_wino < t_direct
+            pick = self.pick.get(key)
+            if pick is None:   # first time at this shape: the fastest path wins (all timed on this input)
+                times = {0: _time_us(lambda: bias_act_nhwc_(_rows(F.conv2d(x, self.w, None, **self.kw)), self.b))}
+                for m, u in self.u.items():
+                    t2 = (m + 2) ** 2
+                    tiles = _lib.lib().dtt_winograd_tiles(x.shape[0], x.shape[2], x.shape[3], self.dil, m)
+                    if 4 * t2 * tiles * max(x.shape[1], u.shape[2]) > (1 << 30):
+                        continue   # transform buffers out of proportion
+                    times[m] = _time_us(lambda: winograd_conv3x3_nhwc(x, u, self.b, self.dil, True, m))
+                pick = self.pick[key] = min(times, key=times.get)
                 if os.environ.get("DTT_WINOGRAD_VERBOSE"):
-                    print("[dtt] conv3x3 %s dil %d: direct %.1f us, winograd %.1f us" % (key, self.dil, t_direct, t_wino))
+                    print("[dtt] conv3x3 %s dil %d: %s -> %s" % (key, self.dil, ", ".join(
+                        "%s %.1f us" % ("direct" if m == 0 else "F(%d,3)" % m, t) for m, t in sorted(times.items())),
+                        "direct" if pick == 0 else "F(%d,3)" % pick))
             if pick:
-                return winograd_conv3x3_nhwc(x, self.u, self.b, self.dil, True)
+                return winograd_conv3x3_nhwc(x, self.u[pick], self.b, self.dil, True, pick)
         y = F.conv2d(x, self.w, None, **self.kw)
         bias_act_nhwc_(_rows(y), self.b)
         return y
