@@ -31,65 +31,94 @@ __device__ __forceinline__ void decode_tile(const WinoGeom& g, long t, int& n, i
   n = (int)t;
 }
 
-struct f4 {
-  float x, y, z, w;
+// VW consecutive channels per thread (4: one 16-byte access; 1 / 2: more threads and fewer registers per thread, for the
+// launches that would otherwise not fill the chip -- a F(4x4, 3x3) thread holds 36 values per channel)
+template <int VW>
+struct vec {
+  float v[VW];
 };
-__device__ __forceinline__ f4 operator+(f4 a, f4 b) { return {a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
-__device__ __forceinline__ f4 operator-(f4 a, f4 b) { return {a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w}; }
-__device__ __forceinline__ f4 operator*(float s, f4 a) { return {s * a.x, s * a.y, s * a.z, s * a.w}; }
-__device__ __forceinline__ f4 ld4(const float* p) { const float4 v = *reinterpret_cast<const float4*>(p); return {v.x, v.y, v.z, v.w}; }
-__device__ __forceinline__ void st4(float* p, f4 v) { *reinterpret_cast<float4*>(p) = make_float4(v.x, v.y, v.z, v.w); }
+template <int VW>
+__device__ __forceinline__ vec<VW> operator+(vec<VW> a, vec<VW> b) {
+  vec<VW> r;
+#pragma unroll
+  for (int i = 0; i < VW; ++i) r.v[i] = a.v[i] + b.v[i];
+  return r;
+}
+template <int VW>
+__device__ __forceinline__ vec<VW> operator-(vec<VW> a, vec<VW> b) {
+  vec<VW> r;
+#pragma unroll
+  for (int i = 0; i < VW; ++i) r.v[i] = a.v[i] - b.v[i];
+  return r;
+}
+template <int VW>
+__device__ __forceinline__ vec<VW> operator*(float s, vec<VW> a) {
+  vec<VW> r;
+#pragma unroll
+  for (int i = 0; i < VW; ++i) r.v[i] = s * a.v[i];
+  return r;
+}
+template <int VW>
+__device__ __forceinline__ vec<VW> ldv(const float* p) {
+  vec<VW> r;
+  __builtin_memcpy(&r, __builtin_assume_aligned(p, 4 * VW), 4 * VW);
+  return r;
+}
+template <int VW>
+__device__ __forceinline__ void stv(float* p, vec<VW> v) { __builtin_memcpy(__builtin_assume_aligned(p, 4 * VW), &v, 4 * VW); }
+template <int VW>
+__device__ __forceinline__ vec<VW> zerov() {
+  vec<VW> r;
+#pragma unroll
+  for (int i = 0; i < VW; ++i) r.v[i] = 0.f;
+  return r;
+}
 
 // B^T applied to one line of M + 2 values, in place
-template <int M>
-__device__ __forceinline__ void bt_line(f4* v, int stride);
-template <>
-__device__ __forceinline__ void bt_line<2>(f4* v, int s) {   // rows (1 0 -1 0), (0 1 1 0), (0 -1 1 0), (0 1 0 -1)
-  const f4 d0 = v[0], d1 = v[s], d2 = v[2 * s], d3 = v[3 * s];
-  v[0] = d0 - d2; v[s] = d1 + d2; v[2 * s] = d2 - d1; v[3 * s] = d1 - d3;
-}
-template <>
-__device__ __forceinline__ void bt_line<4>(f4* v, int s) {
-  // (4 0 -5 0 1 0), (0 -4 -4 1 1 0), (0 4 -4 -1 1 0), (0 -2 -1 2 1 0), (0 2 -1 -2 1 0), (0 4 0 -5 0 1)
-  const f4 d0 = v[0], d1 = v[s], d2 = v[2 * s], d3 = v[3 * s], d4 = v[4 * s], d5 = v[5 * s];
-  const f4 a = d4 - 4.f * d2, b = d3 - 4.f * d1, c = d4 - d2, e = 2.f * (d3 - d1);
-  v[0] = 4.f * d0 - 5.f * d2 + d4;
-  v[s] = a + b; v[2 * s] = a - b;
-  v[3 * s] = c + e; v[4 * s] = c - e;
-  v[5 * s] = 4.f * d1 - 5.f * d3 + d5;
+template <int M, typename V>
+__device__ __forceinline__ void bt_line(V* v, int s) {
+  if constexpr (M == 2) {   // rows (1 0 -1 0), (0 1 1 0), (0 -1 1 0), (0 1 0 -1)
+    const V d0 = v[0], d1 = v[s], d2 = v[2 * s], d3 = v[3 * s];
+    v[0] = d0 - d2; v[s] = d1 + d2; v[2 * s] = d2 - d1; v[3 * s] = d1 - d3;
+  } else {   // (4 0 -5 0 1 0), (0 -4 -4 1 1 0), (0 4 -4 -1 1 0), (0 -2 -1 2 1 0), (0 2 -1 -2 1 0), (0 4 0 -5 0 1)
+    const V d0 = v[0], d1 = v[s], d2 = v[2 * s], d3 = v[3 * s], d4 = v[4 * s], d5 = v[5 * s];
+    const V a = d4 - 4.f * d2, b = d3 - 4.f * d1, c = d4 - d2, e = 2.f * (d3 - d1);
+    v[0] = 4.f * d0 - 5.f * d2 + d4;
+    v[s] = a + b; v[2 * s] = a - b;
+    v[3 * s] = c + e; v[4 * s] = c - e;
+    v[5 * s] = 4.f * d1 - 5.f * d3 + d5;
+  }
 }
 
 // A^T applied to one line of M + 2 values -> M values (written to out[0 .. M-1] with stride so)
-template <int M>
-__device__ __forceinline__ void at_line(const f4* v, int s, f4* out, int so);
-template <>
-__device__ __forceinline__ void at_line<2>(const f4* v, int s, f4* out, int so) {   // (1 1 1 0), (0 1 -1 -1)
-  out[0] = v[0] + v[s] + v[2 * s];
-  out[so] = v[s] - v[2 * s] - v[3 * s];
-}
-template <>
-__device__ __forceinline__ void at_line<4>(const f4* v, int s, f4* out, int so) {
-  // (1 1 1 1 1 0), (0 1 -1 2 -2 0), (0 1 1 4 4 0), (0 1 -1 8 -8 1)
-  const f4 p = v[s] + v[2 * s], q = v[s] - v[2 * s], r = v[3 * s] + v[4 * s], t = v[3 * s] - v[4 * s];
-  out[0] = v[0] + p + r;
-  out[so] = q + 2.f * t;
-  out[2 * so] = p + 4.f * r;
-  out[3 * so] = q + 8.f * t + v[5 * s];
+template <int M, typename V>
+__device__ __forceinline__ void at_line(const V* v, int s, V* out, int so) {
+  if constexpr (M == 2) {   // (1 1 1 0), (0 1 -1 -1)
+    out[0] = v[0] + v[s] + v[2 * s];
+    out[so] = v[s] - v[2 * s] - v[3 * s];
+  } else {   // (1 1 1 1 1 0), (0 1 -1 2 -2 0), (0 1 1 4 4 0), (0 1 -1 8 -8 1)
+    const V p = v[s] + v[2 * s], q = v[s] - v[2 * s], r = v[3 * s] + v[4 * s], t = v[3 * s] - v[4 * s];
+    out[0] = v[0] + p + r;
+    out[so] = q + 2.f * t;
+    out[2 * so] = p + 4.f * r;
+    out[3 * so] = q + 8.f * t + v[5 * s];
+  }
 }
 
-// one thread = one (tile, 4 channels): (M+2)^2 guarded float4 loads, B^T d B, (M+2)^2 float4 stores
-template <int M>
+// one thread = one (tile, VW channels): (M+2)^2 guarded loads, B^T d B, (M+2)^2 stores
+template <int M, int VW>
 __global__ __launch_bounds__(kThreads) void wino_input_kernel(const float* __restrict__ x, float* __restrict__ V, WinoGeom g,
                                                               int C) {
   constexpr int T = M + 2;
-  const int c4n = C >> 2;
+  using vt = vec<VW>;
+  const int cn = C / VW;
   const long idx = (long)blockIdx.x * kThreads + threadIdx.x;
-  if (idx >= g.tiles * c4n) return;
-  const int c = (int)(idx % c4n) << 2;
-  const long tile = idx / c4n;
+  if (idx >= g.tiles * cn) return;
+  const int c = (int)(idx % cn) * VW;
+  const long tile = idx / cn;
   int n, py, px, ty, tx;
   decode_tile(g, tile, n, py, px, ty, tx);
-  f4 d[T * T];
+  vt d[T * T];
 #pragma unroll
   for (int a = 0; a < T; ++a) {
     const int iy = (M * ty - 1 + a) * g.d + py;
@@ -97,7 +126,7 @@ __global__ __launch_bounds__(kThreads) void wino_input_kernel(const float* __res
     for (int b = 0; b < T; ++b) {
       const int ix = (M * tx - 1 + b) * g.d + px;
       const bool in = iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
-      d[a * T + b] = in ? ld4(x + (((long)n * g.H + iy) * g.W + ix) * C + c) : f4{0.f, 0.f, 0.f, 0.f};
+      d[a * T + b] = in ? ldv<VW>(x + (((long)n * g.H + iy) * g.W + ix) * C + c) : zerov<VW>();
     }
   }
 #pragma unroll
@@ -107,33 +136,34 @@ __global__ __launch_bounds__(kThreads) void wino_input_kernel(const float* __res
   const long stride = g.tiles * C;
   float* dst = V + tile * C + c;
 #pragma unroll
-  for (int i = 0; i < T * T; ++i) st4(dst + i * stride, d[i]);
+  for (int i = 0; i < T * T; ++i) stv<VW>(dst + i * stride, d[i]);
 }
 
-// one thread = one (tile, 4 output channels): (M+2)^2 float4 loads, A^T m A, bias (+ ReLU), up to M^2 guarded stores
-template <int M, bool RELU>
+// one thread = one (tile, VW output channels): (M+2)^2 loads, A^T m A, bias (+ ReLU), up to M^2 guarded stores
+template <int M, int VW, bool RELU>
 __global__ __launch_bounds__(kThreads) void wino_output_kernel(const float* __restrict__ Mm, const float* __restrict__ bias,
                                                                float* __restrict__ y, WinoGeom g, int K) {
   constexpr int T = M + 2;
-  const int k4n = K >> 2;
+  using vt = vec<VW>;
+  const int kn = K / VW;
   const long idx = (long)blockIdx.x * kThreads + threadIdx.x;
-  if (idx >= g.tiles * k4n) return;
-  const int k = (int)(idx % k4n) << 2;
-  const long tile = idx / k4n;
+  if (idx >= g.tiles * kn) return;
+  const int k = (int)(idx % kn) * VW;
+  const long tile = idx / kn;
   int n, py, px, ty, tx;
   decode_tile(g, tile, n, py, px, ty, tx);
   const long stride = g.tiles * K;
   const float* src = Mm + tile * K + k;
-  f4 m[T * T];
+  vt m[T * T];
 #pragma unroll
-  for (int i = 0; i < T * T; ++i) m[i] = ld4(src + i * stride);
-  f4 t[M * T];   // A^T m : M rows x T columns
+  for (int i = 0; i < T * T; ++i) m[i] = ldv<VW>(src + i * stride);
+  vt t[M * T];   // A^T m : M rows x T columns
 #pragma unroll
   for (int b = 0; b < T; ++b) at_line<M>(m + b, T, t + b, T);
-  const f4 bv = ld4(bias + k);
+  const vt bv = ldv<VW>(bias + k);
 #pragma unroll
   for (int i = 0; i < M; ++i) {
-    f4 o[M];
+    vt o[M];
     at_line<M>(t + i * T, 1, o, 1);
     const int oy = (M * ty + i) * g.d + py;
     if (oy >= g.H) continue;
@@ -141,9 +171,12 @@ __global__ __launch_bounds__(kThreads) void wino_output_kernel(const float* __re
     for (int j = 0; j < M; ++j) {
       const int ox = (M * tx + j) * g.d + px;
       if (ox >= g.W) continue;
-      f4 v = o[j] + bv;
-      if (RELU) v = {fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
-      st4(y + (((long)n * g.H + oy) * g.W + ox) * K + k, v);
+      vt v = o[j] + bv;
+      if (RELU) {
+#pragma unroll
+        for (int q = 0; q < VW; ++q) v.v[q] = fmaxf(v.v[q], 0.f);
+      }
+      stv<VW>(y + (((long)n * g.H + oy) * g.W + ox) * K + k, v);
     }
   }
 }
@@ -173,10 +206,13 @@ extern "C" int dtt_winograd_input_transform(const float* x, float* v, int images
   DTT_REQUIRE(channels > 0 && channels % 4 == 0, "winograd: channels must be a multiple of 4 (got %d)", channels);
   WinoGeom g;
   if (!make_geom(images, height, width, dilation, m, g)) return 0;
-  const long n = g.tiles * (channels / 4);
-  const dim3 grid((unsigned)dtt_cdiv(n, kThreads));
-  if (m == 2) hipLaunchKernelGGL(wino_input_kernel<2>, grid, dim3(kThreads), 0, stream, x, v, g, channels);
-  else hipLaunchKernelGGL(wino_input_kernel<4>, grid, dim3(kThreads), 0, stream, x, v, g, channels);
+  // 16-byte accesses when that still gives every CU a few workgroups, otherwise one channel per thread
+  const int vw = g.tiles * (channels / 4) >= 4L * 256 * kThreads ? 4 : 1;
+  const dim3 grid((unsigned)dtt_cdiv(g.tiles * (channels / vw), kThreads));
+  if (m == 2 && vw == 4) hipLaunchKernelGGL((wino_input_kernel<2, 4>), grid, dim3(kThreads), 0, stream, x, v, g, channels);
+  else if (m == 2) hipLaunchKernelGGL((wino_input_kernel<2, 1>), grid, dim3(kThreads), 0, stream, x, v, g, channels);
+  else if (vw == 4) hipLaunchKernelGGL((wino_input_kernel<4, 4>), grid, dim3(kThreads), 0, stream, x, v, g, channels);
+  else hipLaunchKernelGGL((wino_input_kernel<4, 1>), grid, dim3(kThreads), 0, stream, x, v, g, channels);
   DTT_CHECK_LAUNCH("wino_input_kernel");
   return 1;
 }
@@ -188,12 +224,15 @@ extern "C" int dtt_winograd_output_transform(const float* mm, const float* bias,
   DTT_REQUIRE(channels > 0 && channels % 4 == 0, "winograd: channels must be a multiple of 4 (got %d)", channels);
   WinoGeom g;
   if (!make_geom(images, height, width, dilation, m, g)) return 0;
-  const long n = g.tiles * (channels / 4);
-  const dim3 grid((unsigned)dtt_cdiv(n, kThreads));
-  if (m == 2 && relu) hipLaunchKernelGGL((wino_output_kernel<2, true>), grid, dim3(kThreads), 0, stream, mm, bias, y, g, channels);
-  else if (m == 2) hipLaunchKernelGGL((wino_output_kernel<2, false>), grid, dim3(kThreads), 0, stream, mm, bias, y, g, channels);
-  else if (relu) hipLaunchKernelGGL((wino_output_kernel<4, true>), grid, dim3(kThreads), 0, stream, mm, bias, y, g, channels);
-  else hipLaunchKernelGGL((wino_output_kernel<4, false>), grid, dim3(kThreads), 0, stream, mm, bias, y, g, channels);
+  const int vw = g.tiles * (channels / 4) >= 4L * 256 * kThreads ? 4 : 1;
+  const dim3 grid((unsigned)dtt_cdiv(g.tiles * (channels / vw), kThreads));
+#define DTT_WINO_OUT(MM, VW, RL) \
+  hipLaunchKernelGGL((wino_output_kernel<MM, VW, RL>), grid, dim3(kThreads), 0, stream, mm, bias, y, g, channels)
+  if (m == 2 && vw == 4) { if (relu) DTT_WINO_OUT(2, 4, true); else DTT_WINO_OUT(2, 4, false); }
+  else if (m == 2) { if (relu) DTT_WINO_OUT(2, 1, true); else DTT_WINO_OUT(2, 1, false); }
+  else if (vw == 4) { if (relu) DTT_WINO_OUT(4, 4, true); else DTT_WINO_OUT(4, 4, false); }
+  else { if (relu) DTT_WINO_OUT(4, 1, true); else DTT_WINO_OUT(4, 1, false); }
+#undef DTT_WINO_OUT
   DTT_CHECK_LAUNCH("wino_output_kernel");
   return 1;
 }
