@@ -213,6 +213,30 @@ def test_winograd_conv3x3_matches_direct_convolution():
             assert err < tol, ((n, c, k, h, w, d, m), err)
 
 
+def test_winograd_conv3x3_random_shapes():
+    """Random map sizes / channel counts / dilations / batch sizes through both Winograd variants (partial tiles, uneven
+    sub-lattices, the one-channel-per-thread and the 16-byte transform kernels)."""
+    import torch.nn.functional as F
+    from dtt.fuse import winograd_conv3x3_nhwc, winograd_weights
+    dev = torch.device("cuda:0")
+    rs = np.random.RandomState(8)
+    g = torch.Generator().manual_seed(22)
+    for it in range(24):
+        n, d = int(rs.randint(1, 4)), int(rs.choice([1, 1, 2, 3, 6]))
+        c, k = 4 * int(rs.randint(1, 40)), 4 * int(rs.randint(1, 40))
+        h, w = int(rs.randint(1, 45)), int(rs.randint(1, 70))
+        if it == 0:
+            n, c, k, h, w, d = 4, 512, 128, 38, 67, 1   # enough threads for the 16-byte kernels
+        x = torch.randn(n, c, h, w, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+        wt = (torch.randn(k, c, 3, 3, generator=g) / (3.0 * c ** 0.5)).to(dev)
+        b = torch.randn(k, generator=g).to(dev)
+        ref = torch.relu(F.conv2d(x.double(), wt.double(), b.double(), 1, d, d))
+        for m, tol in ((2, 2e-5), (4, 1e-4)):
+            out = winograd_conv3x3_nhwc(x, winograd_weights(wt, m), b, d, True, m)
+            err = (out.double() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-6)
+            assert err < tol, ((n, c, k, h, w, d, m), err)
+
+
 def test_drivers_on_an_ilsvrc_devkit(tmp_path):
     """The drivers on real-layout data: a synthetic ILSVRC devkit (tests/data_fixture.py) read through dtt.data -- VID
     training pairs, alternating VID / DET batches, then the VID test split through the test loader and the VOC-style
