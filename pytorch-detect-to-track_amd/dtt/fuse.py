@@ -386,7 +386,7 @@ class _NhwcConv:
         self.kw = base.kw
         self.is_gemm = conv.kernel_size == (1, 1) and conv.stride == (1, 1)
         self.u = None          # Winograd-domain filters {m: U}, for 3x3 / stride 1 / padding == dilation layers
-        self.pick = {}         # per input shape: 0 = MIOpen, 2 / 4 = the Winograd variant that won the timing
+        self.pick = {}         # per map size (C, H, W): 0 = MIOpen, 2 / 4 = the Winograd variant that won the timing
         if self.is_gemm:
             self.wt = base.w.view(base.w.shape[0], base.w.shape[1]).t().contiguous()   # (Cin, Cout)
             self.zero_b = torch.zeros_like(self.b)
@@ -416,9 +416,9 @@ class _NhwcConv:
             out = torch.empty((a.shape[0], self.wt.shape[1]), dtype=a.dtype, device=a.device)
             return _from_rows(gemm_bias_act_(out, a, self.wt, self.b), n, h, w)
         if self.u is not None:
-            key = tuple(x.shape)
+            key = tuple(x.shape[1:])   # per map size, whatever the batch: the same images give the same arithmetic
             pick = self.pick.get(key)
-            if pick is None:   # first time at this shape: the fastest path wins (all timed on this input)
+            if pick is None:   # first time at this map size: the fastest path wins (all timed on this input)
                 times = {0: _time_us(lambda: bias_act_nhwc_(_rows(F.conv2d(x, self.w, None, **self.kw)), self.b))}
                 for m, u in self.u.items():
                     t2 = (m + 2) ** 2
