@@ -128,11 +128,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
+    # DTT_BENCH_BACKEND=gloo: developer switch to exercise the multi-rank control flow on a box with fewer GPUs than ranks
+    # (ranks then share devices; inference mode only -- the training path all-reduces device buffers over RCCL)
+    backend = os.environ.get("DTT_BENCH_BACKEND", "nccl")
+    local = local if backend == "nccl" else local % torch.cuda.device_count()
     torch.cuda.set_device(local)  # before the process group exists: RCCL binds its communicator to the current device
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
 
     from dtt.config import apply_dataset_defaults, cfg
     from dtt.synth import build_model, calibrate_batchnorm_, make_batch
@@ -190,7 +194,7 @@ def main():
     elapsed = time.perf_counter() - t0
     used = kt.detach()
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
