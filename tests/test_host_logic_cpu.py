@@ -257,3 +257,30 @@ def test_affine_grid_gen_matches_corner_aligned_affine_grid():
     px = (grid[:, 0, :, 0] + 1) / 2 * (W - 1)
     np.testing.assert_allclose(px[:, 0].numpy(), b[:, 0].numpy(), atol=1e-4)
     np.testing.assert_allclose(px[:, -1].numpy(), b[:, 2].numpy(), atol=1e-4)
+
+
+def test_winograd_filter_transform_and_layout():
+    """dtt.fuse.winograd_weights: U[(i, j), c, k] = (G g G^T)[i, j] of filter (k, c), for F(2x2,3x3) and F(4x4,3x3).
+    Checked by running the whole Winograd identity on the CPU with the textbook B^T / A^T (the matrices the HIP transform
+    kernels in csrc/winograd.hip hard-code): sum_c U .* (B^T d B) followed by A^T . A must reproduce the 3x3 correlation."""
+    import torch.nn.functional as F
+    from dtt.fuse import winograd_weights
+    BT = {2: torch.tensor([[1., 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], dtype=torch.float64),
+          4: torch.tensor([[4., 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1, 1, 0], [0, -2, -1, 2, 1, 0],
+                           [0, 2, -1, -2, 1, 0], [0, 4, 0, -5, 0, 1]], dtype=torch.float64)}
+    AT = {2: torch.tensor([[1., 1, 1, 0], [0, 1, -1, -1]], dtype=torch.float64),
+          4: torch.tensor([[1., 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 0], [0, 1, 1, 4, 4, 0], [0, 1, -1, 8, -8, 1]],
+                          dtype=torch.float64)}
+    g = torch.Generator().manual_seed(2)
+    for m in (2, 4):
+        t = m + 2
+        c, k = 5, 3
+        w = torch.randn(k, c, 3, 3, generator=g)
+        u = winograd_weights(w, m).double()                     # (t*t, c, k)
+        assert u.shape == (t * t, c, k)
+        d = torch.randn(c, t, t, generator=g, dtype=torch.float64)   # one input tile
+        v = torch.einsum("ia,cab,jb->ijc", BT[m], d, BT[m]).reshape(t * t, c)
+        mm = torch.einsum("pc,pck->pk", v, u).reshape(t, t, k)
+        y = torch.einsum("ia,abk,jb->kij", AT[m], mm, AT[m])   # (k, m, m)
+        ref = F.conv2d(d[None], w.double())[0]                 # valid 3x3 correlation of the tile: (k, m, m)
+        np.testing.assert_allclose(y.numpy(), ref.numpy(), rtol=0, atol=1e-5)
