@@ -378,7 +378,9 @@ def _time_us(fn, reps=5):
 
 class _NhwcConv:
     """One folded convolution for the channels-last trunk: 1x1 stride-1 layers are plain GEMMs over the (pixels, C)
-    view (hipBLASLt, bias + ReLU in the GEMM epilogue); everything else is MIOpen's NHWC kernel + the fused pass."""
+    view (hipBLASLt, bias + ReLU in the GEMM epilogue); 3x3 stride-1 layers run in Winograd form (HIP transforms around
+    batched GEMMs) when that beats MIOpen on the layer's own input (timed once per map size); everything else is
+    MIOpen's NHWC kernel + the fused bias / ReLU pass."""
 
     def __init__(self, conv, bn=None, extra_bias=None):
         base = _FusedConv(conv, bn)
