@@ -84,6 +84,35 @@ def test_evaluate_detections_end_to_end(data_cfg):
     assert os.path.exists(os.path.join(str(tmp / "eval"), "airplane_pr.pkl"))
 
 
+def test_loader_batches_collate_through_torch_dataloader(data_cfg):
+    """The training path of trainval_net.py: ratio-sorted pairs, batch-permuting sampler, default collate.  Every batch
+    holds frame pairs padded / cropped to one size: data (B, 2, 3, H, W), im_info (B, 2, 3), gt (B, 2, 30, 6), num (B, 2, 1),
+    and im_info carries the padded size."""
+    import torch
+    from dtt.data import combined_roidb, roibatchLoader, sampler
+    cfg, gold, tmp = data_cfg
+    np.random.seed(5)
+    torch.manual_seed(5)
+    imdb, pairs, ratio_list, ratio_index = combined_roidb("imagenet_vid_train")
+    bs = 2
+    ds = roibatchLoader(pairs, ratio_list, ratio_index, bs, imdb.num_classes, training=True)
+    loader = torch.utils.data.DataLoader(ds, batch_size=bs, sampler=sampler(len(pairs), bs), num_workers=0)
+    seen = 0
+    for data, im_info, gt, num in loader:
+        b = data.shape[0]
+        seen += b
+        assert data.shape[1:3] == (2, 3) and im_info.shape == (b, 2, 3) and gt.shape == (b, 2, 30, 6) and num.shape == (b, 2, 1)
+        assert torch.all(im_info[..., 0] == data.shape[3]) and torch.all(im_info[..., 1] == data.shape[4])
+        for i in range(b):
+            for leg in range(2):
+                n = int(num[i, leg, 0])
+                boxes = gt[i, leg, :n]
+                assert n >= 1 and torch.all(boxes[:, 2] > boxes[:, 0]) and torch.all(boxes[:, 3] > boxes[:, 1])
+                assert float(boxes[:, 2].max()) <= data.shape[4] and float(boxes[:, 3].max()) <= data.shape[3]
+                assert torch.all(gt[i, leg, n:] == 0)
+    assert seen == len(pairs)
+
+
 def test_sampler_keeps_batches_together():
     """trainval_net.py:125-150: whole batches are permuted, the remainder goes last."""
     import torch
