@@ -285,6 +285,27 @@ int dtt_transpose_batched(const float* in, float* out, int batch, int rows, int 
 int dtt_gemm_bias_act(float* out, const float* a, const float* w, const float* bias, const float* residual,
                       long rows, int k, int n, int relu, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---------------------------------------------------------------- R-FCN 1x1 heads + position-major PSRoI pooling
+ * dtt_head_gemm replaces the cuDNN 1x1 convolutions RFCN_cls_net / RFCN_bbox_net / corr_bbox_net
+ * (faster_rcnn/rfcn.py:49-53, 133-134, 194; resnet.py:311-312) at inference: an exact-fp32 MFMA GEMM over channels-last
+ * pixel rows.   out[m][n] = sum_k x[m][k] * w[n][k] + bias[n]  for n < n_store.
+ *   x (M, K) rows ldx floats apart, K % 32 == 0;  w (n_rows, K) row-major, n_rows % 16 == 0, rows in the order the
+ *   channels are to be emitted (zero rows as padding);  bias (n_rows);  out (M, ldc);  n_store % 4 == 0;  all pointers
+ *   16-byte aligned.  passes = 0 lets the library choose how many sub-ranges of the channel tiles a workgroup walks
+ *   (stores of one sub-range drain under the MFMAs of the next).
+ * The callers emit the position-major layout  n = head_offset + bin*cp + ctop  (bin = ph*G + pw; reference channel
+ * (ctop*G + ph)*G + pw, psroi_pooling_kernel.cu:62), which dtt_psroi_pm_forward pools:
+ * PSROIPoolForward (psroi_pooling_kernel.cu:15-79) + the G x G average vote (rfcn.py:62-64, 136-140) with lanes = classes.
+ *   map: first float of the head inside pixel 0; pixel (b, h, w) starts pixel_stride * ((b*height + h)*width + w) floats
+ *   later; cp = classes-per-bin padding (4 or 32), output_dim <= cp; rois (num_rois, 5);
+ *   vote_out (num_rois, output_dim); pooled_out (num_rois, output_dim, pooled, pooled) or NULL.
+ * Same bin arithmetic and summation order as dtt_psroi_pool_vote_forward on the equivalent NCHW map: bit-identical. */
+int dtt_head_gemm(const float* x, long ldx, int M, int K, const float* w, const float* bias, int n_rows,
+                  float* out, long ldc, int n_store, int passes, void* stream);
+int dtt_psroi_pm_forward(const float* map, long pixel_stride, int cp, int batch_size, int num_rois, int height,
+                         int width, int pooled, const float* rois, float spatial_scale, int output_dim,
+                         float* vote_out, float* pooled_out, void* stream);
+
 /* ---------------------------------------------------------------- zero-jump Viterbi tube linking
  * Replaces VideoPostProcessor._make_tubes / _zero_jump_link / _score_of_edge (lib/model/utils/tracking_utils.py:
  * 86-124, 127-264, 268-290) for `problems` independent (video, class) problems of `frames` frames each, in three

@@ -1,0 +1,488 @@
+// R-FCN 1x1 heads on the matrix cores + the position-sensitive pooling that consumes their output (gfx950).
+//
+// The reference computes the score maps with cuDNN 1x1 convolutions (faster_rcnn/rfcn.py:49-53, 133-140,
+// resnet.py:311-312: RFCN_cls_net 512 -> 31*49, RFCN_bbox_net 512 -> 4*49, corr_bbox_net 1051 -> 4*49) into NCHW
+// maps whose channel c = (ctop*7 + ph)*7 + pw, and PSROIPoolForward (psroi_pooling_kernel.cu:15-79) then walks one
+// channel plane per output bin: neighbouring threads read addresses H*W floats apart.
+//
+// Here the head is ONE exact-f32 MFMA GEMM over the channels-last trunk output (rows = pixels, K contiguous) that emits
+// a POSITION-MAJOR map:  out[pixel][bin*CP + ctop]  with bin = ph*7 + pw and the ctop of one bin contiguous (CP = classes
+// padded to a power of two; the weight rows are permuted once on the host).  Pooling then has lanes = classes: every
+// element of a bin is ONE aligned 128-byte (31 classes) / 16-byte (4 box deltas) read shared by all the classes of that
+// bin, no LDS staging of planes, no bank conflicts, and the 7x7 vote runs in the same workgroup.
+//
+// head_gemm_kernel  persistent, one workgroup per CU: a strip of TPX*16 pixels x a contiguous range of 16-channel
+//                   tiles, processed in `passes` sub-ranges so that the stores of pass p drain underneath the MFMAs of
+//                   pass p+1.  Both operands are K-contiguous, so a chunk of 32 k is one 128-byte line per row; rows are
+//                   staged global -> LDS by LDS-DMA (global_load_lds_dwordx4) with the 16-byte parts of a row XOR-swizzled
+//                   on the SOURCE side (the DMA destination is lane-linear), which makes the operand reads
+//                   (one ds_read_b128 = the k-quad of 4 consecutive MFMAs) bank-conflict free.  v_mfma_f32_16x16x4_f32 is
+//                   bitwise an fp32 fma chain: no precision is traded.  A = weights (rows -> 4 consecutive channels per
+//                   lane in the accumulator), B = pixels, so the epilogue is one 16-byte store per accumulator.
+// psroi_pm_kernel   one workgroup per RoI; lane = (bin slot, class).  Bin geometry and summation order are the
+//                   reference's, so pooled bins and votes are bit-identical to the oracle's on the same map.
+#include <stdlib.h>
+#include <type_traits>
+#include "common.h"
+#include "psroi_bin.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+
+constexpr int kBK = 32;   // k per stage = one 128-byte line per row
+
+constexpr int kMaxPasses = 8;
+
+#ifdef DTT_HEAD_STAMP   // developer timeline: shader-clock stamps of workgroup 0 (tools/head_timeline.py)
+__device__ unsigned long long dtt_head_stamps[8 * 512];
+#define HEAD_STAMP(w, idx) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && (idx) < 512) dtt_head_stamps[(w) * 512 + (idx)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define HEAD_STAMP(w, idx) do {} while (0)
+#endif
+
+struct HeadGeom {
+  const float* x; long ldx;   // (M, K) pixel rows (channels-last), ldx floats between rows
+  const float* w;             // (nt_total*16, K): output channels in emitted order, zero rows as padding
+  const float* bias;          // nt_total*16
+  float* out; long ldc;       // (M, ldc); columns >= n_store are never written
+  int M, K, n_store;
+  int nt_total, n_groups, strips, passes;
+  int pass_len[kMaxPasses];   // channel tiles per pass (the last pass takes what is left of the group)
+  int ablate;                 // developer timing experiments (DTT_HEAD_ABLATE): 1 no DMA, 2 no MFMA, 4 no stores, 8 no DMA wait, 16 no X DMA, 32 no W DMA
+};
+
+// One LDS-DMA instruction in the scalar-base form: 16 bytes per lane from sbase + voff (per-lane byte offset) to LDS byte
+// address lds_addr + lane * 16.  Written as asm so that the loader's instruction stream is SALU + VMEM only: a VALU
+// address add would queue behind the MFMAs of the compute wave that shares the SIMD (see head_gemm_kernel).
+__device__ __forceinline__ void dma16(const char* sbase, unsigned voff, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+               :
+               : "s"(lds_addr), "v"(voff), "s"(sbase)
+               : "memory", "m0");
+}
+__device__ __forceinline__ const char* uniform_ptr(const char* p) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)), lo = (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+  return (const char*)(((unsigned long long)hi << 32) | (unsigned long long)lo);
+}
+
+__device__ __forceinline__ int part_begin(int n, int k, int i) { return (int)((unsigned)(n * i) / (unsigned)k); }
+
+// first tile (relative to the group) of pass p, p in [0, passes]
+__device__ __forceinline__ int pass_begin(const HeadGeom& g, int ntg, int p) {
+  if (p >= g.passes) return ntg;
+  int b = 0;
+  for (int q = 0; q < p; ++q) b += g.pass_len[q];
+  return min(b, ntg);
+}
+
+// Compute side of one pass (= one sub-range of the workgroup's channel tiles, all K) with a compile-time tile count
+// per wave: the accumulators sit in fixed registers for the whole K loop.  The compute waves never issue a load from
+// global memory, so nothing ever makes them wait for their own stores: the tile of pass p drains underneath pass p+1.
+//
+// A chunk (32 k) is 2 * NG segments = (16-k half) x (group of TPG pixel tiles); a segment is CNT blocks of 4 * TPG MFMAs
+// (one weight fragment against the group's pixel fragments).  Operands are requested one block (weights) / one segment
+// (pixels) ahead of the MFMAs that consume them, and the barrier that publishes chunk s+1 sits BEFORE the last segment of
+// chunk s: the first operands of chunk s+1 are fetched underneath that segment, so the matrix pipe does not drain at
+// chunk boundaries.  Three LDS stages make that legal (after barrier s+1 the loaders fill stage s+2 while stages s and
+// s+1 are both still being read).
+template <int TPX, int NTW, int CNT, bool PIN>
+__device__ __forceinline__ void head_pass(const HeadGeom& g, const float* lds, int s_begin, int tile0, int t0, int cnt,
+                                          int p0, int lane, int wave) {
+  constexpr int XROWS = TPX * 16;
+  constexpr int STAGE = (XROWS + 4 * NTW * 16) * kBK;
+  constexpr int NG = (TPX % 2 == 0 && TPX > 5) ? 2 : 1, TPG = TPX / NG, NSEG = 2 * NG;
+  const int KC = g.K / kBK;
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int sw[2] = {(lg ^ (lane & 7)) * 4, ((4 + lg) ^ (lane & 7)) * 4};   // swizzled k-quad offsets, two 16-k halves
+  // the accumulators start from the bias (read while the first chunk is still landing): nothing but stores at the end
+  f32x4 acc[CNT][TPX];
+#pragma unroll
+  for (int t = 0; t < CNT; ++t) {
+    const f32x4 b4 = *reinterpret_cast<const f32x4*>(g.bias + (long)min(tile0 + t, g.nt_total - 1) * 16 + 4 * lg);
+#pragma unroll
+    for (int pt = 0; pt < TPX; ++pt) acc[t][pt] = b4;
+  }
+  // every wave runs CNT tiles (a wave that owns fewer recomputes a neighbour's: the barrier makes the step as long as
+  // its slowest wave anyway, and the extra tile is never stored)
+  const int xrow = l15 * kBK;
+  const int wrow = (XROWS + min(t0, 4 * NTW - CNT) * 16 + l15) * kBK;
+  auto stage_of = [&](int s) { return lds + (s % 3) * STAGE; };
+  auto read_bx = [&](f32x4 (&dst)[TPG], const float* st, int seg) {
+    const int hh = seg / NG, pxg = seg % NG;
+#pragma unroll
+    for (int q = 0; q < TPG; ++q) dst[q] = *reinterpret_cast<const f32x4*>(st + xrow + (pxg * TPG + q) * 16 * kBK + sw[hh]);
+  };
+  auto read_a = [&](const float* st, int hh, int t) { return *reinterpret_cast<const f32x4*>(st + wrow + t * 16 * kBK + sw[hh]); };
+
+  // Operand traffic is batched: ONE burst of LDS reads per segment fetches everything the NEXT segment needs (its pixel
+  // fragments, and the CNT weight fragments when the 16-k half changes).  A lone ds_read between two MFMAs costs the
+  // single-wave MFMA stream ~36 cycles whatever its width, further reads in the same burst ~15 each
+  // (tools/probes/mfma_lds.hip), so fewer, fatter interruptions win.
+  f32x4 bx[2][TPG], aw[2][CNT];
+  HEAD_STAMP(wave, 2 * s_begin);
+  __builtin_amdgcn_s_barrier();   // the first chunk of the pass has landed
+  HEAD_STAMP(wave, 2 * s_begin + 1);
+  if (!(g.ablate & 2)) {
+    read_bx(bx[0], stage_of(s_begin), 0);
+#pragma unroll
+    for (int t = 0; t < CNT; ++t) aw[0][t] = read_a(stage_of(s_begin), 0, t);
+  }
+  auto do_step = [&](auto last_tag, int kc) {
+    constexpr bool LAST = decltype(last_tag)::value;   // last chunk of the pass: nothing to publish or prefetch
+    const float* cur = stage_of(s_begin + kc);
+    const float* nxt = stage_of(s_begin + kc + 1);
+#pragma unroll
+    for (int seg = 0; seg < NSEG; ++seg) {
+      const int hh = seg / NG, pxg = seg % NG;
+      if (seg == NSEG - 1 && !LAST) {
+        HEAD_STAMP(wave, 2 * (s_begin + kc + 1));
+        __builtin_amdgcn_s_barrier();   // chunk kc+1 has landed; the loaders move on to kc+2
+        HEAD_STAMP(wave, 2 * (s_begin + kc + 1) + 1);
+      }
+      if (g.ablate & 2) continue;
+      if (seg < NSEG - 1) {
+        read_bx(bx[(seg + 1) & 1], cur, seg + 1);
+        if ((seg + 1) / NG != hh) {
+#pragma unroll
+          for (int t = 0; t < CNT; ++t) aw[1][t] = read_a(cur, 1, t);
+        }
+      } else if (!LAST) {
+        read_bx(bx[0], nxt, 0);
+#pragma unroll
+        for (int t = 0; t < CNT; ++t) aw[0][t] = read_a(nxt, 0, t);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < CNT; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int q = 0; q < TPG; ++q)
+            acc[t][pxg * TPG + q] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[hh][t][j], bx[seg & 1][q][j], acc[t][pxg * TPG + q], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  auto pin = [&]() {   // keep the accumulators in the AGPR half of the register file: the MFMA then reads A / B from
+                       // VGPR banks and C from AGPR banks (VGPR-resident accumulators cost ~5 cycles per MFMA in operand fetch)
+#pragma unroll
+    for (int t = 0; t < CNT; ++t)
+#pragma unroll
+      for (int pt = 0; pt < TPX; ++pt) if constexpr (PIN) asm volatile("" : "+a"(acc[t][pt]));
+  };
+  pin();
+  for (int kc = 0; kc + 1 < KC; ++kc) { do_step(std::false_type{}, kc); pin(); }
+  do_step(std::true_type{}, KC - 1);
+  HEAD_STAMP(wave, 400 + 4 * (s_begin / KC));
+#pragma unroll
+  for (int t = 0; t < CNT; ++t) {
+    if (t < cnt && !(g.ablate & 4)) {
+      const int col = (tile0 + t) * 16 + 4 * lg;
+#pragma unroll
+      for (int pt = 0; pt < TPX; ++pt) {
+        const int row = p0 + pt * 16 + l15;
+        if (row < g.M && col < g.n_store) *reinterpret_cast<f32x4*>(g.out + (long)row * g.ldc + col) = acc[t][pt];
+      }
+    }
+  }
+  HEAD_STAMP(wave, 401 + 4 * (s_begin / KC));
+}
+
+// 4 compute waves (one per SIMD) + NLOAD loader waves.  Loaders move chunk s+1 global -> LDS by LDS-DMA while the compute
+// waves run the MFMAs of chunk s; one barrier per chunk, three LDS stages (see head_pass).
+template <int TPX, int NTW, int NLOAD, bool PIN>
+__global__ __launch_bounds__((4 + NLOAD) * 64) void head_gemm_kernel(HeadGeom g) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int XROWS = TPX * 16;
+  constexpr int STAGE = (XROWS + 4 * NTW * 16) * kBK;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int item = dtt_xcd_remap(blockIdx.x, gridDim.x);
+  // ablate & 64: channel groups of a strip on different XCDs (group-major order) instead of side by side on one XCD
+  const int grp = (g.ablate & 64) ? item / g.strips : item % g.n_groups;
+  const int strip = (g.ablate & 64) ? item - grp * g.strips : item / g.n_groups;
+  const int p0 = strip * XROWS;
+  const int nt_lo = part_begin(g.nt_total, g.n_groups, grp);
+  const int ntg = part_begin(g.nt_total, g.n_groups, grp + 1) - nt_lo;
+  const int KC = g.K / kBK;
+
+  if (wave >= 4) {
+    // ---- loader: per chunk, the X rows of the strip and the W rows of the pass's tiles; 8 rows (1 KB) per instruction,
+    // the 16-byte parts of a row XOR-swizzled on the source side (the LDS image of an instruction is lane-linear).
+    // Instruction i of a chunk belongs to loader i % NLOAD.  Per-lane byte offsets are fixed for the whole launch; only
+    // the wave-uniform bases move (k0 per chunk, the W row block per pass).
+    static_assert((XROWS / 8) % NLOAD == 0, "X instructions split evenly over the loaders");
+    constexpr int NX = XROWS / 8 / NLOAD;
+    const int lw = wave - 4;
+    // The loader shares its SIMD with a compute wave that always has an MFMA ready to issue; at equal priority the older
+    // (compute) wave wins every arbitration and the DMA instructions only get out while the compute waves sit at the
+    // barrier -- one whole chunk late.  A handful of high-priority instructions per chunk cost the MFMA stream nothing.
+    if (!(g.ablate & 128)) __builtin_amdgcn_s_setprio(3);
+    const int r8 = lane >> 3;
+    const unsigned part = (unsigned)(((lane & 7) ^ r8) << 4);   // bytes
+    unsigned xoff[NX];
+#pragma unroll
+    for (int j = 0; j < NX; ++j) xoff[j] = (unsigned)min(p0 + (j * NLOAD + lw) * 8 + r8, g.M - 1) * (unsigned)(g.ldx * 4) + part;
+    const unsigned woff = (unsigned)(lw * 8 + r8) * (unsigned)(g.K * 4) + part;
+    const unsigned wstep = (unsigned)(8 * NLOAD) * (unsigned)(g.K * 4);
+    const char* xb = reinterpret_cast<const char*>(g.x);
+    const unsigned lds_base = (unsigned)(unsigned long)(const __attribute__((address_space(3))) float*)lds;
+    int s = 0;
+    for (int pass = 0; pass < g.passes; ++pass) {
+      const int pb = pass_begin(g, ntg, pass), L = pass_begin(g, ntg, pass + 1) - pb;
+      const int nw = (2 * L - lw + NLOAD - 1) / NLOAD;    // this loader's W instructions per chunk
+      const char* wb = reinterpret_cast<const char*>(g.w + (long)(nt_lo + pb) * 16 * g.K);
+      // one straight-line burst of DMA instructions per chunk (the loader shares its SIMD with a compute wave: the
+      // fewer instructions it issues, the fewer times the MFMA stream next to it is interrupted)
+      auto chunk = [&](auto nw_tag) {
+        constexpr int NWI = decltype(nw_tag)::value;
+        for (int kc = 0; kc < KC; ++kc, ++s) {
+          const unsigned stage = lds_base + (unsigned)((s % 3) * STAGE * 4 + lw * 1024);
+          if (!(g.ablate & 1)) {
+            const char* xs = uniform_ptr(xb);
+#pragma unroll
+            for (int j = 0; j < NX; ++j)
+              if (!(g.ablate & 16)) dma16(xs, xoff[j], stage + j * NLOAD * 1024);
+            if constexpr (NWI >= 0) {
+#pragma unroll
+              for (int i = 0; i < NWI; ++i)
+                if (!(g.ablate & 32)) dma16(uniform_ptr(wb + (size_t)i * wstep), woff, stage + (XROWS / 8 + i * NLOAD) * 1024);
+            } else {   // more instructions per chunk than the unrolled variants cover
+              const char* ws = wb;
+              unsigned dst = stage + XROWS / 8 * 1024;
+              for (int i = 0; i < nw; ++i, ws += wstep, dst += NLOAD * 1024) dma16(uniform_ptr(ws), woff, dst);
+            }
+          }
+          xb += kBK * 4;
+          wb += kBK * 4;
+          HEAD_STAMP(wave, 3 * s);
+          if (!(g.ablate & 8)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          HEAD_STAMP(wave, 3 * s + 1);
+          __builtin_amdgcn_s_barrier();   // chunk s is in LDS; every compute wave has finished chunk s-2 (the stage refilled next)
+          HEAD_STAMP(wave, 3 * s + 2);
+        }
+      };
+      switch (nw) {
+        case 0: chunk(std::integral_constant<int, 0>{}); break;
+        case 1: chunk(std::integral_constant<int, 1>{}); break;
+        case 2: chunk(std::integral_constant<int, 2>{}); break;
+        case 3: chunk(std::integral_constant<int, 3>{}); break;
+        case 4: chunk(std::integral_constant<int, 4>{}); break;
+        case 5: chunk(std::integral_constant<int, 5>{}); break;
+        case 6: chunk(std::integral_constant<int, 6>{}); break;
+        case 7: chunk(std::integral_constant<int, 7>{}); break;
+        case 8: chunk(std::integral_constant<int, 8>{}); break;
+        default: chunk(std::integral_constant<int, -1>{}); break;
+      }
+      xb -= (long)KC * kBK * 4;
+    }
+    return;
+  }
+
+  HEAD_STAMP(wave, 500);
+  int s_begin = 0;
+  for (int pass = 0; pass < g.passes; ++pass, s_begin += KC) {
+    const int pb = pass_begin(g, ntg, pass), L = pass_begin(g, ntg, pass + 1) - pb;
+    const int cmax = (L + 3) >> 2;   // workgroup-uniform tiles per wave in this pass
+    const int t0 = part_begin(L, 4, wave), cnt = part_begin(L, 4, wave + 1) - t0;
+    const int tile0 = nt_lo + pb + t0;
+#define DTT_HEAD_PASS(C) head_pass<TPX, NTW, C, PIN>(g, lds, s_begin, tile0, t0, cnt, p0, lane, wave)
+    if constexpr (NTW >= 7) { if (cmax == 7) { DTT_HEAD_PASS(7); continue; } }
+    if constexpr (NTW >= 6) { if (cmax == 6) { DTT_HEAD_PASS(6); continue; } }
+    if constexpr (NTW >= 5) { if (cmax == 5) { DTT_HEAD_PASS(5); continue; } }
+    if constexpr (NTW >= 4) { if (cmax == 4) { DTT_HEAD_PASS(4); continue; } }
+    if constexpr (NTW >= 3) { if (cmax == 3) { DTT_HEAD_PASS(3); continue; } }
+    if constexpr (NTW >= 2) { if (cmax == 2) { DTT_HEAD_PASS(2); continue; } }
+    DTT_HEAD_PASS(1);
+#undef DTT_HEAD_PASS
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ pooling
+// One workgroup per RoI, NW waves.  CP = padded classes per bin (power of two <= 64); lane = (slot, class), a wave holds
+// 64 / CP bin slots, the workgroup NW * 64 / CP, so the P*P bins take ceil(P*P / slots) rounds.  map(b, h, w, bin, c) =
+// map[((b*H + h)*W + w) * pixel_stride + bin*CP + c].  Bins land in LDS [bin][CP]; the vote (rfcn.py:62-64: AvgPool2d over
+// the P x P bins) is the reference's row-major sum followed by one division; `pooled` (optional) receives the bins in the
+// reference layout (R, od, P, P).
+template <int CP, int NW>
+__global__ __launch_bounds__(NW * 64) void psroi_pm_kernel(const float* __restrict__ map, long pixel_stride, int height,
+                                                           int width, const float* __restrict__ rois,
+                                                           float spatial_scale, int pooled, int output_dim,
+                                                           float* __restrict__ vote, float* __restrict__ pooled_out) {
+  extern __shared__ __attribute__((aligned(16))) float bins[];   // [pooled*pooled][CP]
+  constexpr int SLOTS = NW * 64 / CP;
+  const int n = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int c = tid % CP, slot = tid / CP;
+  float roi[5];
+#pragma unroll
+  for (int q = 0; q < 5; ++q) roi[q] = rois[(long)n * 5 + q];
+  const int b = (int)roi[0];
+  const int nbins = pooled * pooled;
+  const float* img = map + (long)b * height * width * pixel_stride + c;
+  for (int bin = slot; bin < nbins; bin += SLOTS) {
+    const int ph = bin / pooled, pw = bin - ph * pooled;
+    const Bin g = psroi_bin(roi, spatial_scale, ph, pw, pooled, pooled, height, width);
+    float sum = 0.f;
+    if (!g.empty) {
+      const int nw = g.wend - g.wstart, area = (g.hend - g.hstart) * nw;
+      const float* p = img + (long)bin * CP;
+      // (h, w) row-major walk, 8 loads in flight, adds in order
+      int h = g.hstart, w = g.wstart;
+      for (int i = 0; i < area; i += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          v[u] = (i + u < area) ? p[((long)h * width + w) * pixel_stride] : 0.f;
+          if (++w == g.wend) { w = g.wstart; ++h; }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (i + u < area) sum += v[u];
+      }
+      sum = sum / (float)area;
+    }
+    bins[bin * CP + c] = sum;
+  }
+  __syncthreads();
+  if (tid < output_dim) {   // tid == class here (slot 0)
+    float s = 0.f;
+    for (int k = 0; k < nbins; ++k) s += bins[k * CP + tid];
+    vote[(long)n * output_dim + tid] = s / (float)nbins;
+  }
+  if (pooled_out) {
+    float* o = pooled_out + (long)n * output_dim * nbins;
+    for (int i = tid; i < output_dim * nbins; i += NW * 64) {
+      const int ct = i / nbins, k = i - ct * nbins;
+      o[i] = bins[k * CP + ct];
+    }
+  }
+}
+
+template <int TPX, int NTW, int NLOAD, bool PIN>
+int launch_head(const HeadGeom& g, hipStream_t stream) {
+  constexpr size_t lds = 3ul * (TPX * 16 + 4 * NTW * 16) * kBK * sizeof(float);
+  static_assert(lds <= 160 * 1024, "three stages must fit the CU's LDS");
+  static bool raised[64] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (lds > 64 * 1024 && !raised[dev & 63]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(head_gemm_kernel<TPX, NTW, NLOAD, PIN>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    DTT_REQUIRE(e == hipSuccess, "head_gemm: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
+    raised[dev & 63] = true;
+  }
+  dtt_prof_begin("head_gemm", stream);
+  hipLaunchKernelGGL((head_gemm_kernel<TPX, NTW, NLOAD, PIN>), dim3(g.n_groups * g.strips), dim3((4 + NLOAD) * 64), lds, stream, g);
+  dtt_prof_end("head_gemm", stream);
+  DTT_CHECK_LAUNCH("head_gemm");
+  return 1;
+}
+
+// tiles per pass for a group of `per_group` tiles: full passes of 4 * ntw tiles, then the remainder; a caller asking for
+// more passes gets the tail split further (the last pass is what is left to store when the MFMAs end -- every earlier
+// pass drains underneath its successor -- but each pass re-streams the pixel strip)
+void plan_passes(HeadGeom& g, int per_group, int ntw, int passes) {
+  const int cap = 4 * ntw;
+  int n = 0, left = per_group;
+  while (left > 0 && n < kMaxPasses - 1) {
+    int len = min(cap, left);
+    const int full_left = dtt_cdiv(left - len, cap);             // passes the greedy plan still needs after this one
+    if (passes > 0 && n + 1 + full_left < passes && len > 4 && left > 4) {
+      // spread what is left over the passes still wanted, in multiples of the 4 waves
+      const int want = passes - n;
+      len = min(cap, max(4, dtt_cdiv(dtt_cdiv(left, want), 4) * 4));
+    }
+    g.pass_len[n++] = len;
+    left -= len;
+  }
+  if (left > 0) g.pass_len[n++] = left;
+  g.passes = n;
+}
+
+}  // namespace
+
+#ifdef DTT_HEAD_STAMP
+extern "C" int dtt_head_stamps_read(unsigned long long* host, int n) {
+  (void)hipDeviceSynchronize();
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(dtt_head_stamps), sizeof(unsigned long long) * n) == hipSuccess;
+}
+#endif
+
+// out[m][n] = sum_k x[m][k] * w[n][k] + bias[n]  for n < n_store  (the 1x1 convolution of rfcn.py:49-53 over
+// channels-last pixel rows, channels emitted in the order of w's rows).
+extern "C" int dtt_head_gemm(const float* x, long ldx, int M, int K, const float* w, const float* bias, int n_rows,
+                             float* out, long ldc, int n_store, int passes, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  DTT_REQUIRE(x && w && bias && out, "head_gemm: null pointer");
+  DTT_REQUIRE(M > 0 && K > 0 && K % kBK == 0, "head_gemm: K (%d) must be a positive multiple of %d", K, kBK);
+  DTT_REQUIRE(n_rows > 0 && n_rows % 16 == 0, "head_gemm: weight rows (%d) must be padded to a multiple of 16", n_rows);
+  DTT_REQUIRE(n_store > 0 && n_store <= n_rows && n_store % 4 == 0 && ldc >= n_store && ldc % 4 == 0 && ldx % 4 == 0 && ldx >= K,
+              "head_gemm: bad leading dimensions / n_store");
+  DTT_REQUIRE((((size_t)x | (size_t)w | (size_t)out | (size_t)bias) & 15) == 0, "head_gemm: pointers must be 16-byte aligned");
+  HeadGeom g;
+  g.x = x; g.ldx = ldx; g.w = w; g.bias = bias; g.out = out; g.ldc = ldc;
+  g.M = M; g.K = K; g.n_store = n_store; g.nt_total = n_rows / 16;
+  g.ablate = getenv("DTT_HEAD_ABLATE") ? atoi(getenv("DTT_HEAD_ABLATE")) : 0;
+  int ncu = 256;
+  {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      ncu = prop.multiProcessorCount;
+  }
+  static const int nload = getenv("DTT_HEAD_NLOAD") ? atoi(getenv("DTT_HEAD_NLOAD")) : 4;   // developer A/B switches
+  if (g.nt_total >= 28) {
+    // wide heads (31*49 classes [+ 4*49 box deltas]): pixel strips x channel groups, one workgroup per CU
+    static const int ntw_env = getenv("DTT_HEAD_NTW") ? atoi(getenv("DTT_HEAD_NTW")) : 4;
+    static const int pin_env = getenv("DTT_HEAD_PIN") ? atoi(getenv("DTT_HEAD_PIN")) : 0;
+    const int tpx = 10, ntw = 4;
+    g.strips = dtt_cdiv(M, tpx * 16);
+    g.n_groups = max(1, min(ncu / max(g.strips, 1), g.nt_total));
+    while (dtt_cdiv(g.nt_total, g.n_groups) > kMaxPasses * 4 * ntw) ++g.n_groups;
+    plan_passes(g, dtt_cdiv(g.nt_total, g.n_groups), ntw, passes);
+    (void)ntw_env; (void)pin_env;
+    return nload == 2 ? launch_head<10, 4, 2, false>(g, stream) : launch_head<10, 4, 4, false>(g, stream);
+  }
+  // narrow heads (4*49 box deltas alone): 32-pixel strips, every tile of the row in one pass
+  constexpr int TPX = 2, NTW = 4;
+  DTT_REQUIRE(g.nt_total <= 4 * NTW, "head_gemm: %d channel tiles not covered by the narrow configuration", g.nt_total);
+  g.strips = dtt_cdiv(M, TPX * 16);
+  g.n_groups = 1;
+  plan_passes(g, g.nt_total, NTW, 1);
+  return launch_head<TPX, NTW, 1, false>(g, stream);
+}
+
+// Position-sensitive pooling + vote over a position-major map (see the header comment).  map: (batch, H, W) pixels of
+// `pixel_stride` floats; this call reads floats [bin*cp + c] of a pixel for bin < pooled^2, c < output_dim (callers point
+// `map` at the first float of the head they pool: class scores or box deltas).  vote_out (num_rois, output_dim);
+// pooled_out (num_rois, output_dim, pooled, pooled) or NULL.
+extern "C" int dtt_psroi_pm_forward(const float* map, long pixel_stride, int cp, int batch_size, int num_rois, int height,
+                                    int width, int pooled, const float* rois, float spatial_scale, int output_dim,
+                                    float* vote_out, float* pooled_out, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  DTT_REQUIRE(batch_size > 0 && height > 0 && width > 0 && pooled > 0 && output_dim > 0 && num_rois >= 0, "psroi_pm: bad shape");
+  DTT_REQUIRE(cp >= output_dim && (long)pooled * pooled * cp <= pixel_stride, "psroi_pm: %d bins x %d do not fit the pixel stride %ld",
+              pooled * pooled, cp, pixel_stride);
+  if (num_rois == 0) return 1;
+  DTT_REQUIRE(map && rois && vote_out, "psroi_pm: null pointer");
+  const size_t lds = (size_t)pooled * pooled * cp * sizeof(float);
+  DTT_REQUIRE(lds <= 64 * 1024, "psroi_pm: pooled size too large");
+  dtt_prof_begin("psroi_pm", stream);
+  if (cp == 32) {
+    hipLaunchKernelGGL((psroi_pm_kernel<32, 5>), dim3(num_rois), dim3(5 * 64), lds, stream, map, pixel_stride, height, width,
+                       rois, spatial_scale, pooled, output_dim, vote_out, pooled_out);
+  } else if (cp == 4) {
+    hipLaunchKernelGGL((psroi_pm_kernel<4, 4>), dim3(num_rois), dim3(4 * 64), lds, stream, map, pixel_stride, height, width, rois,
+                       spatial_scale, pooled, output_dim, vote_out, pooled_out);
+  } else {
+    dtt_set_error("psroi_pm: classes-per-bin padding %d not instantiated (4 or 32)", cp);
+    return 0;
+  }
+  dtt_prof_end("psroi_pm", stream);
+  DTT_CHECK_LAUNCH("psroi_pm");
+  return 1;
+}

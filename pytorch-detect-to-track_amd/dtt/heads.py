@@ -1,0 +1,109 @@
+"""R-FCN 1x1 heads + position-sensitive pooling in the position-major layout (csrc/heads.hip).
+
+The reference runs `RFCN_cls_net` / `RFCN_bbox_net` / `corr_bbox_net` as cuDNN 1x1 convolutions into NCHW score maps
+whose channel is (ctop*7 + ph)*7 + pw (faster_rcnn/rfcn.py:49-53, resnet.py:311-312) and pools them with
+`_PSRoIPooling` + `AvgPool2d((7,7))` (rfcn.py:40-43, 62-64, 133-140).  Here the same arithmetic is laid out for the
+hardware: the heads are one exact-fp32 MFMA GEMM over the channels-last trunk output (`dtt_head_gemm`) that writes, per
+pixel, the 49 bins one after the other with the classes of a bin contiguous (padded to `cp`), and the pooling kernel
+(`dtt_psroi_pm_forward`) reads one aligned run of classes per bin element.  Weights are only permuted / zero padded
+(`pack_heads`); the parameters, the state_dict and the checkpoint layout are untouched.
+"""
+import torch
+
+from . import _lib
+from ._lib import check, ptr, require_f32_contig, require_gpu, stream_ptr
+
+
+def _pow2_at_least(n):
+    p = 1
+    while p < n:
+        p *= 2
+    return p
+
+
+class PackedHeads:
+    """Row-permuted copy of one or more 1x1 head convolutions that share their input.
+
+    heads[i] = dict(offset=first float of the head inside a pixel row, cp=classes-per-bin padding, od=output_dim,
+    group=G); `w` is (rows16, K), `bias` (rows16,), `n_store` the floats of a pixel row that the GEMM writes,
+    `stride` the floats between pixels (a multiple of 32: every bin run of the first head starts on a 128-byte line)."""
+
+    def __init__(self, convs, group=7, k_pad=None):
+        dev = convs[0].weight.device
+        K = convs[0].weight.shape[1]
+        Kp = K if k_pad is None else int(k_pad)
+        rows, biases, self.heads = [], [], []
+        off = 0
+        for conv in convs:
+            w = conv.weight.detach().reshape(conv.weight.shape[0], -1).float()
+            assert w.shape[1] == K, "heads must share their input"
+            od = w.shape[0] // (group * group)
+            assert od * group * group == w.shape[0]
+            cp = _pow2_at_least(od)
+            b = conv.bias.detach().float() if conv.bias is not None else torch.zeros(w.shape[0], device=dev)
+            # emitted row bin*cp + c  <-  reference channel c*G*G + bin
+            wp = torch.zeros(group * group, cp, Kp, device=dev)
+            wp[:, :od, :K] = w.view(od, group * group, K).permute(1, 0, 2)
+            bp = torch.zeros(group * group, cp, device=dev)
+            bp[:, :od] = b.view(od, group * group).t()
+            rows.append(wp.reshape(-1, Kp))
+            biases.append(bp.reshape(-1))
+            self.heads.append(dict(offset=off, cp=cp, od=od, group=group))
+            off += group * group * cp
+        self.n_store = off
+        n16 = -(-off // 16) * 16
+        w = torch.cat(rows, 0)
+        b = torch.cat(biases, 0)
+        if n16 > off:
+            w = torch.cat([w, torch.zeros(n16 - off, Kp, device=dev)], 0)
+            b = torch.cat([b, torch.zeros(n16 - off, device=dev)], 0)
+        self.w = w.contiguous()
+        self.bias = b.contiguous()
+        self.K = Kp
+        self.stride = -(-off // 32) * 32
+
+
+def head_gemm(x_rows, packed, out=None, passes=0):
+    """x_rows (M, K) fp32, row-major (channels-last pixels) -> out (M, packed.stride); columns < packed.n_store are
+    written: out[m, n] = sum_k x[m, k] * w[n, k] + bias[n]."""
+    require_gpu(x_rows)
+    require_f32_contig("x_rows", x_rows)
+    M, K = x_rows.shape
+    if K != packed.K:
+        raise ValueError("head_gemm: input has %d channels, the packed heads expect %d" % (K, packed.K))
+    if out is None:
+        out = torch.empty((M, packed.stride), dtype=torch.float32, device=x_rows.device)
+    with torch.cuda.device(x_rows.device):
+        check(_lib.lib().dtt_head_gemm(ptr(x_rows), K, M, K, ptr(packed.w), ptr(packed.bias), packed.w.shape[0], ptr(out),
+                                       out.stride(0), packed.n_store, int(passes), stream_ptr(x_rows.device)), "head_gemm")
+    return out
+
+
+def psroi_pm(pm_map, head, batch, height, width, rois, spatial_scale, want_pooled=False):
+    """Position-sensitive pooling + 7x7 vote over a position-major map.
+
+    pm_map (batch*height*width, stride) as written by `head_gemm`; head = one entry of PackedHeads.heads; rois (R, 5).
+    Returns vote (R, od) [and pooled (R, od, G, G) in the reference layout when want_pooled]."""
+    require_gpu(pm_map, rois)
+    require_f32_contig("rois", rois)
+    if rois.dim() != 2 or rois.size(1) != 5:
+        raise ValueError("rois must have shape (R, 5) [batch_idx, x1, y1, x2, y2], got %s" % (tuple(rois.shape),))
+    assert pm_map.dtype == torch.float32 and pm_map.stride(1) == 1 and pm_map.shape[0] == batch * height * width
+    R, od, G = rois.size(0), head["od"], head["group"]
+    vote = torch.empty((R, od), dtype=torch.float32, device=pm_map.device)
+    pooled = torch.empty((R, od, G, G), dtype=torch.float32, device=pm_map.device) if want_pooled else None
+    base = pm_map.data_ptr() + 4 * head["offset"]
+    import ctypes
+    with torch.cuda.device(pm_map.device):
+        check(_lib.lib().dtt_psroi_pm_forward(ctypes.c_void_p(base), pm_map.stride(0), head["cp"], batch, R, height, width, G,
+                                              ptr(rois), float(spatial_scale), od, ptr(vote), ptr(pooled),
+                                              stream_ptr(pm_map.device)), "psroi_pm")
+    return (vote, pooled) if want_pooled else vote
+
+
+def pm_to_nchw(pm_map, head, batch, height, width):
+    """The head's score map in the reference layout (batch, od*G*G, H, W) -- for tests and for callers that want the
+    reference tensor."""
+    G, od, cp, off = head["group"], head["od"], head["cp"], head["offset"]
+    v = pm_map[:, off:off + G * G * cp].reshape(batch, height, width, G * G, cp)[..., :od]
+    return v.permute(0, 4, 3, 1, 2).reshape(batch, od * G * G, height, width).contiguous()

@@ -1,0 +1,126 @@
+"""Hand-written R-FCN heads (exact-fp32 MFMA GEMM, position-major output) and the lanes = classes PSRoI pooling
+(csrc/heads.hip) through the C ABI: head output against F.conv2d in fp32 (1e-4), pooled bins and votes bit-identical
+to the CPU oracle on the same map.  Needs an MI355X."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from dtt import _lib
+    _lib.lib()
+    return torch.device("cuda:0")
+
+
+def _convs(dev, K, ods, seed):
+    g = torch.Generator().manual_seed(seed)
+    convs = []
+    for od in ods:
+        c = torch.nn.Conv2d(K, od * 49, 1)
+        c.weight.data = torch.randn(c.weight.shape, generator=g) * 0.05
+        c.bias.data = torch.randn(c.bias.shape, generator=g) * 0.1
+        convs.append(c.to(dev))
+    return convs
+
+
+def _rois(rng, n, batch, H, W):
+    from test_gpu_ops import random_rois
+    return random_rois(rng, n, batch, H * 16, W * 16)
+
+
+@pytest.mark.parametrize("B,H,W,K,ods,passes", [
+    (4, 38, 67, 512, (31, 4), 0),      # BASELINE configs[2]: both legs of two frame pairs, class + box heads in one GEMM
+    (4, 38, 67, 512, (31, 4), 1),
+    (4, 38, 67, 512, (31, 4), 4),
+    (2, 36, 63, 512, (31, 4), 0),      # configs[4] map size, one pair
+    (1, 19, 32, 512, (31,), 0),        # configs[0] map size, class head alone
+    (2, 38, 67, 1056, (4,), 0),        # tracking head: 1051 input channels padded to 1056, narrow configuration
+    (1, 5, 7, 64, (4,), 0),
+    (3, 9, 11, 96, (31, 4), 0),
+])
+def test_head_gemm_matches_conv2d(dev, B, H, W, K, ods, passes):
+    from dtt.heads import PackedHeads, head_gemm, pm_to_nchw
+    convs = _convs(dev, K, ods, seed=K + H)
+    packed = PackedHeads(convs)
+    g = torch.Generator().manual_seed(1)
+    x = torch.relu(torch.randn(B, K, H, W, generator=g)).to(dev)
+    rows = x.permute(0, 2, 3, 1).reshape(-1, K).contiguous()
+    out = head_gemm(rows, packed, passes=passes)
+    assert out.shape == (B * H * W, packed.stride)
+    for conv, head in zip(convs, packed.heads):
+        ref = F.conv2d(x.double(), conv.weight.double(), conv.bias.double())
+        got = pm_to_nchw(out, head, B, H, W)
+        err = float((got.double() - ref).abs().max())
+        assert err < 1e-4, err
+        # exact-fp32 MFMA: the error is fp32 round-off of a K-term sum, far inside the tolerance
+        assert err < 2e-5 * max(1.0, float(ref.abs().max()))
+        # padding classes of a bin are exact zeros (zero weight rows, zero bias)
+        if head["cp"] > head["od"]:
+            pad = out[:, head["offset"]:head["offset"] + 49 * head["cp"]].reshape(-1, 49, head["cp"])[..., head["od"]:]
+            assert float(pad.abs().max()) == 0.0
+
+
+def test_head_gemm_k_padding(dev):
+    """1051 tracking channels (rfcn.py:166-174) padded with zero columns to the kernel's K granularity."""
+    from dtt.heads import PackedHeads, head_gemm, pm_to_nchw
+    convs = _convs(dev, 1051, (4,), seed=3)
+    packed = PackedHeads(convs, k_pad=1056)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 1051, 10, 13, generator=g).to(dev)
+    rows = torch.zeros(2 * 10 * 13, 1056, device=dev)
+    rows[:, :1051] = x.permute(0, 2, 3, 1).reshape(-1, 1051)
+    got = pm_to_nchw(head_gemm(rows, packed), packed.heads[0], 2, 10, 13)
+    ref = F.conv2d(x.double(), convs[0].weight.double(), convs[0].bias.double())
+    assert float((got.double() - ref).abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize("B,H,W,ods,R", [(4, 38, 67, (31, 4), 1200), (2, 36, 63, (31, 4), 600), (1, 19, 32, (31,), 300),
+                                         (2, 7, 9, (4,), 40), (3, 50, 21, (31, 4), 77)])
+def test_psroi_pm_bit_identical_to_oracle(dev, B, H, W, ods, R):
+    from dtt.heads import PackedHeads, pm_to_nchw, psroi_pm
+    convs = _convs(dev, 32, ods, seed=5)
+    packed = PackedHeads(convs)
+    rng = np.random.RandomState(B * 100 + H)
+    pm = torch.from_numpy(rng.normal(size=(B * H * W, packed.stride)).astype(np.float32)).to(dev)
+    rois = _rois(rng, R, B, H, W)
+    rois_d = torch.from_numpy(rois).to(dev)
+    for head in packed.heads:
+        nchw = pm_to_nchw(pm, head, B, H, W).cpu().numpy()
+        ref_pooled, _ = O.psroi_pool_forward(nchw, rois, 7, 7, 1.0 / 16, 7, head["od"])
+        # the vote of rfcn.py:62-64: row-major sum of the 49 bins, one division (same order as csrc/psroi.hip `psroi_vote`)
+        s = np.zeros(ref_pooled.shape[:2], np.float32)
+        for k in range(49):
+            s = (s + ref_pooled.reshape(R, head["od"], 49)[:, :, k]).astype(np.float32)
+        ref_vote = (s / np.float32(49)).astype(np.float32)
+        vote, pooled = psroi_pm(pm, head, B, H, W, rois_d, 1.0 / 16, want_pooled=True)
+        assert np.array_equal(pooled.cpu().numpy(), ref_pooled)
+        assert np.array_equal(vote.cpu().numpy(), ref_vote)
+        assert torch.equal(psroi_pm(pm, head, B, H, W, rois_d, 1.0 / 16), vote)
+
+
+def test_psroi_pm_matches_plane_kernel_on_head_output(dev):
+    """End to end on the same weights: head GEMM -> position-major pooling  ==  plane-stationary PSRoI kernel on the
+    NCHW view of that map (bit for bit), and within 1e-4 of F.conv2d -> reference-layout pooling."""
+    from dtt.heads import PackedHeads, head_gemm, pm_to_nchw, psroi_pm
+    from dtt.ops import psroi_pool_vote
+    B, H, W, K = 2, 38, 67, 512
+    convs = _convs(dev, K, (31, 4), seed=9)
+    packed = PackedHeads(convs)
+    g = torch.Generator().manual_seed(4)
+    x = torch.relu(torch.randn(B, K, H, W, generator=g)).to(dev)
+    pm = head_gemm(x.permute(0, 2, 3, 1).reshape(-1, K).contiguous(), packed)
+    rng = np.random.RandomState(11)
+    rois = torch.from_numpy(_rois(rng, 600, B, H, W)).to(dev)
+    for conv, head in zip(convs, packed.heads):
+        vote = psroi_pm(pm, head, B, H, W, rois, 1.0 / 16)
+        _, v2 = psroi_pool_vote(pm_to_nchw(pm, head, B, H, W), rois, 7, 7, 1.0 / 16, 7, head["od"])
+        assert torch.equal(vote, v2)
+        _, v3 = psroi_pool_vote(F.conv2d(x, conv.weight, conv.bias).contiguous(), rois, 7, 7, 1.0 / 16, 7, head["od"])
+        assert float((vote - v3).abs().max()) < 1e-4
