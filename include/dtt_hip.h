@@ -64,6 +64,16 @@ int dtt_correlation_forward(float* output, int ob, int oc, int oh, int ow, long 
                             int pad_size, int kernel_size, int max_displacement,
                             int stride1, int stride2, int corr_type_multiply,
                             void* stream);
+/* Same, with explicit output strides: element (n, d, y, x) is written to output[n * out_batch_stride + d *
+ * out_channel_stride + (y * ow + x) * out_pixel_stride].  (oh*ow, 1) is the call above; (1, ld) writes a column block of a
+ * position-major (pixels, ld) matrix -- the layout dtt_head_gemm reads, so the three correlations of rfcn.py:166-174
+ * land directly in the tracking head's input rows. */
+int dtt_correlation_forward_strided(float* output, int ob, int oc, int oh, int ow, long out_batch_stride,
+                                    long out_channel_stride, long out_pixel_stride,
+                                    const float* input1, int ic, int ih, int iw, const float* input2,
+                                    void* workspace, size_t workspace_bytes,
+                                    int pad_size, int kernel_size, int max_displacement,
+                                    int stride1, int stride2, int corr_type_multiply, void* stream);
 /* kernel_size must be 1 (the only value D&T uses, rfcn.py:58-60).  gradInput1/2 are fully
  * written (no pre-zeroing needed).  For stride1 > 1 this is the mathematically correct gradient;
  * the reference indexes out of bounds there (correlation_cuda_kernel.cu:120-121, 212-213). */

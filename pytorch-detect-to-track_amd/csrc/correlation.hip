@@ -724,7 +724,8 @@ __global__ __launch_bounds__(kThreads, MINW) void corr_fwd_glds(const float* __r
 // (correlation_cuda_kernel.cu:100 `reduce_sum / nelems`) and scatters the in-window entries to NCHW.
 template <int NBR>
 __global__ __launch_bounds__(kThreads) void corr_fwd_reduce(const float* __restrict__ ws, float* __restrict__ out,
-                                                            long out_batch_stride, FastGeom g, float nelems) {
+                                                            long out_batch_stride, long out_ch_stride,
+                                                            long out_px_stride, FastGeom g, float nelems) {
   using K = Cfg<NBR>;
   constexpr int ROW = NBR * 256;                 // floats of one N-block row: [nbx][reg][lane]
   __shared__ __attribute__((aligned(16))) float frag[ROW];
@@ -750,8 +751,11 @@ __global__ __launch_bounds__(kThreads) void corr_fwd_reduce(const float* __restr
   // outputs whose halo row hr = tj + iy falls in this block row: tj in [4*nby - 3, 4*nby + 3]
   const int tj_lo = max(0, 4 * nby - 3), tj_hi = min(g.D - 1, 4 * nby + 3);
   const int total = (tj_hi - tj_lo + 1) * g.D * 16;
+  // thread order follows the output layout: NCHW (channel stride > 1) walks the 16 pixels of the block fastest,
+  // position-major output (channel stride 1: the displacements of a pixel are contiguous) the displacements
+  const int nq = (tj_hi - tj_lo + 1) * g.D;
   for (int idx = tid; idx < total; idx += kThreads) {
-    const int p = idx & 15, q = idx >> 4;
+    const int p = out_ch_stride == 1 ? idx / nq : idx & 15, q = out_ch_stride == 1 ? idx - p * nq : idx >> 4;
     const int tj = tj_lo + q / g.D, ti = q % g.D;  // already offset by +R
     const int iy = p >> 2, ix = p & 3;
     const int hr = tj + iy;
@@ -765,14 +769,15 @@ __global__ __launch_bounds__(kThreads) void corr_fwd_reduce(const float* __restr
     const int tjg = tj + g.qy + g.Rfull - g.R, tig = ti + g.qx + g.Rfull - g.R;   // index in the full window
     const int qy = py + (tjg - g.Rfull) * g.s, qx = px + (tig - g.Rfull) * g.s;
     const bool in_image = py >= 0 && py < g.H && px >= 0 && px < g.W && qy >= 0 && qy < g.H && qx >= 0 && qx < g.W;
-    o[((long)(tjg * g.Dfull + tig) * g.oh + y) * g.ow + x] = in_image ? frag[((hc >> 2) * 4 + ix) * 64 + lane] / nelems : 0.f;
+    o[(long)(tjg * g.Dfull + tig) * out_ch_stride + ((long)y * g.ow + x) * out_px_stride] = in_image ? frag[((hc >> 2) * 4 + ix) * 64 + lane] / nelems : 0.f;
   }
 }
 
 // Generic forward (any kernel_size / strides): one wave per output pixel, lanes over channels, wave
 // reduction per displacement.  Slow path, kept for API completeness (correlation.py:5-13 defaults).
 __global__ __launch_bounds__(64) void corr_fwd_generic(const float* __restrict__ in1, const float* __restrict__ in2,
-                                                       float* __restrict__ out, long out_batch_stride, int C, int H,
+                                                       float* __restrict__ out, long out_batch_stride,
+                                                       long out_ch_stride, long out_px_stride, int C, int H,
                                                        int W, int oc, int oh, int ow, int pad, int ksize, int maxd,
                                                        int s1, int s2) {
   const int n = blockIdx.z, by = blockIdx.y, bx = blockIdx.x, lane = threadIdx.x;
@@ -801,7 +806,7 @@ __global__ __launch_bounds__(64) void corr_fwd_generic(const float* __restrict__
       for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
       if (lane == 0) {
         const int tc = (tj + drad) * dsize + (ti + drad);
-        out[(long)n * out_batch_stride + ((long)tc * oh + by) * ow + bx] = acc / nelems;
+        out[(long)n * out_batch_stride + (long)tc * out_ch_stride + ((long)by * ow + bx) * out_px_stride] = acc / nelems;
       }
     }
 }
@@ -1112,7 +1117,7 @@ size_t ws_bytes(const FastGeom& g, int batch) {
 }
 
 template <int NBR, bool PIPE, int MINW, bool VEC4>
-int launch_fast(float* output, long out_batch_stride, const float* in1, const float* in2, void* workspace,
+int launch_fast(float* output, long out_batch_stride, long out_ch_stride, long out_px_stride, const float* in1, const float* in2, void* workspace,
                 size_t workspace_bytes, const FastGeom& g, int batch, hipStream_t stream) {
   using K = Cfg<NBR>;
   const size_t need = ws_bytes<NBR>(g, batch);
@@ -1166,7 +1171,7 @@ int launch_fast(float* output, long out_batch_stride, const float* in1, const fl
   DTT_CHECK_LAUNCH("corr_fwd_mfma");
   dtt_prof_begin("corr_fwd_reduce", stream);
   hipLaunchKernelGGL(corr_fwd_reduce<NBR>, dim3(ntiles * 4, NBR, batch), dim3(kThreads), 0, stream,
-                     static_cast<const float*>(workspace), output, out_batch_stride, g, (float)g.C);
+                     static_cast<const float*>(workspace), output, out_batch_stride, out_ch_stride, out_px_stride, g, (float)g.C);
   dtt_prof_end("corr_fwd_reduce", stream);
   DTT_CHECK_LAUNCH("corr_fwd_reduce");
   return 1;
@@ -1205,11 +1210,33 @@ extern "C" size_t dtt_correlation_forward_workspace_bytes(int batch, int ic, int
   return nbr == 3 ? ws_bytes<3>(g, batch) : (nbr == 5 ? ws_bytes<5>(g, batch) : ws_bytes<9>(g, batch));
 }
 
+extern "C" int dtt_correlation_forward_strided(float* output, int ob, int oc, int oh, int ow, long out_batch_stride,
+                                               long out_ch_stride, long out_px_stride, const float* input1, int ic,
+                                               int ih, int iw, const float* input2, void* workspace,
+                                               size_t workspace_bytes, int pad_size, int kernel_size,
+                                               int max_displacement, int stride1, int stride2, int corr_type_multiply,
+                                               void* stream_);
+
 extern "C" int dtt_correlation_forward(float* output, int ob, int oc, int oh, int ow, long out_batch_stride,
                                        const float* input1, int ic, int ih, int iw, const float* input2,
                                        void* workspace, size_t workspace_bytes, int pad_size, int kernel_size,
                                        int max_displacement, int stride1, int stride2, int corr_type_multiply,
                                        void* stream_) {
+  DTT_REQUIRE(out_batch_stride >= (long)oc * oh * ow, "correlation forward: out_batch_stride too small");
+  return dtt_correlation_forward_strided(output, ob, oc, oh, ow, out_batch_stride, (long)oh * ow, 1, input1, ic, ih, iw,
+                                         input2, workspace, workspace_bytes, pad_size, kernel_size, max_displacement,
+                                         stride1, stride2, corr_type_multiply, stream_);
+}
+
+// Element (n, d, y, x) of the output lives at output[n * out_batch_stride + d * out_ch_stride + (y * ow + x) *
+// out_px_stride]: (oh*ow, 1) is the reference's NCHW tensor (or a channel slice of a bigger one), (1, ld) a column
+// block of a position-major (pixels, ld) matrix -- the layout the tracking head's GEMM consumes.
+extern "C" int dtt_correlation_forward_strided(float* output, int ob, int oc, int oh, int ow, long out_batch_stride,
+                                               long out_ch_stride, long out_px_stride, const float* input1, int ic,
+                                               int ih, int iw, const float* input2, void* workspace,
+                                               size_t workspace_bytes, int pad_size, int kernel_size,
+                                               int max_displacement, int stride1, int stride2, int corr_type_multiply,
+                                               void* stream_) {
   (void)corr_type_multiply;  // accepted and ignored, as in the reference kernels
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   DTT_REQUIRE(output && input1 && input2, "correlation forward: null pointer");
@@ -1218,12 +1245,12 @@ extern "C" int dtt_correlation_forward(float* output, int ob, int oc, int oh, in
     return 0;
   DTT_REQUIRE(ob > 0 && oc == eoc && oh == eoh && ow == eow,
               "correlation forward: output is (%d,%d,%d,%d), expected (B,%d,%d,%d)", ob, oc, oh, ow, eoc, eoh, eow);
-  DTT_REQUIRE(out_batch_stride >= (long)oc * oh * ow, "correlation forward: out_batch_stride too small");
+  DTT_REQUIRE(out_ch_stride > 0 && out_px_stride > 0 && out_batch_stride > 0, "correlation forward: bad output strides");
   int nbr;
   if (fast_path(kernel_size, stride1, stride2, max_displacement, &nbr)) {
     const FastGeom g = make_geom(ob, ic, ih, iw, oc, oh, ow, pad_size, max_displacement, stride1);
-    if (nbr == 3) return launch_fast<3, true, DTT_CORR_MINW, true>(output, out_batch_stride, input1, input2, workspace, workspace_bytes, g, ob, stream);
-    if (nbr == 5) return launch_fast<5, true, DTT_CORR_MINW, true>(output, out_batch_stride, input1, input2, workspace, workspace_bytes, g, ob, stream);
+    if (nbr == 3) return launch_fast<3, true, DTT_CORR_MINW, true>(output, out_batch_stride, out_ch_stride, out_px_stride, input1, input2, workspace, workspace_bytes, g, ob, stream);
+    if (nbr == 5) return launch_fast<5, true, DTT_CORR_MINW, true>(output, out_batch_stride, out_ch_stride, out_px_stride, input1, input2, workspace, workspace_bytes, g, ob, stream);
 #ifndef DTT_CORR_NO_QUADRANTS
     // 8 < R <= 16 (BASELINE config 5: d = 16): the 81-accumulator instantiation runs one wave per SIMD.  The window is
     // instead covered by four (2*8+1)^2 sub-windows centred at (+-(R-8), +-(R-8)) -- the same arithmetic per output, so
@@ -1240,17 +1267,17 @@ extern "C" int dtt_correlation_forward(float* output, int ob, int oc, int oh, in
 #ifdef DTT_CORR_QDEBUG
           q.qy = DTT_CORR_QDEBUG_Y; q.qx = DTT_CORR_QDEBUG_X;   // one fixed window (debug)
 #endif
-          if (!launch_fast<5, true, DTT_CORR_MINW, true>(output, out_batch_stride, input1, input2, workspace, workspace_bytes,
-                                                         q, ob, stream))
+          if (!launch_fast<5, true, DTT_CORR_MINW, true>(output, out_batch_stride, out_ch_stride, out_px_stride, input1, input2,
+                                                         workspace, workspace_bytes, q, ob, stream))
             return 0;
         }
       return 1;
     }
 #endif
-    return launch_fast<9, false, 1, false>(output, out_batch_stride, input1, input2, workspace, workspace_bytes, g, ob, stream);
+    return launch_fast<9, false, 1, false>(output, out_batch_stride, out_ch_stride, out_px_stride, input1, input2, workspace, workspace_bytes, g, ob, stream);
   }
   hipLaunchKernelGGL(corr_fwd_generic, dim3(ow, oh, ob), dim3(64), 0, stream, input1, input2, output,
-                     out_batch_stride, ic, ih, iw, oc, oh, ow, pad_size, kernel_size, max_displacement, stride1, stride2);
+                     out_batch_stride, out_ch_stride, out_px_stride, ic, ih, iw, oc, oh, ow, pad_size, kernel_size, max_displacement, stride1, stride2);
   DTT_CHECK_LAUNCH("corr_fwd_generic");
   return 1;
 }

@@ -302,55 +302,80 @@ __global__ __launch_bounds__((4 + NLOAD) * 64) void head_gemm_kernel(HeadGeom g)
 }
 
 // ------------------------------------------------------------------------------------------------ pooling
-// One workgroup per RoI, NW waves.  CP = padded classes per bin (power of two <= 64); lane = (slot, class), a wave holds
-// 64 / CP bin slots, the workgroup NW * 64 / CP, so the P*P bins take ceil(P*P / slots) rounds.  map(b, h, w, bin, c) =
+// One workgroup per RoI.  A lane owns VPL = CP / LPB consecutive classes of ONE bin (16-byte loads); the LPB neighbouring
+// lanes cover the classes of that bin, so a wave instruction gathers whole 128-byte (31 classes) / 16-byte (4 box deltas)
+// runs of 64 / LPB different bins at once and nothing is ever reduced across lanes: every (bin, class) sum is one lane's
+// sequential walk over the bin in the reference's (h, w) order, with kFlight positions in flight.  map(b, h, w, bin, c) =
 // map[((b*H + h)*W + w) * pixel_stride + bin*CP + c].  Bins land in LDS [bin][CP]; the vote (rfcn.py:62-64: AvgPool2d over
-// the P x P bins) is the reference's row-major sum followed by one division; `pooled` (optional) receives the bins in the
-// reference layout (R, od, P, P).
-template <int CP, int NW>
+// the P x P bins) is the reference's row-major sum followed by one division; `pooled_out` (optional) receives the bins in
+// the reference layout (R, od, P, P).  All RoIs are resident at once (4 waves per RoI at the 31-class shape).
+template <int CP, int LPB, int NW, int POOLED>
 __global__ __launch_bounds__(NW * 64) void psroi_pm_kernel(const float* __restrict__ map, long pixel_stride, int height,
                                                            int width, const float* __restrict__ rois,
-                                                           float spatial_scale, int pooled, int output_dim,
+                                                           float spatial_scale, int pooled_rt, int output_dim,
                                                            float* __restrict__ vote, float* __restrict__ pooled_out) {
   extern __shared__ __attribute__((aligned(16))) float bins[];   // [pooled*pooled][CP]
-  constexpr int SLOTS = NW * 64 / CP;
+  constexpr int VPL = CP / LPB, NV = VPL / 4;   // classes / 16-byte pieces per lane
+  constexpr int SLOTS = NW * 64 / LPB;          // bins in flight per workgroup
+  constexpr int kFlight = 8;
+  const int pooled = POOLED > 0 ? POOLED : pooled_rt;
   const int n = blockIdx.x;
   const int tid = threadIdx.x;
-  const int c = tid % CP, slot = tid / CP;
+  const int cq = tid % LPB, slot = tid / LPB;
   float roi[5];
 #pragma unroll
   for (int q = 0; q < 5; ++q) roi[q] = rois[(long)n * 5 + q];
   const int b = (int)roi[0];
   const int nbins = pooled * pooled;
-  const float* img = map + (long)b * height * width * pixel_stride + c;
+  const float* img = map + (long)b * height * width * pixel_stride + cq * VPL;
   for (int bin = slot; bin < nbins; bin += SLOTS) {
     const int ph = bin / pooled, pw = bin - ph * pooled;
     const Bin g = psroi_bin(roi, spatial_scale, ph, pw, pooled, pooled, height, width);
-    float sum = 0.f;
+    f32x4 sum[NV];
+#pragma unroll
+    for (int q = 0; q < NV; ++q) sum[q] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (!g.empty) {
       const int nw = g.wend - g.wstart, area = (g.hend - g.hstart) * nw;
       const float* p = img + (long)bin * CP;
-      // (h, w) row-major walk, 8 loads in flight, adds in order
+      // (h, w) row-major walk, kFlight positions in flight, adds in order
       int h = g.hstart, w = g.wstart;
-      for (int i = 0; i < area; i += 8) {
-        float v[8];
+      for (int i = 0; i < area; i += kFlight) {
+        f32x4 v[kFlight][NV];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          v[u] = (i + u < area) ? p[((long)h * width + w) * pixel_stride] : 0.f;
+        for (int u = 0; u < kFlight; ++u) {
+          if (i + u < area) {
+            const float* src = p + ((long)h * width + w) * pixel_stride;
+#pragma unroll
+            for (int q = 0; q < NV; ++q) v[u][q] = *reinterpret_cast<const f32x4*>(src + 4 * q);
+          }
           if (++w == g.wend) { w = g.wstart; ++h; }
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
-          if (i + u < area) sum += v[u];
+        for (int u = 0; u < kFlight; ++u)
+          if (i + u < area) {
+#pragma unroll
+            for (int q = 0; q < NV; ++q) sum[q] += v[u][q];
+          }
       }
-      sum = sum / (float)area;
+      const float fa = (float)area;
+#pragma unroll
+      for (int q = 0; q < NV; ++q) sum[q] = f32x4{sum[q][0] / fa, sum[q][1] / fa, sum[q][2] / fa, sum[q][3] / fa};
     }
-    bins[bin * CP + c] = sum;
+#pragma unroll
+    for (int q = 0; q < NV; ++q) *reinterpret_cast<f32x4*>(&bins[bin * CP + cq * VPL + 4 * q]) = sum[q];
   }
   __syncthreads();
-  if (tid < output_dim) {   // tid == class here (slot 0)
+  if (tid < output_dim) {   // one thread per class
     float s = 0.f;
-    for (int k = 0; k < nbins; ++k) s += bins[k * CP + tid];
+    if (POOLED > 0) {       // all loads first, then the adds in order
+      float v[POOLED > 0 ? POOLED * POOLED : 1];
+#pragma unroll
+      for (int k = 0; k < POOLED * POOLED; ++k) v[k] = bins[k * CP + tid];
+#pragma unroll
+      for (int k = 0; k < POOLED * POOLED; ++k) s += v[k];
+    } else {
+      for (int k = 0; k < nbins; ++k) s += bins[k * CP + tid];
+    }
     vote[(long)n * output_dim + tid] = s / (float)nbins;
   }
   if (pooled_out) {
@@ -469,19 +494,22 @@ extern "C" int dtt_psroi_pm_forward(const float* map, long pixel_stride, int cp,
               pooled * pooled, cp, pixel_stride);
   if (num_rois == 0) return 1;
   DTT_REQUIRE(map && rois && vote_out, "psroi_pm: null pointer");
+  DTT_REQUIRE(((size_t)map & 15) == 0 && pixel_stride % 4 == 0, "psroi_pm: the map must be 16-byte aligned with a pixel stride that is a multiple of 4 floats");
   const size_t lds = (size_t)pooled * pooled * cp * sizeof(float);
   DTT_REQUIRE(lds <= 64 * 1024, "psroi_pm: pooled size too large");
   dtt_prof_begin("psroi_pm", stream);
+#define DTT_PM_LAUNCH(CPV, LPBV, NWV, PV)                                                                                   \
+  hipLaunchKernelGGL((psroi_pm_kernel<CPV, LPBV, NWV, PV>), dim3(num_rois), dim3(NWV * 64), lds, stream, map, pixel_stride, \
+                     height, width, rois, spatial_scale, pooled, output_dim, vote_out, pooled_out)
   if (cp == 32) {
-    hipLaunchKernelGGL((psroi_pm_kernel<32, 5>), dim3(num_rois), dim3(5 * 64), lds, stream, map, pixel_stride, height, width,
-                       rois, spatial_scale, pooled, output_dim, vote_out, pooled_out);
+    if (pooled == 7) DTT_PM_LAUNCH(32, 4, 4, 7); else DTT_PM_LAUNCH(32, 4, 4, 0);
   } else if (cp == 4) {
-    hipLaunchKernelGGL((psroi_pm_kernel<4, 4>), dim3(num_rois), dim3(4 * 64), lds, stream, map, pixel_stride, height, width, rois,
-                       spatial_scale, pooled, output_dim, vote_out, pooled_out);
+    if (pooled == 7) DTT_PM_LAUNCH(4, 1, 1, 7); else DTT_PM_LAUNCH(4, 1, 1, 0);
   } else {
     dtt_set_error("psroi_pm: classes-per-bin padding %d not instantiated (4 or 32)", cp);
     return 0;
   }
+#undef DTT_PM_LAUNCH
   dtt_prof_end("psroi_pm", stream);
   DTT_CHECK_LAUNCH("psroi_pm");
   return 1;

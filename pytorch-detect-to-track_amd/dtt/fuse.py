@@ -474,6 +474,9 @@ class FusedTrunkNHWC:
         # take the Winograd path, and handed to _RPN.head() through `rpn_conv1`
         self.rpn_conv = _NhwcConv(model.RFCN_rpn.RPN_Conv)
         self.rpn_conv1 = None
+        self.pm_heads = False     # set by fuse_for_inference when the position-major tail is active
+        self.top_rows = None
+        self.top_hw = None
 
     @torch.no_grad()
     def __call__(self, x):
@@ -486,16 +489,29 @@ class FusedTrunkNHWC:
             feats.append(x)
         top = self.top.act(feats[3])
         self.rpn_conv1 = _to_nchw(self.rpn_conv.act(top))
+        if self.pm_heads:
+            # the hand-written heads read the channels-last rows directly; nothing downstream needs `top` in NCHW
+            self.top_rows, self.top_hw = _rows(top), (top.shape[2], top.shape[3])
+            return _to_nchw(feats[1]), _to_nchw(feats[2]), _to_nchw(feats[3]), top
         return _to_nchw(feats[1]), _to_nchw(feats[2]), _to_nchw(feats[3]), _to_nchw(top)
 
 
 def fuse_for_inference(model, channels_last=True):
     """Build the fused trunk from the model's current weights (call again after loading a checkpoint)."""
     model._fused_trunk = FusedTrunkNHWC(model) if channels_last else FusedTrunk(model)
+    model._pm_tail = None
+    if channels_last and os.environ.get("DTT_PM_HEADS", "1") != "0":
+        # hand-written heads + position-major PSRoI pooling (dtt.heads); needs the class-agnostic box head of D&T
+        # (rfcn.py:52-53, resnet.py:311: 4 * 49 box channels) and at most 32 classes
+        if model.n_reg_classes == 1 and model.n_classes <= 32 and model.RFCN_cls_net.weight.shape[1] % 32 == 0:
+            from .heads import PositionMajorTail
+            model._pm_tail = PositionMajorTail(model)
+            model._fused_trunk.pm_heads = True
     return model
 
 
 def unfuse(model):
     model._fused_trunk = None
     model._fused_train_trunk = None
+    model._pm_tail = None
     return model

@@ -28,7 +28,9 @@ class PackedHeads:
     group=G); `w` is (rows16, K), `bias` (rows16,), `n_store` the floats of a pixel row that the GEMM writes,
     `stride` the floats between pixels (a multiple of 32: every bin run of the first head starts on a 128-byte line)."""
 
-    def __init__(self, convs, group=7, k_pad=None):
+    def __init__(self, convs, group=7, k_pad=None, in_perm=None):
+        """in_perm (optional, length K): input channel j of the packed heads is input channel in_perm[j] of the
+        convolutions (callers whose activation rows are not in the reference's channel order)."""
         dev = convs[0].weight.device
         K = convs[0].weight.shape[1]
         Kp = K if k_pad is None else int(k_pad)
@@ -36,6 +38,8 @@ class PackedHeads:
         off = 0
         for conv in convs:
             w = conv.weight.detach().reshape(conv.weight.shape[0], -1).float()
+            if in_perm is not None:
+                w = w[:, in_perm.to(dev)]
             assert w.shape[1] == K, "heads must share their input"
             od = w.shape[0] // (group * group)
             assert od * group * group == w.shape[0]
@@ -107,3 +111,44 @@ def pm_to_nchw(pm_map, head, batch, height, width):
     G, od, cp, off = head["group"], head["od"], head["cp"], head["offset"]
     v = pm_map[:, off:off + G * G * cp].reshape(batch, height, width, G * G, cp)[..., :od]
     return v.permute(0, 4, 3, 1, 2).reshape(batch, od * G * G, height, width).contiguous()
+
+
+class PositionMajorTail:
+    """Inference tail of `_RFCN.forward` (rfcn.py:133-140, 166-196) in the position-major layout, built from the model's
+    current weights (dtt.fuse.fuse_for_inference; rebuild after loading a checkpoint):
+
+      det   RFCN_cls_net + RFCN_bbox_net as ONE GEMM over the channels-last `top` rows (both legs, all images)
+      trk   corr_bbox_net over rows  [bbox_t | bbox_t+tau | corr3 | corr4 | corr5 | 0-pad]  -- the box-delta columns are
+            copied out of the det map (position-major order, so the weight's input channels are permuted to match) and
+            the three correlations write their columns directly (dtt.ops.correlation_forward_rows)
+    """
+
+    def __init__(self, model):
+        self.det = PackedHeads([model.RFCN_cls_net, model.RFCN_bbox_net])
+        self.cls_head, self.loc_head = self.det.heads
+        self.trk = None
+        conv = getattr(model, "corr_bbox_net", None)
+        if conv is not None:
+            G = self.loc_head["group"]
+            nb = self.loc_head["od"] * G * G                     # 196 box-delta channels per leg
+            K = conv.weight.shape[1]
+            perm = torch.arange(K)
+            # buffer column leg*nb + bin*od + k  <-  reference channel leg*nb + k*G*G + bin
+            od = self.loc_head["od"]
+            b, k = torch.meshgrid(torch.arange(G * G), torch.arange(od), indexing="ij")
+            for leg in range(2):
+                perm[leg * nb:(leg + 1) * nb] = (leg * nb + k * G * G + b).reshape(-1)
+            self.trk_k = -(-K // 32) * 32
+            self.trk = PackedHeads([conv], k_pad=self.trk_k, in_perm=perm)
+            self.trk_head = self.trk.heads[0]
+            self.n_box = nb
+            self.trk_in = K
+        self._rows = {}
+
+    def tracking_rows(self, n_pixels, device):
+        """(n_pixels, K padded) scratch whose padding columns are zero (written once)."""
+        key = (n_pixels, device)
+        buf = self._rows.get(key)
+        if buf is None:
+            buf = self._rows[key] = torch.zeros((n_pixels, self.trk_k), dtype=torch.float32, device=device)
+        return buf

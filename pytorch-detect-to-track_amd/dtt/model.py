@@ -218,6 +218,51 @@ class _RFCN(nn.Module):
             off += ch
         return buf
 
+    def _inference_tail_pm(self, pm, fused, c3, c4, c5, all_rois, side, n_legs, B, dev):
+        """rfcn.py:133-140, 166-196 at inference on the position-major layout: one MFMA GEMM for the class + box heads of
+        every image (`dtt_head_gemm`), lanes = classes PSRoI pooling + vote (`dtt_psroi_pm_forward`), the tracking
+        head's input rows assembled in place (box-delta columns copied, correlations written by their reduce kernels)."""
+        from .heads import head_gemm, psroi_pm
+        from .ops import correlation_forward_rows
+        top_rows, (H, W) = fused.top_rows, fused.top_hw
+        fused.top_rows = None
+        cur = torch.cuda.current_stream(dev)
+        det = head_gemm(top_rows, pm.det)                          # (n_legs*B*H*W, stride)
+        single_frame = n_legs == 1
+        trk = None
+        if not single_frame:
+            hw = H * W
+            rows = pm.tracking_rows(B * hw, dev)
+            off, nb = pm.loc_head["offset"], pm.n_box
+            dv = det.view(n_legs, B * hw, det.shape[1])
+            rows[:, 0:nb] = dv[0][:, off:off + nb]
+            rows[:, nb:2 * nb] = dv[1][:, off:off + nb]
+            col = 2 * nb
+            for l, f in zip((self.conv3_corr_layer, self.conv4_corr_layer, self.conv5_corr_layer), (c3, c4, c5)):
+                oc = correlation_output_shape(f.size(1), f.size(2), f.size(3), l.pad_size, l.kernel_size, l.max_displacement,
+                                              l.stride1, l.stride2)[0]
+                correlation_forward_rows(rows, col, f[:B].contiguous(), f[B:2 * B].contiguous(), l.pad_size, l.kernel_size,
+                                         l.max_displacement, l.stride1, l.stride2, l.corr_multiply)
+                col += oc
+            assert col == pm.trk_in, "tracking feature width %d != corr_bbox_net input %d" % (col, pm.trk_in)
+            trk = head_gemm(rows, pm.trk)                           # (B*H*W, stride)
+        cur.wait_stream(side)
+        all_rois.record_stream(cur)
+        R = all_rois.size(1)
+        flat_rois = all_rois.view(-1, 5)
+        scale = self.RFCN_psroi_cls_pool.spatial_scale
+        score = psroi_pm(det, pm.cls_head, n_legs * B, H, W, flat_rois, scale)
+        prob = F.softmax(score, dim=1).view(n_legs, B, R, -1)
+        pred = psroi_pm(det, pm.loc_head, n_legs * B, H, W, flat_rois, scale).view(n_legs, B, R, -1)
+        leg_rois = all_rois.view(n_legs, B, R, 5).clone()
+        for i in range(1, n_legs):
+            leg_rois[i, :, :, 0] -= i * B  # batch index within the leg
+        zeros = torch.zeros(n_legs, 1, device=dev)
+        tracking_pred = torch.zeros(0, 4, device=dev)
+        if trk is not None:
+            tracking_pred = psroi_pm(trk, pm.trk_head, B, H, W, leg_rois[0].view(-1, 5), scale)   # frame-t RoIs (rfcn.py:192)
+        return leg_rois, prob, pred, tracking_pred, zeros, zeros, zeros, zeros, [], zeros[0]
+
     def forward(self, im_data, im_info, gt_boxes, num_boxes):
         im_data = im_data.permute(1, 0, 2, 3, 4).contiguous()  # (n_legs, B, C, H, W)
         im_info = im_info.permute(1, 0, 2).contiguous().detach()
@@ -250,9 +295,13 @@ class _RFCN(nn.Module):
             with torch.cuda.stream(side):
                 all_rois = self.RFCN_rpn.proposals(rpn_prob, rpn_bbox, im_info.view(n_legs * B, -1))
             rpn_prob.record_stream(side); rpn_bbox.record_stream(side)
+        leg = lambda t, i: t[i * B:(i + 1) * B]
+        pm = getattr(self, "_pm_tail", None)
+        if pm is not None and side is not None and n_legs <= 2 and getattr(fused, "top_rows", None) is not None:
+            # hand-written heads + position-major pooling (dtt.heads): no NCHW score maps at all
+            return self._inference_tail_pm(pm, fused, c3, c4, c5, all_rois, side, n_legs, B, dev)
         cls_maps = self.RFCN_cls_net(top)
         bbox_maps = self.RFCN_bbox_net(top)
-        leg = lambda t, i: t[i * B:(i + 1) * B]
         conv3 = [leg(c3, i) for i in range(n_legs)]
         conv4 = [leg(c4, i) for i in range(n_legs)]
         conv5 = [leg(c5, i) for i in range(n_legs)]

@@ -64,6 +64,34 @@ def correlation_forward_into(out, input1, input2, pad_size, kernel_size, max_dis
     return out
 
 
+def correlation_forward_rows(rows, col, input1, input2, pad_size, kernel_size, max_displacement, stride1, stride2,
+                             corr_multiply=1):
+    """Write the correlation of two (B,C,H,W) maps into columns [col, col + oc) of `rows`, a position-major
+    (B*oh*ow, ld) fp32 matrix (row = output pixel, batch-major): the tracking head's GEMM input (dtt.heads)."""
+    require_gpu(rows, input1, input2)
+    require_f32_contig("input1", input1)
+    require_f32_contig("input2", input2)
+    if input1.shape != input2.shape:
+        raise ValueError("correlation: input shapes differ: %s vs %s" % (tuple(input1.shape), tuple(input2.shape)))
+    B, C, H, W = input1.shape
+    oc, oh, ow = correlation_output_shape(C, H, W, pad_size, kernel_size, max_displacement, stride1, stride2)
+    if rows.dim() != 2 or rows.dtype != torch.float32 or rows.stride(1) != 1 or rows.shape[0] != B * oh * ow \
+            or col < 0 or col + oc > rows.shape[1]:
+        raise ValueError("correlation: rows must be float32 (%d, >= %d) with unit column stride" % (B * oh * ow, col + oc))
+    L = _lib.lib()
+    nbytes = L.dtt_correlation_forward_workspace_bytes(B, C, H, W, pad_size, kernel_size, max_displacement, stride1,
+                                                       stride2)
+    ws = _workspace(nbytes, input1.device)
+    ld = rows.stride(0)
+    out = ctypes.c_void_p(rows.data_ptr() + 4 * col)
+    with torch.cuda.device(input1.device):
+        check(L.dtt_correlation_forward_strided(out, B, oc, oh, ow, oh * ow * ld, 1, ld, ptr(input1), C, H, W, ptr(input2),
+                                                ptr(ws), nbytes, pad_size, kernel_size, max_displacement, stride1,
+                                                stride2, corr_multiply, stream_ptr(input1.device)),
+              "correlation forward (position-major)")
+    return rows
+
+
 class CorrelationFunction(Function):
     @staticmethod
     def forward(ctx, input1, input2, pad_size, kernel_size, max_displacement, stride1, stride2, corr_multiply):

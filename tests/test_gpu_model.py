@@ -152,7 +152,7 @@ def test_fused_inference_trunk_matches_reference_graph():
             got = model._im_to_head(x)
             unfuse(model)
             for a, b in zip(got, ref):
-                assert a.is_contiguous() and a.shape == b.shape
+                assert a.shape == b.shape   # (`top` stays channels-last when the position-major heads consume its rows)
                 scale = float(b.abs().max())
                 # fp32 reordering through ~50 layers: 1.1e-4 of the map's range with BatchNorm folded and library GEMMs in
                 # place of MIOpen, 1.6e-4 when the 3x3 layers additionally take the Winograd F(4x4, 3x3) path (which
@@ -399,3 +399,58 @@ def test_single_frame_rfcn_matches_leg0_of_the_pair(dev=None):
         same = dist < 1e-2
         assert float(same.float().mean()) > 0.9, float(same.float().mean())
         assert float((single[1][0, b][same] - pair[1][0, b][j[same]]).abs().max()) <= 1e-3
+
+
+def test_position_major_tail_matches_nchw_tail(monkeypatch):
+    """The inference tail on the hand-written heads + position-major pooling (dtt.heads, what `_RFCN.forward` runs after
+    fuse_for_inference) against the reference graph of rfcn.py:133-140, 166-196 on the SAME trunk maps and RoIs: library
+    1x1 convolutions into NCHW score maps, plane-stationary PSRoI kernels, cat + corr_bbox_net.  Class probabilities, box
+    deltas and tracking deltas within 1e-4 (fp32 summation order of the GEMMs is the only difference)."""
+    import torch.nn.functional as F
+    from dtt.config import cfg
+    from dtt.fuse import fuse_for_inference
+    from dtt.ops import psroi_vote
+    from dtt.synth import build_model, calibrate_batchnorm_, make_batch
+    dev = torch.device("cuda:0")
+    model = build_model(50, cfg=cfg).to(dev).eval()
+    monkeypatch.setenv("DTT_PM_HEADS", "1")
+    for shape in ((2, 256, 352), (1, 300, 500)):
+        B = shape[0]
+        im, info, gt, nb = make_batch(B, shape[1], shape[2], seed=5, device=dev)
+        calibrate_batchnorm_(model, im[:, 0])
+        fuse_for_inference(model)
+        pm, fused = model._pm_tail, model._fused_trunk
+        assert pm is not None and fused.pm_heads
+        with torch.no_grad():
+            out = model(im, info, gt, nb)                      # the production path (position-major tail inside)
+            flat = im.permute(1, 0, 2, 3, 4).reshape(2 * B, *im.shape[2:])
+            c3, c4, c5, top = model._im_to_head(flat)
+            conv1, fused.rpn_conv1 = fused.rpn_conv1, None
+            _, _, rpn_prob, rpn_bbox = model.RFCN_rpn.head(top, conv1)
+            info2 = info.permute(1, 0, 2).reshape(2 * B, -1).contiguous()
+            all_rois = model.RFCN_rpn.proposals(rpn_prob, rpn_bbox, info2)
+            side = torch.cuda.Stream(device=dev)
+            got = model._inference_tail_pm(pm, fused, c3, c4, c5, all_rois, side, 2, B, dev)
+            # reference graph on the same maps
+            top_nchw = top.contiguous()
+            cls_maps, bbox_maps = model.RFCN_cls_net(top_nchw), model.RFCN_bbox_net(top_nchw)
+            flat_rois = all_rois.view(-1, 5)
+            R = all_rois.size(1)
+            prob = F.softmax(psroi_vote(cls_maps, flat_rois, 7, 7, 1 / 16.0, 7, model.n_classes), 1).view(2, B, R, -1)
+            pred = psroi_vote(bbox_maps, flat_rois, 7, 7, 1 / 16.0, 7, 4).view(2, B, R, -1)
+            feat = model._tracking_features([bbox_maps[:B], bbox_maps[B:]], [c3[:B], c3[B:]], [c4[:B], c4[B:]], [c5[:B], c5[B:]])
+            trk = psroi_vote(model.corr_bbox_net(feat), all_rois[:B].reshape(-1, 5).contiguous(), 7, 7, 1 / 16.0, 7, 4)
+        torch.cuda.synchronize()
+        assert got[0].shape == (2, B, R, 5) and torch.equal(got[0][0], all_rois[:B])
+        for name, a, b in (("cls_prob", got[1], prob), ("bbox_pred", got[2], pred), ("tracking_pred", got[3], trk)):
+            assert a.shape == b.shape, name
+            err = float((a - b).abs().max())
+            # 1e-4 at O(1) magnitudes; the random-init tracking branch of the 1-image case reaches |x| ~ 1e4, where the
+            # fp32 summation order of two exact-fp32 GEMMs differs by more than that in absolute terms
+            assert err < 1e-4 * max(1.0, float(b.abs().max())), (name, err, float(b.abs().max()))
+        for i in (1, 2, 3):   # and the full forward produced finite outputs of the contract's shapes
+            assert out[i].shape == got[i].shape and bool(torch.isfinite(out[i]).all())
+        # single-frame mode (BASELINE configs 1-2) takes the same tail without the tracking branch
+        with torch.no_grad():
+            one = model(im[:, :1], info[:, :1], gt[:, :1], nb[:, :1])
+        assert one[3].shape[0] == 0 and one[1].shape == (1, B, R, model.n_classes)
