@@ -130,7 +130,12 @@ class sampler(Sampler):
     """trainval_net.py:125-150: shuffles whole batches (consecutive, ratio-sorted indices stay together); the remainder
     that does not fill a batch goes last, in order."""
 
-    def __init__(self, train_size, batch_size):
+    def __init__(self, train_size, batch_size, seed=None):
+        """seed: None reproduces the reference (the permutation comes from torch's global CPU generator); an int makes
+        the permutation a function of (seed, epoch) only -- what several processes that shard the same epoch need, so
+        that their shards stay disjoint whatever else each process has drawn from the global generator."""
+        self.seed = seed
+        self.epoch = 0
         self.num_data = train_size
         self.num_per_batch = int(train_size / batch_size)
         self.batch_size = batch_size
@@ -138,7 +143,14 @@ class sampler(Sampler):
         self.leftover = torch.arange(self.num_per_batch * batch_size, train_size).long()
 
     def __iter__(self):
-        starts = torch.randperm(self.num_per_batch).view(-1, 1) * self.batch_size
+        if self.seed is None:
+            perm = torch.randperm(self.num_per_batch)
+        else:
+            g = torch.Generator()
+            g.manual_seed(int(self.seed) * 1000003 + self.epoch)
+            perm = torch.randperm(self.num_per_batch, generator=g)
+            self.epoch += 1
+        starts = perm.view(-1, 1) * self.batch_size
         order = (starts.expand(self.num_per_batch, self.batch_size) + self.range).view(-1)
         if self.leftover.numel():
             order = torch.cat((order, self.leftover), 0)

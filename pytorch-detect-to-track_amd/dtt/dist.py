@@ -156,6 +156,33 @@ class DataParallelSnippets(nn.Module):
         return self.module.state_dict(*a, **k)
 
 
+def broadcast_module_state(module, process_group=None, src=0):
+    """Rank `src`'s parameters and buffers (BatchNorm statistics included) to every rank.  Must run BEFORE anything
+    that snapshots them into constants (dtt.fuse.fuse_for_training folds the frozen-BatchNorm statistics and the frozen
+    stem / stage weights): replicas that fold different statistics compute different functions for the whole run."""
+    if not dist.is_initialized() or dist.get_world_size(process_group) == 1:
+        return module
+    with torch.no_grad():
+        seen = set()
+        for t in list(module.parameters()) + list(module.buffers()):
+            if t.data_ptr() in seen or not t.is_floating_point():
+                continue
+            seen.add(t.data_ptr())
+            dist.broadcast(t.data, src=src, group=process_group)
+    return module
+
+
+def prepare_replica(model, world, channels_last=True, process_group=None):
+    """The start-up order of a training replica: broadcast rank 0's state -> fold the frozen constants
+    (fuse_for_training, which also moves the trainable filters to channels-last memory) -> lay out the gradient buckets
+    (DataParallelSnippets) after that.  Returns the runner."""
+    from .fuse import fuse_for_training
+    if world > 1:
+        broadcast_module_state(model, process_group)
+    fuse_for_training(model, channels_last=channels_last)
+    return DataParallelSnippets(model, world, process_group=process_group)
+
+
 def shard_snippets(n_snippets, rank, world):
     """Contiguous, balanced split of snippet indices [0, n) across ranks (DataParallel scatter semantics)."""
     base, rem = divmod(n_snippets, world)
@@ -179,8 +206,7 @@ def make_optimizer(model, cfg, lr=None, optimizer="sgd"):
         else:
             groups.append({"params": [p], "lr": lr, "weight_decay": T.WEIGHT_DECAY})
     if optimizer == "adam":
-        for g in groups:
-            g["lr"] *= 0.1
+        # the reference scales only the lr it PRINTS by 0.1 (trainval_net.py:290-292); the groups keep the full rate
         return torch.optim.Adam(groups)
     return GroupedSGD(groups, momentum=T.MOMENTUM)
 

@@ -51,10 +51,14 @@ def calibrate_batchnorm_(model, images):
     return model
 
 
-def build_model(num_layers=101, n_classes=31, class_agnostic=True, seed=3, cfg=None):
+def build_model(num_layers=101, n_classes=31, class_agnostic=True, seed=3, cfg=None, pretrained=False,
+                pretrained_rfcn=False):
+    """pretrained / pretrained_rfcn: start from data/pretrained_model/res101.pth / rfcn_detect.pth as the reference
+    driver does for real datasets (trainval_net.py:264-269); the synthetic benchmarks use random weights."""
     from .model import resnet
     torch.manual_seed(seed)
     classes = ["__background__"] + ["c%d" % i for i in range(1, n_classes)]
-    m = resnet(classes, num_layers, pretrained=False, pretrained_rfcn=False, class_agnostic=class_agnostic, cfg=cfg)
+    m = resnet(classes, num_layers, pretrained=pretrained, pretrained_rfcn=pretrained_rfcn, class_agnostic=class_agnostic,
+               cfg=cfg)
     m.create_architecture()
     return m

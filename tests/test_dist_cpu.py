@@ -90,3 +90,55 @@ def test_two_rank_gradients_match_single_process():
 
 
 PORT = _free_port()
+
+
+def _fold_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "pytorch-detect-to-track_amd")]
+    from dtt.config import cfg
+    from dtt.dist import prepare_replica
+    from dtt.synth import build_model
+    model = build_model(50, cfg=cfg, seed=3 + rank)       # different weights per rank ...
+    with torch.no_grad():                                 # ... and different "calibrated" BatchNorm statistics per rank
+        gen = torch.Generator().manual_seed(50 + rank)
+        for m in model.modules():
+            if isinstance(m, nn.BatchNorm2d):
+                m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=gen))
+                m.running_var.copy_(torch.rand(m.running_var.shape, generator=gen) + 0.5)
+    model.train()
+    prepare_replica(model, world, channels_last=True)
+    ft = model._fused_train_trunk
+    sig = [float(t.double().sum()) for t in ft.scales + ft.shifts]
+    sig += [float(ft.stem.w.double().sum()), float(ft.stem.b.double().sum())]
+    sig += [float(blk.c1.w.double().sum()) for stage in ft.frozen for blk in stage]
+    sig += [float(p.detach().double().sum()) for p in model.parameters()]
+    if rank == 0:
+        ref = build_model(50, cfg=cfg, seed=3)
+        q.put((sig, float(sum(p.detach().double().sum() for p in ref.parameters()))))
+    else:
+        q.put((sig, None))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_replicas_fold_identical_constants():
+    """dtt.dist.prepare_replica: rank 0's weights and BatchNorm statistics reach every rank BEFORE fuse_for_training
+    snapshots them (frozen-BatchNorm scales / shifts, folded stem and frozen-stage weights), so all replicas compute the
+    same function; the per-rank statistics they started with are gone."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fold_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get() for _ in range(world)]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    sigs = [g[0] for g in got]
+    assert sigs[0] == sigs[1] and len(sigs[0]) > 100

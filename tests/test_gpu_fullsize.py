@@ -12,6 +12,8 @@ Checked through size-independent properties that pin the result without it:
   * PSRoI pooling: constant maps pool to the constant, linearity in the features, adjoint identity for the backward,
     and a float64 recomputation of sampled bins.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -269,3 +271,61 @@ def test_roi_align_pool_crop_config5_size_vs_oracle(dev):
     go3 = torch.randn(oc.shape, device=dev)
     oc.backward(go3)
     np.testing.assert_allclose(it.grad.cpu().numpy(), O.roi_crop_backward(img, grid, go3.cpu().numpy()), rtol=1e-5, atol=1e-5)
+
+
+def test_config4_per_rank_training_step_full_size():
+    """BASELINE configs[3]'s per-rank workload: ONE Res-101 D&T training step at 600 x 1067 with 2 frame pairs (4 images)
+    through the fused channels-last training trunk -- anchor targets, RoI / tracking target sampling, the five losses,
+    backward through PSRoI pooling and the three correlations.  Checks: contract shapes, finite losses and gradients for
+    every trainable parameter, and a directional derivative: the loss change along a random direction in the R-FCN / tracking
+    head weights (the parameters fed by the PSRoI and correlation backward kernels) matches <grad, direction>."""
+    from dtt.config import apply_dataset_defaults, cfg, cfg_from_file
+    from dtt.dist import prepare_replica
+    from dtt.synth import build_model, calibrate_batchnorm_, make_batch
+    apply_dataset_defaults("imagenet_vid")
+    cfg_from_file(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cfgs", "res101.yml"))
+    dev = torch.device("cuda:0")
+    B, H, W = 2, 600, 1067
+    model = build_model(101, cfg=cfg).to(dev)
+    im, info, gt, nb = make_batch(B, H, W, seed=3, device=dev)
+    calibrate_batchnorm_(model, im[:, 0])
+    model.train()
+    runner = prepare_replica(model, 1, channels_last=True)
+
+    def loss_of():
+        np.random.seed(cfg.RNG_SEED)   # same anchor / RoI samples on every evaluation
+        out = runner(im, info, gt, nb)
+        return out, out[4].mean() + out[5].mean() + out[6].mean() + out[7].mean() + out[9].mean()
+
+    runner.zero_grad(set_to_none=True)
+    out, loss = loss_of()
+    loss.backward()
+    runner.finish_gradients()
+    torch.cuda.synchronize()
+    N = cfg.TRAIN.BATCH_SIZE
+    assert tuple(out[0].shape) == (2, B, N, 5) and tuple(out[1].shape) == (2, B, N, 31) and tuple(out[8].shape) == (2, B, N)
+    assert tuple(out[3].shape) == (B * gt.size(2), 4)
+    assert all(bool(torch.isfinite(out[i]).all()) for i in (4, 5, 6, 7, 9)) and np.isfinite(float(loss))
+    n_grad = 0
+    for n, p in model.named_parameters():
+        if p.requires_grad:
+            assert p.grad is not None and bool(torch.isfinite(p.grad).all()), n
+            n_grad += 1
+    assert n_grad > 100
+    # (these heads do not feed the RPN: the proposals, hence the sampled RoIs, stay the same under the perturbation)
+    heads = [model.RFCN_cls_net.weight, model.RFCN_bbox_net.weight, model.corr_bbox_net.weight]
+    g = torch.Generator().manual_seed(1)
+    dirs = [torch.randn(p.shape, generator=g).to(dev) * float(p.detach().abs().mean()) for p in heads]
+    predicted = sum(float((p.grad * d).sum()) for p, d in zip(heads, dirs))
+    eps = 0.02
+    vals = []
+    for sgn in (1.0, -1.0):
+        with torch.no_grad():
+            for p, d in zip(heads, dirs):
+                p.add_(d, alpha=sgn * eps)
+        vals.append(float(loss_of()[1].detach()))   # same (training) graph as the step above
+        with torch.no_grad():
+            for p, d in zip(heads, dirs):
+                p.add_(d, alpha=-sgn * eps)
+    measured = (vals[0] - vals[1]) / (2 * eps)
+    assert abs(measured - predicted) <= 0.05 * max(abs(predicted), abs(measured)) + 1e-3, (measured, predicted)

@@ -168,7 +168,7 @@ def test_drivers_round_trip_checkpoint(tmp_path):
     import test_net
     import trainval_net
     save = str(tmp_path / "models")
-    trainval_net.main(["--dataset", "synthetic", "--net", "res50", "--bs", "1", "--cag", "--epochs", "1",
+    trainval_net.main(["--dataset", "synthetic", "--net", "res50", "--bs", "1", "--cag", "--epochs", "2",   # epoch 1 only
                        "--iters_per_epoch", "2", "--disp_interval", "1", "--save_dir", save, "--height", "224",
                        "--width", "320", "--lr", "1e-5"])
     ck_path = os.path.join(save, "res50", "synthetic", "rfcn_detect_track_1_1_1.pth")
@@ -255,13 +255,15 @@ def test_drivers_on_an_ilsvrc_devkit(tmp_path):
     fx.build_devkit(cfg.DATA_DIR)
     save = str(tmp_path / "models")
     try:
-        trainval_net.main(["--dataset", "imagenet_vid", "--net", "res50", "--bs", "2", "--cag", "--epochs", "1",
+        trainval_net.main(["--dataset", "imagenet_vid", "--net", "res50", "--bs", "2", "--cag", "--epochs", "2", "--init", "random",
                            "--disp_interval", "2", "--save_dir", save, "--lr", "1e-5", "--set", "TRAIN.SCALES", "(96,)"])
         ck = torch.load(os.path.join(save, "res50", "imagenet_vid", "rfcn_detect_track_1_1_5.pth"), map_location="cpu")
         assert ck["epoch"] == 2  # 13 training pairs / batch 2 -> 6 steps
-        trainval_net.main(["--dataset", "imagenet_vid+imagenet_det", "--net", "res50", "--bs", "1", "--cag", "--epochs", "1",
-                           "--save_dir", save, "--lr", "1e-5", "--set", "TRAIN.SCALES", "(96,)"])
-        assert os.path.exists(os.path.join(save, "res50", "imagenet_vid+imagenet_det", "rfcn_detect_track_1_1_1.pth"))
+        trainval_net.main(["--dataset", "imagenet_vid+imagenet_det", "--net", "res50", "--bs", "1", "--cag", "--epochs", "2",
+                           "--init", "random", "--save_dir", save, "--lr", "1e-5", "--set", "TRAIN.SCALES", "(96,)"])
+        # VID and DET batches alternate for 2 * int(min(train sizes) / bs) steps (trainval_net.py:312-315, 340-347)
+        import glob
+        assert glob.glob(os.path.join(save, "res50", "imagenet_vid+imagenet_det", "rfcn_detect_track_1_1_*.pth"))
         out = str(tmp_path / "dets")
         m_ap = test_net.main(["--dataset", "imagenet_vid", "--net", "res50", "--cfg", "cfgs/res50.yml", "--cag",
                               "--load_dir", save, "--checksession", "1", "--checkepoch", "1", "--checkpoint", "5",

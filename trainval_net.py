@@ -9,7 +9,8 @@ all-reduced over RCCL, dtt/dist.py).  `--dataset imagenet_vid` / `imagenet_vid+i
 cfg.DATA_DIR/ILSVRC through dtt/data (the reference's roidb / loader semantics); `--dataset synthetic` (the default: no
 dataset ships with this repo) draws batches of the same layout from the seeded generator.
 
-    python trainval_net.py --dataset synthetic --net res101 --bs 2 --cag --epochs 1 --iters_per_epoch 20
+    python trainval_net.py --dataset synthetic --net res101 --bs 2 --cag --epochs 2 --iters_per_epoch 20   # epoch 1 only, as
+                                                          # the reference's range(start_epoch, max_epochs) (trainval_net.py:317)
     torchrun --nproc-per-node 8 --master-addr 127.0.0.1 trainval_net.py --mGPUs --bs 2 --cag ...
 """
 import argparse
@@ -57,6 +58,10 @@ def parse_args(argv=None):
     p.add_argument("--iters_per_epoch", default=100, type=int)
     p.add_argument("--height", default=600, type=int)
     p.add_argument("--width", default=1067, type=int)
+    p.add_argument("--init", default=None, choices=("reference", "random"),
+                   help="initial weights: 'reference' = data/pretrained_model/{res101,rfcn_detect}.pth as the reference "
+                        "driver (default for real datasets), 'random' = random init + BatchNorm statistics calibrated on the "
+                        "first batch (default for --dataset synthetic; there are no weight files in this repo)")
     p.add_argument("--set", dest="set_cfgs", default=None, nargs=argparse.REMAINDER,
                    help="cfg overrides, KEY VALUE pairs (as test_net.py:50-52)")
     return p.parse_args(argv)
@@ -78,7 +83,9 @@ def _build_loaders(args, cfg, rank, world):
         if rank == 0:
             print("{:d} roidb frame pairs in {}".format(len(pairs), name))
         ds = roibatchLoader(pairs, ratio_list, ratio_index, args.batch_size * world, imdb.num_classes, training=True)
-        order = sampler(len(pairs), args.batch_size * world)
+        # every rank must draw the SAME permutation each epoch for its slots to be disjoint: the sampler owns a generator
+        # seeded from (RNG_SEED, dataset, epoch) instead of reading torch's global one (single process: the reference's)
+        order = sampler(len(pairs), args.batch_size * world, seed=None if world == 1 else cfg.RNG_SEED + 7919 * k)
 
         class _Shard(torch.utils.data.Sampler):  # rank r takes slots [r*bs, (r+1)*bs) of every global batch
             def __iter__(self):
@@ -98,7 +105,7 @@ def _build_loaders(args, cfg, rank, world):
 def main(argv=None):
     args = parse_args(argv)
     from dtt.config import apply_dataset_defaults, cfg, cfg_from_file
-    from dtt.dist import DataParallelSnippets, make_optimizer, shard_snippets
+    from dtt.dist import make_optimizer
     from dtt.synth import build_model, calibrate_batchnorm_, make_batch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -117,14 +124,20 @@ def main(argv=None):
     if args.set_cfgs:
         from dtt.config import cfg_from_list
         cfg_from_list(args.set_cfgs)
-    np.random.seed(cfg.RNG_SEED + rank)  # trainval_net.py:183 (+rank: each process samples its own anchors / RoIs)
     loaders = None
     if args.dataset != "synthetic":
         loaders = _build_loaders(args, cfg, rank, world)  # ImageNet VID (+ DET) under cfg.DATA_DIR/ILSVRC (dtt/data)
+    # after the roidb is built (combined_roidb re-seeds numpy with 123 for its shuffle, roidb.py:95):
+    np.random.seed(cfg.RNG_SEED + rank)  # trainval_net.py:183 (+rank: each process samples its own anchors / RoIs)
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     layers = {"res50": 50, "res101": 101, "res152": 152}[args.net]
-    model = build_model(layers, class_agnostic=args.class_agnostic, cfg=cfg).to(dev)
+    synthetic = args.dataset == "synthetic"
+    # real datasets start from the reference's initial weights (trainval_net.py:264-269: res101 from rfcn_detect.pth,
+    # res50 / res152 from the ImageNet trunk); the synthetic runs use random weights
+    init = args.init or ("random" if synthetic else "reference")
+    model = build_model(layers, class_agnostic=args.class_agnostic, cfg=cfg, pretrained=init == "reference" and args.net != "res101",
+                        pretrained_rfcn=init == "reference" and args.net == "res101").to(dev)
     output_dir = os.path.join(args.save_dir, args.net, args.dataset)
     os.makedirs(output_dir, exist_ok=True)
     optimizer = make_optimizer(model, cfg, lr=args.lr, optimizer=args.optimizer)
@@ -142,21 +155,28 @@ def main(argv=None):
         if rank == 0:
             print("loaded checkpoint %s" % load_name)
     # global batch = --bs snippets per process (per-snippet sharding; both frames of a pair stay on one GPU)
-    first = (tuple(t.to(dev) for t in next(iter(loaders[0]))) if loaders else
-             make_batch(args.batch_size, args.height, args.width, seed=1000 + rank, device=dev))
-    calibrate_batchnorm_(model, first[0][:, 0])
+    if init == "random" and not args.resume:
+        # random-init trunks only: give the frozen BatchNorm layers the statistics of the first batch.  Loaded weights
+        # (pretrained / resumed) keep theirs -- the frozen BatchNorm IS those statistics (resnet.py:290-295).
+        first = (tuple(t.to(dev) for t in next(iter(loaders[0]))) if loaders else
+                 make_batch(args.batch_size, args.height, args.width, seed=1000, device=dev))
+        calibrate_batchnorm_(model, first[0][:, 0])
     model.train()
-    from dtt.fuse import fuse_for_training
-    fuse_for_training(model, channels_last=True)  # also moves the trainable filters to channels-last memory ...
-    runner = DataParallelSnippets(model, world)   # ... so the gradient buckets are laid out after it
-    for epoch in range(args.start_epoch, args.max_epochs + 1):
+    # broadcast rank 0's state, THEN fold the frozen constants, THEN lay out the gradient buckets (dtt.dist)
+    from dtt.dist import prepare_replica
+    runner = prepare_replica(model, world, channels_last=True)
+    if loaders:   # trainval_net.py:312-315: train_size = the (smaller) roidb; VID and DET alternate when both are given
+        sizes = [len(l.dataset) for l in loaders]
+        per_epoch = int(min(sizes) / (args.batch_size * world))
+        n_steps_data = 2 * per_epoch if len(loaders) > 1 else per_epoch
+    for epoch in range(args.start_epoch, args.max_epochs):   # trainval_net.py:317
         if epoch % (args.lr_decay_step + 1) == 0:
             for g in optimizer.param_groups:  # adjust_learning_rate (net_utils.py:63-66)
                 g["lr"] *= args.lr_decay_gamma
             lr *= args.lr_decay_gamma
         loss_temp, start = 0.0, time.time()
         iters = [iter(l) for l in loaders] if loaders else None
-        n_steps = args.iters_per_epoch if not loaders else min(len(l) for l in loaders)
+        n_steps = args.iters_per_epoch if not loaders else min(n_steps_data, min(len(l) for l in loaders) * len(loaders))
         for step in range(n_steps):
             if loaders:  # VID and DET batches alternate when both are given (trainval_net.py:340-347)
                 im, info, gt, nb = (t.to(dev, non_blocking=True) for t in next(iters[step % len(iters)]))
