@@ -13,9 +13,11 @@ inference path shards by video snippet with no collective
 full training step (forward + backward + SGD, gradients all-reduced over RCCL).
 
 The one JSON line carries, besides the contract fields:
-  roofline      the dominant hot-path kernel (conv5 cross-frame correlation, exact-f32 MFMA): algorithmic
-                FLOPs per launch / its launch duration measured with HIP events on the launch stream
-                inside the timed region (C-ABI hook dtt_profile_attach)
+  roofline      the dominant hot-path op (conv5 cross-frame correlation: exact-f32 MFMA banded product + slice
+                reduction, timed as ONE op): algorithmic FLOPs (and bytes) per op / its duration measured with HIP
+                events on the launch stream inside the timed region (C-ABI hook dtt_profile_attach); both the
+                MFMA and the HBM fraction
+  secondary     the hand-written R-FCN heads (MFMA) and the class PSRoI pooling (HBM) of the same step
   cpu_baseline  the same forward for ONE frame pair through stock PyTorch CPU convolutions + the CPU
                 oracle of every hot-path op (oracle/cpu_graph.py), on this box's host cores
 """
@@ -51,6 +53,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--disp", type=int, default=8, help="correlation max displacement (8 = reference; 16 = BASELINE config 5)")
     ap.add_argument("--nchw-trunk", action="store_true", help="inference: keep the fused trunk in NCHW (A/B against channels-last)")
+    ap.add_argument("--pooling", choices=("psroi", "align", "pool", "crop"), default="psroi",
+                    help="psroi = the reference's R-FCN graph; align / pool / crop additionally pool the 512-channel top map "
+                         "per RoI (BASELINE config 5: --pooling align --disp 16 --height 563 --width 1000 --batch 1)")
+    ap.add_argument("--cpu-passes", type=int, default=5, help="timed passes of the CPU baseline (median is reported)")
     return ap.parse_args()
 
 
@@ -97,29 +103,53 @@ class KernelTimer:
         return d[n // 2]
 
 
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(args, cfg):
-    """One frame pair through the CPU graph (stock PyTorch convs + oracle ops) on the host cores."""
+    """The same forward for ONE frame pair through the CPU graph (stock PyTorch fp32 convolutions + the oracle's OpenMP
+    restatement of every hot-path op, oracle/cpu_graph.py) on this box's host cores -- SURVEY 8d's protocol on a bounded
+    sample: the thread count is swept (one pass each), then one warm-up and `--cpu-passes` timed passes at the best
+    count; the median is reported.  Context, not the target: the reference has no CPU path for these ops at all."""
     from dtt.synth import build_model, calibrate_batchnorm_, make_batch
     from oracle import cpu_graph, oracle_lib
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    # many-core hosts: beyond ~32 threads the fp32 CPU convolutions of a single 600x1067 image stop scaling
-    # (and oversubscribed OpenMP teams get much slower), so the baseline uses at most 32 cores and says so
-    ncores = max(1, min(avail, 32))
-    torch.set_num_threads(ncores)
-    oracle_lib.set_num_threads(ncores)
     m = build_model(args.layers, cfg=cfg).eval()
     im, info, _, _ = make_batch(1, args.height, args.width, seed=3)
     calibrate_batchnorm_(m, im[:, 0])
-    t0 = time.time()
-    cpu_graph.rfcn_forward_test(m, im, info, cfg)
-    dt = time.time() - t0
-    return {"value": round(1.0 / dt, 4), "unit": "frame-pairs/s", "cores": int(ncores), "host_cores": int(avail),
-            "kind": "port",
-            "sample": "1 frame pair (B=1, %dx%d, Res-%d D&T test forward), one pass: torch CPU fp32 convs + "
-                      "oracle/ ops (OpenMP over independent outputs), %.1f s" % (args.height, args.width, args.layers, dt)}
+
+    def one(threads):
+        torch.set_num_threads(threads)
+        oracle_lib.set_num_threads(threads)
+        t0 = time.perf_counter()
+        cpu_graph.rfcn_forward_test(m, im, info, cfg)
+        return time.perf_counter() - t0
+
+    one(min(avail, 32))                                        # untimed: page in weights, OpenMP teams, oneDNN primitives
+    sweep = {}
+    for t in sorted({t for t in (8, 16, 32, 64) if t <= avail}):   # beyond 64 the single-image convolutions only get slower
+        sweep[t] = one(t)
+    best = min(sweep, key=sweep.get)
+    one(best)                                                  # warm-up at the chosen count
+    times = sorted(one(best) for _ in range(max(1, args.cpu_passes)))
+    med = times[len(times) // 2]
+    return {"value": round(1.0 / med, 4), "unit": "frame-pairs/s", "cores": int(best), "host_cores": int(avail),
+            "cpu_model": _cpu_model(), "kind": "port",
+            "passes": len(times), "pass_seconds": [round(t, 3) for t in times],
+            "thread_sweep_seconds": {str(k): round(v, 3) for k, v in sweep.items()},
+            "sample": "1 frame pair (B=1, %dx%d, Res-%d D&T test forward): torch CPU fp32 convs + oracle/ ops (OpenMP over "
+                      "independent outputs); thread count swept, 1 warm-up + %d timed passes at %d threads, median %.2f s"
+                      % (args.height, args.width, args.layers, len(times), best, med)}
 
 
 def main():
@@ -142,17 +172,17 @@ def main():
     from dtt.synth import build_model, calibrate_batchnorm_, make_batch
     apply_dataset_defaults("imagenet_vid")
     cfg.CORR_MAX_DISPLACEMENT = args.disp
+    cfg.RFCN_ROI_FEATURES = "" if args.pooling == "psroi" else args.pooling
     torch.backends.cudnn.benchmark = True
 
     model = build_model(args.layers, cfg=cfg).to(dev)
     im, info, gt, nb = make_batch(args.batch, args.height, args.width, seed=3 + rank, device=dev)
     calibrate_batchnorm_(model, im[:, 0])
     if args.mode == "train":
-        from dtt.dist import DataParallelSnippets, make_optimizer
-        from dtt.fuse import fuse_for_training
+        from dtt.dist import make_optimizer, prepare_replica
         model.train()
-        fuse_for_training(model, channels_last=not args.nchw_trunk)  # frozen BatchNorm folded out of the activation path (same gradients for the weights)
-        runner = DataParallelSnippets(model, world)
+        # rank 0's state to every rank, THEN the frozen BatchNorm folded out of the activation path, THEN the buckets
+        runner = prepare_replica(model, world, channels_last=not args.nchw_trunk)
         opt = make_optimizer(model, cfg, lr=1e-4)
 
         def step():
@@ -180,11 +210,12 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
-    # conv3, conv4, conv5 correlations, in that order; for 8 < R <= 16 (d = 12 / 16) conv4 and conv5 are four R = 8
-    # sub-window launches each
+    # Correlation ops per step, in launch order: conv5, conv4, conv3 (largest first; the training graph keeps the
+    # reference's conv3, conv4, conv5 order).  For 8 < R <= 16 (d = 12 / 16) conv4 and conv5 are four R = 8 sub-window ops
+    # each.  The tag "corr_fwd_op" brackets a whole op: banded-product kernel + slice reduction.
     n_sub = 4 if args.disp in (12, 16) else 1
-    launches_per_step = 1 + 2 * n_sub
-    kt = KernelTimer("corr_fwd_mfma", launches_per_step * args.steps, dev)
+    ops_per_step = 1 + 2 * n_sub
+    kt = KernelTimer("corr_fwd_op", ops_per_step * args.steps, dev)
     kt.attach()
     sync()
     t0 = time.perf_counter()
@@ -198,37 +229,46 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    psroi_us = None
-    if rank == 0 and args.mode == "infer":
-        # the class PSRoI pooling of the same step, timed the same way in a few extra (untimed) steps --
-        # the library records one tag at a time.  Three PSRoI launches per step: class scores, boxes, tracking.
-        n_extra = min(args.steps, 10)
-        kp = KernelTimer("psroi_fwd_plane", 3 * n_extra, dev)
-        kp.attach()
-        for _ in range(n_extra):
+    def extra(tag, per_step, pick, n=8):
+        """A few more (untimed) steps with another kernel's launches bracketed -- the library records one tag at a time.
+        pick(durations of one step) -> the launch of interest; returns its mean in us (None if the tag never fired)."""
+        k = KernelTimer(tag, per_step * n, dev)
+        k.attach()
+        for _ in range(n):
             step()
         torch.cuda.synchronize(dev)
-        d = kp.durations_us(kp.detach())
-        if len(d) >= 3:
-            cls = d[0::3]
-            psroi_us = sum(cls) / len(cls)
+        d = k.durations_us(k.detach())
+        vals = [pick(d[i:i + per_step]) for i in range(0, len(d) - per_step + 1, per_step)]
+        return sum(vals) / len(vals) if vals else None
+
     if rank == 0:
         durs = kt.durations_us(used)
-        conv5 = [sum(durs[i + 1 + n_sub:i + launches_per_step]) for i in range(0, len(durs) - launches_per_step + 1, launches_per_step)]
-        avg5 = sum(conv5) / max(len(conv5), 1)
+        c5 = (lambda d: sum(d[:n_sub])) if args.mode == "infer" else (lambda d: sum(d[1 + n_sub:]))
+        conv5 = [c5(durs[i:i + ops_per_step]) for i in range(0, len(durs) - ops_per_step + 1, ops_per_step)]
+        op_us = sum(conv5) / max(len(conv5), 1)
         B = args.batch
         H16, W16 = -(-args.height // 16), -(-args.width // 16)
         D2 = (2 * args.disp + 1) ** 2
         flops = 2.0 * 2048 * D2 * H16 * W16 * B            # SURVEY 8d: 2*C*D^2*oH*oW per frame pair
         bytes_ = (2 * 2048 * H16 * W16 * 4 + D2 * H16 * W16 * 4) * B
-        achieved = flops / (avg5 * 1e-6) / 1e12 if avg5 > 0 else 0.0
-        # HBM bytes per launch come from a separate rocprofv3 --pmc pass (profiles/r01_pmc_conv5.json); only quoted
-        # when this run has the shape that pass was taken on
-        traffic = None
+        achieved = flops / (op_us * 1e-6) / 1e12 if op_us > 0 else 0.0
+        hbm = bytes_ / (op_us * 1e-6) / 1e9 if op_us > 0 else 0.0
+        main_us = red_us = head_us = psroi_us = None
+        if args.mode == "infer":
+            main_us = extra("corr_fwd_mfma", ops_per_step, c5)
+            red_us = extra("corr_fwd_reduce", ops_per_step, c5)
+            n_head = 2      # class + box heads, then the tracking head
+            if model._pm_tail is not None:
+                head_us = extra("head_gemm", n_head, lambda d: d[0])
+                psroi_us = extra("psroi_pm", 3, lambda d: d[0])
+        # HBM bytes of the op come from a separate rocprofv3 --pmc pass over the same launch (profiles/r02_pmc_conv5.json,
+        # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes); quoted only for the shape that pass was taken on
+        traffic, traffic_src = None, None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_conv5.json")))
-            if (args.batch, args.height, args.width) == (2, 600, 1067):
-                traffic = pmc["traffic_bytes_per_launch"]
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_conv5.json")))
+            if (args.batch, args.height, args.width, args.disp) == (2, 600, 1067, 8):
+                traffic = pmc["traffic_bytes_per_op"]
+                traffic_src = "static: " + pmc.get("source", "profiles/r02_pmc_conv5.json")
         except (OSError, ValueError, KeyError):
             pass
         pairs = args.batch * world * args.steps
@@ -245,29 +285,48 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "Res-%d D&T siamese 2-frame %s step, %dx%d, correlation d=%d + PSRoI, bs=%d per GPU "
-                                   "(BASELINE.json configs[2]); random-init weights, BN statistics calibrated on the "
+            "config": {"workload": "Res-%d D&T siamese 2-frame %s step, %dx%d, correlation d=%d + PSRoI%s, bs=%d per GPU "
+                                   "(BASELINE.json configs[%d]); random-init weights, BN statistics calibrated on the "
                                    "synthetic input" % (args.layers, "inference" if args.mode == "infer" else "training",
-                                                        args.height, args.width, args.disp, args.batch),
+                                                        args.height, args.width, args.disp,
+                                                        "" if args.pooling == "psroi" else " + RoI-%s of the 512-ch top map" % args.pooling,
+                                                        args.batch, 4 if args.disp == 16 else 2),
                        "global_batch": args.batch * world, "parallelism": "dp%d (per-snippet sharding%s)" %
                        (world, ", RCCL gradient all-reduce" if args.mode == "train" else ", no collective")},
-            "roofline": {"kernel": "%s (conv5 correlation, 2048 ch, d=%d; profiling label corr_fwd_mfma)" % ("corr_fwd_glds<5>" if args.disp <= 8 else "4 x corr_fwd_glds<5> sub-windows", args.disp), "bound": "mfma",
-                         "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                         "launch_us": round(avg5, 2), "launches_timed": len(conv5),
+            # the dominant hot-path op: conv5 cross-frame correlation (exact-f32 MFMA banded product + slice reduction),
+            # timed as ONE op with HIP events on its launch stream inside the timed region (other streams keep running
+            # beside it, as in production)
+            "roofline": {"kernel": "conv5 correlation op = %s + corr_fwd_reduce<5> (2048 ch, d=%d; event tag corr_fwd_op)"
+                                   % ("corr_fwd_glds<5>" if args.disp <= 8 else "4 x corr_fwd_glds<5> sub-windows", args.disp),
+                         "bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+                         "hbm": {"achieved": round(hbm, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm / HBM_PEAK_GBS, 4)},
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "op_us": round(op_us, 2), "ops_timed": len(conv5),
+                         "kernel_us": {"banded_product": None if main_us is None else round(main_us, 2),
+                                       "slice_reduction": None if red_us is None else round(red_us, 2)},
                          "event_bracket_overhead_us": round(KernelTimer.event_pair_overhead_us(dev), 2),
-                         "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": bytes_,
-                         "hbm_view": {"achieved_GBs": round(bytes_ / (avg5 * 1e-6) / 1e9, 1) if avg5 > 0 else 0.0,
-                                      "peak_GBs": HBM_PEAK_GBS}},
+                         "algorithmic_flops_per_op": flops, "algorithmic_bytes_per_op": bytes_},
         }
+        sec = {}
+        if head_us:
+            n_img = 2 * args.batch
+            hf = 2.0 * n_img * H16 * W16 * 512 * (31 * 49 + 4 * 49)     # 3.96 + 0.51 GFLOP per image per leg
+            sec["heads"] = {"kernel": "head_gemm_kernel (RFCN_cls_net + RFCN_bbox_net of %d images in one exact-f32 MFMA GEMM, "
+                                      "position-major output)" % n_img, "bound": "mfma",
+                            "achieved": round(hf / (head_us * 1e-6) / 1e12, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": round(hf / (head_us * 1e-6) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4), "launch_us": round(head_us, 2),
+                            "algorithmic_flops_per_launch": hf}
         if psroi_us:
             n_img, od = 2 * args.batch, 31 * 49
-            ps_bytes = n_img * od * H16 * W16 * 4 + n_img * cfg.TEST.RPN_POST_NMS_TOP_N * od * 4   # score maps in, pooled bins out
-            out["secondary"] = {"psroi_cls": {"kernel": "psroi_fwd_plane (R-FCN class scores: %d x %d x %d x %d maps, %d RoIs)" %
-                                              (n_img, od, H16, W16, n_img * cfg.TEST.RPN_POST_NMS_TOP_N), "bound": "hbm",
-                                              "achieved": round(ps_bytes / (psroi_us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS,
-                                              "unit": "GB/s", "frac": round(ps_bytes / (psroi_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                                              "launch_us": round(psroi_us, 2), "algorithmic_bytes_per_launch": ps_bytes}}
+            ps_bytes = n_img * od * H16 * W16 * 4 + n_img * cfg.TEST.RPN_POST_NMS_TOP_N * 31 * 4   # score maps in, votes out
+            sec["psroi_cls"] = {"kernel": "psroi_pm_kernel (R-FCN class scores: %d x %d x %d x %d position-major map, %d RoIs, "
+                                          "pooling + 7x7 vote)" % (n_img, od, H16, W16, n_img * cfg.TEST.RPN_POST_NMS_TOP_N),
+                                "bound": "hbm", "achieved": round(ps_bytes / (psroi_us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                                "unit": "GB/s", "frac": round(ps_bytes / (psroi_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                "launch_us": round(psroi_us, 2), "algorithmic_bytes_per_launch": ps_bytes}
+        if sec:
+            out["secondary"] = sec
         if world == 1 and not args.no_cpu_baseline and args.mode == "infer":
             out["cpu_baseline"] = cpu_baseline(args, cfg)
         print(json.dumps(out), flush=True)

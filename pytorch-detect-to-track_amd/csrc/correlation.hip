@@ -1135,6 +1135,7 @@ int launch_fast(float* output, long out_batch_stride, long out_ch_stride, long o
     attr = true;
   }
   const int ntiles = g.tiles_x * g.tiles_y;
+  dtt_prof_begin("corr_fwd_op", stream);     // the whole op: banded product + slice reduction
   dtt_prof_begin("corr_fwd_mfma", stream);
   bool launched = false;
 #ifndef DTT_CORR_NO_GLDS
@@ -1173,6 +1174,7 @@ int launch_fast(float* output, long out_batch_stride, long out_ch_stride, long o
   hipLaunchKernelGGL(corr_fwd_reduce<NBR>, dim3(ntiles * 4, NBR, batch), dim3(kThreads), 0, stream,
                      static_cast<const float*>(workspace), output, out_batch_stride, out_ch_stride, out_px_stride, g, (float)g.C);
   dtt_prof_end("corr_fwd_reduce", stream);
+  dtt_prof_end("corr_fwd_op", stream);
   DTT_CHECK_LAUNCH("corr_fwd_reduce");
   return 1;
 }

@@ -90,6 +90,12 @@ cfg = AttrDict({
     # config 5 asks for d = 16; set via `--set CORR_MAX_DISPLACEMENT 16` (changes corr_bbox_net's input width, so
     # checkpoints are only interchangeable at the default)
     "CORR_MAX_DISPLACEMENT": 8,
+    # not in the reference's config either: its _RFCN ignores POOLING_MODE and always pools with PSRoI (rfcn.py:40-44,
+    # SURVEY appendix A #4).  BASELINE.json's config 5 asks for "RoI-Align path + correlation d=16": with
+    # RFCN_ROI_FEATURES = "align" | "pool" | "crop" the detector ALSO pools the 512-channel `top` map with the op the
+    # legacy head selects by POOLING_MODE (faster_rcnn.py:72-83) for every RoI it scores and exposes the result as
+    # `model.roi_feat` (the 10-tuple of rfcn.py:249-250 is unchanged).  "" = reference behaviour.
+    "RFCN_ROI_FEATURES": "",
 })
 
 

@@ -21,7 +21,8 @@ import torch.nn.functional as F
 from torch import nn
 
 from .config import cfg as _global_cfg
-from .ops import Correlation, _PSRoIPooling, correlation_forward_into, correlation_output_shape, psroi_pool_vote, psroi_vote
+from .ops import (Correlation, RoIAlignAvg, _PSRoIPooling, _RoIPooling, correlation_forward_into, correlation_output_shape,
+                  psroi_pool_vote, psroi_vote, roi_crop_pool)
 from .rpn import _AnchorTargetLayer, _ProposalLayer
 from .targets import _ProposalTargetLayer, _TrackingProposalTargetLayer
 
@@ -181,6 +182,10 @@ class _RFCN(nn.Module):
         self.conv3_corr_layer = Correlation(pad_size=d, kernel_size=1, max_displacement=d, stride1=2, stride2=2)
         self.conv4_corr_layer = Correlation(pad_size=d, kernel_size=1, max_displacement=d, stride1=1, stride2=1)
         self.conv5_corr_layer = Correlation(pad_size=d, kernel_size=1, max_displacement=d, stride1=1, stride2=1)
+        # legacy-head RoI pooling of `top` (faster_rcnn.py:33-37, 72-83), only run when cfg.RFCN_ROI_FEATURES asks for it
+        self.RFCN_roi_align = RoIAlignAvg(P, P, 1.0 / 16.0)
+        self.RFCN_roi_pool = _RoIPooling(P, P, 1.0 / 16.0)
+        self.roi_feat = None
         self.RFCN_cls_score = nn.AvgPool2d((7, 7), stride=(7, 7))
         self.RFCN_bbox_pred = nn.AvgPool2d((7, 7), stride=(7, 7))
         self.RFCN_tracking_pred = nn.AvgPool2d((7, 7), stride=(7, 7))
@@ -191,6 +196,25 @@ class _RFCN(nn.Module):
             return vote(pool(feat, rois)).squeeze(3).squeeze(2)
         return psroi_vote(feat, rois, pool.pooled_height, pool.pooled_width, pool.spatial_scale, pool.group_size,
                           pool.output_dim)
+
+    def _roi_features(self, top, flat_rois):
+        """cfg.RFCN_ROI_FEATURES: pool the 512-channel `top` map for the RoIs being scored with the legacy head's op
+        (faster_rcnn.py:72-83) -> (R_total, 512, P, P), kept in `self.roi_feat`.  BASELINE config 5's "RoI-Align path"."""
+        mode = getattr(self._cfg, "RFCN_ROI_FEATURES", "")
+        if not mode:
+            self.roi_feat = None
+            return None
+        rois = flat_rois.detach().contiguous()
+        top = top if top.is_contiguous() else top.contiguous()   # the pooling kernels read NCHW planes
+        if mode == "align":
+            self.roi_feat = self.RFCN_roi_align(top, rois)
+        elif mode == "pool":
+            self.roi_feat = self.RFCN_roi_pool(top, rois)
+        elif mode == "crop":
+            self.roi_feat = roi_crop_pool(top, rois, self._cfg.POOLING_SIZE, self._cfg.CROP_RESIZE_WITH_MAX_POOL)
+        else:
+            raise ValueError("cfg.RFCN_ROI_FEATURES must be '', 'align', 'pool' or 'crop' (got %r)" % (mode,))
+        return self.roi_feat
 
     def _tracking_features(self, rfcn_bbox, conv3, conv4, conv5):
         """cat([bbox_t, bbox_t+tau, corr3, corr4, corr5], 1) (rfcn.py:166-174).  Without autograd the
@@ -218,7 +242,7 @@ class _RFCN(nn.Module):
             off += ch
         return buf
 
-    def _inference_tail_pm(self, pm, fused, c3, c4, c5, all_rois, side, n_legs, B, dev):
+    def _inference_tail_pm(self, pm, fused, c3, c4, c5, all_rois, side, n_legs, B, dev, top=None):
         """rfcn.py:133-140, 166-196 at inference on the position-major layout: one MFMA GEMM for the class + box heads of
         every image (`dtt_head_gemm`), lanes = classes PSRoI pooling + vote (`dtt_psroi_pm_forward`), the tracking
         head's input rows assembled in place (box-delta columns copied, correlations written by their reduce kernels)."""
@@ -227,30 +251,37 @@ class _RFCN(nn.Module):
         top_rows, (H, W) = fused.top_rows, fused.top_hw
         fused.top_rows = None
         cur = torch.cuda.current_stream(dev)
-        det = head_gemm(top_rows, pm.det)                          # (n_legs*B*H*W, stride)
         single_frame = n_legs == 1
-        trk = None
+        trk = rows = None
+        hw = H * W
         if not single_frame:
-            hw = H * W
+            # correlations first: they only need the trunk maps, and what runs beside them on the side stream at this
+            # point is the proposal layer's select / sort (one workgroup per image)
             rows = pm.tracking_rows(B * hw, dev)
+            col, jobs = 2 * pm.n_box, []
+            for l, f in zip((self.conv3_corr_layer, self.conv4_corr_layer, self.conv5_corr_layer), (c3, c4, c5)):
+                oc = correlation_output_shape(f.size(1), f.size(2), f.size(3), l.pad_size, l.kernel_size, l.max_displacement,
+                                              l.stride1, l.stride2)[0]
+                jobs.append((l, f, col))
+                col += oc
+            assert col == pm.trk_in, "tracking feature width %d != corr_bbox_net input %d" % (col, pm.trk_in)
+            for l, f, c0 in reversed(jobs):   # largest first (conv5, conv4, conv3): it fits beside the select / sort kernel
+                correlation_forward_rows(rows, c0, f[:B].contiguous(), f[B:2 * B].contiguous(), l.pad_size, l.kernel_size,
+                                         l.max_displacement, l.stride1, l.stride2, l.corr_multiply)
+        det = head_gemm(top_rows, pm.det)                          # (n_legs*B*H*W, stride)
+        if not single_frame:
             off, nb = pm.loc_head["offset"], pm.n_box
             dv = det.view(n_legs, B * hw, det.shape[1])
             rows[:, 0:nb] = dv[0][:, off:off + nb]
             rows[:, nb:2 * nb] = dv[1][:, off:off + nb]
-            col = 2 * nb
-            for l, f in zip((self.conv3_corr_layer, self.conv4_corr_layer, self.conv5_corr_layer), (c3, c4, c5)):
-                oc = correlation_output_shape(f.size(1), f.size(2), f.size(3), l.pad_size, l.kernel_size, l.max_displacement,
-                                              l.stride1, l.stride2)[0]
-                correlation_forward_rows(rows, col, f[:B].contiguous(), f[B:2 * B].contiguous(), l.pad_size, l.kernel_size,
-                                         l.max_displacement, l.stride1, l.stride2, l.corr_multiply)
-                col += oc
-            assert col == pm.trk_in, "tracking feature width %d != corr_bbox_net input %d" % (col, pm.trk_in)
             trk = head_gemm(rows, pm.trk)                           # (B*H*W, stride)
         cur.wait_stream(side)
         all_rois.record_stream(cur)
         R = all_rois.size(1)
         flat_rois = all_rois.view(-1, 5)
         scale = self.RFCN_psroi_cls_pool.spatial_scale
+        if top is not None:
+            self._roi_features(top, flat_rois)
         score = psroi_pm(det, pm.cls_head, n_legs * B, H, W, flat_rois, scale)
         prob = F.softmax(score, dim=1).view(n_legs, B, R, -1)
         pred = psroi_pm(det, pm.loc_head, n_legs * B, H, W, flat_rois, scale).view(n_legs, B, R, -1)
@@ -299,7 +330,7 @@ class _RFCN(nn.Module):
         pm = getattr(self, "_pm_tail", None)
         if pm is not None and side is not None and n_legs <= 2 and getattr(fused, "top_rows", None) is not None:
             # hand-written heads + position-major pooling (dtt.heads): no NCHW score maps at all
-            return self._inference_tail_pm(pm, fused, c3, c4, c5, all_rois, side, n_legs, B, dev)
+            return self._inference_tail_pm(pm, fused, c3, c4, c5, all_rois, side, n_legs, B, dev, top=top)
         cls_maps = self.RFCN_cls_net(top)
         bbox_maps = self.RFCN_bbox_net(top)
         conv3 = [leg(c3, i) for i in range(n_legs)]
@@ -322,6 +353,7 @@ class _RFCN(nn.Module):
                 all_rois, _, _ = self.RFCN_rpn(top, im_info.view(n_legs * B, -1), None, None)
             R = all_rois.size(1)
             flat_rois = all_rois.view(-1, 5)
+            self._roi_features(top, flat_rois)
             score = self._pool_vote(self.RFCN_psroi_cls_pool, self.RFCN_cls_score, cls_maps, flat_rois)
             prob = F.softmax(score, dim=1).view(n_legs, B, R, -1)
             pred = self._pool_vote(self.RFCN_psroi_loc_pool, self.RFCN_bbox_pred, bbox_maps, flat_rois)
@@ -354,6 +386,9 @@ class _RFCN(nn.Module):
             rois.append(leg_rois)
             rpn_loss_cls.append(l_cls.view(1)); rpn_loss_bbox.append(l_box.view(1))
             flat_rois = leg_rois.view(-1, 5)
+            if getattr(self._cfg, "RFCN_ROI_FEATURES", ""):
+                feats = (feats if i else []) + [self._roi_features(top_i.detach(), flat_rois)]
+                self.roi_feat = feats
             score = self._pool_vote(self.RFCN_psroi_cls_pool, self.RFCN_cls_score, cls_map, flat_rois)
             prob = F.softmax(score, dim=1)
             pred = self._pool_vote(self.RFCN_psroi_loc_pool, self.RFCN_bbox_pred, bbox_map, flat_rois)

@@ -329,3 +329,48 @@ def test_config4_per_rank_training_step_full_size():
                 p.add_(d, alpha=-sgn * eps)
     measured = (vals[0] - vals[1]) / (2 * eps)
     assert abs(measured - predicted) <= 0.05 * max(abs(predicted), abs(measured)) + 1e-3, (measured, predicted)
+
+
+def test_config5_graph_roi_align_path_full_size(dev):
+    """BASELINE configs[4] end to end at its frame size: Res-101 D&T on a 563 x 1000 pair (36 x 63 maps), correlation
+    d = 16 (33 x 33 displacements, 2859-channel tracking head) and the RoI-Align path (cfg.RFCN_ROI_FEATURES = "align":
+    RoIAlignAvg(7, 7, 1/16) of the 512-channel `top` map for the 300 RoIs of each image, faster_rcnn.py:72-83 /
+    roi_align/modules/roi_align.py:18-29) next to the PSRoI heads.  The model's RoI-Align features are checked against
+    the oracle on the model's own `top` map and RoIs: 8 x 8 one-tap bilinear samples bit for bit, then the 2 x 2 average."""
+    import copy
+    from oracle import oracle_lib as O
+    from dtt.config import cfg
+    from dtt.fuse import fuse_for_inference
+    from dtt.ops import RoIAlign
+    from dtt.synth import build_model, calibrate_batchnorm_, make_batch
+    c = copy.deepcopy(cfg)
+    c.CORR_MAX_DISPLACEMENT = 16
+    c.RFCN_ROI_FEATURES = "align"
+    model = build_model(101, class_agnostic=True, cfg=c).to(dev).eval()
+    assert model.corr_bbox_net.in_channels == 2859
+    im, info, gt, nb = make_batch(1, 563, 1000, seed=11, device=dev)
+    calibrate_batchnorm_(model, im[:, 0])
+    fuse_for_inference(model)
+    captured = {}
+    orig = model._roi_features
+
+    def spy(top, flat_rois):
+        captured["top"], captured["rois"] = top.detach().clone(), flat_rois.detach().clone()
+        return orig(top, flat_rois)
+    model._roi_features = spy
+    with torch.no_grad():
+        out = model(im, info, gt, nb)
+    torch.cuda.synchronize()
+    rois, cls_prob, bbox_pred, tracking_pred = out[:4]
+    R = rois.shape[2]
+    assert tuple(rois.shape) == (2, 1, R, 5) and tuple(cls_prob.shape) == (2, 1, R, 31) and R == c.TEST.RPN_POST_NMS_TOP_N
+    assert tuple(tracking_pred.shape) == (R, 4) and bool(torch.isfinite(tracking_pred).all())
+    feat = model.roi_feat
+    top = captured["top"].contiguous()
+    assert tuple(top.shape) == (2, 512, 36, 63) and tuple(feat.shape) == (2 * R, 512, 7, 7)
+    assert torch.equal(captured["rois"].view(2, 1, R, 5)[0], rois[0])        # the RoIs that were scored (leg 0 as is)
+    ref8 = O.roi_align_forward(top.cpu().numpy(), captured["rois"].cpu().numpy(), 8, 8, 1 / 16.0)
+    got8 = RoIAlign(8, 8, 1 / 16.0)(top, captured["rois"])
+    np.testing.assert_array_equal(got8.cpu().numpy(), ref8)
+    ref = torch.nn.functional.avg_pool2d(torch.from_numpy(ref8), 2, 1).numpy()
+    np.testing.assert_allclose(feat.cpu().numpy(), ref, rtol=1e-6, atol=1e-6 * max(1.0, float(np.abs(ref).max())))
