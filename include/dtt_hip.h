@@ -239,6 +239,40 @@ int dtt_anchor_target_finish(const float* gt_boxes, int im_h0, int im_w0, const 
                              float* labels_out, float* bbox_targets, float* bbox_inside_weights,
                              float* bbox_outside_weights, void* stream);
 
+/* ---------------------------------------------------------------- RoI / tracking target samplers (training)
+ * Replace _ProposalTargetLayer._sample_rois_pytorch (rpn/proposal_target_layer_cascade.py:121-208: IoU against the
+ * ground truth, fg / bg classification, random sampling of rois_per_image RoIs, target encoding + normalisation; its
+ * per-image / per-RoI Python loops and host syncs) and _TrackingProposalTargetLayer.forward
+ * (rpn/tracking_proposal_target_layer.py:33-196).
+ * Candidates of an image = its num_rois proposals (all_rois (images, num_rois, 5)) followed by its num_gt ground-truth
+ * boxes (gt_boxes (images, num_gt, gt_stride >= 5) rows [x1,y1,x2,y2,cls,..]; num_gt <= 64), as :42-46 appends them.
+ *   assign   int32 (images, num_rois + num_gt): arg-max ground-truth row of every candidate (first maximum)
+ *   fg_list / bg_list  int32, same shape: candidate indices with max IoU >= fg_thresh / in [bg_thresh_lo, bg_thresh_hi),
+ *            ascending (what torch.nonzero returns in the reference); counts int32 (images, 2) = their lengths
+ * dtt_proposal_target_sample then writes rois (images, n_out, 5), labels (images, n_out), targets / inside / outside
+ * (images, n_out, 4) and status int32 (images) (1 = no candidate of either kind: the reference raises there).  Which
+ * candidates: EITHER pos int32 (images, n_out) + fg_n int32 (images) (device arrays: slot j < fg_n[b] takes
+ * fg_list[b][pos[b][j]], the others bg_list[b][pos[b][j]] -- the host has drawn them from its generator after reading
+ * counts) OR, with both NULL, u_fg (images, num_rois + num_gt) and u_bg (images, n_out) float64 uniforms in [0, 1) drawn
+ * without knowledge of the counts: the fg_n = min(fg_per_image, fg count) smallest keys u_fg[b][k], k < fg count, select a
+ * uniform foreground subset without replacement, background slot j takes bg_list[b][floor(u_bg[b][j - fg_n] * bg count)]
+ * (with only one kind of candidate, all n_out slots index it through u_bg, as :165-181).  mean4 / std4 / inside4 are HOST
+ * arrays of 4 floats (cfg.TRAIN.BBOX_NORMALIZE_MEANS / _STDS / BBOX_INSIDE_WEIGHTS).
+ * dtt_tracking_target: gt_boxes (2, images, num_gt, 6) [x1,y1,x2,y2,cls,track_id], num_boxes int64 (2, images); outputs as
+ * above with n_out = num_gt. */
+int dtt_proposal_target_assign(const float* all_rois, const float* gt_boxes, int images, int num_rois, int num_gt,
+                               int gt_stride, float fg_thresh, float bg_thresh_hi, float bg_thresh_lo, int* assign,
+                               int* fg_list, int* bg_list, int* counts, void* stream);
+int dtt_proposal_target_sample(const float* all_rois, const float* gt_boxes, int images, int num_rois, int num_gt,
+                               int gt_stride, const int* assign, const int* fg_list, const int* bg_list, const int* counts,
+                               const int* pos, const int* fg_n, const double* u_fg, const double* u_bg, int n_out,
+                               int fg_per_image, const float* mean4_host, const float* std4_host,
+                               const float* inside4_host, int normalize, float* rois_out, float* labels_out,
+                               float* targets_out, float* inside_out, float* outside_out, int* status, void* stream);
+int dtt_tracking_target(const float* gt_boxes, const long* num_boxes, int images, int num_gt, const float* mean4_host,
+                        const float* std4_host, const float* inside4_host, int normalize, float* rois_out,
+                        float* labels_out, float* targets_out, float* inside_out, float* outside_out, void* stream);
+
 /* ---------------------------------------------------------------- test-time per-class NMS
  * Replaces the per-class loop of the reference's test driver (test_net.py:274-301): for every class j >= 1
  * threshold scores[:, j] > score_thresh, sort descending (ties: lower RoI index first), NMS(nms_thresh), then the

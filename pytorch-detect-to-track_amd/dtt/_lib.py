@@ -47,6 +47,9 @@ SIGNATURES = {
     "dtt_proposal_forward": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _Z, _P]),
     "dtt_anchor_target_assign": (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _F, _F, _I, _P, _P, _P, _P, _P]),
     "dtt_anchor_target_disable": (_I, [_P, _P, _P, _I, _I, _P]),
+    "dtt_proposal_target_assign": (_I, [_P, _P, _I, _I, _I, _I, _F, _F, _F, _P, _P, _P, _P, _P]),
+    "dtt_proposal_target_sample": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "dtt_tracking_target": (_I, [_P, _P, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P]),
     "dtt_class_nms": (_I, [_P, _P, _I, _I, _I, _I, _F, _F, _I, _P, _P, _P]),
     "dtt_bias_act_inplace": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "dtt_bias_act_nhwc_inplace": (_I, [_P, _P, _P, _L, _I, _I, _P]),

@@ -55,6 +55,9 @@ cfg = AttrDict({
         "RPN_MIN_SIZE": 8,
         "RPN_BBOX_INSIDE_WEIGHTS": (1.0, 1.0, 1.0, 1.0),  # (*)
         "RPN_POSITIVE_WEIGHT": -1.0,             # (*)
+        # not in the reference: how the RoI sampler consumes numpy's generator (dtt/targets.py): "device" = counts stay on
+        # the GPU, "reference" = the reference's exact draw order (one 8-byte host read per image)
+        "SAMPLER_RNG": "device",
         "USE_ALL_GT": True, "BN_TRAIN": False,
     },
     "TEST": {

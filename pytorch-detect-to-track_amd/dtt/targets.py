@@ -1,15 +1,30 @@
 """Training-time target samplers that sit between the proposal layer and PSRoI pooling
-(SURVEY.md section 8f rank 1).  Tensor code on the device; the random draws consume numpy's global RNG on
-the host in exactly the reference's order, so a seeded run samples the same RoIs.
+(SURVEY.md section 8f rank 1), on the device (csrc/targets.hip through the C ABI; no CPU path).
 
   _ProposalTargetLayer          rpn/proposal_target_layer_cascade.py:20-208
   _TrackingProposalTargetLayer  rpn/tracking_proposal_target_layer.py:20-196
+
+RoI sampling draws from numpy's global generator, as the reference does.  cfg.TRAIN.SAMPLER_RNG selects how:
+  "device"     (default) the host draws, per image, one uniform per candidate + one per output slot WITHOUT looking at
+               the device; the kernel turns them into the reference's selection (a uniform subset of the foreground
+               candidates without replacement, background slots with replacement) -- nothing is read back inside the
+               training step;
+  "reference"  the host reads the two candidate counts of each image (8 bytes) and consumes the generator exactly as
+               the reference (`np.random.permutation(fg)`, `np.random.rand(bg_n)`): for a given seed the sampled RoIs
+               are the reference's, bit for bit (pinned by tests/golden/targets.npz).
 """
+import ctypes
+
 import numpy as np
 import torch
 from torch import nn
 
-from .rpn import bbox_overlaps_batch, bbox_transform_batch
+from . import _lib
+from ._lib import check, ptr, require_gpu, stream_ptr
+
+
+def _f4(v):
+    return (ctypes.c_float * 4)(*[float(x) for x in v])
 
 
 class _ProposalTargetLayer(nn.Module):
@@ -23,62 +38,65 @@ class _ProposalTargetLayer(nn.Module):
             cfg = _cfg
         self._cfg = cfg
         self._num_classes = nclasses
-        T = cfg.TRAIN
-        self.register_buffer("means", torch.tensor(T.BBOX_NORMALIZE_MEANS, dtype=torch.float32), persistent=False)
-        self.register_buffer("stds", torch.tensor(T.BBOX_NORMALIZE_STDS, dtype=torch.float32), persistent=False)
-        self.register_buffer("inside_w", torch.tensor(T.BBOX_INSIDE_WEIGHTS, dtype=torch.float32), persistent=False)
+        self.last_status = None   # int32 (B,) on the device: 1 = an image had neither fg nor bg candidates (the reference raises)
 
     def forward(self, all_rois, gt_boxes, num_boxes):
         T = self._cfg.TRAIN
+        require_gpu(all_rois, gt_boxes)
         dev = gt_boxes.device
-        gt_append = torch.zeros_like(gt_boxes)
-        gt_append[:, :, 1:5] = gt_boxes[:, :, :4]
-        all_rois = torch.cat([all_rois, gt_append], 1)  # gt boxes join the candidates (:42-46)
-        rois_per_image = int(T.BATCH_SIZE / 1)
-        fg_per_image = int(np.round(T.FG_FRACTION * rois_per_image)) or 1
-
-        overlaps = bbox_overlaps_batch(all_rois, gt_boxes[:, :, :5])
-        max_ov, assign = overlaps.max(2)
-        B = overlaps.size(0)
-        labels_all = torch.gather(gt_boxes[:, :, 4], 1, assign)
-        # host side: which candidates to keep (numpy RNG, :137-186)
-        mo = max_ov.detach().cpu().numpy()
-        keep = np.zeros((B, rois_per_image), dtype=np.int64)
-        n_fg = np.zeros((B,), dtype=np.int64)
-        for i in range(B):
-            fg = np.nonzero(mo[i] >= T.FG_THRESH)[0]
-            bg = np.nonzero((mo[i] < T.BG_THRESH_HI) & (mo[i] >= T.BG_THRESH_LO))[0]
-            if fg.size > 0 and bg.size > 0:
-                fg_n = min(fg_per_image, fg.size)
-                fg = fg[np.random.permutation(fg.size)[:fg_n]]
-                bg_n = rois_per_image - fg_n
-                bg = bg[np.floor(np.random.rand(bg_n) * bg.size).astype(np.int64)]
-            elif fg.size > 0:
-                fg = fg[np.floor(np.random.rand(rois_per_image) * fg.size).astype(np.int64)]
-                fg_n, bg = rois_per_image, bg[:0]
-            elif bg.size > 0:
-                bg = bg[np.floor(np.random.rand(rois_per_image) * bg.size).astype(np.int64)]
-                fg_n, fg = 0, fg[:0]
+        all_rois = all_rois.detach().float().contiguous()
+        gt = gt_boxes.detach().float().contiguous()
+        B, R, _ = all_rois.shape
+        G, gs = gt.shape[1], gt.shape[2]
+        N = R + G
+        n_out = int(T.BATCH_SIZE / 1)
+        fg_per_image = int(np.round(T.FG_FRACTION * n_out)) or 1
+        L = _lib.lib()
+        i32 = dict(dtype=torch.int32, device=dev)
+        assign, fg_list, bg_list = (torch.empty((B, N), **i32) for _ in range(3))
+        counts = torch.empty((B, 2), **i32)
+        st = stream_ptr(dev)
+        with torch.cuda.device(dev):
+            check(L.dtt_proposal_target_assign(ptr(all_rois), ptr(gt), B, R, G, gs, float(T.FG_THRESH), float(T.BG_THRESH_HI),
+                                               float(T.BG_THRESH_LO), ptr(assign), ptr(fg_list), ptr(bg_list), ptr(counts), st),
+                  "proposal_target assign")
+            pos = fgn = ufg = ubg = None
+            if getattr(T, "SAMPLER_RNG", "device") == "reference":
+                ch = counts.cpu().numpy()                       # the one host read of this mode
+                pos_h = np.zeros((B, n_out), dtype=np.int32)
+                fgn_h = np.zeros((B,), dtype=np.int32)
+                for i in range(B):                                # proposal_target_layer_cascade.py:137-186
+                    nf, nbg = int(ch[i, 0]), int(ch[i, 1])
+                    if nf > 0 and nbg > 0:
+                        k = min(fg_per_image, nf)
+                        p_fg = np.random.permutation(nf)[:k]
+                        p_bg = np.floor(np.random.rand(n_out - k) * nbg).astype(np.int64)
+                    elif nf > 0:
+                        k, p_fg, p_bg = n_out, np.floor(np.random.rand(n_out) * nf).astype(np.int64), np.zeros((0,), np.int64)
+                    elif nbg > 0:
+                        k, p_fg, p_bg = 0, np.zeros((0,), np.int64), np.floor(np.random.rand(n_out) * nbg).astype(np.int64)
+                    else:
+                        raise ValueError("bg_num_rois = 0 and fg_num_rois = 0, this should not happen!")
+                    pos_h[i] = np.concatenate([p_fg, p_bg])
+                    fgn_h[i] = k
+                pos = torch.from_numpy(pos_h).to(dev)
+                fgn = torch.from_numpy(fgn_h).to(dev)
             else:
-                raise ValueError("bg_num_rois = 0 and fg_num_rois = 0, this should not happen!")
-            keep[i] = np.concatenate([fg, bg])
-            n_fg[i] = fg_n
-        keep_t = torch.from_numpy(keep).to(dev)
-        n_fg_t = torch.from_numpy(n_fg).to(dev)
-        labels = torch.gather(labels_all, 1, keep_t)
-        pos = torch.arange(rois_per_image, device=dev).unsqueeze(0)
-        labels = torch.where(pos < n_fg_t.unsqueeze(1), labels, torch.zeros_like(labels))  # bg labels -> 0 (:193-194)
-        rois = torch.gather(all_rois, 1, keep_t.unsqueeze(2).expand(-1, -1, 5)).clone()
-        rois[:, :, 0] = torch.arange(B, device=dev, dtype=rois.dtype).unsqueeze(1)
-        gt_sel = torch.gather(gt_boxes, 1, torch.gather(assign, 1, keep_t).unsqueeze(2).expand(-1, -1, gt_boxes.size(2)))
-        targets = bbox_transform_batch(rois[:, :, 1:5], gt_sel[:, :, :4])
-        if T.BBOX_NORMALIZE_TARGETS_PRECOMPUTED:
-            targets = (targets - self.means.to(dev)) / self.stds.to(dev)
-        fgmask = (labels > 0).unsqueeze(2).to(targets.dtype)
-        bbox_targets = targets * fgmask
-        inside = self.inside_w.to(dev).view(1, 1, 4) * fgmask
-        outside = (inside > 0).float()
-        return rois, labels, bbox_targets, inside, outside
+                ufg = torch.from_numpy(np.random.rand(B, N)).to(dev)
+                ubg = torch.from_numpy(np.random.rand(B, n_out)).to(dev)
+            f32 = dict(dtype=torch.float32, device=dev)
+            rois = torch.empty((B, n_out, 5), **f32)
+            labels = torch.empty((B, n_out), **f32)
+            targets, inside, outside = (torch.empty((B, n_out, 4), **f32) for _ in range(3))
+            status = torch.empty((B,), **i32)
+            check(L.dtt_proposal_target_sample(ptr(all_rois), ptr(gt), B, R, G, gs, ptr(assign), ptr(fg_list), ptr(bg_list),
+                                               ptr(counts), ptr(pos), ptr(fgn), ptr(ufg), ptr(ubg), n_out, fg_per_image,
+                                               _f4(T.BBOX_NORMALIZE_MEANS), _f4(T.BBOX_NORMALIZE_STDS), _f4(T.BBOX_INSIDE_WEIGHTS),
+                                               int(bool(T.BBOX_NORMALIZE_TARGETS_PRECOMPUTED)), ptr(rois), ptr(labels),
+                                               ptr(targets), ptr(inside), ptr(outside), ptr(status), st),
+                  "proposal_target sample")
+        self.last_status = status
+        return rois, labels, targets, inside, outside
 
 
 class _TrackingProposalTargetLayer(nn.Module):
@@ -94,42 +112,23 @@ class _TrackingProposalTargetLayer(nn.Module):
             from .config import cfg as _cfg
             cfg = _cfg
         self._cfg = cfg
-        T = cfg.TRAIN
-        self.register_buffer("means", torch.tensor(T.BBOX_NORMALIZE_MEANS, dtype=torch.float32), persistent=False)
-        self.register_buffer("stds", torch.tensor(T.BBOX_NORMALIZE_STDS, dtype=torch.float32), persistent=False)
-        self.register_buffer("inside_w", torch.tensor(T.BBOX_INSIDE_WEIGHTS, dtype=torch.float32), persistent=False)
 
     def forward(self, gt_boxes, num_boxes):
+        T = self._cfg.TRAIN
+        require_gpu(gt_boxes)
         dev = gt_boxes.device
-        _, B, G, _ = gt_boxes.shape
-        nb = num_boxes.reshape(2, B).to(dev)
-        idx = torch.arange(G, device=dev).view(1, G)
-        v0 = idx < nb[0].view(B, 1)
-        v1 = idx < nb[1].view(B, 1)
-        id0, id1 = gt_boxes[0, :, :, 5], gt_boxes[1, :, :, 5]
-        corr = (id0.unsqueeze(2) == id1.unsqueeze(1)) & v0.unsqueeze(2) & v1.unsqueeze(1)  # (B, G_t, G_t+tau)
-        has0, has1 = corr.any(2), corr.any(1)
-        ok = has0.any(1) & has1.any(1)
-        big = torch.finfo(gt_boxes.dtype).max
-
-        def packed(frame, has, ids):
-            key = torch.where(has, ids, torch.full_like(ids, big))
-            order = torch.sort(key, dim=1, descending=False, stable=True)[1]
-            g = torch.gather(frame, 1, order.unsqueeze(2).expand(-1, -1, frame.size(2)))
-            keepn = has.sum(1, keepdim=True)
-            return g * (idx < keepn).unsqueeze(2).to(g.dtype)
-
-        r0 = packed(gt_boxes[0], has0, id0) * ok.view(B, 1, 1).to(gt_boxes.dtype)
-        r1 = packed(gt_boxes[1], has1, id1) * ok.view(B, 1, 1).to(gt_boxes.dtype)
-        labels = r0[:, :, 4]
-        rois = torch.zeros((B, G, 5), dtype=gt_boxes.dtype, device=dev)
-        rois[:, :, 0] = torch.arange(B, device=dev, dtype=gt_boxes.dtype).unsqueeze(1)
-        rois[:, :, 1:] = gt_boxes[0, :, :, :4]
-        rois = rois * ok.view(B, 1, 1).to(rois.dtype)
-        targets = bbox_transform_batch(r0[:, :, :4], r1[:, :, :4])
-        if self._cfg.TRAIN.BBOX_NORMALIZE_TARGETS_PRECOMPUTED:
-            targets = (targets - self.means.to(dev)) / self.stds.to(dev)
-        fgmask = (labels > 0).unsqueeze(2).to(targets.dtype)
-        targets = targets * fgmask
-        inside = self.inside_w.to(dev).view(1, 1, 4) * fgmask
-        return rois, labels, targets, inside, (inside > 0).float()
+        gt = gt_boxes.detach().float().contiguous()
+        _, B, G, six = gt.shape
+        if six != 6:
+            raise ValueError("tracking targets need (2, B, G, 6) boxes [x1,y1,x2,y2,cls,track_id]")
+        nb = num_boxes.reshape(2, B).to(device=dev, dtype=torch.int64).contiguous()
+        f32 = dict(dtype=torch.float32, device=dev)
+        rois = torch.empty((B, G, 5), **f32)
+        labels = torch.empty((B, G), **f32)
+        targets, inside, outside = (torch.empty((B, G, 4), **f32) for _ in range(3))
+        with torch.cuda.device(dev):
+            check(_lib.lib().dtt_tracking_target(ptr(gt), ptr(nb), B, G, _f4(T.BBOX_NORMALIZE_MEANS), _f4(T.BBOX_NORMALIZE_STDS),
+                                                 _f4(T.BBOX_INSIDE_WEIGHTS), int(bool(T.BBOX_NORMALIZE_TARGETS_PRECOMPUTED)),
+                                                 ptr(rois), ptr(labels), ptr(targets), ptr(inside), ptr(outside), stream_ptr(dev)),
+                  "tracking_target")
+        return rois, labels, targets, inside, outside

@@ -98,7 +98,7 @@ def test_model_builds_with_reference_checkpoint_layout():
 def test_target_layers_shapes_and_rng():
     from dtt.config import cfg
     from dtt.synth import make_batch
-    from dtt.targets import _ProposalTargetLayer, _TrackingProposalTargetLayer
+    from oracle.targets_oracle import _ProposalTargetLayer, _TrackingProposalTargetLayer
     _, _, gt, nb = make_batch(2, 300, 400, seed=1)
     gtl = gt.permute(1, 0, 2, 3).contiguous()
     nbl = nb.permute(1, 0, 2).contiguous()
@@ -121,10 +121,10 @@ def test_target_layers_shapes_and_rng():
 
 
 def test_target_layers_match_reference_golden():
-    """dtt.targets vs the reference's _ProposalTargetLayer / _TrackingProposalTargetLayer run by
+    """oracle.targets_oracle (the restatement tests/test_gpu_targets.py checks the HIP kernels against) vs the reference's _ProposalTargetLayer / _TrackingProposalTargetLayer run by
     tests/golden/make_golden.py (same numpy seed -> same sampled RoIs)."""
     from dtt.config import cfg, cfg_from_file
-    from dtt.targets import _ProposalTargetLayer, _TrackingProposalTargetLayer
+    from oracle.targets_oracle import _ProposalTargetLayer, _TrackingProposalTargetLayer
     cfg_from_file(os.path.join(ROOT, "cfgs", "res101.yml"))
     g = np.load(os.path.join(ROOT, "tests", "golden", "targets.npz"))
     gt = torch.from_numpy(g["gt_boxes"])
