@@ -74,9 +74,12 @@ int dtt_correlation_forward_strided(float* output, int ob, int oc, int oh, int o
                                     void* workspace, size_t workspace_bytes,
                                     int pad_size, int kernel_size, int max_displacement,
                                     int stride1, int stride2, int corr_type_multiply, void* stream);
-/* kernel_size must be 1 (the only value D&T uses, rfcn.py:58-60).  gradInput1/2 are fully
- * written (no pre-zeroing needed).  For stride1 > 1 this is the mathematically correct gradient;
- * the reference indexes out of bounds there (correlation_cuda_kernel.cu:120-121, 212-213). */
+/* Any kernel_size / strides (D&T itself uses kernel_size 1, rfcn.py:58-60: that case runs on the matrix cores).
+ * gradInput1/2 are fully written (no pre-zeroing needed).  The gradients are the mathematically exact adjoint of
+ * dtt_correlation_forward.  The reference's own backward departs from its forward in two places, which are NOT
+ * reproduced: for stride1 > 1 it indexes gradOutput out of bounds (correlation_cuda_kernel.cu:120-121, 212-213), and for
+ * kernel_size > 1 it sums the outputs whose index lies within kernel_rad of (x - max_displacement) / stride1 (:128-132,
+ * 222-226), i.e. treats the patch of its forward (anchored at its top-left corner, :48-49, 56-63) as centred. */
 int dtt_correlation_backward(const float* gradOutput, int gob, int goc, int goh, int gow,
                              const float* input1, int ic, int ih, int iw,
                              const float* input2,
@@ -304,6 +307,11 @@ int dtt_bias_act_nhwc_inplace(float* x, const float* bias, const float* residual
  * of the Winograd form of the trunk's 3x3 convolutions (faster_rcnn/resnet.py:76-78 `conv3x3`). */
 int dtt_gemm_batched(float* out, const float* a, const float* w, int batch, long rows, int k, int n, void* workspace,
                      size_t workspace_bytes, void* stream);
+/* One-time candidate timing for a shape of dtt_gemm_batched: launches the library's candidates on the caller's operands
+ * (`out` receives the product) and SYNCHRONISES the stream; the winner is remembered per (device, shape).  Call it before
+ * the first dtt_gemm_batched of a shape, outside timed / captured regions.  Without it the first heuristic runs. */
+int dtt_gemm_batched_tune(float* out, const float* a, const float* w, int batch, long rows, int k, int n, void* workspace,
+                          size_t workspace_bytes, void* stream);
 
 /* Winograd transforms for a 3x3, stride-1, padding == dilation convolution on channels-last maps (the reference's
  * faster_rcnn/resnet.py:76-78, 307 are plain nn.Conv2d calls).  m = 2: F(2x2, 3x3), 16 products; m = 4: F(4x4, 3x3), 36
@@ -325,9 +333,15 @@ int dtt_transpose_batched(const float* in, float* out, int batch, int rows, int 
 /* Row-major GEMM with the bottleneck epilogue: out (rows, n) = act(a (rows, k) * w (k, n) + bias[n] (+ residual
  * (rows, n))); residual may be NULL and may alias out.  A library GEMM (hipBLASLt) -- the entry point exists for the
  * epilogue: frozen-BatchNorm shift + `out += residual` + ReLU of faster_rcnn/resnet.py:100-107 in the GEMM itself.
- * workspace: caller-owned scratch for the library (32 MiB is plenty); plans are cached per shape. */
+ * workspace: caller-owned scratch for the library (32 MiB is plenty); plans are cached per (device, shape). */
 int dtt_gemm_bias_act(float* out, const float* a, const float* w, const float* bias, const float* residual,
                       long rows, int k, int n, int relu, void* workspace, size_t workspace_bytes, void* stream);
+/* One-time candidate timing for a shape (and epilogue variant) of dtt_gemm_bias_act: the products go to `scratch` (rows * n
+ * floats owned by the caller), a / w / bias / residual are only read; launches every candidate a few times and
+ * SYNCHRONISES the stream -- the only entry points of this library that do (with dtt_gemm_batched_tune); the hot entry point
+ * above never allocates, frees or synchronises and runs the first heuristic for a shape that was never tuned. */
+int dtt_gemm_tune(const float* a, const float* w, const float* bias, const float* residual, long rows, int k, int n,
+                  int relu, float* scratch, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------- R-FCN 1x1 heads + position-major PSRoI pooling
  * dtt_head_gemm replaces the cuDNN 1x1 convolutions RFCN_cls_net / RFCN_bbox_net / corr_bbox_net

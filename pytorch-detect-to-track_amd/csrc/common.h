@@ -33,6 +33,17 @@ void dtt_set_error(const char* fmt, ...);
 void dtt_prof_begin(const char* tag, hipStream_t stream);
 void dtt_prof_end(const char* tag, hipStream_t stream);
 
+// "hipFuncSetAttribute already applied" flags: function attributes (the dynamic-LDS limit) are per DEVICE, so a
+// process that drives several GPUs needs one flag per device.  Racing first calls merely set the attribute twice.
+struct DttDeviceOnce {
+  bool done[64] = {};
+  bool& here() {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    return done[d & 63];
+  }
+};
+
 static inline int dtt_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // XCD-aware remap of a linear workgroup id (8 XCDs; block b runs on XCD b % 8): gives each XCD a

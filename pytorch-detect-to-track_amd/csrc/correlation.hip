@@ -811,16 +811,22 @@ __global__ __launch_bounds__(64) void corr_fwd_generic(const float* __restrict__
     }
 }
 
-// Backward, kernel_size 1.  One thread per input element; gradients are the mathematically exact
-// adjoint of the forward (the reference's stride1 > 1 indexing is out of bounds, see dtt_hip.h).
-//   gradInput1[n,c,y,x] = 1/C * sum_tc gradOut[n,tc,oy,ox] * in2pad[n,c,y+j2,x+i2],  (oy,ox) = ((y+pad-d)/s1, ..) exact
-//   gradInput2[n,c,y,x] = 1/C * sum_tc gradOut[n,tc,oy,ox] * in1pad[n,c,y-j2,x-i2],  (oy,ox) = ((y+pad-d-j2)/s1, ..) exact
+// Backward, any kernel_size / strides.  One thread per input element; gradients are the mathematically exact adjoint
+// of the forward (see dtt_hip.h for where the reference's own backward departs from its forward).  With the forward
+//   out[n,tc,oy,ox] = 1/(k*k*C) * sum_{c, 0<=j,i<k} in1pad[n,c,oy*s1+d+j, ox*s1+d+i] * in2pad[n,c,oy*s1+d+j+j2, ox*s1+d+i+i2]
+// (padded coordinates, (j2, i2) = displacement tc, d = max_displacement) a padded pixel (yp, xp) of frame 1 is touched by
+// the outputs with oy*s1 in [yp-d-(k-1), yp-d], and one of frame 2 by those with oy*s1 in [yp-d-j2-(k-1), yp-d-j2]:
+//   gradInput1[n,c,y,x] = 1/(k*k*C) * sum_tc in2pad[n,c,yp+j2,xp+i2] * sum_{covering (oy,ox)} gradOut[n,tc,oy,ox]
+//   gradInput2[n,c,y,x] = 1/(k*k*C) * sum_tc in1pad[n,c,yp-j2,xp-i2] * sum_{covering (oy,ox)} gradOut[n,tc,oy,ox]
+__device__ __forceinline__ int floordiv(int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
+__device__ __forceinline__ int ceildiv(int a, int b) { return -floordiv(-a, b); }
+
 __global__ void corr_bwd_simple(const float* __restrict__ gout, const float* __restrict__ in1,
                                 const float* __restrict__ in2, float* __restrict__ g1, float* __restrict__ g2, int B,
-                                int C, int H, int W, int oc, int oh, int ow, int pad, int maxd, int s1, int s2) {
+                                int C, int H, int W, int oc, int oh, int ow, int pad, int ksize, int maxd, int s1, int s2) {
   const long total = (long)B * C * H * W;
-  const int drad = maxd / s2, dsize = 2 * drad + 1;
-  const float nelems = (float)C;
+  const int drad = maxd / s2, dsize = 2 * drad + 1, kext = ksize - 1;
+  const float nelems = (float)(ksize * ksize * C);
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
     const int x = idx % W, y = (idx / W) % H, c = (idx / ((long)W * H)) % C, n = idx / ((long)W * H * C);
     const float* go = gout + (long)n * oc * oh * ow;
@@ -830,14 +836,17 @@ __global__ void corr_bwd_simple(const float* __restrict__ gout, const float* __r
     // ---- input1
     float a1 = 0.f;
     {
-      const int ry = yp - maxd, rx = xp - maxd;
-      if (ry >= 0 && rx >= 0 && ry % s1 == 0 && rx % s1 == 0 && ry / s1 < oh && rx / s1 < ow) {
-        const int oy = ry / s1, ox = rx / s1;
+      const int oy0 = max(ceildiv(yp - maxd - kext, s1), 0), oy1 = min(floordiv(yp - maxd, s1), oh - 1);
+      const int ox0 = max(ceildiv(xp - maxd - kext, s1), 0), ox1 = min(floordiv(xp - maxd, s1), ow - 1);
+      if (oy0 <= oy1 && ox0 <= ox1) {
         for (int tc = 0; tc < oc; ++tc) {
           const int i2 = (tc % dsize - drad) * s2, j2 = (tc / dsize - drad) * s2;
           const int yb = y + j2, xb = x + i2;
           if (yb < 0 || yb >= H || xb < 0 || xb >= W) continue;
-          a1 += go[((long)tc * oh + oy) * ow + ox] * f2[yb * W + xb];
+          float gs = 0.f;
+          for (int oy = oy0; oy <= oy1; ++oy)
+            for (int ox = ox0; ox <= ox1; ++ox) gs += go[((long)tc * oh + oy) * ow + ox];
+          a1 += gs * f2[yb * W + xb];
         }
       }
     }
@@ -845,13 +854,14 @@ __global__ void corr_bwd_simple(const float* __restrict__ gout, const float* __r
     float a2 = 0.f;
     for (int tc = 0; tc < oc; ++tc) {
       const int i2 = (tc % dsize - drad) * s2, j2 = (tc / dsize - drad) * s2;
-      const int ry = yp - maxd - j2, rx = xp - maxd - i2;
-      if (ry < 0 || rx < 0 || ry % s1 != 0 || rx % s1 != 0) continue;
-      const int oy = ry / s1, ox = rx / s1;
-      if (oy >= oh || ox >= ow) continue;
       const int ya = y - j2, xa = x - i2;
       if (ya < 0 || ya >= H || xa < 0 || xa >= W) continue;
-      a2 += go[((long)tc * oh + oy) * ow + ox] * f1[ya * W + xa];
+      const int oy0 = max(ceildiv(yp - maxd - j2 - kext, s1), 0), oy1 = min(floordiv(yp - maxd - j2, s1), oh - 1);
+      const int ox0 = max(ceildiv(xp - maxd - i2 - kext, s1), 0), ox1 = min(floordiv(xp - maxd - i2, s1), ow - 1);
+      float gs = 0.f;
+      for (int oy = oy0; oy <= oy1; ++oy)
+        for (int ox = ox0; ox <= ox1; ++ox) gs += go[((long)tc * oh + oy) * ow + ox];
+      a2 += gs * f1[ya * W + xa];
     }
     g1[idx] = a1 / nelems;
     g2[idx] = a2 / nelems;
@@ -1034,7 +1044,8 @@ template <int NBR, int MINW>
 int launch_bwd(const float* gout, const float* in1, const float* in2, float* g1, float* g2, const FastGeom& g,
                int batch, hipStream_t stream) {
   const size_t lds = bwd_lds_bytes<NBR>();
-  static bool attr = false;
+  static DttDeviceOnce attr_once;
+  bool& attr = attr_once.here();   // the attribute is per device, not per process
   if (!attr) {
     hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(corr_bwd_mfma<NBR, false, MINW>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1123,7 +1134,8 @@ int launch_fast(float* output, long out_batch_stride, long out_ch_stride, long o
   const size_t need = ws_bytes<NBR>(g, batch);
   DTT_REQUIRE(workspace && workspace_bytes >= need, "correlation forward: workspace too small (%zu < %zu)",
               workspace_bytes, need);
-  static bool attr = false;
+  static DttDeviceOnce attr_once;
+  bool& attr = attr_once.here();   // the attribute is per device, not per process
   if (!attr) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(corr_fwd_mfma<NBR, PIPE, MINW>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)K::LDS);
@@ -1143,7 +1155,8 @@ int launch_fast(float* output, long out_batch_stride, long out_ch_stride, long o
   // than the register-staged one)
   if (NBR <= 5 && g.s == 1 && g.C % kGKc == 0 && g.c_per_split % kGKc == 0 && g.W >= 4 && (((g.origin - g.R) % 4) + 4) % 4 == 0) {
     using G = GCfg<NBR>;
-    static bool gattr = false;
+    static DttDeviceOnce gattr_once;
+  bool& gattr = gattr_once.here();   // the attribute is per device, not per process
     if (!gattr) {
       hipError_t e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(corr_fwd_glds<NBR, MINW>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
@@ -1292,7 +1305,6 @@ extern "C" int dtt_correlation_backward(const float* gradOutput, int gob, int go
   (void)corr_type_multiply;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   DTT_REQUIRE(gradOutput && input1 && input2 && gradInput1 && gradInput2, "correlation backward: null pointer");
-  DTT_REQUIRE(kernel_size == 1, "correlation backward: only kernel_size == 1 is supported (got %d)", kernel_size);
   int eoc, eoh, eow;
   if (!dtt_correlation_output_shape(ic, ih, iw, pad_size, kernel_size, max_displacement, stride1, stride2, &eoc, &eoh, &eow))
     return 0;
@@ -1305,7 +1317,7 @@ extern "C" int dtt_correlation_backward(const float* gradOutput, int gob, int go
   }
   const long total = (long)gob * ic * ih * iw;
   hipLaunchKernelGGL(corr_bwd_simple, dim3(min(dtt_cdiv(total, 256), 1 << 20)), dim3(256), 0, stream, gradOutput,
-                     input1, input2, gradInput1, gradInput2, gob, ic, ih, iw, goc, goh, gow, pad_size,
+                     input1, input2, gradInput1, gradInput2, gob, ic, ih, iw, goc, goh, gow, pad_size, kernel_size,
                      max_displacement, stride1, stride2);
   DTT_CHECK_LAUNCH("corr_bwd_simple");
   return 1;

@@ -22,7 +22,7 @@ struct Plan {
   hipblasLtMatmulDesc_t desc = nullptr;
   hipblasLtMatrixLayout_t la = nullptr, lb = nullptr, lc = nullptr;
   hipblasLtMatmulHeuristicResult_t heur;
-  bool ok = false;
+  bool ok = false, tuned = false;
 };
 
 std::mutex g_mu;
@@ -31,10 +31,36 @@ std::map<std::tuple<int, long, int, int, int, int>, Plan> g_plans;              
 
 }  // namespace
 
+namespace {
+// tune_scratch != NULL: time the library's candidates once on the caller's operands (products go to tune_scratch, rows * n
+// floats; synchronises the stream) and remember the winner for this shape.  NULL: never allocates, never synchronises --
+// a shape that was not tuned runs the library's first heuristic.
+int gemm_bias_act_impl(float* out, const float* a, const float* w, const float* bias, const float* residual, long rows,
+                       int k, int n, int relu, void* workspace, size_t workspace_bytes, hipStream_t stream,
+                       float* tune_scratch, bool run);
+}
+
 extern "C" int dtt_gemm_bias_act(float* out, const float* a, const float* w, const float* bias,
                                  const float* residual, long rows, int k, int n, int relu, void* workspace,
                                  size_t workspace_bytes, void* stream_) {
-  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  return gemm_bias_act_impl(out, a, w, bias, residual, rows, k, n, relu, workspace, workspace_bytes,
+                            static_cast<hipStream_t>(stream_), nullptr, true);
+}
+
+// One-time candidate timing for a shape of dtt_gemm_bias_act (call it before the first product of that shape, outside
+// any timed or captured region: it launches every candidate a few times and synchronises the stream).  scratch: rows * n
+// floats owned by the caller; a / w / bias / residual are only read.
+extern "C" int dtt_gemm_tune(const float* a, const float* w, const float* bias, const float* residual, long rows, int k,
+                             int n, int relu, float* scratch, void* workspace, size_t workspace_bytes, void* stream_) {
+  DTT_REQUIRE(scratch, "gemm_tune: scratch (rows * n floats) is required");
+  return gemm_bias_act_impl(scratch, a, w, bias, residual, rows, k, n, relu, workspace, workspace_bytes,
+                            static_cast<hipStream_t>(stream_), scratch, false);
+}
+
+namespace {
+int gemm_bias_act_impl(float* out, const float* a, const float* w, const float* bias, const float* residual, long rows,
+                       int k, int n, int relu, void* workspace, size_t workspace_bytes, hipStream_t stream,
+                       float* tune_scratch, bool run) {
   DTT_REQUIRE(out && a && w && bias, "gemm_bias_act: null pointer");
   DTT_REQUIRE(rows > 0 && k > 0 && n > 0, "gemm_bias_act: bad shape");
   int dev = 0;
@@ -43,6 +69,11 @@ extern "C" int dtt_gemm_bias_act(float* out, const float* a, const float* w, con
   hipblasLtHandle_t& handle = g_handles[dev];
   if (!handle) DTT_REQUIRE(hipblasLtCreate(&handle) == HIPBLAS_STATUS_SUCCESS, "gemm_bias_act: hipblasLtCreate failed");
   Plan& p = g_plans[std::make_tuple(dev, rows, k, n, relu, residual ? 1 : 0)];
+  if (p.ok && tune_scratch && !p.tuned) {   // built from the first heuristic earlier: redo the selection with timing
+    hipblasLtMatmulDescDestroy(p.desc);
+    hipblasLtMatrixLayoutDestroy(p.la); hipblasLtMatrixLayoutDestroy(p.lb); hipblasLtMatrixLayoutDestroy(p.lc);
+    p = Plan();
+  }
   if (!p.ok) {
     DTT_REQUIRE(hipblasLtMatmulDescCreate(&p.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F) == HIPBLAS_STATUS_SUCCESS,
                 "gemm_bias_act: desc");
@@ -70,7 +101,7 @@ extern "C" int dtt_gemm_bias_act(float* out, const float* a, const float* w, con
     static hipblasLtMatmulHeuristicResult_t cand[kMaxCand];  // under g_mu
     int found = 0;
     const char* tune_env = getenv("DTT_GEMM_AUTOTUNE");
-    const bool tune = !(tune_env && tune_env[0] == '0');
+    const bool tune = tune_scratch && !(tune_env && tune_env[0] == '0');
     const hipblasStatus_t st = hipblasLtMatmulAlgoGetHeuristic(handle, p.desc, p.la, p.lb, p.lc, p.lc, pref,
                                                                tune ? kMaxCand : 1, cand, &found);
     hipblasLtMatmulPreferenceDestroy(pref);
@@ -78,10 +109,9 @@ extern "C" int dtt_gemm_bias_act(float* out, const float* a, const float* w, con
                 k, n);
     int best = 0;
     if (found > 1) {
-      float* scratch = nullptr;
+      float* scratch = tune_scratch;
       hipEvent_t e0 = nullptr, e1 = nullptr;
-      if (hipMalloc(&scratch, (size_t)rows * n * sizeof(float)) == hipSuccess && hipEventCreate(&e0) == hipSuccess &&
-          hipEventCreate(&e1) == hipSuccess) {
+      if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
         const float alpha = 1.f, beta = residual ? 1.f : 0.f;
         const float* c = residual ? residual : scratch;
         float best_ms = 1e30f;
@@ -104,14 +134,15 @@ extern "C" int dtt_gemm_bias_act(float* out, const float* a, const float* w, con
       (void)hipGetLastError();
       if (e0) (void)hipEventDestroy(e0);
       if (e1) (void)hipEventDestroy(e1);
-      if (scratch) (void)hipFree(scratch);
       if (getenv("DTT_GEMM_AUTOTUNE_VERBOSE"))
         fprintf(stderr, "[dtt] gemm %ld x %d x %d relu=%d res=%d: %d candidates, picked #%d\n", rows, k, n, relu,
                 residual ? 1 : 0, found, best);
     }
     p.heur = cand[best];
     p.ok = true;
+    p.tuned = tune_scratch != nullptr;
   }
+  if (!run) return 1;
   DTT_REQUIRE(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias)) ==
                   HIPBLAS_STATUS_SUCCESS, "gemm_bias_act: bias pointer");
   DTT_REQUIRE(p.heur.workspaceSize <= (workspace ? workspace_bytes : 0), "gemm_bias_act: workspace too small (%zu < %zu)",
@@ -123,6 +154,7 @@ extern "C" int dtt_gemm_bias_act(float* out, const float* a, const float* w, con
   DTT_REQUIRE(st == HIPBLAS_STATUS_SUCCESS, "gemm_bias_act: hipblasLtMatmul failed (%d)", (int)st);
   return 1;
 }
+}  // namespace
 
 // Strided-batched row-major GEMM without epilogue: out[b] (rows, n) = a[b] (rows, k) * w[b] (k, n), operands packed
 // back to back (the 16 products of a Winograd F(2x2, 3x3) convolution, csrc/winograd.hip).  Same transposed column-major
@@ -131,9 +163,25 @@ namespace {
 std::map<std::tuple<int, int, long, int, int>, Plan> g_batched_plans;   // (device, batch, rows, k, n)
 }
 
+namespace {
+int gemm_batched_impl(float* out, const float* a, const float* w, int batch, long rows, int k, int n, void* workspace,
+                      size_t workspace_bytes, hipStream_t stream, bool tune_now);
+}
+
 extern "C" int dtt_gemm_batched(float* out, const float* a, const float* w, int batch, long rows, int k, int n,
                                 void* workspace, size_t workspace_bytes, void* stream_) {
-  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  return gemm_batched_impl(out, a, w, batch, rows, k, n, workspace, workspace_bytes, static_cast<hipStream_t>(stream_), false);
+}
+
+// One-time candidate timing for a shape of dtt_gemm_batched (synchronises the stream; `out` receives the product).
+extern "C" int dtt_gemm_batched_tune(float* out, const float* a, const float* w, int batch, long rows, int k, int n,
+                                     void* workspace, size_t workspace_bytes, void* stream_) {
+  return gemm_batched_impl(out, a, w, batch, rows, k, n, workspace, workspace_bytes, static_cast<hipStream_t>(stream_), true);
+}
+
+namespace {
+int gemm_batched_impl(float* out, const float* a, const float* w, int batch, long rows, int k, int n, void* workspace,
+                      size_t workspace_bytes, hipStream_t stream, bool tune_now) {
   DTT_REQUIRE(out && a && w, "gemm_batched: null pointer");
   DTT_REQUIRE(batch > 0 && rows > 0 && k > 0 && n > 0, "gemm_batched: bad shape");
   int dev = 0;
@@ -144,6 +192,11 @@ extern "C" int dtt_gemm_batched(float* out, const float* a, const float* w, int 
   const uint64_t ws = workspace ? workspace_bytes : 0;
   const float alpha = 1.f, beta = 0.f;
   Plan& p = g_batched_plans[std::make_tuple(dev, batch, rows, k, n)];
+  if (p.ok && tune_now && !p.tuned) {
+    hipblasLtMatmulDescDestroy(p.desc);
+    hipblasLtMatrixLayoutDestroy(p.la); hipblasLtMatrixLayoutDestroy(p.lb); hipblasLtMatrixLayoutDestroy(p.lc);
+    p = Plan();
+  }
   if (!p.ok) {
     DTT_REQUIRE(hipblasLtMatmulDescCreate(&p.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F) == HIPBLAS_STATUS_SUCCESS,
                 "gemm_batched: desc");
@@ -170,7 +223,7 @@ extern "C" int dtt_gemm_batched(float* out, const float* a, const float* w, int 
     static hipblasLtMatmulHeuristicResult_t cand[kMaxCand];  // under g_mu
     int found = 0;
     const char* tune_env = getenv("DTT_GEMM_AUTOTUNE");
-    const bool tune = !(tune_env && tune_env[0] == '0');
+    const bool tune = tune_now && !(tune_env && tune_env[0] == '0');
     const hipblasStatus_t st = hipblasLtMatmulAlgoGetHeuristic(handle, p.desc, p.la, p.lb, p.lc, p.lc, pref,
                                                                tune ? kMaxCand : 1, cand, &found);
     hipblasLtMatmulPreferenceDestroy(pref);
@@ -204,6 +257,7 @@ extern "C" int dtt_gemm_batched(float* out, const float* a, const float* w, int 
     }
     p.heur = cand[best];
     p.ok = true;
+    p.tuned = tune_now;
   }
   DTT_REQUIRE(p.heur.workspaceSize <= ws, "gemm_batched: workspace too small (%zu < %zu)", (size_t)ws,
               (size_t)p.heur.workspaceSize);
@@ -212,3 +266,4 @@ extern "C" int dtt_gemm_batched(float* out, const float* a, const float* w, int 
   DTT_REQUIRE(st == HIPBLAS_STATUS_SUCCESS, "gemm_batched: hipblasLtMatmul failed (%d)", (int)st);
   return 1;
 }
+}  // namespace

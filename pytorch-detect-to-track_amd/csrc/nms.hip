@@ -267,7 +267,8 @@ int dtt_nms_batched_launch(const float* boxes, int boxes_dim, long box_batch_str
   DTT_REQUIRE(boxes_dim >= 4, "nms: boxes_dim must be >= 4 (got %d)", boxes_dim);
   const size_t lds = sweep_lds_bytes(cb);
   DTT_REQUIRE(lds <= 160 * 1024, "nms: %d boxes exceed the LDS-resident sweep state (%zu B)", n_max, lds);
-  static bool attr_set = false;
+  static DttDeviceOnce attr_set_once;
+  bool& attr_set = attr_set_once.here();   // the attribute is per device, not per process
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(nms_sweep_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

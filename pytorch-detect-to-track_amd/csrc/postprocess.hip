@@ -175,7 +175,8 @@ extern "C" int dtt_class_nms(const float* scores, const float* boxes, int images
   DTT_REQUIRE(num_rois <= kMaxR, "class_nms: at most %d RoIs per image (got %d)", kMaxR, num_rois);
   const int P = next_pow2(num_rois), W = P / 64;
   const size_t lds = (size_t)P * 8 + (size_t)P * 16 + (size_t)P * W * 8 + (size_t)P * 2 + 16;
-  static bool attr = false;
+  static DttDeviceOnce attr_once;
+  bool& attr = attr_once.here();   // the attribute is per device, not per process
   if (!attr) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(class_nms_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -255,7 +255,8 @@ extern "C" int dtt_proposal_forward(const float* cls_prob, const float* bbox_pre
   int* num_ws = reinterpret_cast<int*>(w);
 
   const size_t lds = (size_t)g.P * 8 + (16 + 8) * 4;
-  static bool attr = false;
+  static DttDeviceOnce attr_once;
+  bool& attr = attr_once.here();   // the attribute is per device, not per process
   if (!attr) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(proposal_select_sort<true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

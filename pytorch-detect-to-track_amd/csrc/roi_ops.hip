@@ -406,7 +406,8 @@ extern "C" int dtt_roi_align_forward_planes(const float* bottom_data, float spat
   if (lds > 150 * 1024)   // planes do not fit LDS: thread-per-output path
     return dtt_roi_align_forward(bottom_data, spatial_scale, num_rois, height, width, channels, aligned_height,
                                  aligned_width, bottom_rois, top_data, pool_mode, stream);
-  static bool attr = false;
+  static DttDeviceOnce attr_once;
+  bool& attr = attr_once.here();   // the attribute is per device, not per process
   if (!attr) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(roi_align_planes),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);  // + static list_n

@@ -236,7 +236,8 @@ extern "C" int dtt_tube_link(const float* dets, int det_stride, const int* n, co
   d.P = problems; d.F = frames; d.T = T; d.Nmax = max_dets; d.Mmax = trk ? max_tracklets : 1; d.K = max_per_image;
   d.det_stride = det_stride;
   unsigned* bonus = static_cast<unsigned*>(workspace);
-  static bool attr = false;
+  static DttDeviceOnce attr_once;
+  bool& attr = attr_once.here();   // the attribute is per device, not per process
   if (!attr) {
     hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(tube_frame_nms_kernel),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

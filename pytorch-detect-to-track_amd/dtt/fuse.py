@@ -252,6 +252,7 @@ def bias_act_nhwc_(y2d, bias, relu=True, residual2d=None):
 
 
 _GEMM_WS = {}
+_GEMM_TUNED = set()
 
 
 def gemm_bias_act_(out2d, a2d, wt, bias, residual2d=None, relu=True):
@@ -263,6 +264,16 @@ def gemm_bias_act_(out2d, a2d, wt, bias, residual2d=None, relu=True):
     if ws is None:
         ws = _GEMM_WS[dev] = torch.empty(32 << 20, dtype=torch.uint8, device=dev)
     L = _lib.lib()
+    key = (dev, a2d.shape[0], a2d.shape[1], wt.shape[1], bool(relu), residual2d is not None)
+    if key not in _GEMM_TUNED:
+        # first product of this shape: let the library time its candidates on these operands (explicit, synchronising
+        # entry point; the hot one below never allocates or waits)
+        _GEMM_TUNED.add(key)
+        scratch = torch.empty((a2d.shape[0], wt.shape[1]), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            check(L.dtt_gemm_tune(ptr(a2d), ptr(wt), ptr(bias), ptr(residual2d) if residual2d is not None else None,
+                                  a2d.shape[0], a2d.shape[1], wt.shape[1], int(relu), ptr(scratch), ptr(ws), ws.numel(),
+                                  stream_ptr(dev)), "gemm_tune")
     with torch.cuda.device(dev):
         check(L.dtt_gemm_bias_act(ptr(out2d), ptr(a2d), ptr(wt), ptr(bias), ptr(residual2d) if residual2d is not None else None,
                                   a2d.shape[0], a2d.shape[1], wt.shape[1], int(relu), ptr(ws), ws.numel(),
@@ -358,6 +369,10 @@ def winograd_conv3x3_nhwc(x, u, bias, dilation=1, relu=True, m=2):
     st = stream_ptr(dev)
     with torch.cuda.device(dev):
         check(L.dtt_winograd_input_transform(ptr(x), ptr(v), n, h, w, c, dilation, m, st), "winograd input transform")
+        bkey = (dev, "batched", t2, tiles, c, k)
+        if bkey not in _GEMM_TUNED:
+            _GEMM_TUNED.add(bkey)
+            check(L.dtt_gemm_batched_tune(ptr(mm), ptr(v), ptr(u), t2, tiles, c, k, ptr(ws), ws.numel(), st), "gemm_batched_tune")
         check(L.dtt_gemm_batched(ptr(mm), ptr(v), ptr(u), t2, tiles, c, k, ptr(ws), ws.numel(), st), "gemm_batched")
         check(L.dtt_winograd_output_transform(ptr(mm), ptr(bias), ptr(y), n, h, w, k, dilation, m, int(relu), st),
               "winograd output transform")

@@ -131,18 +131,22 @@ class _AnchorTargetLayer(nn.Module):
     def forward(self, input):
         rpn_cls_score, gt_boxes, im_info, _num_boxes = input
         T = self._cfg.TRAIN
-        if T.RPN_POSITIVE_WEIGHT >= 0:
-            raise NotImplementedError("only uniform RPN example weighting (RPN_POSITIVE_WEIGHT < 0) is supported; "
-                                      "the reference's other branch never defines the weights (:157-159)")
+        if T.RPN_POSITIVE_WEIGHT >= 0 and not (0 < T.RPN_POSITIVE_WEIGHT < 1):
+            raise AssertionError("RPN_POSITIVE_WEIGHT must be negative (uniform weighting) or in (0, 1)")   # :149-150
         return anchor_target_forward(gt_boxes, im_info, self._anchors, rpn_cls_score.size(2), rpn_cls_score.size(3),
                                      self._feat_stride, T.RPN_BATCHSIZE, T.RPN_FG_FRACTION, T.RPN_NEGATIVE_OVERLAP,
                                      T.RPN_POSITIVE_OVERLAP, T.RPN_CLOBBER_POSITIVES,
-                                     T.RPN_BBOX_INSIDE_WEIGHTS[0])
+                                     T.RPN_BBOX_INSIDE_WEIGHTS[0], positive_weight=T.RPN_POSITIVE_WEIGHT)
 
 
 def anchor_target_forward(gt_boxes, im_info, anchors, height, width, feat_stride, rpn_batchsize=256,
                           fg_fraction=0.5, negative_overlap=0.3, positive_overlap=0.7, clobber_positives=False,
-                          inside_weight=1.0, rng=np.random):
+                          inside_weight=1.0, rng=np.random, positive_weight=-1.0):
+    """positive_weight < 0: every sampled anchor weighs 1 / num_examples (anchor_target_layer.py:143-147).  In (0, 1): the
+    branch the reference asserts on but never finishes (:148-150 leave positive_weights / negative_weights undefined, a
+    NameError at :152) is completed the way the py-faster-rcnn layer it was ported from defines it: positives share
+    `positive_weight`, negatives 1 - positive_weight, i.e. p / num_positives and (1 - p) / num_negatives -- counted, like
+    num_examples, on the LAST image of the batch (:144 `labels[i]`)."""
     require_gpu(gt_boxes)
     dev = gt_boxes.device
     gt = gt_boxes.detach()[:, :, :5].float().contiguous()
@@ -178,12 +182,17 @@ def anchor_target_forward(gt_boxes, im_info, anchors, height, width, feat_stride
             after = [(int(c[0]), int(c[1])) for c in counts_h]
         num_examples = after[B - 1][0] + after[B - 1][1]  # LAST image only (anchor_target_layer.py:154)
         w = float(np.float32(1.0) / np.float32(num_examples)) if num_examples > 0 else math.inf
+        w_pos = w_neg = w
+        if positive_weight >= 0:
+            n_pos, n_neg = after[B - 1]
+            w_pos = float(np.float32(positive_weight) / np.float32(n_pos)) if n_pos > 0 else math.inf
+            w_neg = float(np.float32(1.0 - positive_weight) / np.float32(n_neg)) if n_neg > 0 else math.inf
         labels_out = torch.empty((B, 1, A * height, width), dtype=torch.float32, device=dev)
         targets = torch.empty((B, 4 * A, height, width), dtype=torch.float32, device=dev)
         inside = torch.empty_like(targets)
         outside = torch.empty_like(targets)
         check(L.dtt_anchor_target_finish(ptr(gt), im_h0, im_w0, ptr(anchors), ptr(labels), ptr(argmax), B, G, A,
-                                         height, width, int(feat_stride), float(inside_weight), w, w,
+                                         height, width, int(feat_stride), float(inside_weight), w_pos, w_neg,
                                          ptr(labels_out), ptr(targets), ptr(inside), ptr(outside), stream_ptr(dev)),
               "anchor_target finish")
     return [labels_out, targets, inside, outside]

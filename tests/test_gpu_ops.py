@@ -185,6 +185,54 @@ def test_correlation_backward(dev, case):
     np.testing.assert_allclose(t2.grad.cpu().numpy(), g2, rtol=0, atol=1e-4)
 
 
+def _corr_autograd_f64(x1, x2, pad, k, d, s1, s2):
+    """Independent formulation of the forward (correlation_cuda_kernel.cu:34-106: k x k patches anchored at their top-left
+    corner (oy*s1 + d, ox*s1 + d) in padded coordinates, displaced by multiples of s2, mean over k*k*C) in float64 torch
+    ops, so that autograd supplies both gradients."""
+    import torch.nn.functional as F
+    B, C, H, W = x1.shape
+    r = d // s2
+    p1, p2 = F.pad(x1, (pad,) * 4), F.pad(F.pad(x2, (pad,) * 4), (d,) * 4)   # second pad: every displaced window exists
+    pH, pW = H + 2 * pad, W + 2 * pad
+    krad = (k - 1) // 2
+    oh = int(np.ceil((pH - 2 * (krad + d)) / s1)); ow = int(np.ceil((pW - 2 * (krad + d)) / s1))
+    ys = torch.arange(oh) * s1 + d; xs = torch.arange(ow) * s1 + d
+    out = []
+    for tj in range(-r, r + 1):
+        for ti in range(-r, r + 1):
+            acc = 0
+            for j in range(k):
+                for i in range(k):
+                    a = p1[:, :, (ys + j)[:, None], (xs + i)[None, :]]
+                    b = p2[:, :, (ys + j + tj * s2 + d)[:, None], (xs + i + ti * s2 + d)[None, :]]
+                    acc = acc + (a * b).sum(1)
+            out.append(acc / (k * k * C))
+    return torch.stack(out, 1)
+
+
+@pytest.mark.parametrize("case", [(1, 6, 12, 13, 4, 3, 4, 1, 2), (2, 5, 11, 9, 3, 3, 2, 1, 1), (1, 4, 14, 15, 6, 5, 4, 2, 2),
+                                  (1, 7, 10, 12, 2, 1, 2, 2, 1), (1, 3, 9, 9, 4, 3, 4, 2, 1)])
+def test_correlation_backward_any_kernel_size_is_the_exact_adjoint(dev, case):
+    """kernel_size > 1 and stride1 > 1 (where the reference's own backward departs from its forward, see include/dtt_hip.h):
+    the HIP forward equals the independent float64 formulation and both HIP gradients equal its autograd gradients."""
+    from dtt.ops import Correlation
+    B, C, H, W, pad, k, d, s1, s2 = case
+    rng = np.random.RandomState(sum(case) + 7)
+    x1 = rng.normal(size=(B, C, H, W)).astype(np.float32)
+    x2 = rng.normal(size=(B, C, H, W)).astype(np.float32)
+    a1, a2 = torch.from_numpy(x1).double().requires_grad_(True), torch.from_numpy(x2).double().requires_grad_(True)
+    ref = _corr_autograd_f64(a1, a2, pad, k, d, s1, s2)
+    t1, t2 = cu(x1, dev).requires_grad_(True), cu(x2, dev).requires_grad_(True)
+    out = Correlation(pad, k, d, s1, s2)(t1, t2)
+    assert tuple(out.shape) == tuple(ref.shape)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), atol=1e-5)
+    gout = rng.normal(size=tuple(out.shape)).astype(np.float32)
+    out.backward(cu(gout, dev))
+    ref.backward(torch.from_numpy(gout).double())
+    np.testing.assert_allclose(t1.grad.cpu().numpy(), a1.grad.numpy(), atol=1e-5)
+    np.testing.assert_allclose(t2.grad.cpu().numpy(), a2.grad.numpy(), atol=1e-5)
+
+
 def test_correlation_into_concat_slice(dev):
     from dtt.ops import correlation_forward_into
     rng = np.random.RandomState(4)
@@ -379,6 +427,38 @@ def test_anchor_target_vs_oracle_bit_exact(dev):
                                 torch.from_numpy(base).float(), H, W, 16)
     for a, b in zip(got, ref):
         np.testing.assert_array_equal(a.cpu().numpy(), b)
+
+
+def test_anchor_target_positive_weight(dev):
+    """cfg.TRAIN.RPN_POSITIVE_WEIGHT in (0, 1) (anchor_target_layer.py:148-152; see dtt.rpn.anchor_target_forward for how
+    the reference's unfinished branch is completed): labels / targets / inside weights as with uniform weighting, outside
+    weights p / #positives on positives and (1 - p) / #negatives on negatives, counted on the last image."""
+    from dtt.rpn import anchor_target_forward, generate_anchors
+    rng = np.random.RandomState(3)
+    B, H, W = 2, 19, 32
+    base = torch.from_numpy(generate_anchors(scales=(4, 8, 16, 32))).float()
+    A = base.shape[0]
+    gt = np.zeros((B, 20, 5), np.float32)
+    for b in range(B):
+        for i in range(3 + b):
+            x1, y1 = rng.uniform(0, 350), rng.uniform(0, 180)
+            gt[b, i] = [x1, y1, x1 + rng.uniform(40, 150), y1 + rng.uniform(40, 110), 1 + i]
+    info = torch.tensor([[H * 16.0, W * 16.0, 1.0]] * B)
+    np.random.seed(5)
+    uni = anchor_target_forward(cu(gt, dev), info, base, H, W, 16)
+    np.random.seed(5)
+    p = 0.3
+    wtd = anchor_target_forward(cu(gt, dev), info, base, H, W, 16, positive_weight=p)
+    for a, b in zip(uni[:3], wtd[:3]):
+        assert torch.equal(a, b)
+    labels = wtd[0].view(B, A, H, W)                                   # (B, 1, A*H, W) -> anchor-major
+    n_pos, n_neg = int((labels[B - 1] == 1).sum()), int((labels[B - 1] == 0).sum())
+    assert n_pos > 0 and n_neg > 0
+    out_w = wtd[3].view(B, A, 4, H, W)
+    pos = (labels == 1).unsqueeze(2).expand_as(out_w)
+    neg = (labels == 0).unsqueeze(2).expand_as(out_w)
+    assert torch.all(out_w[pos] == np.float32(p) / np.float32(n_pos)) and torch.all(out_w[neg] == np.float32(1 - p) / np.float32(n_neg))
+    assert torch.all(out_w[~(pos | neg)] == 0)
 
 
 # ------------------------------------------------------------------------ test-time per-class NMS
