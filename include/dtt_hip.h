@@ -74,6 +74,22 @@ int dtt_correlation_forward_strided(float* output, int ob, int oc, int oh, int o
                                     void* workspace, size_t workspace_bytes,
                                     int pad_size, int kernel_size, int max_displacement,
                                     int stride1, int stride2, int corr_type_multiply, void* stream);
+/* The same forward on CHANNELS-LAST inputs: input1 / input2 are (ob, ih, iw, ic) row-major, i.e. what the reference's own
+ * kernel reads after its `channels_first` repack (correlation_cuda_kernel.cu:10-32, 296-340) -- callers whose trunk is
+ * channels-last skip both that repack and the NHWC -> NCHW hand-over.  Output addressing as above.  One launch per op (per
+ * sub-window for 8 < max_displacement / stride <= 16): the channel slices of a tile are reduced in-launch by its last
+ * arriver (in slice order: deterministic).  Supported: kernel_size 1, stride1 == stride2 = s, pad and displacement
+ * multiples of s, ic % 16 == 0, max_displacement / s <= 8 or in {12, 16}; 16-byte aligned inputs.  workspace: caller-owned,
+ * dtt_correlation_nhwc_workspace_bytes(...) bytes (tickets + one slab per channel slice); its first bytes are cleared by a
+ * stream-ordered memset on every call. */
+size_t dtt_correlation_nhwc_workspace_bytes(int batch, int ic, int ih, int iw, int pad_size, int kernel_size,
+                                            int max_displacement, int stride1, int stride2);
+int dtt_correlation_forward_nhwc(float* output, int ob, int oc, int oh, int ow, long out_batch_stride,
+                                 long out_channel_stride, long out_pixel_stride,
+                                 const float* input1, int ic, int ih, int iw, const float* input2,
+                                 void* workspace, size_t workspace_bytes,
+                                 int pad_size, int kernel_size, int max_displacement,
+                                 int stride1, int stride2, void* stream);
 /* Any kernel_size / strides (D&T itself uses kernel_size 1, rfcn.py:58-60: that case runs on the matrix cores).
  * gradInput1/2 are fully written (no pre-zeroing needed).  The gradients are the mathematically exact adjoint of
  * dtt_correlation_forward.  The reference's own backward departs from its forward in two places, which are NOT

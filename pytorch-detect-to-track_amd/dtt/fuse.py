@@ -505,9 +505,10 @@ class FusedTrunkNHWC:
         top = self.top.act(feats[3])
         self.rpn_conv1 = _to_nchw(self.rpn_conv.act(top))
         if self.pm_heads:
-            # the hand-written heads read the channels-last rows directly; nothing downstream needs `top` in NCHW
+            # the position-major tail reads channels-last memory directly (head GEMM over the `top` rows, channels-last
+            # correlation kernel over conv3 / conv4 / conv5): no layout hand-over at all
             self.top_rows, self.top_hw = _rows(top), (top.shape[2], top.shape[3])
-            return _to_nchw(feats[1]), _to_nchw(feats[2]), _to_nchw(feats[3]), top
+            return feats[1], feats[2], feats[3], top
         return _to_nchw(feats[1]), _to_nchw(feats[2]), _to_nchw(feats[3]), _to_nchw(top)
 
 

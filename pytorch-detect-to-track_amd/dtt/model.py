@@ -247,7 +247,7 @@ class _RFCN(nn.Module):
         every image (`dtt_head_gemm`), lanes = classes PSRoI pooling + vote (`dtt_psroi_pm_forward`), the tracking
         head's input rows assembled in place (box-delta columns copied, correlations written by their reduce kernels)."""
         from .heads import head_gemm, psroi_pm
-        from .ops import correlation_forward_rows
+        from .ops import correlation_forward_nhwc, correlation_forward_rows
         top_rows, (H, W) = fused.top_rows, fused.top_hw
         fused.top_rows = None
         cur = torch.cuda.current_stream(dev)
@@ -266,8 +266,13 @@ class _RFCN(nn.Module):
                 col += oc
             assert col == pm.trk_in, "tracking feature width %d != corr_bbox_net input %d" % (col, pm.trk_in)
             for l, f, c0 in reversed(jobs):   # largest first (conv5, conv4, conv3): it fits beside the select / sort kernel
-                correlation_forward_rows(rows, c0, f[:B].contiguous(), f[B:2 * B].contiguous(), l.pad_size, l.kernel_size,
-                                         l.max_displacement, l.stride1, l.stride2, l.corr_multiply)
+                if f.is_contiguous(memory_format=torch.channels_last) and not f.is_contiguous():
+                    # channels-last trunk maps: the single-launch channels-last kernel, no transposes
+                    correlation_forward_nhwc(f[:B], f[B:2 * B], l.pad_size, l.kernel_size, l.max_displacement, l.stride1,
+                                             l.stride2, rows=rows, col=c0)
+                else:
+                    correlation_forward_rows(rows, c0, f[:B].contiguous(), f[B:2 * B].contiguous(), l.pad_size, l.kernel_size,
+                                             l.max_displacement, l.stride1, l.stride2, l.corr_multiply)
         det = head_gemm(top_rows, pm.det)                          # (n_legs*B*H*W, stride)
         if not single_frame:
             off, nb = pm.loc_head["offset"], pm.n_box

@@ -92,6 +92,40 @@ def correlation_forward_rows(rows, col, input1, input2, pad_size, kernel_size, m
     return rows
 
 
+def correlation_forward_nhwc(input1, input2, pad_size, kernel_size, max_displacement, stride1, stride2, rows=None, col=0):
+    """Correlation of two channels-last (B, C, H, W)-shaped maps (memory order B, H, W, C -- the channels-last trunk's
+    own layout) without any layout change in front of the op (`dtt_correlation_forward_nhwc`).
+    rows is None: returns the reference's (B, D*D, oh, ow) NCHW tensor.  Otherwise writes columns [col, col + D*D) of
+    `rows`, a position-major (B*oh*ow, ld) matrix (the tracking head's GEMM input, dtt.heads)."""
+    require_gpu(input1, input2)
+    if input1.shape != input2.shape or input1.dim() != 4:
+        raise ValueError("correlation: input shapes differ: %s vs %s" % (tuple(input1.shape), tuple(input2.shape)))
+    for name, t in (("input1", input1), ("input2", input2)):
+        if t.dtype != torch.float32 or not t.is_contiguous(memory_format=torch.channels_last):
+            raise ValueError("%s must be float32 in channels-last memory" % name)
+    B, C, H, W = input1.shape
+    oc, oh, ow = correlation_output_shape(C, H, W, pad_size, kernel_size, max_displacement, stride1, stride2)
+    L = _lib.lib()
+    nbytes = L.dtt_correlation_nhwc_workspace_bytes(B, C, H, W, pad_size, kernel_size, max_displacement, stride1, stride2)
+    if nbytes == 0:
+        raise ValueError("correlation (channels-last): unsupported geometry (kernel_size 1, stride1 == stride2, C % 16 == 0)")
+    ws = _workspace(nbytes, input1.device)
+    if rows is None:
+        out = torch.empty((B, oc, oh, ow), dtype=torch.float32, device=input1.device)
+        optr, sb, sc, sp, ret = ptr(out), oc * oh * ow, oh * ow, 1, out
+    else:
+        if rows.dim() != 2 or rows.dtype != torch.float32 or rows.stride(1) != 1 or rows.shape[0] != B * oh * ow \
+                or col < 0 or col + oc > rows.shape[1]:
+            raise ValueError("correlation: rows must be float32 (%d, >= %d) with unit column stride" % (B * oh * ow, col + oc))
+        ld = rows.stride(0)
+        optr, sb, sc, sp, ret = ctypes.c_void_p(rows.data_ptr() + 4 * col), oh * ow * ld, 1, ld, rows
+    with torch.cuda.device(input1.device):
+        check(L.dtt_correlation_forward_nhwc(optr, B, oc, oh, ow, sb, sc, sp, ptr(input1), C, H, W, ptr(input2), ptr(ws), nbytes,
+                                             pad_size, kernel_size, max_displacement, stride1, stride2,
+                                             stream_ptr(input1.device)), "correlation forward (channels-last)")
+    return ret
+
+
 class CorrelationFunction(Function):
     @staticmethod
     def forward(ctx, input1, input2, pad_size, kernel_size, max_displacement, stride1, stride2, corr_multiply):

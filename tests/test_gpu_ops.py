@@ -233,6 +233,47 @@ def test_correlation_backward_any_kernel_size_is_the_exact_adjoint(dev, case):
     np.testing.assert_allclose(t2.grad.cpu().numpy(), a2.grad.numpy(), atol=1e-5)
 
 
+NHWC_CASES = [
+    (2, 64, 38, 67, 8, 1, 8, 1, 1),     # conv4 / conv5 geometry at the 600 px map size (fewer channels)
+    (2, 2048, 38, 67, 8, 1, 8, 1, 1),   # conv5 at full size: 4 channel slices per tile, in-launch slab reduction
+    (2, 512, 75, 134, 8, 1, 8, 2, 2),   # conv3 at full size: stride 2 = the stride-1 problem on the even lattice
+    (1, 48, 37, 45, 8, 1, 8, 2, 2),     # odd map sizes under stride 2
+    (1, 32, 36, 63, 16, 1, 16, 1, 1),   # config 5: R = 16 as four R = 8 sub-windows
+    (1, 32, 18, 22, 12, 1, 12, 1, 1),   # R = 12 the same way
+    (3, 16, 9, 11, 4, 1, 4, 1, 1),      # R = 4 (3 x 3 window blocks), tiny map, one chunk per slice
+    (1, 48, 21, 17, 3, 1, 3, 1, 1),     # R = 3 inside the R = 4 instantiation
+    (1, 32, 20, 27, 6, 1, 6, 1, 1),     # R = 6 inside the R = 8 instantiation
+    (1, 16, 16, 16, 6, 1, 4, 1, 1),     # pad > displacement: output pixels inside the padding
+    (2, 32, 13, 19, 2, 1, 4, 1, 1),     # pad < displacement: the output is smaller than the map
+    (1, 16, 5, 4, 8, 1, 8, 1, 1),       # map smaller than one tile
+]
+
+
+@pytest.mark.parametrize("case", NHWC_CASES)
+def test_correlation_nhwc_forward(dev, case):
+    """The channels-last kernel (dtt_correlation_forward_nhwc) against the oracle on the same values, in both output
+    layouts (NCHW tensor; columns of a position-major matrix), and run-to-run identical (the slab reduction is ordered)."""
+    from dtt.ops import correlation_forward_nhwc
+    B, C, H, W, pad, k, d, s1, s2 = case
+    rng = np.random.RandomState(sum(case))
+    x1 = np.maximum(rng.normal(size=(B, C, H, W)), 0).astype(np.float32)
+    x2 = np.maximum(np.roll(x1, (1, -2), (2, 3)) + 0.3 * rng.normal(size=x1.shape), 0).astype(np.float32)
+    ref = O.correlation_forward(x1, x2, pad, k, d, s1, s2)
+    t1 = cu(x1, dev).contiguous(memory_format=torch.channels_last)
+    t2 = cu(x2, dev).contiguous(memory_format=torch.channels_last)
+    out = correlation_forward_nhwc(t1, t2, pad, k, d, s1, s2)
+    assert tuple(out.shape) == ref.shape
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=0, atol=1e-4)  # north-star tolerance: 1e-4 fp32
+    assert np.abs(out.cpu().numpy() - ref).max() < 2e-6 * max(1.0, np.abs(ref).max() * C ** 0.5)
+    oc, oh, ow = ref.shape[1:]
+    rows = torch.full((B * oh * ow, oc + 11), 7.0, device=dev)
+    correlation_forward_nhwc(t1, t2, pad, k, d, s1, s2, rows=rows, col=5)
+    assert torch.equal(rows[:, 5:5 + oc].reshape(B, oh, ow, oc).permute(0, 3, 1, 2), out)
+    assert bool((rows[:, :5] == 7).all()) and bool((rows[:, 5 + oc:] == 7).all())
+    for _ in range(3):
+        assert torch.equal(correlation_forward_nhwc(t1, t2, pad, k, d, s1, s2), out)
+
+
 def test_correlation_into_concat_slice(dev):
     from dtt.ops import correlation_forward_into
     rng = np.random.RandomState(4)
