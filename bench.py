@@ -210,10 +210,12 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
-    # Correlation ops per step, in launch order: conv5, conv4, conv3 (largest first; the training graph keeps the
-    # reference's conv3, conv4, conv5 order).  For 8 < R <= 16 (d = 12 / 16) conv4 and conv5 are four R = 8 sub-window ops
-    # each.  The tag "corr_fwd_op" brackets a whole op: banded-product kernel + slice reduction.
-    n_sub = 4 if args.disp in (12, 16) else 1
+    # The tag "corr_fwd_op" brackets a whole op.  Inference on the channels-last
+    # trunk: ONE launch of corr_nhwc_kernel per op (ticket memset + product + in-launch slice reduction; four launches
+    # for the 8 < R <= 16 sub-windows of d = 12 / 16, inside one bracket).  NCHW maps (training, --nchw-trunk): banded-product
+    # kernel + slice-reduction kernel per op, and for d = 12 / 16 conv4 / conv5 are four R = 8 sub-window ops each.
+    nhwc_corr = args.mode == "infer" and not args.nchw_trunk and getattr(model, "_pm_tail", None) is not None
+    n_sub = 4 if (args.disp in (12, 16) and not nhwc_corr) else 1
     ops_per_step = 1 + 2 * n_sub
     kt = KernelTimer("corr_fwd_op", ops_per_step * args.steps, dev)
     kt.attach()
@@ -243,7 +245,14 @@ def main():
 
     if rank == 0:
         durs = kt.durations_us(used)
-        c5 = (lambda d: sum(d[:n_sub])) if args.mode == "infer" else (lambda d: sum(d[1 + n_sub:]))
+        # which of a step's ops is conv5: channels-last inference launches conv3, conv5, conv4 (dtt/model.py explains the
+        # order); NCHW inference conv5, conv4, conv3; the training graph keeps the reference's conv3, conv4, conv5
+        if nhwc_corr:
+            c5 = lambda d: d[1]
+        elif args.mode == "infer":
+            c5 = lambda d: sum(d[:n_sub])
+        else:
+            c5 = lambda d: sum(d[1 + n_sub:])
         conv5 = [c5(durs[i:i + ops_per_step]) for i in range(0, len(durs) - ops_per_step + 1, ops_per_step)]
         op_us = sum(conv5) / max(len(conv5), 1)
         B = args.batch
@@ -254,9 +263,14 @@ def main():
         achieved = flops / (op_us * 1e-6) / 1e12 if op_us > 0 else 0.0
         hbm = bytes_ / (op_us * 1e-6) / 1e9 if op_us > 0 else 0.0
         main_us = red_us = head_us = psroi_us = None
+        assert used == ops_per_step * args.steps, "expected %d correlation ops per step, saw %d in %d steps" % (
+            ops_per_step, used, args.steps)
         if args.mode == "infer":
-            main_us = extra("corr_fwd_mfma", ops_per_step, c5)
-            red_us = extra("corr_fwd_reduce", ops_per_step, c5)
+            if nhwc_corr:
+                main_us = extra("corr_nhwc", ops_per_step, c5)
+            else:
+                main_us = extra("corr_fwd_mfma", ops_per_step, c5)
+                red_us = extra("corr_fwd_reduce", ops_per_step, c5)
             n_head = 2      # class + box heads, then the tracking head
             if model._pm_tail is not None:
                 head_us = extra("head_gemm", n_head, lambda d: d[0])
@@ -296,15 +310,19 @@ def main():
             # the dominant hot-path op: conv5 cross-frame correlation (exact-f32 MFMA banded product + slice reduction),
             # timed as ONE op with HIP events on its launch stream inside the timed region (other streams keep running
             # beside it, as in production)
-            "roofline": {"kernel": "conv5 correlation op = %s + corr_fwd_reduce<5> (2048 ch, d=%d; event tag corr_fwd_op)"
-                                   % ("corr_fwd_glds<5>" if args.disp <= 8 else "4 x corr_fwd_glds<5> sub-windows", args.disp),
+            "roofline": {"kernel": ("conv5 correlation op = ticket memset + %scorr_nhwc_kernel<5> (channels-last, 2048 ch, d=%d: "
+                                    "exact-f32 MFMA banded product, in-launch slice reduction; event tag corr_fwd_op)"
+                                    % ("" if args.disp <= 8 else "4 sub-window launches of ", args.disp)) if nhwc_corr else
+                                   ("conv5 correlation op = %s + corr_fwd_reduce<5> (2048 ch, d=%d; event tag corr_fwd_op)"
+                                    % ("corr_fwd_glds<5>" if args.disp <= 8 else "4 x corr_fwd_glds<5> sub-windows", args.disp)),
                          "bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
                          "hbm": {"achieved": round(hbm, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm / HBM_PEAK_GBS, 4)},
                          "traffic": traffic, "traffic_source": traffic_src,
                          "op_us": round(op_us, 2), "ops_timed": len(conv5),
-                         "kernel_us": {"banded_product": None if main_us is None else round(main_us, 2),
-                                       "slice_reduction": None if red_us is None else round(red_us, 2)},
+                         "kernel_us": ({"corr_nhwc_kernel": None if main_us is None else round(main_us, 2)} if nhwc_corr else
+                                       {"banded_product": None if main_us is None else round(main_us, 2),
+                                        "slice_reduction": None if red_us is None else round(red_us, 2)}),
                          "event_bracket_overhead_us": round(KernelTimer.event_pair_overhead_us(dev), 2),
                          "algorithmic_flops_per_op": flops, "algorithmic_bytes_per_op": bytes_},
         }

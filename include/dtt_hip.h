@@ -80,8 +80,10 @@ int dtt_correlation_forward_strided(float* output, int ob, int oc, int oh, int o
  * sub-window for 8 < max_displacement / stride <= 16): the channel slices of a tile are reduced in-launch by its last
  * arriver (in slice order: deterministic).  Supported: kernel_size 1, stride1 == stride2 = s, pad and displacement
  * multiples of s, ic % 16 == 0, max_displacement / s <= 8 or in {12, 16}; 16-byte aligned inputs.  workspace: caller-owned,
- * dtt_correlation_nhwc_workspace_bytes(...) bytes (tickets + one slab per channel slice); its first bytes are cleared by a
- * stream-ordered memset on every call. */
+ * dtt_correlation_nhwc_workspace_bytes(...) bytes (a 64 KB ticket area + one slab per channel slice).  CONTRACT: zero-fill
+ * it once after allocation; every call leaves the ticket area zeroed again, so one buffer serves any number of calls (of
+ * any geometry it is large enough for) issued on one stream at a time -- there is no per-call memset.  Calls that may
+ * overlap on different streams need a workspace each. */
 size_t dtt_correlation_nhwc_workspace_bytes(int batch, int ic, int ih, int iw, int pad_size, int kernel_size,
                                             int max_displacement, int stride1, int stride2);
 int dtt_correlation_forward_nhwc(float* output, int ob, int oc, int oh, int ow, long out_batch_stride,
@@ -345,6 +347,14 @@ int dtt_winograd_output_transform(const float* mm, const float* bias, float* y, 
  * the channels-last trunk and the NCHW maps the operators above read (NHWC -> NCHW: rows = H*W, cols = C), which the
  * reference never needs because its trunk is NCHW throughout (faster_rcnn/resnet.py:325-343).  in != out. */
 int dtt_transpose_batched(const float* in, float* out, int batch, int rows, int cols, void* stream);
+
+/* Column blocks of a row-major matrix gathered side by side: dst[r][k * ncols + c] = src[k * src_block_rows + r][c] for
+ * k < n_blocks, r < rows, c < ncols (dst / src point at the first column of interest; leading dimensions in floats).
+ * This is rfcn.py:133-140's `torch.cat((bbox_t, bbox_t+tau, ...), dim=1)` for the two legs' box-delta columns on
+ * position-major rows (the correlation kernels write their columns of the same rows directly).  16-byte aligned pointers,
+ * ncols / dst_ld / src_ld multiples of 4. */
+int dtt_gather_column_blocks(float* dst, long dst_ld, const float* src, long src_ld, long src_block_rows, int n_blocks,
+                             long rows, int ncols, void* stream);
 
 /* Row-major GEMM with the bottleneck epilogue: out (rows, n) = act(a (rows, k) * w (k, n) + bias[n] (+ residual
  * (rows, n))); residual may be NULL and may alias out.  A library GEMM (hipBLASLt) -- the entry point exists for the

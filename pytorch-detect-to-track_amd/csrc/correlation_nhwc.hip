@@ -23,6 +23,7 @@
 //     (NCHW planes or position-major rows).  No second kernel, no split-K partials beyond one slab per slice.
 #include <stdlib.h>
 #include <type_traits>
+#include <algorithm>
 #include "common.h"
 
 namespace {
@@ -43,6 +44,7 @@ struct NGeom {
   int tiles_x, tiles_y, ksplit, c_per_split, batch;
   float* out; long out_sb, out_sc, out_sp;   // element (n, d, y, x) at out[n*sb + d*sc + (y*ow + x)*sp]
   float* slabs; int* tickets;
+  int trace_slot;
   int ablate;   // developer timing experiments (DTT_CORR_NHWC_ABLATE): 1 no DMA, 2 no MFMA, 4 no epilogue
 };
 
@@ -57,6 +59,20 @@ __device__ __forceinline__ const char* uptr(const char* p) {
   const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)), lo = (unsigned)__builtin_amdgcn_readfirstlane((int)v);
   return (const char*)(((unsigned long long)hi << 32) | (unsigned long long)lo);
 }
+
+#ifdef DTT_WG_TRACE   // developer build (tools/build_variant.sh): where and when every workgroup of the conv5 launches ran
+__device__ unsigned long long dtt_nhwc_trace[16 * 256 * 4];
+#define NHWC_TRACE(slot, v) do { if (g.trace_slot >= 0 && threadIdx.x == 0 && blockIdx.x < 256) \
+    dtt_nhwc_trace[(g.trace_slot * 256 + blockIdx.x) * 4 + (slot)] = (v); } while (0)
+__device__ __forceinline__ unsigned long long nhwc_hw_id() {
+  unsigned id, xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(id));
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  return ((unsigned long long)(xcc & 15) << 16) | (((id >> 13) & 7) << 8) | ((id >> 8) & 15);
+}
+#else
+#define NHWC_TRACE(slot, v) do {} while (0)
+#endif
 
 template <int NBR>
 struct NCfg {
@@ -79,9 +95,17 @@ __global__ __launch_bounds__(kNThreads) void corr_nhwc_kernel(NGeom g) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ntiles = g.tiles_x * g.tiles_y;
+#ifdef DTT_WG_TRACE
+  NHWC_TRACE(0, wall_clock64());
+  NHWC_TRACE(1, nhwc_hw_id());
+#endif
   const int item = dtt_xcd_remap(blockIdx.x, gridDim.x);
-  // slices of one tile sit side by side (same XCD: the reducer reads its neighbours' slabs out of that L2)
-  const int ks = item % g.ksplit, tile = (item / g.ksplit) % ntiles, n = item / (g.ksplit * ntiles);
+  // The tiles of one (image, channel slice) sit side by side: an XCD's contiguous run of items shares that slice's
+  // halo pixels through its L2 (30 tiles x 4 slices x 2 images = one (image, slice) per XCD at the 600 px shapes).  The
+  // slices of a tile then run on different XCDs; their slabs meet in memory (write-through stores, agent-scope acquire).
+  int ks, tile, n;
+  if (g.ablate & 64) { ks = item % g.ksplit; tile = (item / g.ksplit) % ntiles; n = item / (g.ksplit * ntiles); }
+  else { tile = item % ntiles; ks = (item / ntiles) % g.ksplit; n = item / (g.ksplit * ntiles); }
   const int ty0 = (tile / g.tiles_x) * kTY, tx0 = (tile % g.tiles_x) * kTX;
   const int c_begin = ks * g.c_per_split, c_end = min(g.C, c_begin + g.c_per_split);
   const int nch = (c_end - c_begin) / kKC;
@@ -187,6 +211,7 @@ __global__ __launch_bounds__(kNThreads) void corr_nhwc_kernel(NGeom g) {
     __syncthreads();
   }
 
+  NHWC_TRACE(2, wall_clock64());
   if (g.ablate & 16) return;
   // ---- the channel slices of the tile meet in the workspace: slab [(n, tile)][slice][block][nb][lane] of 4 floats
   const long slab_floats = 6l * K::NB * 256;
@@ -307,6 +332,7 @@ __global__ __launch_bounds__(kNThreads) void corr_nhwc_kernel(NGeom g) {
   };
   if (g.R == K::R) write_out(std::integral_constant<int, 2 * K::R + 1>{});
   else write_out(std::integral_constant<int, 0>{});
+  NHWC_TRACE(3, wall_clock64());
 }
 
 template <int NBR>
@@ -352,11 +378,19 @@ int plan_nhwc(int batch, int C, int oh, int ow, int R, NPlan* p) {
   p->ksplit = (C + cps - 1) / cps;
   const int nb = p->nbr * p->nbr;
   p->slab_bytes = p->ksplit > 1 ? (size_t)tiles * p->ksplit * 6 * nb * 256 * sizeof(float) : 0;
-  p->ticket_bytes = ((size_t)tiles * sizeof(int) + 255) & ~(size_t)255;
+  // a fixed 64 KB ticket area for anything up to 16384 tiles: geometries of that size share one zero-filled workspace
+  p->ticket_bytes = std::max((size_t)65536, ((size_t)tiles * sizeof(int) + 255) & ~(size_t)255);
   return 1;
 }
 
 }  // namespace
+
+#ifdef DTT_WG_TRACE
+extern "C" int dtt_nhwc_trace_read(unsigned long long* host, int n) {
+  (void)hipDeviceSynchronize();
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(dtt_nhwc_trace), sizeof(unsigned long long) * n) == hipSuccess;
+}
+#endif
 
 extern "C" size_t dtt_correlation_nhwc_workspace_bytes(int batch, int ic, int ih, int iw, int pad_size, int kernel_size,
                                                        int max_displacement, int stride1, int stride2) {
@@ -369,6 +403,9 @@ extern "C" size_t dtt_correlation_nhwc_workspace_bytes(int batch, int ic, int ih
   return p.slab_bytes + p.ticket_bytes;
 }
 
+// WORKSPACE CONTRACT: zero-fill the workspace (hipMemset) once after allocating it; every call leaves its ticket area
+// zeroed again, so the same buffer serves any number of calls on ONE stream at a time (calls that may overlap on different
+// streams need a workspace each).  There is no per-call memset: it was a 5 us launch in front of a 23-115 us kernel.
 // input1 / input2: (batch, ih, iw, ic) channels-last.  Output addressing as dtt_correlation_forward_strided.  Supports
 // kernel_size 1, stride1 == stride2 = s, (max_displacement - pad_size) % s == 0, ic % 16 == 0 and max_displacement / s <= 8, or
 // 16 with a multiple-of-4 ... (four sub-windows); everything else: transpose and call dtt_correlation_forward_strided.
@@ -400,6 +437,11 @@ extern "C" int dtt_correlation_forward_nhwc(float* output, int ob, int oc, int o
   g.Rfull = Rfull; g.Dfull = 2 * Rfull + 1;
   g.batch = ob;
   g.ablate = getenv("DTT_CORR_NHWC_ABLATE") ? atoi(getenv("DTT_CORR_NHWC_ABLATE")) : 0;
+  g.trace_slot = -1;
+#ifdef DTT_WG_TRACE
+  static int trace_launches = 0;
+  if (ic == 2048) g.trace_slot = trace_launches++ % 16;
+#endif
   g.out = output; g.out_sb = out_batch_stride; g.out_sc = out_ch_stride; g.out_sp = out_px_stride;
   const int R = Rfull > 8 ? 8 : Rfull;
   NPlan p;
@@ -409,8 +451,7 @@ extern "C" int dtt_correlation_forward_nhwc(float* output, int ob, int oc, int o
   g.R = R; g.tiles_x = p.tiles_x; g.tiles_y = p.tiles_y; g.ksplit = p.ksplit; g.c_per_split = p.c_per_split;
   g.tickets = static_cast<int*>(workspace);
   g.slabs = reinterpret_cast<float*>(static_cast<char*>(workspace) + p.ticket_bytes);
-  // the tickets start from zero on every call (a previous call that failed mid-way must not poison this one)
-  DTT_REQUIRE(hipMemsetAsync(g.tickets, 0, p.ticket_bytes, stream) == hipSuccess, "correlation (channels-last): memset failed");
+  // (the tickets are zero on entry -- workspace contract -- and the reducer of every tile zeroes its own again)
   dtt_prof_begin("corr_fwd_op", stream);
   dtt_prof_begin("corr_nhwc", stream);
   int ok = 1;

@@ -119,6 +119,18 @@ __global__ __launch_bounds__(kThreads) void transpose_tiles(const float* __restr
   }
 }
 
+// dst[r][dst_col + k * ncols + c] = src[k * src_block_rows + r][src_col + c]: column blocks of a row-major matrix gathered
+// side by side (float4 per lane, one row segment per run of lanes)
+__global__ __launch_bounds__(kThreads) void gather_column_blocks_kernel(float* __restrict__ dst, long dst_ld, const float* __restrict__ src,
+                                                                       long src_ld, long src_block_rows, int n_blocks, long rows, int c4) {
+  const long total = rows * n_blocks * c4;
+  for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < total; i += (long)gridDim.x * kThreads) {
+    const long r = i / ((long)n_blocks * c4);
+    const int rem = (int)(i - r * n_blocks * c4), k = rem / c4, c = rem - k * c4;
+    reinterpret_cast<float4*>(dst + r * dst_ld)[rem] = reinterpret_cast<const float4*>(src + (k * src_block_rows + r) * src_ld)[c];
+  }
+}
+
 }  // namespace
 
 extern "C" int dtt_bias_act_nhwc_inplace(float* x, const float* bias, const float* residual, long rows, int channels,
@@ -181,5 +193,25 @@ extern "C" int dtt_transpose_batched(const float* in, float* out, int batch, int
   else if (vw) hipLaunchKernelGGL((transpose_tiles<false, true>), grid, dim3(kThreads), 0, stream, in, out, rows, cols);
   else hipLaunchKernelGGL((transpose_tiles<false, false>), grid, dim3(kThreads), 0, stream, in, out, rows, cols);
   DTT_CHECK_LAUNCH("transpose_tiles");
+  return 1;
+}
+
+// Tracking-head input assembly (rfcn.py:133-140 `torch.cat` of the two legs' box-delta maps, on position-major rows):
+// dst[r][k * ncols + c] = src[k * src_block_rows + r][c] for k < n_blocks, r < rows, c < ncols.  dst / src point at the
+// first column of interest; leading dimensions in floats; everything 16-byte aligned, ncols % 4 == 0.
+extern "C" int dtt_gather_column_blocks(float* dst, long dst_ld, const float* src, long src_ld, long src_block_rows, int n_blocks,
+                                        long rows, int ncols, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  DTT_REQUIRE(dst && src, "gather_column_blocks: null pointer");
+  DTT_REQUIRE(rows > 0 && n_blocks > 0 && ncols > 0 && ncols % 4 == 0 && dst_ld % 4 == 0 && src_ld % 4 == 0 &&
+              dst_ld >= (long)n_blocks * ncols && src_ld >= ncols && src_block_rows >= rows, "gather_column_blocks: bad shape");
+  DTT_REQUIRE(((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15) == 0,
+              "gather_column_blocks: pointers must be 16-byte aligned");
+  const long total = rows * n_blocks * (ncols / 4);
+  long blocks = (total + kThreads - 1) / kThreads;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(gather_column_blocks_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, dst, dst_ld, src, src_ld,
+                     src_block_rows, n_blocks, rows, ncols / 4);
+  DTT_CHECK_LAUNCH("gather_column_blocks_kernel");
   return 1;
 }

@@ -32,6 +32,11 @@ struct PropGeom {
   int P;                   // power-of-two sort size >= topn
 };
 
+#ifdef DTT_WG_TRACE   // developer build: where and when the select / sort workgroups ran (see correlation_nhwc.hip)
+__device__ unsigned long long dtt_sort_trace[16 * 8 * 4];
+__device__ int dtt_sort_trace_launch;
+#endif
+
 constexpr int kEPT = 32;     // score keys cached in registers per thread (n <= 32768), else re-read from L2
 
 // Block-wide sum of a per-wave (uniform) count: lane 0 of each wave posts it, everybody adds the 16 posts.
@@ -64,6 +69,16 @@ __global__ __launch_bounds__(kThreads) void proposal_select_sort(const float* __
   unsigned* wsum = reinterpret_cast<unsigned*>(buf + g.P);
   unsigned* ctl = wsum + 16;  // [3] fill counter
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+#ifdef DTT_WG_TRACE
+  const int trace_slot = dtt_sort_trace_launch % 16;
+  if (tid == 0 && b < 8) {
+    unsigned id, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(id));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    dtt_sort_trace[(trace_slot * 8 + b) * 4 + 0] = wall_clock64();
+    dtt_sort_trace[(trace_slot * 8 + b) * 4 + 1] = ((unsigned long long)(xcc & 15) << 16) | (((id >> 13) & 7) << 8) | ((id >> 8) & 15);
+  }
+#endif
   const float* sc = cls_prob + ((long)b * 2 * g.A + g.A) * g.K;  // fg scores: channels A .. 2A-1
   const int nslots = (g.n + kThreads - 1) / kThreads;
 
@@ -198,6 +213,11 @@ __global__ __launch_bounds__(kThreads) void proposal_select_sort(const float* __
     o.w = fminf(fmaxf(pcy + 0.5f * ph, 0.f), ymax);
     out[r] = o;
   }
+#ifdef DTT_WG_TRACE
+  __syncthreads();
+  if (tid == 0 && b < 8) dtt_sort_trace[(trace_slot * 8 + b) * 4 + 3] = wall_clock64();
+  if (tid == 0 && b == 0) dtt_sort_trace_launch = dtt_sort_trace_launch + 1;   // (racy by design: approximate slotting is enough)
+#endif
 }
 
 int next_pow2(int v) {
@@ -215,6 +235,13 @@ int effective_topn(int batch, int n, int pre_nms_topN) {
 }
 
 }  // namespace
+
+#ifdef DTT_WG_TRACE
+extern "C" int dtt_sort_trace_read(unsigned long long* host, int n) {
+  (void)hipDeviceSynchronize();
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(dtt_sort_trace), sizeof(unsigned long long) * n) == hipSuccess;
+}
+#endif
 
 extern "C" size_t dtt_proposal_workspace_bytes(int batch, int num_anchors, int height, int width,
                                                int pre_nms_topN) {

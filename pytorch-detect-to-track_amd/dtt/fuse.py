@@ -490,7 +490,9 @@ class FusedTrunkNHWC:
         self.rpn_conv = _NhwcConv(model.RFCN_rpn.RPN_Conv)
         self.rpn_conv1 = None
         self.pm_heads = False     # set by fuse_for_inference when the position-major tail is active
+        self.pm_tail = None       # dtt.heads.PositionMajorTail: when set, the class + box head GEMM is issued in here
         self.top_rows = None
+        self.det_rows = None
         self.top_hw = None
 
     @torch.no_grad()
@@ -503,11 +505,18 @@ class FusedTrunkNHWC:
                 x = blk(x)
             feats.append(x)
         top = self.top.act(feats[3])
-        self.rpn_conv1 = _to_nchw(self.rpn_conv.act(top))
         if self.pm_heads:
             # the position-major tail reads channels-last memory directly (head GEMM over the `top` rows, channels-last
             # correlation kernel over conv3 / conv4 / conv5): no layout hand-over at all
             self.top_rows, self.top_hw = _rows(top), (top.shape[2], top.shape[3])
+            if self.pm_tail is not None and os.environ.get("DTT_DET_EARLY", "1") != "0":   # (developer A/B switch)
+                # The class + box head GEMM runs HERE, ahead of the RPN: its grid is one workgroup on every CU, so it
+                # cannot share the chip with the proposal layer's kernels (256 + 4 workgroups: the last 4 wait for, or
+                # squeeze in beside, the others -- 150 -> 200 us when it ran after the correlations, under the NMS sweep).
+                from .heads import head_gemm
+                self.det_rows = head_gemm(self.top_rows, self.pm_tail.det)
+        self.rpn_conv1 = _to_nchw(self.rpn_conv.act(top))
+        if self.pm_heads:
             return feats[1], feats[2], feats[3], top
         return _to_nchw(feats[1]), _to_nchw(feats[2]), _to_nchw(feats[3]), _to_nchw(top)
 
@@ -523,6 +532,7 @@ def fuse_for_inference(model, channels_last=True):
             from .heads import PositionMajorTail
             model._pm_tail = PositionMajorTail(model)
             model._fused_trunk.pm_heads = True
+            model._fused_trunk.pm_tail = model._pm_tail
     return model
 
 

@@ -83,6 +83,21 @@ def head_gemm(x_rows, packed, out=None, passes=0):
     return out
 
 
+def gather_column_blocks(dst, dst_col, src, src_col, rows, n_blocks, ncols):
+    """dst[r, dst_col + k*ncols + c] = src[k*rows + r, src_col + c] (`dtt_gather_column_blocks`): the box-delta columns of the
+    two legs side by side in the tracking head's input rows (rfcn.py:133-140's torch.cat on position-major rows)."""
+    import ctypes
+    require_gpu(dst, src)
+    assert dst.dtype == src.dtype == torch.float32 and dst.stride(1) == 1 and src.stride(1) == 1
+    if dst.shape[0] < rows or src.shape[0] < n_blocks * rows or dst_col + n_blocks * ncols > dst.shape[1] or src_col + ncols > src.shape[1]:
+        raise ValueError("gather_column_blocks: block does not fit (dst %s, src %s)" % (tuple(dst.shape), tuple(src.shape)))
+    with torch.cuda.device(dst.device):
+        check(_lib.lib().dtt_gather_column_blocks(ctypes.c_void_p(dst.data_ptr() + 4 * dst_col), dst.stride(0),
+                                                  ctypes.c_void_p(src.data_ptr() + 4 * src_col), src.stride(0), rows, n_blocks,
+                                                  rows, ncols, stream_ptr(dst.device)), "gather_column_blocks")
+    return dst
+
+
 def psroi_pm(pm_map, head, batch, height, width, rois, spatial_scale, want_pooled=False):
     """Position-sensitive pooling + 7x7 vote over a position-major map.
 

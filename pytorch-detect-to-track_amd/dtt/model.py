@@ -246,7 +246,7 @@ class _RFCN(nn.Module):
         """rfcn.py:133-140, 166-196 at inference on the position-major layout: one MFMA GEMM for the class + box heads of
         every image (`dtt_head_gemm`), lanes = classes PSRoI pooling + vote (`dtt_psroi_pm_forward`), the tracking
         head's input rows assembled in place (box-delta columns copied, correlations written by their reduce kernels)."""
-        from .heads import head_gemm, psroi_pm
+        from .heads import gather_column_blocks, head_gemm, psroi_pm
         from .ops import correlation_forward_nhwc, correlation_forward_rows
         top_rows, (H, W) = fused.top_rows, fused.top_hw
         fused.top_rows = None
@@ -255,8 +255,7 @@ class _RFCN(nn.Module):
         trk = rows = None
         hw = H * W
         if not single_frame:
-            # correlations first: they only need the trunk maps, and what runs beside them on the side stream at this
-            # point is the proposal layer's select / sort (one workgroup per image)
+            # correlations first: they only need the trunk maps
             rows = pm.tracking_rows(B * hw, dev)
             col, jobs = 2 * pm.n_box, []
             for l, f in zip((self.conv3_corr_layer, self.conv4_corr_layer, self.conv5_corr_layer), (c3, c4, c5)):
@@ -265,7 +264,15 @@ class _RFCN(nn.Module):
                 jobs.append((l, f, col))
                 col += oc
             assert col == pm.trk_in, "tracking feature width %d != corr_bbox_net input %d" % (col, pm.trk_in)
-            for l, f, c0 in reversed(jobs):   # largest first (conv5, conv4, conv3): it fits beside the select / sort kernel
+            # Launch order conv3, conv5, conv4.  The select / sort kernel of the side stream (one 1024-thread, 64 KB-LDS
+            # workgroup per image) is dispatched in the same microseconds as the first kernel here, and two dispatches
+            # that race for CUs leave the loser's workgroups parked on a full shader engine until one of ITS CUs frees
+            # up (tools/wg_trace.py, tools/probes/wg_placement.hip): +75 us on the conv5 correlation or +90 us on the
+            # sort when conv5 went first.  With the 23 us conv3 kernel in that slot the race costs at most its length;
+            # conv5 then starts with the sort long placed (it takes the CUs that are really free) and ends before the
+            # NMS mask kernel's small workgroups come to share SIMDs, which is conv4's lot.
+            order = [jobs[0], jobs[2], jobs[1]]
+            for l, f, c0 in order:
                 if f.is_contiguous(memory_format=torch.channels_last) and not f.is_contiguous():
                     # channels-last trunk maps: the single-launch channels-last kernel, no transposes
                     correlation_forward_nhwc(f[:B], f[B:2 * B], l.pad_size, l.kernel_size, l.max_displacement, l.stride1,
@@ -273,12 +280,11 @@ class _RFCN(nn.Module):
                 else:
                     correlation_forward_rows(rows, c0, f[:B].contiguous(), f[B:2 * B].contiguous(), l.pad_size, l.kernel_size,
                                              l.max_displacement, l.stride1, l.stride2, l.corr_multiply)
-        det = head_gemm(top_rows, pm.det)                          # (n_legs*B*H*W, stride)
+        det, fused.det_rows = getattr(fused, "det_rows", None), None    # (n_legs*B*H*W, stride): issued by the fused trunk ...
+        if det is None:
+            det = head_gemm(top_rows, pm.det)                           # ... or here
         if not single_frame:
-            off, nb = pm.loc_head["offset"], pm.n_box
-            dv = det.view(n_legs, B * hw, det.shape[1])
-            rows[:, 0:nb] = dv[0][:, off:off + nb]
-            rows[:, nb:2 * nb] = dv[1][:, off:off + nb]
+            gather_column_blocks(rows, 0, det, pm.loc_head["offset"], B * hw, n_legs, pm.n_box)   # box deltas of both legs
             trk = head_gemm(rows, pm.trk)                           # (B*H*W, stride)
         cur.wait_stream(side)
         all_rois.record_stream(cur)
@@ -314,10 +320,10 @@ class _RFCN(nn.Module):
         c3, c4, c5, top = self._im_to_head(flat)
         side = None
         if not self.training and top.is_cuda and not torch.is_grad_enabled():
-            # The proposal layer (select / sort, NMS mask + sweep) is a handful of single-workgroup-per-image kernels
-            # that leave all but a few CUs idle; it runs on a side stream underneath the head convolutions and the
-            # correlations, which do not depend on it.  (The RPN's own convolutions stay on the main stream: sharing
-            # the CUs with them slowed the correlation kernels by 15 %.)
+            # The proposal layer (select / sort, NMS mask + sweep) is a handful of small kernels that leave most CUs
+            # idle; it runs on a side stream underneath the correlations and the head GEMMs, which do not depend on it.
+            # The RPN's own 1x1 heads stay on the main stream, ahead of the fork: beside the one-workgroup-per-CU
+            # correlation kernels they are starved of CUs (50 -> 220 us) and push the select / sort under the head GEMM.
             cur = torch.cuda.current_stream(dev)
             side = getattr(self, "_side_stream", None)
             if side is None or side.device != dev:

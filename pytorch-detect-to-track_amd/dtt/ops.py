@@ -92,6 +92,9 @@ def correlation_forward_rows(rows, col, input1, input2, pad_size, kernel_size, m
     return rows
 
 
+_NHWC_WORKSPACES = {}
+
+
 def correlation_forward_nhwc(input1, input2, pad_size, kernel_size, max_displacement, stride1, stride2, rows=None, col=0):
     """Correlation of two channels-last (B, C, H, W)-shaped maps (memory order B, H, W, C -- the channels-last trunk's
     own layout) without any layout change in front of the op (`dtt_correlation_forward_nhwc`).
@@ -109,7 +112,11 @@ def correlation_forward_nhwc(input1, input2, pad_size, kernel_size, max_displace
     nbytes = L.dtt_correlation_nhwc_workspace_bytes(B, C, H, W, pad_size, kernel_size, max_displacement, stride1, stride2)
     if nbytes == 0:
         raise ValueError("correlation (channels-last): unsupported geometry (kernel_size 1, stride1 == stride2, C % 16 == 0)")
-    ws = _workspace(nbytes, input1.device)
+    # zero-filled once, then owned by (device, stream): the kernel leaves its ticket area zeroed (C ABI workspace contract)
+    key = (input1.device, torch.cuda.current_stream(input1.device).cuda_stream, nbytes)
+    ws = _NHWC_WORKSPACES.get(key)
+    if ws is None:
+        ws = _NHWC_WORKSPACES[key] = torch.zeros((nbytes,), dtype=torch.uint8, device=input1.device)
     if rows is None:
         out = torch.empty((B, oc, oh, ow), dtype=torch.float32, device=input1.device)
         optr, sb, sc, sp, ret = ptr(out), oc * oh * ow, oh * ow, 1, out

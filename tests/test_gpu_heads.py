@@ -124,3 +124,18 @@ def test_psroi_pm_matches_plane_kernel_on_head_output(dev):
         assert torch.equal(vote, v2)
         _, v3 = psroi_pool_vote(F.conv2d(x, conv.weight, conv.bias).contiguous(), rois, 7, 7, 1.0 / 16, 7, head["od"])
         assert float((vote - v3).abs().max()) < 1e-4
+
+
+def test_gather_column_blocks_matches_slicing():
+    """dtt_gather_column_blocks == the two sliced copies it replaces (box-delta columns of both legs -> tracking rows)."""
+    from dtt.heads import gather_column_blocks
+    g = torch.Generator().manual_seed(5)
+    src = torch.randn(2 * 611, 1744, generator=g).cuda()
+    dst = torch.full((611, 1056), -7.0).cuda()
+    want = dst.clone()
+    want[:, 0:196] = src[:611, 1536:1732]
+    want[:, 196:392] = src[611:, 1536:1732]
+    gather_column_blocks(dst, 0, src, 1536, 611, 2, 196)
+    assert torch.equal(dst, want)
+    with pytest.raises(ValueError):
+        gather_column_blocks(dst, 900, src, 1536, 611, 2, 196)
