@@ -248,7 +248,7 @@ def main():
         # which of a step's ops is conv5: channels-last inference launches conv3, conv5, conv4 (dtt/model.py explains the
         # order); NCHW inference conv5, conv4, conv3; the training graph keeps the reference's conv3, conv4, conv5
         if nhwc_corr:
-            c5 = lambda d: d[1]
+            c5 = lambda d: d[os.environ.get("DTT_CORR_ORDER", "021").index("2")]
         elif args.mode == "infer":
             c5 = lambda d: sum(d[:n_sub])
         else:
@@ -320,6 +320,7 @@ def main():
                          "hbm": {"achieved": round(hbm, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm / HBM_PEAK_GBS, 4)},
                          "traffic": traffic, "traffic_source": traffic_src,
                          "op_us": round(op_us, 2), "ops_timed": len(conv5),
+                         "op_us_min_median_max": [round(v, 1) for v in (min(conv5), sorted(conv5)[len(conv5) // 2], max(conv5))] if conv5 else None,
                          "kernel_us": ({"corr_nhwc_kernel": None if main_us is None else round(main_us, 2)} if nhwc_corr else
                                        {"banded_product": None if main_us is None else round(main_us, 2),
                                         "slice_reduction": None if red_us is None else round(red_us, 2)}),

@@ -225,6 +225,17 @@ int dtt_proposal_forward(const float* cls_prob, const float* bbox_pred, const fl
                          int feat_stride, int pre_nms_topN, int post_nms_topN, float nms_thresh,
                          float* rois_out, int* num_out, void* workspace, size_t workspace_bytes,
                          void* stream);
+/* The same layer in two stream-ordered phases, for callers that overlap it with other work (dtt/model.py starts phase 1 on
+ * a side stream right after the RPN softmax, while the box-delta convolution still runs on the main stream):
+ *   dtt_proposal_select_sort  reads the scores only: per image, the pre_nms_topN best (score, anchor) keys in order -> workspace
+ *   dtt_proposal_decode_nms   decodes + clips those anchors' boxes (bbox_pred, im_info, anchors), NMS, writes rois_out / num_out
+ * Both take the geometry arguments and the workspace of dtt_proposal_forward (which is exactly phase 1 + phase 2 on one
+ * stream); the workspace carries the selection from one to the other. */
+int dtt_proposal_select_sort(const float* cls_prob, int batch, int num_anchors, int height, int width, int pre_nms_topN,
+                             void* workspace, size_t workspace_bytes, void* stream);
+int dtt_proposal_decode_nms(const float* bbox_pred, const float* im_info, const float* anchors, int batch, int num_anchors,
+                            int height, int width, int feat_stride, int pre_nms_topN, int post_nms_topN, float nms_thresh,
+                            float* rois_out, int* num_out, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------- RPN anchor-target layer
  * Replaces _AnchorTargetLayer.forward (rpn/anchor_target_layer.py:48-191) with bbox_overlaps_batch

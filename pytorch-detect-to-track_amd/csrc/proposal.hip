@@ -5,10 +5,12 @@
 // per-image NMS round trips.  Here:
 //   1. proposal_select_sort (one 1024-thread workgroup per image): select the pre_nms_topN best
 //      (score, index) keys straight from the NCHW score map (exact bisection on the key bits, keys cached in
-//      registers), bitonic-sort just those in LDS, and decode +
-//      clip only the survivors (bbox_transform.py:108-134, 156-173).  Keys are (descending score,
-//      ascending anchor index), a total order, so the result is deterministic.
-//   2. the batched NMS of nms.hip (mask tiles + on-device sweep) whose epilogue writes the zero-padded
+//      registers) and bitonic-sort just those in LDS.  Keys are (descending score, ascending anchor index), a total
+//      order, so the result is deterministic.  Needs the SCORES only: callers that overlap the proposal layer with
+//      other work start it as soon as the softmax is done, while the box-delta convolution still runs
+//      (dtt_proposal_select_sort / dtt_proposal_decode_nms).
+//   2. proposal_decode (all CUs): decode + clip only the survivors (bbox_transform.py:108-134, 156-173).
+//   3. the batched NMS of nms.hip (mask tiles + on-device sweep) whose epilogue writes the zero-padded
 //      (B, post_nms_topN, 5) RoI tensor (proposal_layer.py:151-159).
 #include "common.h"
 #include "nms_internal.h"
@@ -33,8 +35,13 @@ struct PropGeom {
 };
 
 #ifdef DTT_WG_TRACE   // developer build: where and when the select / sort workgroups ran (see correlation_nhwc.hip)
-__device__ unsigned long long dtt_sort_trace[16 * 8 * 4];
+__device__ unsigned long long dtt_sort_trace[16 * 8 * 8];
+#define SORT_STAMP(k) do { __syncthreads(); if (threadIdx.x == 0 && blockIdx.x < 8) dtt_sort_trace[(trace_slot * 8 + blockIdx.x) * 8 + (k)] = wall_clock64(); } while (0)
 __device__ int dtt_sort_trace_launch;
+#endif
+
+#ifndef DTT_WG_TRACE
+#define SORT_STAMP(k) do {} while (0)
 #endif
 
 constexpr int kEPT = 32;     // score keys cached in registers per thread (n <= 32768), else re-read from L2
@@ -59,11 +66,8 @@ __device__ __forceinline__ unsigned block_sum(unsigned wave_count, unsigned* wsu
 // "how many keys are below this pivot", each a compare + ballot + popcount per cached key and one
 // 16-way sum through LDS -- no atomics, no histogram, insensitive to how skewed the scores are.
 template <bool CACHE>
-__global__ __launch_bounds__(kThreads) void proposal_select_sort(const float* __restrict__ cls_prob,
-                                                                 const float* __restrict__ bbox_pred,
-                                                                 const float* __restrict__ im_info,
-                                                                 const float* __restrict__ anchors, PropGeom g,
-                                                                 float* __restrict__ boxes_out) {
+__global__ __launch_bounds__(kThreads) void proposal_select_sort(const float* __restrict__ cls_prob, PropGeom g,
+                                                                 unsigned* __restrict__ order_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned long long* buf = reinterpret_cast<unsigned long long*>(smem);
   unsigned* wsum = reinterpret_cast<unsigned*>(buf + g.P);
@@ -75,8 +79,8 @@ __global__ __launch_bounds__(kThreads) void proposal_select_sort(const float* __
     unsigned id, xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(id));
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    dtt_sort_trace[(trace_slot * 8 + b) * 4 + 0] = wall_clock64();
-    dtt_sort_trace[(trace_slot * 8 + b) * 4 + 1] = ((unsigned long long)(xcc & 15) << 16) | (((id >> 13) & 7) << 8) | ((id >> 8) & 15);
+    dtt_sort_trace[(trace_slot * 8 + b) * 8 + 0] = wall_clock64();
+    dtt_sort_trace[(trace_slot * 8 + b) * 8 + 1] = ((unsigned long long)(xcc & 15) << 16) | (((id >> 13) & 7) << 8) | ((id >> 8) & 15);
   }
 #endif
   const float* sc = cls_prob + ((long)b * 2 * g.A + g.A) * g.K;  // fg scores: channels A .. 2A-1
@@ -109,6 +113,7 @@ __global__ __launch_bounds__(kThreads) void proposal_select_sort(const float* __
     return block_sum(c, wsum);
   };
 
+  SORT_STAMP(2);
   unsigned thr_hi = 0xFFFFFFFFu, thr_lo = 0xFFFFFFFFu;  // select (key32, t) <= (thr_hi, thr_lo)
   if (g.topn < g.n) {
     // largest T with count(key < T) < topn  ==  the topn-th smallest key
@@ -141,6 +146,7 @@ __global__ __launch_bounds__(kThreads) void proposal_select_sort(const float* __
       thr_lo = Tt;
     }
   }
+  SORT_STAMP(3);
   // ---- compact the selected keys into LDS (any order; one LDS atomic per wave), pad, sort
   if (tid == 0) ctl[3] = 0;
   __syncthreads();
@@ -175,6 +181,7 @@ __global__ __launch_bounds__(kThreads) void proposal_select_sort(const float* __
   }
   for (int i = g.topn + tid; i < g.P; i += kThreads) buf[i] = ~0ULL;
   __syncthreads();
+  SORT_STAMP(4);
   for (int k = 2; k <= g.P; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
       for (int p = tid; p < (g.P >> 1); p += kThreads) {
@@ -187,37 +194,44 @@ __global__ __launch_bounds__(kThreads) void proposal_select_sort(const float* __
       __syncthreads();
     }
   }
-  // ---- decode + clip the sorted survivors (bbox_transform.py:108-134, 156-173)
+  SORT_STAMP(5);
+  // ---- rank r -> flattened anchor index t = k * A + a
+  for (int r = tid; r < g.topn; r += kThreads) order_out[(long)b * g.topn + r] = (unsigned)buf[r];
+#ifdef DTT_WG_TRACE
+  __syncthreads();
+  if (tid == 0 && b < 8) dtt_sort_trace[(trace_slot * 8 + b) * 8 + 7] = wall_clock64();
+  if (tid == 0 && b == 0) dtt_sort_trace_launch = dtt_sort_trace_launch + 1;   // (racy by design: approximate slotting is enough)
+#endif
+}
+
+// Decode + clip the survivors (bbox_transform.py:108-134, 156-173), one thread per (image, rank).
+__global__ __launch_bounds__(256) void proposal_decode(const unsigned* __restrict__ order, const float* __restrict__ bbox_pred,
+                                                       const float* __restrict__ im_info, const float* __restrict__ anchors,
+                                                       PropGeom g, float* __restrict__ boxes_out) {
+  const int b = blockIdx.y, r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= g.topn) return;
   const float im_h = im_info[b * 3 + 0], im_w = im_info[b * 3 + 1];
   const float xmax = im_w - 1.0f, ymax = im_h - 1.0f;
   const float* dl = bbox_pred + (long)b * 4 * g.A * g.K;
-  float4* out = reinterpret_cast<float4*>(boxes_out) + (long)b * g.topn;
-  for (int r = tid; r < g.topn; r += kThreads) {
-    const unsigned t = (unsigned)buf[r];
-    const int k = t / g.A, a = t - k * g.A;
-    const int h = k / g.W, w = k - h * g.W;
-    const float sx = (float)(w * g.feat_stride), sy = (float)(h * g.feat_stride);
-    const float x1 = anchors[a * 4 + 0] + sx, y1 = anchors[a * 4 + 1] + sy;
-    const float x2 = anchors[a * 4 + 2] + sx, y2 = anchors[a * 4 + 3] + sy;
-    const float dx = dl[(long)(4 * a + 0) * g.K + k], dy = dl[(long)(4 * a + 1) * g.K + k];
-    const float dw = dl[(long)(4 * a + 2) * g.K + k], dh = dl[(long)(4 * a + 3) * g.K + k];
-    const float widths = x2 - x1 + 1.0f, heights = y2 - y1 + 1.0f;
-    const float ctr_x = x1 + 0.5f * widths, ctr_y = y1 + 0.5f * heights;
-    const float pcx = dx * widths + ctr_x, pcy = dy * heights + ctr_y;
-    const float pw = (float)exp((double)dw) * widths;   // correctly rounded binary32 exp (declared semantics)
-    const float ph = (float)exp((double)dh) * heights;
-    float4 o;
-    o.x = fminf(fmaxf(pcx - 0.5f * pw, 0.f), xmax);
-    o.y = fminf(fmaxf(pcy - 0.5f * ph, 0.f), ymax);
-    o.z = fminf(fmaxf(pcx + 0.5f * pw, 0.f), xmax);
-    o.w = fminf(fmaxf(pcy + 0.5f * ph, 0.f), ymax);
-    out[r] = o;
-  }
-#ifdef DTT_WG_TRACE
-  __syncthreads();
-  if (tid == 0 && b < 8) dtt_sort_trace[(trace_slot * 8 + b) * 4 + 3] = wall_clock64();
-  if (tid == 0 && b == 0) dtt_sort_trace_launch = dtt_sort_trace_launch + 1;   // (racy by design: approximate slotting is enough)
-#endif
+  const unsigned t = order[(long)b * g.topn + r];
+  const int k = t / g.A, a = t - k * g.A;
+  const int h = k / g.W, w = k - h * g.W;
+  const float sx = (float)(w * g.feat_stride), sy = (float)(h * g.feat_stride);
+  const float x1 = anchors[a * 4 + 0] + sx, y1 = anchors[a * 4 + 1] + sy;
+  const float x2 = anchors[a * 4 + 2] + sx, y2 = anchors[a * 4 + 3] + sy;
+  const float dx = dl[(long)(4 * a + 0) * g.K + k], dy = dl[(long)(4 * a + 1) * g.K + k];
+  const float dw = dl[(long)(4 * a + 2) * g.K + k], dh = dl[(long)(4 * a + 3) * g.K + k];
+  const float widths = x2 - x1 + 1.0f, heights = y2 - y1 + 1.0f;
+  const float ctr_x = x1 + 0.5f * widths, ctr_y = y1 + 0.5f * heights;
+  const float pcx = dx * widths + ctr_x, pcy = dy * heights + ctr_y;
+  const float pw = (float)exp((double)dw) * widths;   // correctly rounded binary32 exp (declared semantics)
+  const float ph = (float)exp((double)dh) * heights;
+  float4 o;
+  o.x = fminf(fmaxf(pcx - 0.5f * pw, 0.f), xmax);
+  o.y = fminf(fmaxf(pcy - 0.5f * ph, 0.f), ymax);
+  o.z = fminf(fmaxf(pcx + 0.5f * pw, 0.f), xmax);
+  o.w = fminf(fmaxf(pcy + 0.5f * ph, 0.f), ymax);
+  reinterpret_cast<float4*>(boxes_out)[(long)b * g.topn + r] = o;
 }
 
 int next_pow2(int v) {
@@ -243,44 +257,49 @@ extern "C" int dtt_sort_trace_read(unsigned long long* host, int n) {
 }
 #endif
 
-extern "C" size_t dtt_proposal_workspace_bytes(int batch, int num_anchors, int height, int width,
-                                               int pre_nms_topN) {
-  const int n = num_anchors * height * width;
-  const int topn = effective_topn(batch, n, pre_nms_topN);
-  size_t boxes = align_up((size_t)batch * topn * 4 * sizeof(float), 256);
-  size_t mask = align_up((size_t)batch * dtt_nms_mask_bytes(topn), 256);
-  size_t keep = align_up((size_t)batch * topn * sizeof(int), 256);
-  size_t num = 256;
-  return boxes + mask + keep + num;
-}
+namespace {
 
-extern "C" int dtt_proposal_forward(const float* cls_prob, const float* bbox_pred, const float* im_info,
-                                    const float* anchors, int batch, int num_anchors, int height, int width,
-                                    int feat_stride, int pre_nms_topN, int post_nms_topN, float nms_thresh,
-                                    float* rois_out, int* num_out, void* workspace, size_t workspace_bytes,
-                                    void* stream_) {
-  hipStream_t stream = static_cast<hipStream_t>(stream_);
-  DTT_REQUIRE(cls_prob && bbox_pred && im_info && anchors && rois_out, "proposal: null pointer");
-  DTT_REQUIRE(batch > 0 && num_anchors > 0 && height > 0 && width > 0 && feat_stride > 0, "proposal: bad shape");
-  DTT_REQUIRE(post_nms_topN > 0, "proposal: post_nms_topN must be > 0");
+// workspace: boxes (B, topn, 4) | NMS mask | keep | num | order (B, topn)
+struct PropPlan {
   PropGeom g;
+  size_t off_mask, off_keep, off_num, off_order, total, mask_per_image;
+};
+
+PropPlan plan_proposal(int batch, int num_anchors, int height, int width, int feat_stride, int pre_nms_topN) {
+  PropPlan p;
+  PropGeom& g = p.g;
   g.A = num_anchors; g.H = height; g.W = width; g.K = height * width; g.n = g.K * g.A;
   g.feat_stride = feat_stride;
   g.topn = effective_topn(batch, g.n, pre_nms_topN);
   g.P = next_pow2(g.topn);
-  DTT_REQUIRE(g.P <= kMaxSort, "proposal: %d boxes per image exceed the %d-entry LDS sort", g.topn, kMaxSort);
-  const size_t need = dtt_proposal_workspace_bytes(batch, num_anchors, height, width, pre_nms_topN);
-  DTT_REQUIRE(workspace && workspace_bytes >= need, "proposal: workspace too small (%zu < %zu)", workspace_bytes, need);
-  unsigned char* w = static_cast<unsigned char*>(workspace);
-  float* boxes = reinterpret_cast<float*>(w);
-  w += align_up((size_t)batch * g.topn * 4 * sizeof(float), 256);
-  unsigned long long* mask = reinterpret_cast<unsigned long long*>(w);
-  const size_t mask_per_image = dtt_nms_mask_bytes(g.topn);
-  w += align_up((size_t)batch * mask_per_image, 256);
-  int* keep = reinterpret_cast<int*>(w);
-  w += align_up((size_t)batch * g.topn * sizeof(int), 256);
-  int* num_ws = reinterpret_cast<int*>(w);
+  p.mask_per_image = dtt_nms_mask_bytes(g.topn);
+  p.off_mask = align_up((size_t)batch * g.topn * 4 * sizeof(float), 256);
+  p.off_keep = p.off_mask + align_up((size_t)batch * p.mask_per_image, 256);
+  p.off_num = p.off_keep + align_up((size_t)batch * g.topn * sizeof(int), 256);
+  p.off_order = p.off_num + 256;
+  p.total = p.off_order + align_up((size_t)batch * g.topn * sizeof(unsigned), 256);
+  return p;
+}
 
+}  // namespace
+
+extern "C" size_t dtt_proposal_workspace_bytes(int batch, int num_anchors, int height, int width,
+                                               int pre_nms_topN) {
+  return plan_proposal(batch, num_anchors, height, width, 1, pre_nms_topN).total;
+}
+
+// Phase 1 of the proposal layer: per image, the pre_nms_topN best (score, anchor) keys in order -> workspace.  Reads the
+// scores only.
+extern "C" int dtt_proposal_select_sort(const float* cls_prob, int batch, int num_anchors, int height, int width,
+                                        int pre_nms_topN, void* workspace, size_t workspace_bytes, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  DTT_REQUIRE(cls_prob, "proposal: null pointer");
+  DTT_REQUIRE(batch > 0 && num_anchors > 0 && height > 0 && width > 0, "proposal: bad shape");
+  const PropPlan p = plan_proposal(batch, num_anchors, height, width, 1, pre_nms_topN);
+  const PropGeom& g = p.g;
+  DTT_REQUIRE(g.P <= kMaxSort, "proposal: %d boxes per image exceed the %d-entry LDS sort", g.topn, kMaxSort);
+  DTT_REQUIRE(workspace && workspace_bytes >= p.total, "proposal: workspace too small (%zu < %zu)", workspace_bytes, p.total);
+  unsigned* order = reinterpret_cast<unsigned*>(static_cast<unsigned char*>(workspace) + p.off_order);
   const size_t lds = (size_t)g.P * 8 + (16 + 8) * 4;
   static DttDeviceOnce attr_once;
   bool& attr = attr_once.here();   // the attribute is per device, not per process
@@ -294,14 +313,50 @@ extern "C" int dtt_proposal_forward(const float* cls_prob, const float* bbox_pre
   }
   dtt_prof_begin("proposal_select_sort", stream);
   if (g.n <= kEPT * kThreads)
-    hipLaunchKernelGGL(proposal_select_sort<true>, dim3(batch), dim3(kThreads), lds, stream, cls_prob, bbox_pred,
-                       im_info, anchors, g, boxes);
+    hipLaunchKernelGGL(proposal_select_sort<true>, dim3(batch), dim3(kThreads), lds, stream, cls_prob, g, order);
   else
-    hipLaunchKernelGGL(proposal_select_sort<false>, dim3(batch), dim3(kThreads), lds, stream, cls_prob, bbox_pred,
-                       im_info, anchors, g, boxes);
+    hipLaunchKernelGGL(proposal_select_sort<false>, dim3(batch), dim3(kThreads), lds, stream, cls_prob, g, order);
   dtt_prof_end("proposal_select_sort", stream);
   DTT_CHECK_LAUNCH("proposal_select_sort");
+  return 1;
+}
+
+// Phase 2: decode + clip the boxes phase 1 selected (same geometry arguments, same workspace), NMS, RoI tensor.
+extern "C" int dtt_proposal_decode_nms(const float* bbox_pred, const float* im_info, const float* anchors, int batch,
+                                       int num_anchors, int height, int width, int feat_stride, int pre_nms_topN,
+                                       int post_nms_topN, float nms_thresh, float* rois_out, int* num_out, void* workspace,
+                                       size_t workspace_bytes, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  DTT_REQUIRE(bbox_pred && im_info && anchors && rois_out, "proposal: null pointer");
+  DTT_REQUIRE(batch > 0 && num_anchors > 0 && height > 0 && width > 0 && feat_stride > 0, "proposal: bad shape");
+  DTT_REQUIRE(post_nms_topN > 0, "proposal: post_nms_topN must be > 0");
+  const PropPlan p = plan_proposal(batch, num_anchors, height, width, feat_stride, pre_nms_topN);
+  const PropGeom& g = p.g;
+  DTT_REQUIRE(workspace && workspace_bytes >= p.total, "proposal: workspace too small (%zu < %zu)", workspace_bytes, p.total);
+  unsigned char* w = static_cast<unsigned char*>(workspace);
+  float* boxes = reinterpret_cast<float*>(w);
+  unsigned long long* mask = reinterpret_cast<unsigned long long*>(w + p.off_mask);
+  int* keep = reinterpret_cast<int*>(w + p.off_keep);
+  int* num_ws = reinterpret_cast<int*>(w + p.off_num);
+  const unsigned* order = reinterpret_cast<const unsigned*>(w + p.off_order);
+  DTT_REQUIRE(batch <= 65535, "proposal: more than 65535 images in one call");
+  hipLaunchKernelGGL(proposal_decode, dim3((g.topn + 255) / 256, batch), dim3(256), 0, stream, order, bbox_pred, im_info, anchors, g,
+                     boxes);
+  DTT_CHECK_LAUNCH("proposal_decode");
   return dtt_nms_batched_launch(boxes, 4, (long)g.topn * 4, nullptr, g.topn, batch, nms_thresh, post_nms_topN, mask,
-                                (long)(mask_per_image / sizeof(unsigned long long)), keep, g.topn,
+                                (long)(p.mask_per_image / sizeof(unsigned long long)), keep, g.topn,
                                 num_out ? num_out : num_ws, rois_out, post_nms_topN, stream);
+}
+
+extern "C" int dtt_proposal_forward(const float* cls_prob, const float* bbox_pred, const float* im_info,
+                                    const float* anchors, int batch, int num_anchors, int height, int width,
+                                    int feat_stride, int pre_nms_topN, int post_nms_topN, float nms_thresh,
+                                    float* rois_out, int* num_out, void* workspace, size_t workspace_bytes,
+                                    void* stream_) {
+  DTT_REQUIRE(cls_prob && bbox_pred && im_info && anchors && rois_out, "proposal: null pointer");
+  DTT_REQUIRE(post_nms_topN > 0, "proposal: post_nms_topN must be > 0");
+  if (!dtt_proposal_select_sort(cls_prob, batch, num_anchors, height, width, pre_nms_topN, workspace, workspace_bytes, stream_))
+    return 0;
+  return dtt_proposal_decode_nms(bbox_pred, im_info, anchors, batch, num_anchors, height, width, feat_stride, pre_nms_topN,
+                                 post_nms_topN, nms_thresh, rois_out, num_out, workspace, workspace_bytes, stream_);
 }

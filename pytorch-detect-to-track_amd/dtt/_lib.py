@@ -47,6 +47,8 @@ SIGNATURES = {
     "dtt_roi_crop_backward": (_I, [_I] * 8 + [_P, _P, _P, _P, _P]),
     "dtt_proposal_workspace_bytes": (_Z, [_I] * 5),
     "dtt_proposal_forward": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _Z, _P]),
+    "dtt_proposal_select_sort": (_I, [_P, _I, _I, _I, _I, _I, _P, _Z, _P]),
+    "dtt_proposal_decode_nms": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _Z, _P]),
     "dtt_anchor_target_assign": (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _F, _F, _I, _P, _P, _P, _P, _P]),
     "dtt_anchor_target_disable": (_I, [_P, _P, _P, _I, _I, _P]),
     "dtt_proposal_target_assign": (_I, [_P, _P, _I, _I, _I, _I, _F, _F, _F, _P, _P, _P, _P, _P]),

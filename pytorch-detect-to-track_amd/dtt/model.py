@@ -16,6 +16,8 @@ resnet.py:259); `rois_label` is reshaped to (n_legs, B, -1) instead of the hard-
 """
 import math
 
+import os
+
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -129,6 +131,13 @@ class _RPN(nn.Module):
         cls_score_r = self.reshape(cls_score, 2)
         cls_prob = self.reshape(F.softmax(cls_score_r, dim=1), self.nc_score_out)
         return cls_score, cls_score_r, cls_prob, self.RPN_bbox_pred(conv1)
+
+    def head_scores(self, base_feat, conv1=None):
+        """The score half of `head`: (conv1, cls_prob) -- the box-delta convolution is the caller's (inference overlap)."""
+        if conv1 is None:
+            conv1 = F.relu(self.RPN_Conv(base_feat), inplace=True)
+        cls_score_r = self.reshape(self.RPN_cls_score(conv1), 2)
+        return conv1, self.reshape(F.softmax(cls_score_r, dim=1), self.nc_score_out)
 
     def proposals(self, cls_prob, bbox_pred, im_info):
         return self.RPN_proposal((cls_prob.detach(), bbox_pred.detach(), im_info, "TRAIN" if self.training else "TEST"))
@@ -264,14 +273,16 @@ class _RFCN(nn.Module):
                 jobs.append((l, f, col))
                 col += oc
             assert col == pm.trk_in, "tracking feature width %d != corr_bbox_net input %d" % (col, pm.trk_in)
-            # Launch order conv3, conv5, conv4.  The select / sort kernel of the side stream (one 1024-thread, 64 KB-LDS
-            # workgroup per image) is dispatched in the same microseconds as the first kernel here, and two dispatches
-            # that race for CUs leave the loser's workgroups parked on a full shader engine until one of ITS CUs frees
-            # up (tools/wg_trace.py, tools/probes/wg_placement.hip): +75 us on the conv5 correlation or +90 us on the
-            # sort when conv5 went first.  With the 23 us conv3 kernel in that slot the race costs at most its length;
-            # conv5 then starts with the sort long placed (it takes the CUs that are really free) and ends before the
-            # NMS mask kernel's small workgroups come to share SIMDs, which is conv4's lot.
-            order = [jobs[0], jobs[2], jobs[1]]
+            # Launch order conv3, conv5, conv4 (env DTT_CORR_ORDER "021": developer A/B; measured 232.8 frame-pairs/s against
+            # 232.0 for "012" and 232.1 for "210").  The side stream's select / sort (one 1024-thread, 64 KB-LDS workgroup
+            # per image) has been resident for ~15 us when this sequence starts and stays for ~105 us more; its NMS mask
+            # (one-wave workgroups) and sweep (4 x 1024 threads) kernels follow.  A one-workgroup-per-CU kernel dispatched
+            # while a foreign workgroup sits on one of "its" shader engines has, in some steps, one workgroup parked until a
+            # CU of that engine frees up -- until the first of its own workgroups finishes, +60 % on that launch
+            # (tools/wg_trace.py, tools/probes/wg_placement.hip).  conv5 right after the 23 us conv3 kernel sees that
+            # least often (median 118 us, one step in ~8 at 170+); last, under the sweep kernel, its median is 180 us.
+            idx = [int(c) for c in os.environ.get("DTT_CORR_ORDER", "021")]
+            order = [jobs[i] for i in idx]
             for l, f, c0 in order:
                 if f.is_contiguous(memory_format=torch.channels_last) and not f.is_contiguous():
                     # channels-last trunk maps: the single-launch channels-last kernel, no transposes
@@ -320,10 +331,15 @@ class _RFCN(nn.Module):
         c3, c4, c5, top = self._im_to_head(flat)
         side = None
         if not self.training and top.is_cuda and not torch.is_grad_enabled():
-            # The proposal layer (select / sort, NMS mask + sweep) is a handful of small kernels that leave most CUs
-            # idle; it runs on a side stream underneath the correlations and the head GEMMs, which do not depend on it.
-            # The RPN's own 1x1 heads stay on the main stream, ahead of the fork: beside the one-workgroup-per-CU
-            # correlation kernels they are starved of CUs (50 -> 220 us) and push the select / sort under the head GEMM.
+            # The proposal layer (select / sort, decode, NMS mask + sweep) is a handful of small kernels that leave most
+            # CUs idle; it runs on a side stream underneath the correlations and the tracking head, which do not depend
+            # on it.  Its first kernel -- select / sort: one 1024-thread, 64 KB-LDS workgroup per image, 145 us -- needs
+            # the scores only and is started as soon as the softmax is done, while the RPN's box-delta convolution
+            # still runs here: when the one-workgroup-per-CU correlation kernels are dispatched it has long been placed.
+            # (Dispatched in the same microseconds, the two race for CUs and the loser's workgroups stay parked on a
+            # full shader engine until one of ITS CUs frees up: +75 us on a correlation or +90 us on the sort;
+            # tools/wg_trace.py, tools/probes/wg_placement.hip.)  The RPN's own convolutions stay on the main stream:
+            # beside the correlation kernels they are starved of CUs (50 -> 220 us).
             cur = torch.cuda.current_stream(dev)
             side = getattr(self, "_side_stream", None)
             if side is None or side.device != dev:
@@ -332,10 +348,15 @@ class _RFCN(nn.Module):
             conv1 = getattr(fused, "rpn_conv1", None)   # set by the channels-last fused trunk during _im_to_head above
             if conv1 is not None:
                 fused.rpn_conv1 = None
-            _, _, rpn_prob, rpn_bbox = self.RFCN_rpn.head(top, conv1)
+            rpn = self.RFCN_rpn
+            conv1, rpn_prob = rpn.head_scores(top, conv1)
             side.wait_stream(cur)
             with torch.cuda.stream(side):
-                all_rois = self.RFCN_rpn.proposals(rpn_prob, rpn_bbox, im_info.view(n_legs * B, -1))
+                selection = rpn.RPN_proposal.select(rpn_prob.detach(), "TEST")
+            rpn_bbox = rpn.RPN_bbox_pred(conv1)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                all_rois = rpn.RPN_proposal.finish(selection, rpn_bbox.detach(), im_info.view(n_legs * B, -1), "TEST")
             rpn_prob.record_stream(side); rpn_bbox.record_stream(side)
         leg = lambda t, i: t[i * B:(i + 1) * B]
         pm = getattr(self, "_pm_tail", None)

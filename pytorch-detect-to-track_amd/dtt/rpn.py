@@ -55,6 +55,45 @@ class _ProposalLayer(nn.Module):
         return proposal_forward(scores, bbox_deltas, im_info, self._anchors, self._feat_stride,
                                 c.RPN_PRE_NMS_TOP_N, c.RPN_POST_NMS_TOP_N, c.RPN_NMS_THRESH)[0]
 
+    # The same layer in two phases (dtt_proposal_select_sort / dtt_proposal_decode_nms): phase 1 needs the scores only, so a
+    # caller that overlaps the proposal layer with other work starts it before the box deltas exist (dtt/model.py).
+    def select(self, scores, cfg_key):
+        """Phase 1 on the current stream; returns the handle `finish` takes."""
+        require_gpu(scores)
+        scores = scores.detach().float().contiguous()
+        B, twoA, H, W = scores.shape
+        A = self._num_anchors
+        if twoA != 2 * A:
+            raise ValueError("proposal: cls_prob %s does not match %d anchors" % (tuple(scores.shape), A))
+        c = self._cfg[cfg_key]
+        L = _lib.lib()
+        nbytes = L.dtt_proposal_workspace_bytes(B, A, H, W, int(c.RPN_PRE_NMS_TOP_N))
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=scores.device)
+        with torch.cuda.device(scores.device):
+            check(L.dtt_proposal_select_sort(ptr(scores), B, A, H, W, int(c.RPN_PRE_NMS_TOP_N), ptr(ws), nbytes,
+                                             stream_ptr(scores.device)), "proposal select / sort")
+        return ws, scores, (B, A, H, W)
+
+    def finish(self, handle, bbox_deltas, im_info, cfg_key):
+        """Phase 2 on the current stream (which must be ordered after phase 1) -> rois (B, post_nms_topN, 5)."""
+        ws, scores, (B, A, H, W) = handle
+        require_gpu(bbox_deltas)
+        bbox_deltas = bbox_deltas.detach().float().contiguous()
+        if tuple(bbox_deltas.shape) != (B, 4 * A, H, W):
+            raise ValueError("proposal: bbox_pred %s does not match cls_prob %s" % (tuple(bbox_deltas.shape), tuple(scores.shape)))
+        dev = bbox_deltas.device
+        c = self._cfg[cfg_key]
+        im_info = im_info.detach().to(dev, torch.float32).contiguous()
+        anchors = self._anchors.to(dev, torch.float32).contiguous()
+        rois = torch.empty((B, int(c.RPN_POST_NMS_TOP_N), 5), dtype=torch.float32, device=dev)
+        num = torch.empty((B,), dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            check(_lib.lib().dtt_proposal_decode_nms(ptr(bbox_deltas), ptr(im_info), ptr(anchors), B, A, H, W, self._feat_stride,
+                                                     int(c.RPN_PRE_NMS_TOP_N), int(c.RPN_POST_NMS_TOP_N), float(c.RPN_NMS_THRESH),
+                                                     ptr(rois), ptr(num), ptr(ws), ws.numel(), stream_ptr(dev)),
+                  "proposal decode / nms")
+        return rois
+
 
 def proposal_forward(cls_prob, bbox_pred, im_info, anchors, feat_stride, pre_nms_topN, post_nms_topN, nms_thresh):
     """Functional form: returns (rois (B, post, 5), num_valid int32 (B,))."""

@@ -427,6 +427,31 @@ def test_proposal_layer_vs_oracle(dev, B, H, W, pre, post):
     np.testing.assert_array_equal(rois.cpu().numpy(), ref)  # bit-exact rows, order and zero padding
 
 
+def test_proposal_layer_two_phases_across_streams(dev):
+    """_ProposalLayer.select (scores only, side stream) + .finish (box deltas, after a stream dependency) -- the split
+    dtt/model.py uses to start the sort under the RPN's box-delta convolution -- is the one-call layer, bit for bit."""
+    from dtt.config import cfg
+    from dtt.rpn import _ProposalLayer
+    rng = np.random.RandomState(77)
+    layer = _ProposalLayer(16, cfg.ANCHOR_SCALES, cfg.ANCHOR_RATIOS, cfg=cfg).to(dev)
+    A = layer._num_anchors
+    prob, bbox, info = _proposal_inputs(rng, 2, A, 38, 67)
+    prob, bbox, info = cu(prob, dev), cu(bbox, dev), cu(info, dev)
+    ref = layer((prob, bbox, info, "TEST"))
+    side, cur = torch.cuda.Stream(device=dev), torch.cuda.current_stream(dev)
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        handle = layer.select(prob, "TEST")
+    bbox2 = bbox.clone()                       # "still being computed" on the main stream
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        rois = layer.finish(handle, bbox2, info, "TEST")
+    cur.wait_stream(side)
+    assert torch.equal(rois, ref) and float(ref.abs().sum()) > 0
+    with pytest.raises(ValueError):
+        layer.finish(handle, bbox2[:, :4], info, "TEST")
+
+
 @pytest.mark.parametrize("case", ["test_19x32", "train_19x32", "test_6x8", "test_small_pre"])
 def test_proposal_layer_vs_reference_golden(dev, case):
     from dtt.rpn import generate_anchors, proposal_forward

@@ -1,0 +1,29 @@
+#!/bin/bash
+# Regenerates the per-round evidence under gpurun_out/<round>/ on the GPU box (copy what is to be judged into profiles/):
+#   tools/profile_round.sh r02
+# bench stdout (default flags), rocprofv3 kernel-trace summaries (whole run, steady state, one step launch by launch, the tail's
+# per-step overlap), separate --pmc passes over the tail's hand-written kernels, the config-4 / config-3 lines.
+R=${1:-r02}
+cd ${GRAFT_REPO_ROOT:-$(dirname "$0")/..}; export TMPDIR=/tmp
+O=$PWD/gpurun_out/$R; rm -rf $O; mkdir -p $O
+timeout 900 python bench.py > $O/bench_stdout.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/trace -o bench -- python bench.py --no-cpu-baseline --steps 10 --warmup 5 > $O/prof_bench_stdout.log 2>&1
+DB=$(ls $O/trace/*.db | head -1)
+python tools/rocpd_stats.py $DB > $O/bench_kernel_stats.txt 2>&1
+python tools/rocpd_steady.py $DB 5 "corr_nhwc_kernel<3" > $O/bench_steady_state.txt 2>&1
+python tools/rocpd_sequence.py $DB "psroi_pm_kernel<32" > $O/bench_step_sequence.txt 2>&1
+python tools/rocpd_tail_steps.py $DB 8 > $O/bench_tail_overlap.txt 2>&1
+rm -rf $O/trace
+for c in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE; do
+  timeout 400 rocprofv3 --kernel-trace --pmc $c -d $O/pmc_$c -o p -- python tools/pmc_tail.py > $O/pmc_$c.log 2>&1
+  python tools/rocpd_pmc.py $(ls $O/pmc_$c/*.db | head -1) | grep -v "at::\|Cijk\|miopen\|elementwise\|rocclr\|rocprim" >> $O/pmc_tail.txt 2>&1
+  rm -rf $O/pmc_$c $O/pmc_$c.log
+done
+timeout 600 python bench.py --no-cpu-baseline --pooling align --disp 16 --height 563 --width 1000 --batch 1 > $O/bench_config4_stdout.log 2>&1
+timeout 900 python bench.py --mode train --steps 8 --warmup 4 > $O/bench_train_stdout.log 2>&1
+timeout 600 rocprofv3 --kernel-trace -d $O/trace -o tr -- python bench.py --mode train --steps 5 --warmup 3 > $O/prof_train_stdout.log 2>&1
+python tools/rocpd_steady.py $(ls $O/trace/*.db | head -1) 3 "corr_fwd_mfma<3" > $O/train_steady_state.txt 2>&1
+rm -rf $O/trace
+ITERS=20 timeout 300 python tools/time_corr.py > $O/corr_microbench.txt 2>&1
+B=8 ITERS=10 timeout 300 python tools/time_corr.py >> $O/corr_microbench.txt 2>&1
+tail -c 1500 $O/bench_stdout.log

@@ -23,15 +23,17 @@ with torch.no_grad():
 torch.cuda.synchronize()
 L = _lib.lib()
 nt = (ctypes.c_ulonglong * (16 * 256 * 4))()
-st = (ctypes.c_ulonglong * (16 * 8 * 4))()
+st = (ctypes.c_ulonglong * (16 * 8 * 8))()
 assert L.dtt_nhwc_trace_read(nt, len(nt)) and L.dtt_sort_trace_read(st, len(st))
 for slot in range(0, 16, 4):
     wg = [(nt[(slot * 256 + i) * 4 + 0], nt[(slot * 256 + i) * 4 + 1], nt[(slot * 256 + i) * 4 + 2], nt[(slot * 256 + i) * 4 + 3]) for i in range(240)]
     t0 = min(w[0] for w in wg)
     end = max(max(w[2], w[3]) for w in wg)
     # the select / sort launch that overlaps: nearest start
-    best = min(range(16), key=lambda s: abs(int(st[(s * 8) * 4 + 0]) - int(t0)))
-    srt = [(st[(best * 8 + b) * 4 + 0], st[(best * 8 + b) * 4 + 1], st[(best * 8 + b) * 4 + 3]) for b in range(4)]
+    best = min(range(16), key=lambda s: abs(int(st[(s * 8) * 8 + 0]) - int(t0)))
+    srt = [(st[(best * 8 + b) * 8 + 0], st[(best * 8 + b) * 8 + 1], st[(best * 8 + b) * 8 + 7]) for b in range(4)]
+    ph = [[(int(st[(best * 8 + b) * 8 + k]) - int(st[(best * 8 + b) * 8 + 0])) / 100.0 for k in (2, 3, 4, 5, 7)] for b in range(4)]
+    print("    sort phases (us since start: keys loaded, threshold found, compacted, sorted, decoded):", ph)
     late = [(i, w) for i, w in enumerate(wg) if (w[0] - t0) > 1000]
     loc = lambda h: "xcc%d/se%d/cu%d" % (h >> 16, (h >> 8) & 7, h & 15)
     print("conv5 launch %2d: %.1f us; %d workgroups started > 10 us late" % (slot, (end - t0) / 100.0, len(late)))
