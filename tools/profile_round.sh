@@ -26,4 +26,11 @@ python tools/rocpd_steady.py $(ls $O/trace/*.db | head -1) 3 "corr_fwd_mfma<3" >
 rm -rf $O/trace
 ITERS=20 timeout 300 python tools/time_corr.py > $O/corr_microbench.txt 2>&1
 B=8 ITERS=10 timeout 300 python tools/time_corr.py >> $O/corr_microbench.txt 2>&1
+# hardware probes / placement traces behind DESIGN.md 4.10 (binaries: hipcc -O3 tools/probes/*.hip -> tools/_variants/; tools/build_trace_variant.sh)
+[ -x tools/_variants/wg_placement ] && timeout 120 tools/_variants/wg_placement > $O/wg_placement_probe.txt 2>&1
+if [ -x tools/_variants/fetch_calib ]; then
+  timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/calib -o p -- tools/_variants/fetch_calib > $O/fetch_calib.log 2>&1
+  python tools/rocpd_pmc.py $O/calib/*.db > $O/fetch_calib.txt; tail -1 $O/fetch_calib.log >> $O/fetch_calib.txt; rm -rf $O/calib $O/fetch_calib.log
+fi
+[ -f tools/_variants/wgtrace.so ] && DTT_HIP_LIBRARY=$PWD/tools/_variants/wgtrace.so timeout 600 python tools/wg_trace.py 2>&1 | grep -v "Warn\|amdgpu.ids" > $O/wg_trace.txt
 tail -c 1500 $O/bench_stdout.log
