@@ -460,7 +460,7 @@ extern "C" int dtt_head_gemm(const float* x, long ldx, int M, int K, const float
       ncu = prop.multiProcessorCount;
   }
   static const int nload = getenv("DTT_HEAD_NLOAD") ? atoi(getenv("DTT_HEAD_NLOAD")) : 4;   // developer A/B switches
-  if (g.nt_total >= 28) {
+  if (g.nt_total > 16) {   // more channel tiles than the narrow configuration's single pass holds
     // wide heads (31*49 classes [+ 4*49 box deltas]): pixel strips x channel groups, one workgroup per CU
     static const int ntw_env = getenv("DTT_HEAD_NTW") ? atoi(getenv("DTT_HEAD_NTW")) : 4;
     static const int pin_env = getenv("DTT_HEAD_PIN") ? atoi(getenv("DTT_HEAD_PIN")) : 0;

@@ -43,7 +43,7 @@ class PackedHeads:
             assert w.shape[1] == K, "heads must share their input"
             od = w.shape[0] // (group * group)
             assert od * group * group == w.shape[0]
-            cp = _pow2_at_least(od)
+            cp = 4 if od <= 4 else _pow2_at_least(max(od, 32))   # the pooling kernel's instantiations: 4 or 32 classes per bin
             b = conv.bias.detach().float() if conv.bias is not None else torch.zeros(w.shape[0], device=dev)
             # emitted row bin*cp + c  <-  reference channel c*G*G + bin
             wp = torch.zeros(group * group, cp, Kp, device=dev)

@@ -194,10 +194,6 @@ def run_more(N=60, seed=0):
     return bad
 
 
-if __name__ == "__main__":
-    b = run(int(os.environ.get("N", 150)), int(os.environ.get("SEED", 0)))
-    m = run_more(int(os.environ.get("N2", 60)), int(os.environ.get("SEED", 0)))
-    sys.exit(1 if (any(b) or any(m.values())) else 0)
 
 
 def run_ref(N=60, seed=0):
@@ -251,3 +247,79 @@ def run_ref(N=60, seed=0):
             bad["nms"] += 1; print("REF NMS MISMATCH", n, thr, flush=True)
     print("oracle vs reference kernels:", bad, flush=True)
     return bad
+
+
+def run_tail(N=60, seed=0):
+    """Round-2 kernels on random shapes: channels-last correlation (both output layouts) against the oracle, the head GEMM
+    against a float64 product, position-major PSRoI pooling + vote against the oracle pooling of the same scores (bit for bit),
+    the two-phase proposal layer against the one-call layer.  Returns {name: mismatches}."""
+    from dtt.heads import PackedHeads, head_gemm, pm_to_nchw, psroi_pm
+    from dtt.ops import correlation_forward_nhwc, correlation_output_shape
+    dev = torch.device("cuda:0")
+    rs = np.random.RandomState(seed)
+    bad = {"corr_nhwc": 0, "head_gemm": 0, "psroi_pm": 0}
+    for it in range(N):
+        B = rs.randint(1, 4); C = 16 * rs.randint(1, 9); s = int(rs.choice([1, 1, 1, 2]))
+        R = int(rs.choice([1, 2, 3, 4, 5, 6, 7, 8, 8, 8, 12, 16])); d = R * s
+        H = rs.randint(1, 45); W = rs.randint(1, 75)
+        pad = d if rs.rand() < 0.7 else d + s * int(rs.choice([-1, 1, 2])) * (1 if R > 1 else 0)
+        if pad < 0 or (H + 2 * pad - 2 * d + s - 1) // s < 1 or (W + 2 * pad - 2 * d + s - 1) // s < 1:
+            continue
+        x1 = np.maximum(rs.normal(size=(B, C, H, W)), 0).astype(np.float32)
+        x2 = np.maximum(rs.normal(size=(B, C, H, W)), 0).astype(np.float32)
+        ref = O.correlation_forward(x1, x2, pad, 1, d, s, s)
+        t1 = torch.from_numpy(x1).to(dev).contiguous(memory_format=torch.channels_last)
+        t2 = torch.from_numpy(x2).to(dev).contiguous(memory_format=torch.channels_last)
+        out = correlation_forward_nhwc(t1, t2, pad, 1, d, s, s)
+        oc, oh, ow = correlation_output_shape(C, H, W, pad, 1, d, s, s)
+        rows = torch.full((B * oh * ow, oc + 12), -3.0, device=dev)
+        correlation_forward_nhwc(t1, t2, pad, 1, d, s, s, rows=rows, col=8)
+        torch.cuda.synchronize()
+        e = float(np.abs(out.cpu().numpy() - ref).max())
+        r = rows.cpu().numpy()
+        same = np.array_equal(r[:, 8:8 + oc].reshape(B, oh, ow, oc).transpose(0, 3, 1, 2), out.cpu().numpy())
+        untouched = bool((r[:, :8] == -3).all() and (r[:, 8 + oc:] == -3).all())
+        if e > 1e-5 or not same or not untouched:
+            bad["corr_nhwc"] += 1
+            print("CORR NHWC MISMATCH", (B, C, H, W, pad, d, s), e, same, untouched, flush=True)
+    print("corr_nhwc: %d cases, %d bad" % (N, bad["corr_nhwc"]), flush=True)
+    for it in range(N // 2):
+        B = rs.randint(1, 4); H = rs.randint(2, 40); W = rs.randint(2, 70); K = 32 * rs.randint(1, 9)
+        ods = [(31, 4), (31,), (4,), (21, 4), (3,), (17, 2), (32, 1), (5,), (9, 4)][rs.randint(0, 9)]
+        torch.manual_seed(int(rs.randint(1 << 30)))
+        convs = [torch.nn.Conv2d(K, od * 49, 1).to(dev) for od in ods]
+        packed = PackedHeads(convs)
+        x = torch.from_numpy(np.maximum(rs.normal(size=(B, K, H, W)), 0).astype(np.float32)).to(dev)
+        pm = head_gemm(x.permute(0, 2, 3, 1).reshape(-1, K).contiguous(), packed)
+        R = rs.randint(1, 500)
+        x1 = rs.uniform(-40, W * 16, R); y1 = rs.uniform(-40, H * 16, R)
+        rois = np.stack([rs.randint(0, B, R), x1, y1, x1 + rs.uniform(0, W * 14, R), y1 + rs.uniform(0, H * 14, R)], 1).astype(np.float32)
+        if rs.rand() < 0.3:
+            rois[:, 1:] = np.round(rois[:, 1:] / 16) * 16      # bin edges on pixel boundaries
+        rt = torch.from_numpy(rois).to(dev)
+        for conv, head in zip(convs, packed.heads):
+            maps = pm_to_nchw(pm, head, B, H, W)
+            want = torch.nn.functional.conv2d(x.double(), conv.weight.detach().double(), conv.bias.detach().double())
+            rel = float((maps.double() - want).abs().max() / want.abs().max().clamp_min(1e-30))
+            if rel > 1e-5:
+                bad["head_gemm"] += 1
+                print("HEAD GEMM MISMATCH", (B, H, W, K, ods), rel, flush=True)
+            vote, pooled = psroi_pm(pm, head, B, H, W, rt, 1 / 16.0, want_pooled=True)
+            ref_p, _ = O.psroi_pool_forward(maps.cpu().numpy(), rois, 7, 7, 1 / 16.0, 7, head["od"])
+            ref_v = ref_p.reshape(R, head["od"], 49)
+            acc = np.zeros((R, head["od"]), np.float32)
+            for k in range(49):                                  # the reference's AvgPool2d order: row-major sum, then / 49
+                acc = (acc + ref_v[:, :, k]).astype(np.float32)
+            ref_vote = (acc / np.float32(49)).astype(np.float32)
+            if not np.array_equal(pooled.cpu().numpy(), ref_p) or not np.array_equal(vote.cpu().numpy(), ref_vote):
+                bad["psroi_pm"] += 1
+                print("PSROI PM MISMATCH", (B, H, W, K, ods, R), flush=True)
+    print("head_gemm / psroi_pm: %d cases, %d / %d bad" % (N // 2, bad["head_gemm"], bad["psroi_pm"]), flush=True)
+    return bad
+
+
+if __name__ == "__main__":
+    b = run(int(os.environ.get("N", 150)), int(os.environ.get("SEED", 0)))
+    m = run_more(int(os.environ.get("N2", 60)), int(os.environ.get("SEED", 0)))
+    t = run_tail(int(os.environ.get("N3", 80)), int(os.environ.get("SEED", 0)))
+    sys.exit(1 if (any(b) or any(m.values()) or any(t.values())) else 0)

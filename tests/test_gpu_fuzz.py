@@ -24,6 +24,15 @@ def test_random_shape_sweep_remaining_ops():
     assert not any(fuzz_ops.run_more(N=40, seed=5).values())
 
 
+@pytest.mark.parametrize("seed", [2, 23])
+def test_random_shape_sweep_tail_kernels(seed):
+    """Round-2 kernels (channels-last correlation in both output layouts, head GEMM, position-major PSRoI pooling + vote) on
+    random shapes: window radii 1 ... 16, strides, pad != displacement, maps smaller than a tile, 32 ... 256 input channels,
+    1 - 2 heads of 4 ... 31 classes, RoIs hanging over the image, bin edges on pixel boundaries."""
+    import fuzz_ops
+    assert not any(fuzz_ops.run_tail(N=60, seed=seed).values())
+
+
 def test_oracle_against_reference_kernels_on_random_shapes():
     """The CPU oracle against the reference's own kernels (oracle/_ref) over random geometries: bit for bit."""
     import fuzz_ops
