@@ -58,20 +58,59 @@ __device__ __forceinline__ unsigned block_sum(unsigned wave_count, unsigned* wsu
   return tot;
 }
 
-// LDS: buf[P] u64 | wsum[16] | ctl[8]
+// Sort buffer index: one 8-byte pad after every 8 keys.  A thread of a sort pass owns 2 / 4 / 8 keys a power-of-two stride
+// apart; with the pad, the 32 lanes of a ds_read_b64 fall in 32 different bank pairs for the stride-1 pass (72-byte lane
+// stride) as well as for the wider ones.
+__device__ __forceinline__ int sort_slot(int i) { return i + (i >> 3); }
+__host__ __device__ constexpr int sort_slots(int P) { return P + (P >> 3); }
+
+// NST consecutive stages (j = jlow << (NST-1), ..., 2*jlow, jlow) of bitonic phase k in ONE pass over LDS: a thread loads
+// the 2^NST keys that only exchange among themselves in these stages, runs the compare-exchanges in registers and stores
+// them back -- 35 barrier-separated passes for 8192 keys instead of 91.
+template <int NST>
+__device__ __forceinline__ void bitonic_pass(unsigned long long* __restrict__ buf, int P, int k, int jlow, int tid) {
+  constexpr int G = 1 << NST;
+  const int plow = __builtin_ctz(jlow);
+  for (int gi = tid; gi < (P >> NST); gi += kThreads) {
+    const int base = ((gi >> plow) << (plow + NST)) | (gi & (jlow - 1));
+    const bool up = (base & k) == 0;
+    unsigned long long v[G];
+#pragma unroll
+    for (int e = 0; e < G; ++e) v[e] = buf[sort_slot(base + e * jlow)];
+#pragma unroll
+    for (int s = 0; s < NST; ++s) {
+      constexpr int dummy = 0; (void)dummy;
+      const int bit = G >> (s + 1);
+#pragma unroll
+      for (int e = 0; e < G; ++e) {
+        if (e & bit) continue;
+        const unsigned long long lo = v[e], hi = v[e | bit];
+        const bool sw = (lo > hi) == up;
+        v[e] = sw ? hi : lo;
+        v[e | bit] = sw ? lo : hi;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < G; ++e) buf[sort_slot(base + e * jlow)] = v[e];
+  }
+}
+
+// LDS: buf[sort_slots(P)] u64 | wsum[2][16] (+ spare) | ctl[8]
 // Slot e of thread tid is score-map element m = tid + e*kThreads in MEMORY order (m = a*K + k, coalesced);
 // its flattened anchor index is t = k*A + a (proposal_layer.py:102-103).
 //
 // Selection of the topn best keys is an exact MSB-first bisection on the key bits: 32 rounds of
 // "how many keys are below this pivot", each a compare + ballot + popcount per cached key and one
-// 16-way sum through LDS -- no atomics, no histogram, insensitive to how skewed the scores are.
+// 16-way sum through LDS (double-buffered: one barrier per round) -- no atomics, no histogram, insensitive to how
+// skewed the scores are.  (Two bits per round -- three pivots, half the rounds -- was measured slower: the per-key
+// s_bcnt1 / s_add pairs of all 16 waves go through the CU's one scalar unit, 53 us against 30.)
 template <bool CACHE>
 __global__ __launch_bounds__(kThreads) void proposal_select_sort(const float* __restrict__ cls_prob, PropGeom g,
                                                                  unsigned* __restrict__ order_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned long long* buf = reinterpret_cast<unsigned long long*>(smem);
-  unsigned* wsum = reinterpret_cast<unsigned*>(buf + g.P);
-  unsigned* ctl = wsum + 16;  // [3] fill counter
+  unsigned* wsum = reinterpret_cast<unsigned*>(buf + sort_slots(g.P));
+  unsigned* ctl = wsum + 96;  // [3] fill counter
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
 #ifdef DTT_WG_TRACE
   const int trace_slot = dtt_sort_trace_launch % 16;
@@ -87,11 +126,17 @@ __global__ __launch_bounds__(kThreads) void proposal_select_sort(const float* __
   const int nslots = (g.n + kThreads - 1) / kThreads;
 
   unsigned kc[kEPT];
+  unsigned tc[kEPT];   // flattened anchor index t = k*A + a of slot e (m = a*K + k walked incrementally: no division per slot)
   if constexpr (CACHE) {
+    int a = tid / g.K, k = tid - a * g.K;
+    const int da = kThreads / g.K, dk = kThreads - da * g.K;
 #pragma unroll
     for (int e = 0; e < kEPT; ++e) {
       const int m = tid + e * kThreads;
       kc[e] = m < g.n ? desc_key(sc[m]) : 0xFFFFFFFFu;  // padding is never below a pivot
+      tc[e] = (unsigned)(k * g.A + a);
+      k += dk; a += da;
+      if (k >= g.K) { k -= g.K; ++a; }
     }
   }
   auto t_of = [&](int m) -> unsigned {
@@ -118,11 +163,29 @@ __global__ __launch_bounds__(kThreads) void proposal_select_sort(const float* __
   if (g.topn < g.n) {
     // largest T with count(key < T) < topn  ==  the topn-th smallest key
     unsigned T = 0;
+    const int wave = tid >> 6;
 #pragma unroll 1
     for (int bit = 31; bit >= 0; --bit) {
       const unsigned test = T | (1u << bit);
-      if (count_below(test) < (unsigned)g.topn) T = test;
+      unsigned c = 0;
+      if constexpr (CACHE) {
+#pragma unroll
+        for (int e = 0; e < kEPT; ++e) c += (unsigned)__builtin_popcountll(__ballot(kc[e] < test));
+      } else {
+        for (int e = 0; e < nslots; ++e) {
+          const int m = tid + e * kThreads;
+          c += (unsigned)__builtin_popcountll(__ballot(m < g.n && desc_key(sc[min(m, g.n - 1)]) < test));
+        }
+      }
+      unsigned* ws = wsum + (bit & 1) * 16;   // double-buffered: a slower wave may still be reading the previous round's sums
+      if (lane == 0) ws[wave] = c;
+      __syncthreads();                          // one barrier per round
+      unsigned tot = 0;
+#pragma unroll
+      for (int w = 0; w < kThreads / 64; ++w) tot += ws[w];
+      if (tot < (unsigned)g.topn) T = test;
     }
+    __syncthreads();   // (the counts below reuse the first sum buffer)
     thr_hi = T;
     const unsigned below = count_below(T);
     const unsigned upto = T == 0xFFFFFFFFu ? (unsigned)g.n : count_below(T + 1u);
@@ -136,10 +199,16 @@ __global__ __launch_bounds__(kThreads) void proposal_select_sort(const float* __
       for (int bit = tb - 1; bit >= 0; --bit) {
         const unsigned test = Tt | (1u << bit);
         unsigned c = 0;
-        for (int e = 0; e < nslots; ++e) {
-          const int m = tid + e * kThreads;
-          const int mm = min(m, g.n - 1);
-          c += (unsigned)__builtin_popcountll(__ballot(m < g.n && desc_key(sc[mm]) == T && t_of(mm) < test));
+        if constexpr (CACHE) {
+#pragma unroll
+          for (int e = 0; e < kEPT; ++e)   // (padding slots carry key 0xFFFFFFFF: equal to T only if they are wanted anyway ...
+            c += (unsigned)__builtin_popcountll(__ballot(kc[e] == T && tid + e * kThreads < g.n && tc[e] < test));   // ... so test m < n)
+        } else {
+          for (int e = 0; e < nslots; ++e) {
+            const int m = tid + e * kThreads;
+            const int mm = min(m, g.n - 1);
+            c += (unsigned)__builtin_popcountll(__ballot(m < g.n && desc_key(sc[mm]) == T && t_of(mm) < test));
+          }
         }
         if (block_sum(c, wsum) < need) Tt = test;
       }
@@ -158,14 +227,14 @@ __global__ __launch_bounds__(kThreads) void proposal_select_sort(const float* __
         const int leader = __builtin_ctzll(mk);
         if (lane == leader) basei = atomicAdd(&ctl[3], (unsigned)__builtin_popcountll(mk));
         basei = __builtin_amdgcn_readlane(basei, leader);
-        if (take) buf[basei + __builtin_popcountll(mk & ((1ULL << lane) - 1ULL))] = k64;
+        if (take) buf[sort_slot((int)basei + __builtin_popcountll(mk & ((1ULL << lane) - 1ULL)))] = k64;
       }
     };
     if constexpr (CACHE) {
 #pragma unroll
       for (int e = 0; e < kEPT; ++e) {
         const int m = tid + e * kThreads;
-        const unsigned t = t_of(min(m, g.n - 1));
+        const unsigned t = tc[e];
         const bool take = m < g.n && (kc[e] < thr_hi || (kc[e] == thr_hi && t <= thr_lo));
         push(take, ((unsigned long long)kc[e] << 32) | t);
       }
@@ -179,24 +248,21 @@ __global__ __launch_bounds__(kThreads) void proposal_select_sort(const float* __
       }
     }
   }
-  for (int i = g.topn + tid; i < g.P; i += kThreads) buf[i] = ~0ULL;
+  for (int i = g.topn + tid; i < g.P; i += kThreads) buf[sort_slot(i)] = ~0ULL;
   __syncthreads();
   SORT_STAMP(4);
   for (int k = 2; k <= g.P; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int p = tid; p < (g.P >> 1); p += kThreads) {
-        const int i = ((p & ~(j - 1)) << 1) | (p & (j - 1));
-        const int ixj = i | j;
-        const unsigned long long x = buf[i], y = buf[ixj];
-        const bool up = (i & k) == 0;
-        if ((x > y) == up) { buf[i] = y; buf[ixj] = x; }
-      }
+    int j = k >> 1;
+    while (j > 0) {   // stages j, j/2, j/4 (as many as the phase has left) per pass
+      if (j >= 4) { bitonic_pass<3>(buf, g.P, k, j >> 2, tid); j >>= 3; }
+      else if (j == 2) { bitonic_pass<2>(buf, g.P, k, 1, tid); j = 0; }
+      else { bitonic_pass<1>(buf, g.P, k, 1, tid); j = 0; }
       __syncthreads();
     }
   }
   SORT_STAMP(5);
   // ---- rank r -> flattened anchor index t = k * A + a
-  for (int r = tid; r < g.topn; r += kThreads) order_out[(long)b * g.topn + r] = (unsigned)buf[r];
+  for (int r = tid; r < g.topn; r += kThreads) order_out[(long)b * g.topn + r] = (unsigned)buf[sort_slot(r)];
 #ifdef DTT_WG_TRACE
   __syncthreads();
   if (tid == 0 && b < 8) dtt_sort_trace[(trace_slot * 8 + b) * 8 + 7] = wall_clock64();
@@ -300,7 +366,7 @@ extern "C" int dtt_proposal_select_sort(const float* cls_prob, int batch, int nu
   DTT_REQUIRE(g.P <= kMaxSort, "proposal: %d boxes per image exceed the %d-entry LDS sort", g.topn, kMaxSort);
   DTT_REQUIRE(workspace && workspace_bytes >= p.total, "proposal: workspace too small (%zu < %zu)", workspace_bytes, p.total);
   unsigned* order = reinterpret_cast<unsigned*>(static_cast<unsigned char*>(workspace) + p.off_order);
-  const size_t lds = (size_t)g.P * 8 + (16 + 8) * 4;
+  const size_t lds = (size_t)sort_slots(g.P) * 8 + (96 + 8) * 4;
   static DttDeviceOnce attr_once;
   bool& attr = attr_once.here();   // the attribute is per device, not per process
   if (!attr) {
