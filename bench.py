@@ -56,7 +56,7 @@ def parse():
     ap.add_argument("--pooling", choices=("psroi", "align", "pool", "crop"), default="psroi",
                     help="psroi = the reference's R-FCN graph; align / pool / crop additionally pool the 512-channel top map "
                          "per RoI (BASELINE config 5: --pooling align --disp 16 --height 563 --width 1000 --batch 1)")
-    ap.add_argument("--cpu-passes", type=int, default=5, help="timed passes of the CPU baseline (median is reported)")
+    ap.add_argument("--cpu-passes", type=int, default=10, help="timed passes of the CPU baseline (median is reported)")
     return ap.parse_args()
 
 
@@ -116,7 +116,7 @@ def _cpu_model():
 def cpu_baseline(args, cfg):
     """The same forward for ONE frame pair through the CPU graph (stock PyTorch fp32 convolutions + the oracle's OpenMP
     restatement of every hot-path op, oracle/cpu_graph.py) on this box's host cores -- SURVEY 8d's protocol on a bounded
-    sample: the thread count is swept (one pass each), then one warm-up and `--cpu-passes` timed passes at the best
+    sample: the thread count is swept (one pass each), then three warm-up and `--cpu-passes` (10) timed passes at the best
     count; the median is reported.  Context, not the target: the reference has no CPU path for these ops at all."""
     from dtt.synth import build_model, calibrate_batchnorm_, make_batch
     from oracle import cpu_graph, oracle_lib
@@ -140,7 +140,8 @@ def cpu_baseline(args, cfg):
     for t in sorted({t for t in (8, 16, 32, 64) if t <= avail}):   # beyond 64 the single-image convolutions only get slower
         sweep[t] = one(t)
     best = min(sweep, key=sweep.get)
-    one(best)                                                  # warm-up at the chosen count
+    for _ in range(3):                                         # warm-up at the chosen count (3 passes)
+        one(best)
     times = sorted(one(best) for _ in range(max(1, args.cpu_passes)))
     med = times[len(times) // 2]
     return {"value": round(1.0 / med, 4), "unit": "frame-pairs/s", "cores": int(best), "host_cores": int(avail),
@@ -148,7 +149,7 @@ def cpu_baseline(args, cfg):
             "passes": len(times), "pass_seconds": [round(t, 3) for t in times],
             "thread_sweep_seconds": {str(k): round(v, 3) for k, v in sweep.items()},
             "sample": "1 frame pair (B=1, %dx%d, Res-%d D&T test forward): torch CPU fp32 convs + oracle/ ops (OpenMP over "
-                      "independent outputs); thread count swept, 1 warm-up + %d timed passes at %d threads, median %.2f s"
+                      "independent outputs); thread count swept, 3 warm-up + %d timed passes at %d threads, median %.2f s"
                       % (args.height, args.width, args.layers, len(times), best, med)}
 
 

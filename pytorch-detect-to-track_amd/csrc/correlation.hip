@@ -1153,7 +1153,8 @@ int launch_fast(float* output, long out_batch_stride, long out_ch_stride, long o
 #ifndef DTT_CORR_NO_GLDS
   // (R <= 8 only: with the 81 accumulators of the R <= 16 instantiation the LDS-DMA kernel spills and runs 3x slower
   // than the register-staged one)
-  if (NBR <= 5 && g.s == 1 && g.C % kGKc == 0 && g.c_per_split % kGKc == 0 && g.W >= 4 && (((g.origin - g.R) % 4) + 4) % 4 == 0) {
+  if constexpr (NBR <= 5)   // (compile time: the 81-accumulator LDS-DMA instantiation is not built at all)
+  if (g.s == 1 && g.C % kGKc == 0 && g.c_per_split % kGKc == 0 && g.W >= 4 && (((g.origin - g.R) % 4) + 4) % 4 == 0) {
     using G = GCfg<NBR>;
     static DttDeviceOnce gattr_once;
   bool& gattr = gattr_once.here();   // the attribute is per device, not per process

@@ -554,3 +554,19 @@ def test_class_nms_vs_oracle(dev, R, ncls, agnostic, mpi):
             np.testing.assert_array_equal(got[i][j], ref[j], err_msg="image %d class %d" % (i, j))
             total += len(ref[j])
     assert total > 0
+
+
+@pytest.mark.parametrize("case", ["agnostic_300x31", "perclass_120x7", "nocut_80x5", "sparse_60x31"])
+def test_class_nms_vs_reference_loop_golden(dev, case):
+    """dtt_class_nms against the detections the reference's own test_net.py loop (lines 274-301, executed by
+    tests/golden/make_golden_class_nms.py) kept on the same inputs: bit for bit, order included."""
+    from dtt.postprocess import class_nms, to_all_boxes
+    g = np.load(os.path.join(G, "class_nms.npz"))
+    thresh, nms_t, mpi, agn = g[case + "/params"]
+    counts = g[case + "/counts"]
+    want = np.split(g[case + "/dets"], np.cumsum(counts)[:-1])
+    dets, cnt = class_nms(cu(g[case + "/scores"][None], dev), cu(g[case + "/boxes"][None], dev), float(thresh), float(nms_t),
+                          int(mpi), bool(agn))
+    got = to_all_boxes(dets, cnt)[0]
+    for j in range(len(want)):
+        np.testing.assert_array_equal(got[j], want[j].reshape(-1, 5), err_msg="class %d" % j)

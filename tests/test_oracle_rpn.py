@@ -65,3 +65,26 @@ def test_anchor_target_layer_matches_reference(case):
     np.testing.assert_array_equal(outw, g[case + "/outside"])
     np.testing.assert_allclose(tgt, g[case + "/bbox_targets"], rtol=1e-6, atol=1e-6)
     assert (lab == 1).sum() > 0 and (lab == 0).sum() > 0
+
+
+CLASS_NMS_CASES = ["agnostic_300x31", "perclass_120x7", "nocut_80x5", "sparse_60x31"]
+
+
+def _class_nms_case(name):
+    g = np.load(os.path.join(G, "class_nms.npz"))
+    thresh, nms_t, mpi, agn = g[name + "/params"]
+    counts = g[name + "/counts"]
+    dets = np.split(g[name + "/dets"], np.cumsum(counts)[:-1])
+    return g[name + "/scores"], g[name + "/boxes"], float(thresh), float(nms_t), int(mpi), bool(agn), dets
+
+
+@pytest.mark.parametrize("case", CLASS_NMS_CASES)
+def test_class_nms_matches_reference_loop(case):
+    """oracle class_nms against what lines 274-301 of the reference's test_net.py produced when EXECUTED on the same
+    inputs (tests/golden/make_golden_class_nms.py): per-class detections, their order, and the max_per_image cut."""
+    scores, boxes, thresh, nms_t, mpi, agn, want = _class_nms_case(case)
+    got = ro.class_nms(scores, boxes, oracle_lib.nms, thresh, nms_t, mpi, agn)
+    assert len(got) == len(want)
+    for j, (a, b) in enumerate(zip(got, want)):
+        np.testing.assert_array_equal(a, b.reshape(-1, 5), err_msg="class %d" % j)
+    assert sum(len(w) for w in want) > 0
