@@ -498,7 +498,11 @@ class FusedTrunkNHWC:
     @torch.no_grad()
     def __call__(self, x):
         x = x.contiguous(memory_format=torch.channels_last)
-        x = self.pool(self.stem.act(x))
+        # stem: relu(maxpool(conv(x)) + b) instead of maxpool(relu(conv(x) + b)) -- the same values bit for bit (adding one
+        # bias per channel and clamping at zero are monotonic, so they commute with the window maximum; the pool pads with
+        # -inf), but the bias / ReLU pass runs on the pooled map: 41 MB instead of 164 MB read and written (46 -> 12 us)
+        x = self.pool(self.stem.raw(x))
+        bias_act_nhwc_(_rows(x), self.stem.b)
         feats = []
         for stage in self.stages:
             for blk in stage:

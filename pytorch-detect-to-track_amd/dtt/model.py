@@ -317,17 +317,21 @@ class _RFCN(nn.Module):
         return leg_rois, prob, pred, tracking_pred, zeros, zeros, zeros, zeros, [], zeros[0]
 
     def forward(self, im_data, im_info, gt_boxes, num_boxes):
-        im_data = im_data.permute(1, 0, 2, 3, 4).contiguous()  # (n_legs, B, C, H, W)
-        im_info = im_info.permute(1, 0, 2).contiguous().detach()
-        gt_boxes = gt_boxes.permute(1, 0, 2, 3).contiguous().detach()
-        num_boxes = num_boxes.permute(1, 0, 2).contiguous().detach()
-        B = im_data.size(1)
-        n_legs = im_data.size(0)
+        B, n_legs = im_data.size(0), im_data.size(1)
         dev = im_data.device
         # Both legs of the siamese net go through the trunk and the 1x1 heads as ONE batch of n_legs*B images (the
         # reference loops over the legs, rfcn.py:95): BatchNorm is frozen and every op is per-image, so the
         # result is the same, with half the launches and better-filled kernels.
-        flat = im_data.view(n_legs * B, *im_data.shape[2:])
+        chw = im_data.shape[2:]
+        if getattr(getattr(self, "_fused_trunk", None), "pm_heads", False) and not self.training and im_data.is_cuda:
+            # channels-last trunk: leg-major order and channels-last memory in ONE strided copy (instead of two passes)
+            flat = torch.empty((n_legs * B, *chw), dtype=im_data.dtype, device=dev, memory_format=torch.channels_last)
+            flat.view(n_legs, B, *chw).copy_(im_data.permute(1, 0, 2, 3, 4))
+        else:
+            flat = im_data.permute(1, 0, 2, 3, 4).contiguous().view(n_legs * B, *chw)  # (n_legs * B, C, H, W)
+        im_info = im_info.permute(1, 0, 2).contiguous().detach()
+        gt_boxes = gt_boxes.permute(1, 0, 2, 3).contiguous().detach()
+        num_boxes = num_boxes.permute(1, 0, 2).contiguous().detach()
         c3, c4, c5, top = self._im_to_head(flat)
         side = None
         if not self.training and top.is_cuda and not torch.is_grad_enabled():
