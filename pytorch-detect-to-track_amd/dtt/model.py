@@ -274,8 +274,8 @@ class _RFCN(nn.Module):
                 col += oc
             assert col == pm.trk_in, "tracking feature width %d != corr_bbox_net input %d" % (col, pm.trk_in)
             # Launch order conv3, conv5, conv4 (env DTT_CORR_ORDER "021": developer A/B; measured 232.8 frame-pairs/s against
-            # 232.0 for "012" and 232.1 for "210").  The side stream's select / sort (one 1024-thread, 64 KB-LDS workgroup
-            # per image) has been resident for ~15 us when this sequence starts and stays for ~105 us more; its NMS mask
+            # 232.0 for "012" and 232.1 for "210").  The side stream's select / sort (one 1024-thread, 72 KB-LDS workgroup
+            # per image, 84 us) has been resident for ~15 us when this sequence starts and stays for ~70 us more; its NMS mask
             # (one-wave workgroups) and sweep (4 x 1024 threads) kernels follow.  A one-workgroup-per-CU kernel dispatched
             # while a foreign workgroup sits on one of "its" shader engines has, in some steps, one workgroup parked until a
             # CU of that engine frees up -- until the first of its own workgroups finishes, +60 % on that launch
@@ -337,7 +337,7 @@ class _RFCN(nn.Module):
         if not self.training and top.is_cuda and not torch.is_grad_enabled():
             # The proposal layer (select / sort, decode, NMS mask + sweep) is a handful of small kernels that leave most
             # CUs idle; it runs on a side stream underneath the correlations and the tracking head, which do not depend
-            # on it.  Its first kernel -- select / sort: one 1024-thread, 64 KB-LDS workgroup per image, 145 us -- needs
+            # on it.  Its first kernel -- select / sort: one 1024-thread, 72 KB-LDS workgroup per image, 84 us -- needs
             # the scores only and is started as soon as the softmax is done, while the RPN's box-delta convolution
             # still runs here: when the one-workgroup-per-CU correlation kernels are dispatched it has long been placed.
             # (Dispatched in the same microseconds, the two race for CUs and the loser's workgroups stay parked on a
