@@ -29,39 +29,51 @@ __device__ __forceinline__ float dev_iou(const float a0, const float a1, const f
 
 // grid (col_blocks, row_blocks, batch), block 64.  Only tiles with col >= row are produced: the sweep
 // never reads words left of a row's own block (nms_cuda_kernel.cu:139 starts at j = nblock).
+// A workgroup owns column block blockIdx.x and the row blocks row_block0 + blockIdx.y, + gridDim.y, ... < row_block_end
+// (one tile per workgroup in the usual launch; the second phase of a two-phase NMS uses a short grid that loops, so that
+// the images the first phase finished cost a few hundred workgroup exits instead of tens of thousands).
 __global__ __launch_bounds__(kTile) void nms_mask_kernel(const float* __restrict__ boxes, int boxes_dim,
                                                           long box_batch_stride, const int* __restrict__ n_per_image,
                                                           int n_max, float thresh, unsigned long long* __restrict__ mask,
-                                                          long mask_batch_stride, int col_blocks) {
-  const int col_start = blockIdx.x, row_start = blockIdx.y, img = blockIdx.z;
-  if (col_start < row_start) return;
+                                                          long mask_batch_stride, int col_blocks, int row_block0,
+                                                          int row_block_end, int check_done) {
+  const int col_start = blockIdx.x, img = blockIdx.z;
+  // second phase of a two-phase NMS: nothing to do for an image whose sweep already has max_keep survivors
+  if (check_done && mask[img * mask_batch_stride + (long)n_max * col_blocks] != 0ULL) return;
   const int n_boxes = n_per_image ? n_per_image[img] : n_max;
-  if (row_start * kTile >= n_boxes || col_start * kTile >= n_boxes) return;
+  if (col_start * kTile >= n_boxes) return;
   const float* b = boxes + img * box_batch_stride;
   unsigned long long* m = mask + img * mask_batch_stride;
-  const int row_size = min(n_boxes - row_start * kTile, kTile);
   const int col_size = min(n_boxes - col_start * kTile, kTile);
   __shared__ float bb[kTile * 4];
   const int t = threadIdx.x;
-  if (t < col_size) {
-    const float* p = b + (long)(kTile * col_start + t) * boxes_dim;
-    bb[t * 4 + 0] = p[0];
-    bb[t * 4 + 1] = p[1];
-    bb[t * 4 + 2] = p[2];
-    bb[t * 4 + 3] = p[3];
-  }
-  __syncthreads();
-  if (t < row_size) {
-    const int cur = kTile * row_start + t;
-    const float* p = b + (long)cur * boxes_dim;
-    const float a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3];
-    unsigned long long bits = 0;
-    const int start = (row_start == col_start) ? t + 1 : 0;
-    for (int i = start; i < col_size; ++i) {
-      if (dev_iou(a0, a1, a2, a3, bb[i * 4 + 0], bb[i * 4 + 1], bb[i * 4 + 2], bb[i * 4 + 3]) > thresh)
-        bits |= 1ULL << i;
+  bool staged = false;
+  for (int row_start = row_block0 + blockIdx.y; row_start < row_block_end && row_start <= col_start; row_start += gridDim.y) {
+    if (row_start * kTile >= n_boxes) break;
+    if (!staged) {   // (uniform: the loop bounds do not depend on the lane)
+      if (t < col_size) {
+        const float* p = b + (long)(kTile * col_start + t) * boxes_dim;
+        bb[t * 4 + 0] = p[0];
+        bb[t * 4 + 1] = p[1];
+        bb[t * 4 + 2] = p[2];
+        bb[t * 4 + 3] = p[3];
+      }
+      __syncthreads();
+      staged = true;
     }
-    m[(long)cur * col_blocks + col_start] = bits;
+    const int row_size = min(n_boxes - row_start * kTile, kTile);
+    if (t < row_size) {
+      const int cur = kTile * row_start + t;
+      const float* p = b + (long)cur * boxes_dim;
+      const float a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3];
+      unsigned long long bits = 0;
+      const int start = (row_start == col_start) ? t + 1 : 0;
+      for (int i = start; i < col_size; ++i) {
+        if (dev_iou(a0, a1, a2, a3, bb[i * 4 + 0], bb[i * 4 + 1], bb[i * 4 + 2], bb[i * 4 + 3]) > thresh)
+          bits |= 1ULL << i;
+      }
+      m[(long)cur * col_blocks + col_start] = bits;
+    }
   }
 }
 
@@ -85,11 +97,16 @@ __device__ __forceinline__ unsigned long long readlane64(unsigned long long v, i
 //      their row into the later local words with LDS atomics;
 //   C. all waves OR the kept rows' remaining words (later super-chunks) into remv, again in bulk.
 // Optionally writes the surviving boxes straight into the RoI tensor (proposal layer epilogue).
+//
+// Two-phase use (sc_begin / sc_end = range of 1024-box super-chunks; dtt_nms_batched_launch): when only max_keep << n
+// survivors are wanted, the mask rows of the first few super-chunks are computed and swept first; the sweep state (removal
+// words, survivor count) is parked behind the image's mask matrix, state[0] tells the second mask launch and the second
+// sweep whether there is anything left to do.  The keep list itself lives in keep_out all along.
 __global__ __launch_bounds__(kSweepThreads) void nms_sweep_kernel(
-    const unsigned long long* __restrict__ mask, long mask_batch_stride, const int* __restrict__ n_per_image,
+    unsigned long long* __restrict__ mask, long mask_batch_stride, const int* __restrict__ n_per_image,
     int n_max, int col_blocks, int max_keep, int* __restrict__ keep_out, long keep_batch_stride,
     int* __restrict__ num_out, const float* __restrict__ boxes, int boxes_dim, long box_batch_stride,
-    float* __restrict__ rois_out, int rois_rows) {
+    float* __restrict__ rois_out, int rois_rows, int sc_begin, int sc_end, int two_phase) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned long long* sb = reinterpret_cast<unsigned long long*>(smem);            // [kSuper][kRowStride]
   unsigned long long* remv = sb + (size_t)kSuper * kRowStride;                      // [col_blocks]
@@ -99,17 +116,25 @@ __global__ __launch_bounds__(kSweepThreads) void nms_sweep_kernel(
   const int img = blockIdx.x;
   const int n = n_per_image ? n_per_image[img] : n_max;
   const unsigned long long* m = mask + img * mask_batch_stride;
+  unsigned long long* state = mask + img * mask_batch_stride + (long)n_max * col_blocks;   // [0] done, [1] total, [2..] remv
   int* keep = keep_out ? keep_out + img * keep_batch_stride : nullptr;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int cb = (n + kTile - 1) / kTile;
   const int limit = (max_keep > 0 && max_keep < n) ? max_keep : n;
 
-  for (int j = tid; j < col_blocks; j += kSweepThreads) remv[j] = 0;
-  if (tid == 0) { ctl[0] = 0; ctl[1] = 0; ctl[2] = 0; }
+  if (sc_begin > 0) {
+    if (state[0] != 0ULL) return;   // the first phase finished this image (and wrote its outputs)
+    for (int j = tid; j < col_blocks; j += kSweepThreads) remv[j] = state[2 + j];
+    if (tid == 0) { ctl[0] = 0; ctl[1] = (int)state[1]; ctl[2] = 0; }
+  } else {
+    for (int j = tid; j < col_blocks; j += kSweepThreads) remv[j] = 0;
+    if (tid == 0) { ctl[0] = 0; ctl[1] = 0; ctl[2] = 0; }
+  }
   __syncthreads();
 
   const int n_super = (n + kSuper - 1) / kSuper;
-  for (int sc = 0; sc < n_super; ++sc) {
+  const int sc_last = min(sc_end, n_super);
+  for (int sc = sc_begin; sc < sc_last; ++sc) {
     const int base = sc * kSuper;
     const int rows = min(kSuper, n - base);
     const int w0 = sc * kSuperWords;
@@ -226,6 +251,17 @@ __global__ __launch_bounds__(kSweepThreads) void nms_sweep_kernel(
     if (done) break;
   }
   const int total = ctl[1];
+  if (two_phase) {
+    const bool finished = ctl[2] != 0 || sc_last >= n_super;
+    if (sc_begin == 0) {
+      if (!finished) {   // park the state for the second phase
+        for (int j = tid; j < col_blocks; j += kSweepThreads) state[2 + j] = remv[j];
+        if (tid == 0) { state[1] = (unsigned long long)total; state[0] = 0ULL; }
+        return;
+      }
+      if (tid == 0) state[0] = 1ULL;
+    }
+  }
   if (tid == 0 && num_out) num_out[img] = total;
   // ---- optional epilogue: RoI rows [img, x1, y1, x2, y2], zero padded (proposal_layer.py:157-159)
   if (rois_out) {
@@ -255,7 +291,8 @@ size_t sweep_lds_bytes(int col_blocks) {
 
 size_t dtt_nms_mask_bytes(int boxes_num) {
   const long cb = (boxes_num + kTile - 1) / kTile;
-  return (size_t)(boxes_num > 0 ? boxes_num : 1) * (size_t)(cb > 0 ? cb : 1) * sizeof(unsigned long long);
+  // the bit matrix + the parked sweep state of a two-phase run (done flag, survivor count, removal words)
+  return ((size_t)(boxes_num > 0 ? boxes_num : 1) * (size_t)(cb > 0 ? cb : 1) + (size_t)(cb > 0 ? cb : 1) + 8) * sizeof(unsigned long long);
 }
 
 int dtt_nms_batched_launch(const float* boxes, int boxes_dim, long box_batch_stride, const int* n_per_image,
@@ -275,18 +312,38 @@ int dtt_nms_batched_launch(const float* boxes, int boxes_dim, long box_batch_str
     if (e != hipSuccess) { dtt_set_error("nms: cannot raise dynamic LDS limit: %s", hipGetErrorString(e)); return 0; }
     attr_set = true;
   }
-  dim3 grid(cb, cb, batch);
+  // Two phases when few survivors are wanted (the proposal layer keeps 300 of 6000): the sweep visits boxes in score order
+  // and stops at max_keep, so with a keep rate around 40 % it never looks past the first ~750 rows of the bit matrix.
+  // Phase 1 = mask rows + sweep of the first ceil(3 * max_keep / 1024) super-chunks; phase 2 = the rest, both of whose
+  // launches return at once for images phase 1 finished.  Same keep list either way (the sweep is the same recursion).
+  const int n_super = (n_max + kSuper - 1) / kSuper;
+  int split = 0;   // super-chunks in phase 1 (0 = single phase)
+  static const bool single_phase_only = getenv("DTT_NMS_SINGLE_PHASE") != nullptr;   // developer A/B switch
+  if (max_keep > 0 && keep_out && !single_phase_only) {
+    const int r1 = (int)((3L * max_keep + kSuper - 1) / kSuper);
+    if (2 * r1 <= n_super) split = r1;
+  }
+  const int rb1 = split ? split * kSuperWords : cb;   // row blocks of the first mask launch
   dtt_prof_begin("nms_mask", stream);
-  hipLaunchKernelGGL(nms_mask_kernel, grid, dim3(kTile), 0, stream, boxes, boxes_dim, box_batch_stride,
-                     n_per_image, n_max, thresh, mask, mask_batch_stride, cb);
+  hipLaunchKernelGGL(nms_mask_kernel, dim3(cb, rb1, batch), dim3(kTile), 0, stream, boxes, boxes_dim, box_batch_stride,
+                     n_per_image, n_max, thresh, mask, mask_batch_stride, cb, 0, rb1, 0);
   dtt_prof_end("nms_mask", stream);
   DTT_CHECK_LAUNCH("nms_mask_kernel");
   dtt_prof_begin("nms_sweep", stream);
   hipLaunchKernelGGL(nms_sweep_kernel, dim3(batch), dim3(kSweepThreads), lds, stream, mask, mask_batch_stride,
                      n_per_image, n_max, cb, max_keep, keep_out, keep_batch_stride, num_out, boxes, boxes_dim,
-                     box_batch_stride, rois_out, rois_rows);
+                     box_batch_stride, rois_out, rois_rows, 0, split ? split : n_super, split ? 1 : 0);
   dtt_prof_end("nms_sweep", stream);
   DTT_CHECK_LAUNCH("nms_sweep_kernel");
+  if (split) {
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(cb, min(cb - rb1, 8), batch), dim3(kTile), 0, stream, boxes, boxes_dim,
+                       box_batch_stride, n_per_image, n_max, thresh, mask, mask_batch_stride, cb, rb1, cb, 1);
+    DTT_CHECK_LAUNCH("nms_mask_kernel (phase 2)");
+    hipLaunchKernelGGL(nms_sweep_kernel, dim3(batch), dim3(kSweepThreads), lds, stream, mask, mask_batch_stride,
+                       n_per_image, n_max, cb, max_keep, keep_out, keep_batch_stride, num_out, boxes, boxes_dim,
+                       box_batch_stride, rois_out, rois_rows, split, n_super, 1);
+    DTT_CHECK_LAUNCH("nms_sweep_kernel (phase 2)");
+  }
   return 1;
 }
 

@@ -78,6 +78,28 @@ def test_nms_empty_and_max_keep(dev):
         np.testing.assert_array_equal(got, ref[:mk])
 
 
+@pytest.mark.parametrize("n,clusters,mk", [(6000, 200, 300), (6000, 450, 300), (6000, 3000, 300), (12000, 700, 500),
+                                          (2500, 90, 100), (6000, 200, 2000)])
+def test_nms_two_phase_paths(dev, n, clusters, mk):
+    """max_keep << n makes dtt_nms compute / sweep the first 1024-box super-chunks first and the rest only if the keep
+    list is still short (nms.hip: two phases).  Heavily duplicated boxes force the second phase (`clusters` < mk: it never
+    reaches max_keep; a few more clusters than mk: it gets there in phase 2), spread-out boxes finish in the first; one
+    configuration is above the split rule and stays single-phase.  Same keep list as the oracle in every case."""
+    from dtt.ops import nms
+    rng = np.random.RandomState(n + clusters)
+    ctr = rng.uniform(100, 3000, size=(clusters, 2))
+    wh = rng.uniform(40, 120, size=(clusters, 2))
+    which = rng.randint(0, clusters, size=n)
+    which[:clusters // 3] = np.arange(clusters // 3)                      # some clusters show up early, most late
+    jitter = rng.normal(0, 1.5, size=(n, 4))
+    boxes = np.concatenate([ctr[which] - wh[which] / 2, ctr[which] + wh[which] / 2], 1) + jitter
+    dets = np.concatenate([boxes, np.sort(rng.uniform(0, 1, n))[::-1][:, None]], 1).astype(np.float32)
+    ref = O.nms(dets, 0.7)
+    got = nms(cu(dets, dev), 0.7, max_keep=mk).cpu().numpy().ravel()
+    np.testing.assert_array_equal(got, ref[:mk])
+    assert len(ref) >= 50
+
+
 def test_nms_threshold_boundary(dev):
     """IoU within an ulp of the threshold: strict '>' and the exact fp32 op order decide."""
     from dtt.ops import nms
