@@ -144,7 +144,9 @@ int dtt_psroi_vote_forward(const float* bottom_data, float spatial_scale, int ba
  * num_out: int32[1].  Device in -> device out, stream ordered: the greedy sweep
  * (nms_cuda_kernel.cu:131-144) runs on the GPU, nothing is copied to the host.
  * max_keep > 0 lets the sweep stop after max_keep survivors (the proposal layer keeps only the
- * first post_nms_topN, proposal_layer.py:151-152); 0 = keep all (reference behaviour).
+ * first post_nms_topN, proposal_layer.py:151-152); 0 = keep all (reference behaviour).  With max_keep << boxes_num the
+ * IoU bit matrix is computed in two stream-ordered phases -- the rows the sweep needs first, the rest only if the keep list
+ * is still short -- with the same keep list (the workspace holds the matrix plus the parked sweep state).
  */
 size_t dtt_nms_workspace_bytes(int boxes_num);
 int dtt_nms(int* keep_out, int* num_out, const float* boxes, int boxes_num, int boxes_dim,
