@@ -212,8 +212,8 @@ def main():
         step()
     sync()
     # The tag "corr_fwd_op" brackets a whole op.  Inference on the channels-last
-    # trunk: ONE launch of corr_nhwc_kernel per op (ticket memset + product + in-launch slice reduction; four launches
-    # for the 8 < R <= 16 sub-windows of d = 12 / 16, inside one bracket).  NCHW maps (training, --nchw-trunk): banded-product
+    # trunk: ONE launch of corr_nhwc_kernel per op (product + in-launch slice reduction; the four sub-windows of
+    # 8 < R <= 16 (d = 12 / 16) are virtual images of the same launch).  NCHW maps (training, --nchw-trunk): banded-product
     # kernel + slice-reduction kernel per op, and for d = 12 / 16 conv4 / conv5 are four R = 8 sub-window ops each.
     nhwc_corr = args.mode == "infer" and not args.nchw_trunk and getattr(model, "_pm_tail", None) is not None
     n_sub = 4 if (args.disp in (12, 16) and not nhwc_corr) else 1
@@ -313,7 +313,7 @@ def main():
             # beside it, as in production)
             "roofline": {"kernel": ("conv5 correlation op = ticket memset + %scorr_nhwc_kernel<5> (channels-last, 2048 ch, d=%d: "
                                     "exact-f32 MFMA banded product, in-launch slice reduction; event tag corr_fwd_op)"
-                                    % ("" if args.disp <= 8 else "4 sub-window launches of ", args.disp)) if nhwc_corr else
+                                    % ("" if args.disp <= 8 else "four 17x17 sub-windows in one launch of ", args.disp)) if nhwc_corr else
                                    ("conv5 correlation op = %s + corr_fwd_reduce<5> (2048 ch, d=%d; event tag corr_fwd_op)"
                                     % ("corr_fwd_glds<5>" if args.disp <= 8 else "4 x corr_fwd_glds<5> sub-windows", args.disp)),
                          "bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",

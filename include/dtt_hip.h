@@ -76,8 +76,8 @@ int dtt_correlation_forward_strided(float* output, int ob, int oc, int oh, int o
                                     int stride1, int stride2, int corr_type_multiply, void* stream);
 /* The same forward on CHANNELS-LAST inputs: input1 / input2 are (ob, ih, iw, ic) row-major, i.e. what the reference's own
  * kernel reads after its `channels_first` repack (correlation_cuda_kernel.cu:10-32, 296-340) -- callers whose trunk is
- * channels-last skip both that repack and the NHWC -> NCHW hand-over.  Output addressing as above.  One launch per op (per
- * sub-window for 8 < max_displacement / stride <= 16): the channel slices of a tile are reduced in-launch by its last
+ * channels-last skip both that repack and the NHWC -> NCHW hand-over.  Output addressing as above.  One launch per op (the four
+ * sub-windows of 8 < max_displacement / stride <= 16 ride in it as virtual images): the channel slices of a tile are reduced in-launch by its last
  * arriver (in slice order: deterministic).  Supported: kernel_size 1, stride1 == stride2 = s, pad and displacement
  * multiples of s, ic % 16 == 0, max_displacement / s <= 8 or in {12, 16}; 16-byte aligned inputs.  workspace: caller-owned,
  * dtt_correlation_nhwc_workspace_bytes(...) bytes (a 64 KB ticket area + one slab per channel slice).  CONTRACT: zero-fill

@@ -40,7 +40,8 @@ struct NGeom {
   long sy, sx, sb;                   // floats between vertically / horizontally adjacent lattice pixels, between images
   int C, H, W;                       // channels, lattice size (pixels the correlation can touch)
   int oh, ow, origin;                // output size; output (y, x) <-> lattice pixel (origin + y, origin + x)
-  int R, qy, qx, Rfull, Dfull;       // sub-window radius / centre shift, full window (for 8 < R <= 16 in four launches)
+  int R, Rfull, Dfull;               // sub-window radius, full window
+  int nquad, qyv[4], qxv[4];         // 8 < R <= 16: four (2*8+1)^2 sub-windows with these centre shifts, run as four "virtual images" of ONE launch
   int tiles_x, tiles_y, ksplit, c_per_split, batch;
   float* out; long out_sb, out_sc, out_sp;   // element (n, d, y, x) at out[n*sb + d*sc + (y*ow + x)*sp]
   float* slabs; int* tickets;
@@ -106,6 +107,9 @@ __global__ __launch_bounds__(kNThreads) void corr_nhwc_kernel(NGeom g) {
   int ks, tile, n;
   if (g.ablate & 64) { ks = item % g.ksplit; tile = (item / g.ksplit) % ntiles; n = item / (g.ksplit * ntiles); }
   else { tile = item % ntiles; ks = (item / ntiles) % g.ksplit; n = item / (g.ksplit * ntiles); }
+  // (n counts virtual images: sub-window q of image n % batch; tickets / slabs are per virtual image)
+  const int quad = n / g.batch, n_img = n - quad * g.batch;
+  const int qy = g.qyv[quad], qx = g.qxv[quad];
   const int ty0 = (tile / g.tiles_x) * kTY, tx0 = (tile % g.tiles_x) * kTX;
   const int c_begin = ks * g.c_per_split, c_end = min(g.C, c_begin + g.c_per_split);
   const int nch = (c_end - c_begin) / kKC;
@@ -122,8 +126,8 @@ __global__ __launch_bounds__(kNThreads) void corr_nhwc_kernel(NGeom g) {
     int y, x, row;
     if (px < K::HPX) {
       row = px / K::HC;
-      y = ty0 - K::R + row + g.qy + g.origin;
-      x = tx0 - K::R + px % K::HC + g.qx + g.origin;
+      y = ty0 - K::R + row + qy + g.origin;
+      x = tx0 - K::R + px % K::HC + qx + g.origin;
     } else {
       row = (px - K::HPX) / kTX;
       y = ty0 + row + g.origin;
@@ -136,8 +140,8 @@ __global__ __launch_bounds__(kNThreads) void corr_nhwc_kernel(NGeom g) {
     from_f1[i] = instr * 16 >= K::HPX;   // wave-uniform: the frame-t tile starts on an instruction boundary
   }
   static_assert(K::HPX % 16 == 0, "frame boundary on a DMA instruction boundary");
-  const char* b1 = reinterpret_cast<const char*>(g.f1 + (long)n * g.sb + c_begin);
-  const char* b2 = reinterpret_cast<const char*>(g.f2 + (long)n * g.sb + c_begin);
+  const char* b1 = reinterpret_cast<const char*>(g.f1 + (long)n_img * g.sb + c_begin);
+  const char* b2 = reinterpret_cast<const char*>(g.f2 + (long)n_img * g.sb + c_begin);
   const unsigned lds0 = (unsigned)(unsigned long)(const __attribute__((address_space(3))) float*)lds;
   auto issue = [&](int ci) {
     const unsigned st = lds0 + (unsigned)((ci % 3) * K::STAGE * 4);
@@ -263,12 +267,12 @@ __global__ __launch_bounds__(kNThreads) void corr_nhwc_kernel(NGeom g) {
     const int qi = nb / NBR, qj = nb % NBR;
     const int dy = 4 * qi + lg - jy - K::R;                  // displacement inside the sub-window (halo origin = tile - K::R)
     if (dy < -g.R || dy > g.R) return;
-    const int qyy = py + dy + g.qy;
+    const int qyy = py + dy + qy;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int dx = 4 * qj + r - jx - K::R;
       if (dx < -g.R || dx > g.R) continue;
-      const int qxx = pxx + dx + g.qx;
+      const int qxx = pxx + dx + qx;
       const bool in_image = p_img && qyy >= 0 && qyy < g.H && qxx >= 0 && qxx < g.W;
       tilebuf[pxi * DD + (dy + g.R) * D + dx + g.R] = in_image ? v[r] * inv : 0.f;
     }
@@ -306,8 +310,8 @@ __global__ __launch_bounds__(kNThreads) void corr_nhwc_kernel(NGeom g) {
   }
   __syncthreads();
   (void)p_in;
-  float* ob = g.out + (long)n * g.out_sb;
-  const int shift_y = g.qy + g.Rfull - g.R, shift_x = g.qx + g.Rfull - g.R;
+  float* ob = g.out + (long)n_img * g.out_sb;
+  const int shift_y = qy + g.Rfull - g.R, shift_x = qx + g.Rfull - g.R;
   // (the window size is a compile-time constant on the usual path: the index arithmetic below divides by it per element)
   auto write_out = [&](auto dconst) {
     constexpr int DC = decltype(dconst)::value;
@@ -346,7 +350,7 @@ int launch_nhwc(NGeom g, hipStream_t stream) {
     DTT_REQUIRE(e == hipSuccess, "correlation (channels-last): cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
     done = true;
   }
-  hipLaunchKernelGGL((corr_nhwc_kernel<NBR>), dim3(g.tiles_x * g.tiles_y * g.ksplit * g.batch), dim3(kNThreads), K::LDS, stream, g);
+  hipLaunchKernelGGL((corr_nhwc_kernel<NBR>), dim3(g.tiles_x * g.tiles_y * g.ksplit * g.batch * g.nquad), dim3(kNThreads), K::LDS, stream, g);
   DTT_CHECK_LAUNCH("corr_nhwc_kernel");
   return 1;
 }
@@ -399,7 +403,7 @@ extern "C" size_t dtt_correlation_nhwc_workspace_bytes(int batch, int ic, int ih
   if (kernel_size != 1 || stride1 != stride2) return 0;
   const int R = max_displacement / stride2;
   NPlan p;
-  if (!plan_nhwc(batch, ic, oh, ow, R > 8 ? 8 : R, &p)) return 0;
+  if (!plan_nhwc(batch * (R > 8 ? 4 : 1), ic, oh, ow, R > 8 ? 8 : R, &p)) return 0;   // 8 < R <= 16: four sub-windows = four virtual images
   return p.slab_bytes + p.ticket_bytes;
 }
 
@@ -444,8 +448,9 @@ extern "C" int dtt_correlation_forward_nhwc(float* output, int ob, int oc, int o
 #endif
   g.out = output; g.out_sb = out_batch_stride; g.out_sc = out_ch_stride; g.out_sp = out_px_stride;
   const int R = Rfull > 8 ? 8 : Rfull;
+  const int nquad = Rfull > 8 ? 4 : 1;
   NPlan p;
-  DTT_REQUIRE(plan_nhwc(ob, ic, oh, ow, R, &p), "correlation (channels-last): no plan");
+  DTT_REQUIRE(plan_nhwc(ob * nquad, ic, oh, ow, R, &p), "correlation (channels-last): no plan");
   DTT_REQUIRE(workspace && workspace_bytes >= p.slab_bytes + p.ticket_bytes, "correlation (channels-last): workspace too small (%zu < %zu)",
               workspace_bytes, p.slab_bytes + p.ticket_bytes);
   g.R = R; g.tiles_x = p.tiles_x; g.tiles_y = p.tiles_y; g.ksplit = p.ksplit; g.c_per_split = p.c_per_split;
@@ -454,20 +459,16 @@ extern "C" int dtt_correlation_forward_nhwc(float* output, int ob, int oc, int o
   // (the tickets are zero on entry -- workspace contract -- and the reducer of every tile zeroes its own again)
   dtt_prof_begin("corr_fwd_op", stream);
   dtt_prof_begin("corr_nhwc", stream);
-  int ok = 1;
-  if (Rfull <= 8) {
-    g.qy = g.qx = 0;
-    ok = p.nbr == 3 ? launch_nhwc<3>(g, stream) : launch_nhwc<5>(g, stream);
-  } else {
-    // 8 < R <= 16: four (2*8+1)^2 sub-windows centred at (+-(R-8), +-(R-8)); overlapping rows / columns are the same
-    // arithmetic, written twice
-    const int c = Rfull - 8;
-    for (int sy = -1; sy <= 1 && ok; sy += 2)
-      for (int sx = -1; sx <= 1 && ok; sx += 2) {
-        g.qy = sy * c; g.qx = sx * c;
-        ok = launch_nhwc<5>(g, stream);
-      }
+  // 8 < R <= 16: four (2*8+1)^2 sub-windows centred at (+-(R-8), +-(R-8)), overlapping rows / columns being the same
+  // arithmetic written twice -- run as four "virtual images" of ONE launch (the channel split is planned for 4 x batch
+  // images: at batch 1 two slices of 64 chunks per sub-window instead of eight slices of 16 in each of four launches)
+  g.nquad = nquad;
+  const int c = Rfull - 8;
+  for (int q = 0; q < 4; ++q) {
+    g.qyv[q] = nquad == 1 ? 0 : ((q >> 1) ? c : -c);
+    g.qxv[q] = nquad == 1 ? 0 : ((q & 1) ? c : -c);
   }
+  const int ok = p.nbr == 3 ? launch_nhwc<3>(g, stream) : launch_nhwc<5>(g, stream);
   dtt_prof_end("corr_nhwc", stream);
   dtt_prof_end("corr_fwd_op", stream);
   return ok;
