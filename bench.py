@@ -311,7 +311,7 @@ def main():
             # the dominant hot-path op: conv5 cross-frame correlation (exact-f32 MFMA banded product + slice reduction),
             # timed as ONE op with HIP events on its launch stream inside the timed region (other streams keep running
             # beside it, as in production)
-            "roofline": {"kernel": ("conv5 correlation op = ticket memset + %scorr_nhwc_kernel<5> (channels-last, 2048 ch, d=%d: "
+            "roofline": {"kernel": ("conv5 correlation op = %scorr_nhwc_kernel<5> (channels-last, 2048 ch, d=%d: "
                                     "exact-f32 MFMA banded product, in-launch slice reduction; event tag corr_fwd_op)"
                                     % ("" if args.disp <= 8 else "four 17x17 sub-windows in one launch of ", args.disp)) if nhwc_corr else
                                    ("conv5 correlation op = %s + corr_fwd_reduce<5> (2048 ch, d=%d; event tag corr_fwd_op)"

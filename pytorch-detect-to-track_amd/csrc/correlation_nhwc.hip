@@ -1,6 +1,7 @@
 // Cross-frame correlation on channels-last feature maps (gfx950): the forward of Correlation_forward
 // (correlation/src/correlation_cuda_kernel.cu:34-106) for kernel_size 1, stride1 == stride2, max_displacement / stride <= 8
-// -- the three correlations of D&T (rfcn.py:58-60, 170-172) -- reading the trunk's channels-last maps directly.
+// (or 12 / 16: four 17 x 17 sub-windows as virtual images of the same launch) -- the three correlations of D&T
+// (rfcn.py:58-60, 170-172) -- reading the trunk's channels-last maps directly.
 //
 // The reference first repacks both NCHW maps to NHWC (`channels_first`, .cu:10-32) and then walks them with one 32-thread
 // block per output pixel.  The channels-last trunk of this repo already produces NHWC, so this kernel consumes it as is
