@@ -297,9 +297,13 @@ class _RFCN(nn.Module):
         if not single_frame:
             gather_column_blocks(rows, 0, det, pm.loc_head["offset"], B * hw, n_legs, pm.n_box)   # box deltas of both legs
             trk = head_gemm(rows, pm.trk)                           # (B*H*W, stride)
-        cur.wait_stream(side)
-        all_rois.record_stream(cur)
         R = all_rois.size(1)
+        with torch.cuda.stream(side):   # the per-leg copy of the RoIs rides on the side stream, which has slack
+            leg_rois = all_rois.view(n_legs, B, R, 5).clone()
+            for i in range(1, n_legs):
+                leg_rois[i, :, :, 0] -= i * B  # batch index within the leg
+        cur.wait_stream(side)
+        all_rois.record_stream(cur); leg_rois.record_stream(cur)
         flat_rois = all_rois.view(-1, 5)
         scale = self.RFCN_psroi_cls_pool.spatial_scale
         if top is not None:
@@ -307,9 +311,6 @@ class _RFCN(nn.Module):
         score = psroi_pm(det, pm.cls_head, n_legs * B, H, W, flat_rois, scale)
         prob = F.softmax(score, dim=1).view(n_legs, B, R, -1)
         pred = psroi_pm(det, pm.loc_head, n_legs * B, H, W, flat_rois, scale).view(n_legs, B, R, -1)
-        leg_rois = all_rois.view(n_legs, B, R, 5).clone()
-        for i in range(1, n_legs):
-            leg_rois[i, :, :, 0] -= i * B  # batch index within the leg
         zeros = torch.zeros(n_legs, 1, device=dev)
         tracking_pred = torch.zeros(0, 4, device=dev)
         if trk is not None:
