@@ -331,8 +331,9 @@ class _RFCN(nn.Module):
         else:
             flat = im_data.permute(1, 0, 2, 3, 4).contiguous().view(n_legs * B, *chw)  # (n_legs * B, C, H, W)
         im_info = im_info.permute(1, 0, 2).contiguous().detach()
-        gt_boxes = gt_boxes.permute(1, 0, 2, 3).contiguous().detach()
-        num_boxes = num_boxes.permute(1, 0, 2).contiguous().detach()
+        if self.training:   # (inference never looks at the ground truth: two small copy kernels less per step)
+            gt_boxes = gt_boxes.permute(1, 0, 2, 3).contiguous().detach()
+            num_boxes = num_boxes.permute(1, 0, 2).contiguous().detach()
         c3, c4, c5, top = self._im_to_head(flat)
         side = None
         if not self.training and top.is_cuda and not torch.is_grad_enabled():
