@@ -369,6 +369,14 @@ int dtt_transpose_batched(const float* in, float* out, int batch, int rows, int 
 int dtt_gather_column_blocks(float* dst, long dst_ld, const float* src, long src_ld, long src_block_rows, int n_blocks,
                              long rows, int ncols, void* stream);
 
+/* ResNet stem tail on a channels-last map whose frozen-BatchNorm scale is folded into conv1 (faster_rcnn/resnet.py:110-117:
+ * bn1 -> relu -> MaxPool2d(kernel 3, stride 2, padding 0, ceil_mode=True)): y = relu(maxpool(x) + bias[c]) in one pass --
+ * the same values as maxpool(relu(x + bias)), since adding a per-channel constant and clamping at zero are monotonic.
+ * x (images, height, width, channels) -> y (images, oh, ow, channels), oh = ceil((height - 3) / 2) + 1 (same for ow);
+ * channels % 4 == 0, 16-byte aligned pointers, x != y. */
+int dtt_maxpool3s2_bias_relu_nhwc(const float* x, const float* bias, float* y, int images, int height, int width,
+                                  int channels, void* stream);
+
 /* Row-major GEMM with the bottleneck epilogue: out (rows, n) = act(a (rows, k) * w (k, n) + bias[n] (+ residual
  * (rows, n))); residual may be NULL and may alias out.  A library GEMM (hipBLASLt) -- the entry point exists for the
  * epilogue: frozen-BatchNorm shift + `out += residual` + ReLU of faster_rcnn/resnet.py:100-107 in the GEMM itself.

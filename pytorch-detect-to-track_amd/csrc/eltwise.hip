@@ -131,6 +131,36 @@ __global__ __launch_bounds__(kThreads) void gather_column_blocks_kernel(float* _
   }
 }
 
+// y[n][oy][ox][c] = relu(max over the 3x3 / stride-2 window (clipped to the map: ceil_mode, no padding) of x + bias[c]):
+// the ResNet stem's max pool with the folded-BatchNorm shift and the ReLU applied AFTER the maximum (same values: both
+// are monotonic).  One thread = one output pixel x 4 channels; a window row is three 16-byte loads, 256 B per 16 lanes.
+__global__ __launch_bounds__(kThreads) void maxpool3s2_bias_relu_kernel(const float* __restrict__ x, const float* __restrict__ bias,
+                                                                       float* __restrict__ y, int H, int W, int OH, int OW, int c4,
+                                                                       long total) {
+  for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < total; i += (long)gridDim.x * kThreads) {
+    const int c = (int)(i % c4);
+    long t = i / c4;
+    const int ox = (int)(t % OW); t /= OW;
+    const int oy = (int)(t % OH);
+    const long n = t / OH;
+    const float4* src = reinterpret_cast<const float4*>(x) + ((n * H + 2 * oy) * W + 2 * ox) * c4 + c;
+    const int ny = min(3, H - 2 * oy), nx = min(3, W - 2 * ox);
+    float4 m = src[0];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        if (dy < ny && dx < nx) {
+          const float4 v = src[((long)dy * W + dx) * c4];
+          m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+        }
+      }
+    const float4 b = reinterpret_cast<const float4*>(bias)[c];
+    m.x = fmaxf(m.x + b.x, 0.f); m.y = fmaxf(m.y + b.y, 0.f); m.z = fmaxf(m.z + b.z, 0.f); m.w = fmaxf(m.w + b.w, 0.f);
+    reinterpret_cast<float4*>(y)[i] = m;
+  }
+}
+
 }  // namespace
 
 extern "C" int dtt_bias_act_nhwc_inplace(float* x, const float* bias, const float* residual, long rows, int channels,
@@ -213,5 +243,25 @@ extern "C" int dtt_gather_column_blocks(float* dst, long dst_ld, const float* sr
   hipLaunchKernelGGL(gather_column_blocks_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, dst, dst_ld, src, src_ld,
                      src_block_rows, n_blocks, rows, ncols / 4);
   DTT_CHECK_LAUNCH("gather_column_blocks_kernel");
+  return 1;
+}
+
+// ResNet stem tail (faster_rcnn/resnet.py:110-117: bn1 -> relu -> MaxPool2d(3, 2, padding 0, ceil_mode)) on a channels-last map
+// whose BatchNorm scale is already folded into the convolution: y = relu(maxpool(x) + bias), one pass instead of three.
+// x (images, height, width, channels), y (images, out_h, out_w, channels) with out = ceil((size - 3) / 2) + 1.
+extern "C" int dtt_maxpool3s2_bias_relu_nhwc(const float* x, const float* bias, float* y, int images, int height, int width,
+                                             int channels, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  DTT_REQUIRE(x && bias && y && x != y, "maxpool_bias_relu: null / aliased pointer");
+  DTT_REQUIRE(images > 0 && height >= 3 && width >= 3 && channels > 0 && channels % 4 == 0, "maxpool_bias_relu: bad shape");
+  DTT_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(y)) & 15) == 0,
+              "maxpool_bias_relu: pointers must be 16-byte aligned");
+  const int oh = (height - 3 + 1) / 2 + 1, ow = (width - 3 + 1) / 2 + 1;   // ceil((size - 3) / 2) + 1
+  const long total = (long)images * oh * ow * (channels / 4);
+  long blocks = (total + kThreads - 1) / kThreads;
+  if (blocks > 256 * 64) blocks = 256 * 64;
+  hipLaunchKernelGGL(maxpool3s2_bias_relu_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, x, bias, y, height, width, oh, ow,
+                     channels / 4, total);
+  DTT_CHECK_LAUNCH("maxpool3s2_bias_relu_kernel");
   return 1;
 }

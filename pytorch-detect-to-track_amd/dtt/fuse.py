@@ -242,6 +242,18 @@ def fuse_for_training(model, channels_last=False):
 
 
 # ------------------------------------------------------------------------------------------------ channels-last inference
+def maxpool3s2_bias_relu_nhwc(x, bias):
+    """relu(MaxPool2d(3, 2, padding 0, ceil_mode=True)(x) + bias) for a channels-last x, one kernel."""
+    assert x.dtype == torch.float32 and x.is_contiguous(memory_format=torch.channels_last)
+    n, c, h, w = x.shape
+    oh, ow = (h - 3 + 1) // 2 + 1, (w - 3 + 1) // 2 + 1
+    y = torch.empty((n, c, oh, ow), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    with torch.cuda.device(x.device):
+        check(_lib.lib().dtt_maxpool3s2_bias_relu_nhwc(ptr(x), ptr(bias), ptr(y), n, h, w, c, stream_ptr(x.device)),
+              "maxpool3s2_bias_relu")
+    return y
+
+
 def bias_act_nhwc_(y2d, bias, relu=True, residual2d=None):
     """In place on a (rows, C) row-major view: y = act(y + bias[None, :] (+ residual))."""
     L = _lib.lib()
@@ -483,6 +495,10 @@ class FusedTrunkNHWC:
         b = model.RFCN_base
         self.stem = _NhwcConv(b[0], b[1])
         self.pool = b[3]
+        k = lambda v: tuple(v) if isinstance(v, (tuple, list)) else (v, v)
+        self.pool_is_3s2 = (isinstance(self.pool, torch.nn.MaxPool2d) and k(self.pool.kernel_size) == (3, 3) and
+                            k(self.pool.stride) == (2, 2) and k(self.pool.padding) == (0, 0) and k(self.pool.dilation) == (1, 1)
+                            and self.pool.ceil_mode)
         self.stages = [[_NhwcBottleneck(blk) for blk in b[i]] for i in (4, 5, 6, 7)]
         self.top = _NhwcConv(b[8])
         # the RPN's 3x3 convolution + ReLU (rpn.py:60-61) reads the same channels-last map: computed here, where it can
@@ -500,9 +516,14 @@ class FusedTrunkNHWC:
         x = x.contiguous(memory_format=torch.channels_last)
         # stem: relu(maxpool(conv(x)) + b) instead of maxpool(relu(conv(x) + b)) -- the same values bit for bit (adding one
         # bias per channel and clamping at zero are monotonic, so they commute with the window maximum; the pool pads with
-        # -inf), but the bias / ReLU pass runs on the pooled map: 41 MB instead of 164 MB read and written (46 -> 12 us)
-        x = self.pool(self.stem.raw(x))
-        bias_act_nhwc_(_rows(x), self.stem.b)
+        # -inf), but the bias / ReLU pass runs on the pooled map: 41 MB instead of 164 MB read and written (46 -> 12 us) --
+        # and, for the reference's MaxPool2d(3, 2, 0, ceil_mode=True), inside the pooling kernel itself
+        x = self.stem.raw(x)
+        if self.pool_is_3s2:
+            x = maxpool3s2_bias_relu_nhwc(x, self.stem.b)    # dtt_maxpool3s2_bias_relu_nhwc: pool + shift + ReLU in one pass
+        else:
+            x = self.pool(x)
+            bias_act_nhwc_(_rows(x), self.stem.b)
         feats = []
         for stage in self.stages:
             for blk in stage:

@@ -592,3 +592,18 @@ def test_class_nms_vs_reference_loop_golden(dev, case):
     got = to_all_boxes(dets, cnt)[0]
     for j in range(len(want)):
         np.testing.assert_array_equal(got[j], want[j].reshape(-1, 5), err_msg="class %d" % j)
+
+
+@pytest.mark.parametrize("n,c,h,w", [(4, 64, 300, 534), (1, 64, 33, 47), (2, 8, 7, 9), (1, 4, 3, 3), (2, 64, 282, 500)])
+def test_stem_maxpool_bias_relu_fused(dev, n, c, h, w):
+    """dtt_maxpool3s2_bias_relu_nhwc == the reference's stem order relu(x + b) -> MaxPool2d(3, 2, 0, ceil_mode=True)
+    (resnet.py:110-117 with the BatchNorm folded), bit for bit: shift and clamp commute with the window maximum."""
+    import torch.nn.functional as F
+    from dtt.fuse import maxpool3s2_bias_relu_nhwc
+    g = torch.Generator().manual_seed(h * 7 + w)
+    x = torch.randn(n, c, h, w, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    b = torch.randn(c, generator=g).to(dev)
+    want = F.max_pool2d(torch.relu(x + b.view(1, -1, 1, 1)), 3, 2, 0, ceil_mode=True)
+    got = maxpool3s2_bias_relu_nhwc(x, b)
+    assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(got, want)
