@@ -246,10 +246,11 @@ def main():
 
     if rank == 0:
         durs = kt.durations_us(used)
-        # which of a step's ops is conv5: channels-last inference launches conv3, conv5, conv4 (dtt/model.py explains the
-        # order); NCHW inference conv5, conv4, conv3; the training graph keeps the reference's conv3, conv4, conv5
+        # which of a step's ops is conv5: channels-last inference issues conv5 first (ahead of the RPN heads, dtt/model.py),
+        # then conv3, conv4; NCHW inference conv5, conv4, conv3; the training graph keeps the reference's conv3, conv4, conv5
         if nhwc_corr:
-            c5 = lambda d: d[os.environ.get("DTT_CORR_ORDER", "021").index("2")]
+            early = os.environ.get("DTT_CORR5_EARLY", "1") != "0"
+            c5 = lambda d: d[0 if early else os.environ.get("DTT_CORR_ORDER", "021").index("2")]
         elif args.mode == "infer":
             c5 = lambda d: sum(d[:n_sub])
         else:

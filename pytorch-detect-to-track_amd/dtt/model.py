@@ -251,12 +251,36 @@ class _RFCN(nn.Module):
             off += ch
         return buf
 
-    def _inference_tail_pm(self, pm, fused, c3, c4, c5, all_rois, side, n_legs, B, dev, top=None):
+    def _launch_correlations(self, pm, maps, which, B, dev):
+        """Correlations `which` (indices into conv3 / conv4 / conv5) of the frame pair, written as columns of the tracking
+        head's input rows (`pm.tracking_rows`), on the current stream."""
+        from .ops import correlation_forward_nhwc, correlation_forward_rows
+        layers = (self.conv3_corr_layer, self.conv4_corr_layer, self.conv5_corr_layer)
+        hw = maps[2].size(2) * maps[2].size(3)
+        rows = pm.tracking_rows(B * hw, dev)
+        col, jobs = 2 * pm.n_box, []
+        for l, f in zip(layers, maps):
+            oc = correlation_output_shape(f.size(1), f.size(2), f.size(3), l.pad_size, l.kernel_size, l.max_displacement,
+                                          l.stride1, l.stride2)[0]
+            jobs.append((l, f, col))
+            col += oc
+        assert col == pm.trk_in, "tracking feature width %d != corr_bbox_net input %d" % (col, pm.trk_in)
+        for i in which:
+            l, f, c0 = jobs[i]
+            if f.is_contiguous(memory_format=torch.channels_last) and not f.is_contiguous():
+                # channels-last trunk maps: the single-launch channels-last kernel, no transposes
+                correlation_forward_nhwc(f[:B], f[B:2 * B], l.pad_size, l.kernel_size, l.max_displacement, l.stride1,
+                                         l.stride2, rows=rows, col=c0)
+            else:
+                correlation_forward_rows(rows, c0, f[:B].contiguous(), f[B:2 * B].contiguous(), l.pad_size, l.kernel_size,
+                                         l.max_displacement, l.stride1, l.stride2, l.corr_multiply)
+        return rows
+
+    def _inference_tail_pm(self, pm, fused, c3, c4, c5, all_rois, side, n_legs, B, dev, top=None, corr_done=()):
         """rfcn.py:133-140, 166-196 at inference on the position-major layout: one MFMA GEMM for the class + box heads of
         every image (`dtt_head_gemm`), lanes = classes PSRoI pooling + vote (`dtt_psroi_pm_forward`), the tracking
         head's input rows assembled in place (box-delta columns copied, correlations written by their reduce kernels)."""
         from .heads import gather_column_blocks, head_gemm, psroi_pm
-        from .ops import correlation_forward_nhwc, correlation_forward_rows
         top_rows, (H, W) = fused.top_rows, fused.top_hw
         fused.top_rows = None
         cur = torch.cuda.current_stream(dev)
@@ -264,33 +288,16 @@ class _RFCN(nn.Module):
         trk = rows = None
         hw = H * W
         if not single_frame:
-            # correlations first: they only need the trunk maps
-            rows = pm.tracking_rows(B * hw, dev)
-            col, jobs = 2 * pm.n_box, []
-            for l, f in zip((self.conv3_corr_layer, self.conv4_corr_layer, self.conv5_corr_layer), (c3, c4, c5)):
-                oc = correlation_output_shape(f.size(1), f.size(2), f.size(3), l.pad_size, l.kernel_size, l.max_displacement,
-                                              l.stride1, l.stride2)[0]
-                jobs.append((l, f, col))
-                col += oc
-            assert col == pm.trk_in, "tracking feature width %d != corr_bbox_net input %d" % (col, pm.trk_in)
-            # Launch order conv3, conv5, conv4 (env DTT_CORR_ORDER "021": developer A/B; measured 232.8 frame-pairs/s against
-            # 232.0 for "012" and 232.1 for "210").  The side stream's select / sort (one 1024-thread, 72 KB-LDS workgroup
-            # per image, 84 us) has been resident for ~15 us when this sequence starts and stays for ~70 us more; its NMS mask
-            # (one-wave workgroups) and sweep (4 x 1024 threads) kernels follow.  A one-workgroup-per-CU kernel dispatched
-            # while a foreign workgroup sits on one of "its" shader engines has, in some steps, one workgroup parked until a
-            # CU of that engine frees up -- until the first of its own workgroups finishes, +60 % on that launch
-            # (tools/wg_trace.py, tools/probes/wg_placement.hip).  conv5 right after the 23 us conv3 kernel sees that
-            # least often (median 118 us, one step in ~8 at 170+); last, under the sweep kernel, its median is 180 us.
-            idx = [int(c) for c in os.environ.get("DTT_CORR_ORDER", "021")]
-            order = [jobs[i] for i in idx]
-            for l, f, c0 in order:
-                if f.is_contiguous(memory_format=torch.channels_last) and not f.is_contiguous():
-                    # channels-last trunk maps: the single-launch channels-last kernel, no transposes
-                    correlation_forward_nhwc(f[:B], f[B:2 * B], l.pad_size, l.kernel_size, l.max_displacement, l.stride1,
-                                             l.stride2, rows=rows, col=c0)
-                else:
-                    correlation_forward_rows(rows, c0, f[:B].contiguous(), f[B:2 * B].contiguous(), l.pad_size, l.kernel_size,
-                                             l.max_displacement, l.stride1, l.stride2, l.corr_multiply)
+            # The correlations only need the trunk maps.  conv5 (117 us, the largest) has been issued ahead of the RPN's 1x1
+            # heads (forward()), i.e. before the side stream had anything to run: it is dispatched onto an empty chip.  The
+            # kernels that DO run beside the proposal layer are the short ones -- conv3 (24 us) and conv4 (77 us) -- whose
+            # chain with the tracking head (≈ 155 us) is as long as the side stream's (select / sort, decode, NMS ≈ 150 us),
+            # so nothing is lost by taking conv5 out of the overlap.  A one-workgroup-per-CU kernel dispatched while a
+            # foreign workgroup sits on one of "its" shader engines has, in some steps, one workgroup parked until a CU of
+            # that engine frees up (tools/wg_trace.py, tools/probes/wg_placement.hip): that now costs conv4 ≈ 25 us in
+            # some steps instead of conv5 20 - 60.  (env DTT_CORR_ORDER: developer A/B over the order of what is left.)
+            idx = [int(c) for c in os.environ.get("DTT_CORR_ORDER", "021") if int(c) not in corr_done]
+            rows = self._launch_correlations(pm, (c3, c4, c5), idx, B, dev)
         det, fused.det_rows = getattr(fused, "det_rows", None), None    # (n_legs*B*H*W, stride): issued by the fused trunk ...
         if det is None:
             det = head_gemm(top_rows, pm.det)                           # ... or here
@@ -355,6 +362,12 @@ class _RFCN(nn.Module):
             if conv1 is not None:
                 fused.rpn_conv1 = None
             rpn = self.RFCN_rpn
+            pm_early = getattr(self, "_pm_tail", None)
+            corr_done = ()
+            if (pm_early is not None and n_legs == 2 and getattr(fused, "top_rows", None) is not None and
+                    os.environ.get("DTT_CORR5_EARLY", "1") != "0"):
+                self._launch_correlations(pm_early, (c3, c4, c5), (2,), B, dev)   # conv5, on an otherwise empty chip
+                corr_done = (2,)
             conv1, rpn_prob = rpn.head_scores(top, conv1)
             side.wait_stream(cur)
             with torch.cuda.stream(side):
@@ -368,7 +381,7 @@ class _RFCN(nn.Module):
         pm = getattr(self, "_pm_tail", None)
         if pm is not None and side is not None and n_legs <= 2 and getattr(fused, "top_rows", None) is not None:
             # hand-written heads + position-major pooling (dtt.heads): no NCHW score maps at all
-            return self._inference_tail_pm(pm, fused, c3, c4, c5, all_rois, side, n_legs, B, dev, top=top)
+            return self._inference_tail_pm(pm, fused, c3, c4, c5, all_rois, side, n_legs, B, dev, top=top, corr_done=corr_done)
         cls_maps = self.RFCN_cls_net(top)
         bbox_maps = self.RFCN_bbox_net(top)
         conv3 = [leg(c3, i) for i in range(n_legs)]

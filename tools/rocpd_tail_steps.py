@@ -11,7 +11,7 @@ for n, s, e in rows:
     tag = next((t for k, t in short if k in n), None)
     if tag is None:
         continue
-    if tag == "corr3" and (cur is None or any(t == "psroi" for t, _, _ in cur)):
+    if tag == "corr5/4" and (cur is None or any(t == "psroi" for t, _, _ in cur)):
         cur = []; steps.append(cur)
     if cur is not None:
         cur.append((tag, s, e))
