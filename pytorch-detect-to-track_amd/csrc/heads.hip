@@ -472,14 +472,17 @@ extern "C" int dtt_head_gemm(const float* x, long ldx, int M, int K, const float
     (void)ntw_env; (void)pin_env;
     return nload == 2 ? launch_head<10, 4, 2, false>(g, stream) : launch_head<10, 4, 4, false>(g, stream);
   }
-  static const int narrow_cfg = getenv("DTT_HEAD_NARROW") ? atoi(getenv("DTT_HEAD_NARROW")) : 51;   // developer A/B switch (24 = the small-M form)
-  if (narrow_cfg == 51 && M >= 2048) {
-    // narrow heads over many pixels (corr_bbox_net: 5092 x 1056 x 196): 80-pixel strips x groups of 4 channel tiles, one tile per
-    // compute wave, one pass -- 64 strips x 4 groups = one workgroup per CU at the 600 px shape (41 -> 30 us; 32-pixel strips
-    // with all 13 tiles in one workgroup fill 160 CUs)
-    g.strips = dtt_cdiv(M, 5 * 16);
+  static const int narrow_cfg = getenv("DTT_HEAD_NARROW") ? atoi(getenv("DTT_HEAD_NARROW")) : 61;   // developer A/B switch (24 = the small-M form)
+  if ((narrow_cfg == 61 || narrow_cfg == 51) && M >= 2048) {
+    // narrow heads over many pixels (corr_bbox_net: 5092 x 1056 x 196): 96-pixel strips x groups of 4 channel tiles, one tile per
+    // compute wave, one pass -- 54 strips x 4 groups = 216 workgroups at the 600 px shape: 34 us standalone (32-pixel strips with
+    // all 13 tiles in one workgroup: 160 workgroups, 41 us).  80-pixel strips (256 workgroups, 51) are 29 us standalone, but a grid
+    // that fills every CU leaves no room for the NMS sweep's four 1024-thread workgroups that run beside it (sweep 25 -> 50 us).
+    const int tpx = narrow_cfg == 51 ? 5 : 6;
+    g.strips = dtt_cdiv(M, tpx * 16);
     g.n_groups = dtt_cdiv(g.nt_total, 4);
     plan_passes(g, dtt_cdiv(g.nt_total, g.n_groups), 1, 1);
+    if (tpx == 6) return launch_head<6, 1, 2, false>(g, stream);
     return launch_head<5, 1, 2, false>(g, stream);
   }
   // narrow heads (4*49 box deltas alone): 32-pixel strips, every tile of the row in one pass

@@ -29,15 +29,15 @@ __device__ __forceinline__ float dev_iou(const float a0, const float a1, const f
 
 // grid (col_blocks, row_blocks, batch), block 64.  Only tiles with col >= row are produced: the sweep
 // never reads words left of a row's own block (nms_cuda_kernel.cu:139 starts at j = nblock).
-// A workgroup owns column block blockIdx.x and the row blocks row_block0 + blockIdx.y, + gridDim.y, ... < row_block_end
+// A workgroup owns column block col_block0 + blockIdx.x and the row blocks row_block0 + blockIdx.y, + gridDim.y, ... < row_block_end
 // (one tile per workgroup in the usual launch; the second phase of a two-phase NMS uses a short grid that loops, so that
 // the images the first phase finished cost a few hundred workgroup exits instead of tens of thousands).
 __global__ __launch_bounds__(kTile) void nms_mask_kernel(const float* __restrict__ boxes, int boxes_dim,
                                                           long box_batch_stride, const int* __restrict__ n_per_image,
                                                           int n_max, float thresh, unsigned long long* __restrict__ mask,
                                                           long mask_batch_stride, int col_blocks, int row_block0,
-                                                          int row_block_end, int check_done) {
-  const int col_start = blockIdx.x, img = blockIdx.z;
+                                                          int row_block_end, int col_block0, int check_done) {
+  const int col_start = blockIdx.x + col_block0, img = blockIdx.z;
   // second phase of a two-phase NMS: nothing to do for an image whose sweep already has max_keep survivors
   if (check_done && mask[img * mask_batch_stride + (long)n_max * col_blocks] != 0ULL) return;
   const int n_boxes = n_per_image ? n_per_image[img] : n_max;
@@ -107,6 +107,8 @@ __global__ __launch_bounds__(kSweepThreads) void nms_sweep_kernel(
     int n_max, int col_blocks, int max_keep, int* __restrict__ keep_out, long keep_batch_stride,
     int* __restrict__ num_out, const float* __restrict__ boxes, int boxes_dim, long box_batch_stride,
     float* __restrict__ rois_out, int rois_rows, int sc_begin, int sc_end, int two_phase) {
+  // (two_phase, first phase: only mask columns < sc_end * 16 exist yet -- the square the sweep of these super-chunks reads;
+  //  second phase: the rows kept so far are replayed into the removal words of the columns that were computed since)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned long long* sb = reinterpret_cast<unsigned long long*>(smem);            // [kSuper][kRowStride]
   unsigned long long* remv = sb + (size_t)kSuper * kRowStride;                      // [col_blocks]
@@ -124,8 +126,16 @@ __global__ __launch_bounds__(kSweepThreads) void nms_sweep_kernel(
 
   if (sc_begin > 0) {
     if (state[0] != 0ULL) return;   // the first phase finished this image (and wrote its outputs)
-    for (int j = tid; j < col_blocks; j += kSweepThreads) remv[j] = state[2 + j];
-    if (tid == 0) { ctl[0] = 0; ctl[1] = (int)state[1]; ctl[2] = 0; }
+    const int kept_so_far = (int)state[1];
+    const int w_first = sc_begin * kSuperWords;   // first column block the first phase did not have
+    for (int j = tid; j < col_blocks; j += kSweepThreads) {
+      unsigned long long r = state[2 + j];
+      if (j >= w_first && j < cb) {               // replay: every row kept in phase 1 suppresses across the new columns
+        for (int k = 0; k < kept_so_far; ++k) r |= m[(long)keep[k] * col_blocks + j];
+      }
+      remv[j] = r;
+    }
+    if (tid == 0) { ctl[0] = 0; ctl[1] = kept_so_far; ctl[2] = 0; }
   } else {
     for (int j = tid; j < col_blocks; j += kSweepThreads) remv[j] = 0;
     if (tid == 0) { ctl[0] = 0; ctl[1] = 0; ctl[2] = 0; }
@@ -226,7 +236,8 @@ __global__ __launch_bounds__(kSweepThreads) void nms_sweep_kernel(
     //         column j over its share of the kept rows in registers (8 independent loads in flight),
     //         then merges with one LDS atomic.
     const int wnext = w0 + nw;
-    const int nrem = cb - wnext;
+    const int col_end = (two_phase && sc_begin == 0) ? min(cb, sc_end * kSuperWords) : cb;   // columns that exist in this phase
+    const int nrem = col_end - wnext;
     if (!done && nrem > 0 && nk > 0) {
       int jt = 64;
       while (jt < nrem && jt < kSweepThreads) jt <<= 1;
@@ -295,15 +306,28 @@ size_t dtt_nms_mask_bytes(int boxes_num) {
   return ((size_t)(boxes_num > 0 ? boxes_num : 1) * (size_t)(cb > 0 ? cb : 1) + (size_t)(cb > 0 ? cb : 1) + 8) * sizeof(unsigned long long);
 }
 
-int dtt_nms_batched_launch(const float* boxes, int boxes_dim, long box_batch_stride, const int* n_per_image,
-                           int n_max, int batch, float thresh, int max_keep, unsigned long long* mask,
-                           long mask_batch_stride, int* keep_out, long keep_batch_stride, int* num_out,
-                           float* rois_out, int rois_rows, hipStream_t stream) {
+// Two phases when few survivors are wanted (the proposal layer keeps 300 of 6000): the sweep visits boxes in score order
+// and stops at max_keep, so with a keep rate around 40 % it never looks past the first ~750 boxes.  Phase 1 = the bit matrix
+// of the first ceil(3 * max_keep / 1024) super-chunks AGAINST THEMSELVES (rows and columns below R1: 136 tiles per image
+// instead of 4465 at 6000 boxes) + their sweep; phase 2 = every other tile, the kept rows replayed over the new columns,
+// and the rest of the sweep -- both of whose launches return at once for images phase 1 finished.  Same keep list either way
+// (the sweep is the same recursion).  Returns the number of super-chunks in phase 1 (0 = single phase).
+int dtt_nms_split(int n_max, int max_keep, int have_keep_out) {
+  static const bool single_phase_only = getenv("DTT_NMS_SINGLE_PHASE") != nullptr;   // developer A/B switch
+  const int n_super = (n_max + kSuper - 1) / kSuper;
+  if (max_keep > 0 && have_keep_out && !single_phase_only) {
+    const int r1 = (int)((3L * max_keep + kSuper - 1) / kSuper);
+    if (2 * r1 <= n_super) return r1;
+  }
+  return 0;
+}
+
+static int nms_prepare(int n_max, int batch, int boxes_dim, size_t* lds) {
   const int cb = (n_max + kTile - 1) / kTile;
   DTT_REQUIRE(n_max > 0 && batch > 0, "nms: empty problem (n=%d, batch=%d)", n_max, batch);
   DTT_REQUIRE(boxes_dim >= 4, "nms: boxes_dim must be >= 4 (got %d)", boxes_dim);
-  const size_t lds = sweep_lds_bytes(cb);
-  DTT_REQUIRE(lds <= 160 * 1024, "nms: %d boxes exceed the LDS-resident sweep state (%zu B)", n_max, lds);
+  *lds = sweep_lds_bytes(cb);
+  DTT_REQUIRE(*lds <= 160 * 1024, "nms: %d boxes exceed the LDS-resident sweep state (%zu B)", n_max, *lds);
   static DttDeviceOnce attr_set_once;
   bool& attr_set = attr_set_once.here();   // the attribute is per device, not per process
   if (!attr_set) {
@@ -312,21 +336,21 @@ int dtt_nms_batched_launch(const float* boxes, int boxes_dim, long box_batch_str
     if (e != hipSuccess) { dtt_set_error("nms: cannot raise dynamic LDS limit: %s", hipGetErrorString(e)); return 0; }
     attr_set = true;
   }
-  // Two phases when few survivors are wanted (the proposal layer keeps 300 of 6000): the sweep visits boxes in score order
-  // and stops at max_keep, so with a keep rate around 40 % it never looks past the first ~750 rows of the bit matrix.
-  // Phase 1 = mask rows + sweep of the first ceil(3 * max_keep / 1024) super-chunks; phase 2 = the rest, both of whose
-  // launches return at once for images phase 1 finished.  Same keep list either way (the sweep is the same recursion).
+  return 1;
+}
+
+// Phase 1 (split > 0: needs the first split * 1024 boxes only) or the whole NMS (split == 0).
+int dtt_nms_phase1(const float* boxes, int boxes_dim, long box_batch_stride, const int* n_per_image, int n_max, int batch,
+                   float thresh, int max_keep, unsigned long long* mask, long mask_batch_stride, int* keep_out,
+                   long keep_batch_stride, int* num_out, float* rois_out, int rois_rows, int split, hipStream_t stream) {
+  size_t lds;
+  if (!nms_prepare(n_max, batch, boxes_dim, &lds)) return 0;
+  const int cb = (n_max + kTile - 1) / kTile;
   const int n_super = (n_max + kSuper - 1) / kSuper;
-  int split = 0;   // super-chunks in phase 1 (0 = single phase)
-  static const bool single_phase_only = getenv("DTT_NMS_SINGLE_PHASE") != nullptr;   // developer A/B switch
-  if (max_keep > 0 && keep_out && !single_phase_only) {
-    const int r1 = (int)((3L * max_keep + kSuper - 1) / kSuper);
-    if (2 * r1 <= n_super) split = r1;
-  }
-  const int rb1 = split ? split * kSuperWords : cb;   // row blocks of the first mask launch
+  const int rb1 = split ? min(cb, split * kSuperWords) : cb;   // row AND column blocks of the first mask launch
   dtt_prof_begin("nms_mask", stream);
-  hipLaunchKernelGGL(nms_mask_kernel, dim3(cb, rb1, batch), dim3(kTile), 0, stream, boxes, boxes_dim, box_batch_stride,
-                     n_per_image, n_max, thresh, mask, mask_batch_stride, cb, 0, rb1, 0);
+  hipLaunchKernelGGL(nms_mask_kernel, dim3(rb1, rb1, batch), dim3(kTile), 0, stream, boxes, boxes_dim, box_batch_stride,
+                     n_per_image, n_max, thresh, mask, mask_batch_stride, cb, 0, rb1, 0, 0);
   dtt_prof_end("nms_mask", stream);
   DTT_CHECK_LAUNCH("nms_mask_kernel");
   dtt_prof_begin("nms_sweep", stream);
@@ -335,16 +359,41 @@ int dtt_nms_batched_launch(const float* boxes, int boxes_dim, long box_batch_str
                      box_batch_stride, rois_out, rois_rows, 0, split ? split : n_super, split ? 1 : 0);
   dtt_prof_end("nms_sweep", stream);
   DTT_CHECK_LAUNCH("nms_sweep_kernel");
-  if (split) {
-    hipLaunchKernelGGL(nms_mask_kernel, dim3(cb, min(cb - rb1, 8), batch), dim3(kTile), 0, stream, boxes, boxes_dim,
-                       box_batch_stride, n_per_image, n_max, thresh, mask, mask_batch_stride, cb, rb1, cb, 1);
-    DTT_CHECK_LAUNCH("nms_mask_kernel (phase 2)");
-    hipLaunchKernelGGL(nms_sweep_kernel, dim3(batch), dim3(kSweepThreads), lds, stream, mask, mask_batch_stride,
-                       n_per_image, n_max, cb, max_keep, keep_out, keep_batch_stride, num_out, boxes, boxes_dim,
-                       box_batch_stride, rois_out, rois_rows, split, n_super, 1);
-    DTT_CHECK_LAUNCH("nms_sweep_kernel (phase 2)");
-  }
   return 1;
+}
+
+// Phase 2 (split > 0 only; needs every box): the tiles phase 1 skipped and the rest of the sweep.
+int dtt_nms_phase2(const float* boxes, int boxes_dim, long box_batch_stride, const int* n_per_image, int n_max, int batch,
+                   float thresh, int max_keep, unsigned long long* mask, long mask_batch_stride, int* keep_out,
+                   long keep_batch_stride, int* num_out, float* rois_out, int rois_rows, int split, hipStream_t stream) {
+  if (!split) return 1;
+  size_t lds;
+  if (!nms_prepare(n_max, batch, boxes_dim, &lds)) return 0;
+  const int cb = (n_max + kTile - 1) / kTile;
+  const int n_super = (n_max + kSuper - 1) / kSuper;
+  const int rb1 = min(cb, split * kSuperWords);
+  if (cb > rb1) {   // column blocks rb1 .. cb-1, all their rows (a short grid that loops over the row blocks)
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(cb - rb1, 8, batch), dim3(kTile), 0, stream, boxes, boxes_dim, box_batch_stride,
+                       n_per_image, n_max, thresh, mask, mask_batch_stride, cb, 0, cb, rb1, 1);
+    DTT_CHECK_LAUNCH("nms_mask_kernel (phase 2)");
+  }
+  hipLaunchKernelGGL(nms_sweep_kernel, dim3(batch), dim3(kSweepThreads), lds, stream, mask, mask_batch_stride,
+                     n_per_image, n_max, cb, max_keep, keep_out, keep_batch_stride, num_out, boxes, boxes_dim,
+                     box_batch_stride, rois_out, rois_rows, split, n_super, 1);
+  DTT_CHECK_LAUNCH("nms_sweep_kernel (phase 2)");
+  return 1;
+}
+
+int dtt_nms_batched_launch(const float* boxes, int boxes_dim, long box_batch_stride, const int* n_per_image,
+                           int n_max, int batch, float thresh, int max_keep, unsigned long long* mask,
+                           long mask_batch_stride, int* keep_out, long keep_batch_stride, int* num_out,
+                           float* rois_out, int rois_rows, hipStream_t stream) {
+  const int split = dtt_nms_split(n_max, max_keep, keep_out != nullptr);
+  if (!dtt_nms_phase1(boxes, boxes_dim, box_batch_stride, n_per_image, n_max, batch, thresh, max_keep, mask, mask_batch_stride,
+                      keep_out, keep_batch_stride, num_out, rois_out, rois_rows, split, stream))
+    return 0;
+  return dtt_nms_phase2(boxes, boxes_dim, box_batch_stride, n_per_image, n_max, batch, thresh, max_keep, mask, mask_batch_stride,
+                        keep_out, keep_batch_stride, num_out, rois_out, rois_rows, split, stream);
 }
 
 extern "C" size_t dtt_nms_workspace_bytes(int boxes_num) { return dtt_nms_mask_bytes(boxes_num); }

@@ -271,11 +271,15 @@ __global__ __launch_bounds__(kThreads) void proposal_select_sort(const float* __
 }
 
 // Decode + clip the survivors (bbox_transform.py:108-134, 156-173), one thread per (image, rank).
+// Ranks [r0, r1) of every image; with `done` (the NMS's per-image flags, `done_stride` words apart) images whose NMS has
+// finished are skipped (second half of a two-phase run).
 __global__ __launch_bounds__(256) void proposal_decode(const unsigned* __restrict__ order, const float* __restrict__ bbox_pred,
                                                        const float* __restrict__ im_info, const float* __restrict__ anchors,
-                                                       PropGeom g, float* __restrict__ boxes_out) {
-  const int b = blockIdx.y, r = blockIdx.x * 256 + threadIdx.x;
-  if (r >= g.topn) return;
+                                                       PropGeom g, float* __restrict__ boxes_out, int r0, int r1,
+                                                       const unsigned long long* __restrict__ done, long done_stride) {
+  const int b = blockIdx.y, r = r0 + blockIdx.x * 256 + threadIdx.x;
+  if (r >= r1) return;
+  if (done && done[b * done_stride] != 0ULL) return;
   const float im_h = im_info[b * 3 + 0], im_w = im_info[b * 3 + 1];
   const float xmax = im_w - 1.0f, ymax = im_h - 1.0f;
   const float* dl = bbox_pred + (long)b * 4 * g.A * g.K;
@@ -406,12 +410,28 @@ extern "C" int dtt_proposal_decode_nms(const float* bbox_pred, const float* im_i
   int* num_ws = reinterpret_cast<int*>(w + p.off_num);
   const unsigned* order = reinterpret_cast<const unsigned*>(w + p.off_order);
   DTT_REQUIRE(batch <= 65535, "proposal: more than 65535 images in one call");
-  hipLaunchKernelGGL(proposal_decode, dim3((g.topn + 255) / 256, batch), dim3(256), 0, stream, order, bbox_pred, im_info, anchors, g,
-                     boxes);
+  // Two halves when the NMS runs in two phases (nms.hip: post_nms_topN << topn): its first phase only looks at the first
+  // `split` super-chunks of 1024 boxes, so only those are decoded in front of it; the rest is decoded (for the images that
+  // still need it) between the phases.
+  const long mask_stride = (long)(p.mask_per_image / sizeof(unsigned long long));
+  const int split = dtt_nms_split(g.topn, post_nms_topN, 1);
+  const int first = split ? min(g.topn, split * 1024) : g.topn;
+  hipLaunchKernelGGL(proposal_decode, dim3((first + 255) / 256, batch), dim3(256), 0, stream, order, bbox_pred, im_info, anchors, g,
+                     boxes, 0, first, nullptr, 0L);
   DTT_CHECK_LAUNCH("proposal_decode");
-  return dtt_nms_batched_launch(boxes, 4, (long)g.topn * 4, nullptr, g.topn, batch, nms_thresh, post_nms_topN, mask,
-                                (long)(p.mask_per_image / sizeof(unsigned long long)), keep, g.topn,
-                                num_out ? num_out : num_ws, rois_out, post_nms_topN, stream);
+  int* nout = num_out ? num_out : num_ws;
+  if (!dtt_nms_phase1(boxes, 4, (long)g.topn * 4, nullptr, g.topn, batch, nms_thresh, post_nms_topN, mask, mask_stride, keep, g.topn,
+                      nout, rois_out, post_nms_topN, split, stream))
+    return 0;
+  if (!split) return 1;
+  if (g.topn > first) {
+    const long cbw = (g.topn + 63) / 64;
+    hipLaunchKernelGGL(proposal_decode, dim3((g.topn - first + 255) / 256, batch), dim3(256), 0, stream, order, bbox_pred, im_info,
+                       anchors, g, boxes, first, g.topn, mask + (long)g.topn * cbw, mask_stride);
+    DTT_CHECK_LAUNCH("proposal_decode (second half)");
+  }
+  return dtt_nms_phase2(boxes, 4, (long)g.topn * 4, nullptr, g.topn, batch, nms_thresh, post_nms_topN, mask, mask_stride, keep, g.topn,
+                        nout, rois_out, post_nms_topN, split, stream);
 }
 
 extern "C" int dtt_proposal_forward(const float* cls_prob, const float* bbox_pred, const float* im_info,
