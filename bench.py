@@ -3,6 +3,7 @@
 per GPU), with the roofline of the dominant hot-path kernel and a CPU baseline.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus N --steps K --warmup W          # launches its own N ranks (below) when WORLD_SIZE is unset
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -153,9 +154,29 @@ def cpu_baseline(args, cfg):
                       % (args.height, args.width, args.layers, len(times), best, med)}
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher around it: re-run this script as N ranks (one process per GPU) under
+    torch.distributed.run on 127.0.0.1 -- what replaces the reference's single-process nn.DataParallel
+    (trainval_net.py:310-311).  Returns the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL / cross-process device buffers
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(args.gpus, 1))))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, "--gpus %d but the launcher started %d ranks" % (args.gpus, world)
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
@@ -292,7 +313,8 @@ def main():
             "metric": "frame-pairs/sec (600px, Res101 D&T)",
             "value": round(pairs / elapsed, 3),
             "unit": "frame-pairs/s",
-            "n_gpus": world,
+            "n_gpus": dist.get_world_size() if world > 1 else 1,
+            "backend": ("rccl (torch.distributed 'nccl')" if backend == "nccl" else backend) if world > 1 else None,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),

@@ -142,3 +142,28 @@ def test_resize_linear_matches_torch_bilinear():
     scaled, scale = prep_im_for_blob(np.full((30, 40, 3), 128, np.uint8), np.array([[[1.0, 2.0, 3.0]]]), 60, 1000)
     assert scale == 2.0 and scaled.shape == (60, 80, 3)
     np.testing.assert_allclose(scaled[5, 7], [127.0, 126.0, 125.0], rtol=1e-6)
+
+
+def test_rank_shards_of_two_datasets_stay_separate():
+    """trainval_net._Shard: with imagenet_vid+imagenet_det every loader owns its sampler and its length (the
+    shard class used to close over the dataset loop's variables, so the VID loader drew DET-sized permutations)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from dtt.data import sampler
+    from trainval_net import _Shard
+    bs, world = 2, 2
+    sizes = (23, 9)                                                   # VID larger than DET
+    shards = [[_Shard(sampler(n, bs * world, seed=7 + 7919 * k), n, bs, r, world) for r in range(world)]
+              for k, n in enumerate(sizes)]
+    for k, n in enumerate(sizes):
+        full = n - n % (bs * world)
+        per_rank = [list(iter(s)) for s in shards[k]]
+        assert [len(p) for p in per_rank] == [len(shards[k][0])] * world == [full // world] * world
+        union = sorted(i for p in per_rank for i in p)
+        assert union == list(range(full)) and max(union) < n       # disjoint, complete, inside THIS dataset
+        # slots [r*bs, (r+1)*bs) of every global batch: consecutive (ratio-sorted) indices stay together on a rank
+        for p in per_rank:
+            assert all(p[i + 1] == p[i] + 1 for i in range(0, len(p), bs))
+    second_epoch = [list(iter(s)) for s in shards[0]]
+    assert sorted(i for p in second_epoch for i in p) == list(range(20))

@@ -1,0 +1,37 @@
+"""`python bench.py --gpus N` must start its own N ranks (one process per GPU; what replaces the reference's
+nn.DataParallel, trainval_net.py:310-311) and report the world size it actually ran with.  The box has one GPU, so the
+two ranks share cuda:0 and rendezvous over gloo (DTT_BENCH_BACKEND=gloo); on an 8-GPU node the same command line runs
+over RCCL."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(mode):
+    env = dict(os.environ)
+    env["DTT_BENCH_BACKEND"] = "gloo"
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    env.pop("LOCAL_RANK", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+           "--mode", mode, "--layers", "50", "--height", "224", "--width", "320"]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]          # rank 0 prints ONE line
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("mode", ["infer", "train"])
+def test_bench_launches_its_own_ranks(mode):
+    out = _run(mode)
+    assert out["n_gpus"] == 2 and out["backend"] == "gloo"
+    assert out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert out["config"]["global_batch"] == 4 and out["value"] > 0
+    assert out["roofline"]["ops_timed"] == 2

@@ -67,6 +67,24 @@ def parse_args(argv=None):
     return p.parse_args(argv)
 
 
+class _Shard(torch.utils.data.Sampler):
+    """Rank r takes slots [r*bs, (r+1)*bs) of every global batch of one dataset's permuted epoch.  Each loader owns its
+    sampler and pair count (instances, not a closure over the dataset loop: with imagenet_vid+imagenet_det both loaders
+    would otherwise draw from the LAST dataset's sampler)."""
+
+    def __init__(self, order, n_pairs, batch_size, rank, world):
+        self.order, self.n_pairs, self.batch_size, self.rank, self.world = order, n_pairs, batch_size, rank, world
+
+    def __iter__(self):
+        idx = list(iter(self.order))
+        full = len(idx) - len(idx) % (self.batch_size * self.world)
+        g = torch.tensor(idx[:full], dtype=torch.long).view(-1, self.world, self.batch_size)[:, self.rank].reshape(-1)
+        return iter(g.tolist())
+
+    def __len__(self):
+        return (self.n_pairs // (self.batch_size * self.world)) * self.batch_size
+
+
 def _build_loaders(args, cfg, rank, world):
     """The reference's data path (trainval_net.py:186-238): frame-pair roidb(s), aspect-ratio-grouped loader(s) and the
     batch-permuting sampler.  With several processes every rank builds the same roidb and reads its own contiguous shard
@@ -87,16 +105,7 @@ def _build_loaders(args, cfg, rank, world):
         # seeded from (RNG_SEED, dataset, epoch) instead of reading torch's global one (single process: the reference's)
         order = sampler(len(pairs), args.batch_size * world, seed=None if world == 1 else cfg.RNG_SEED + 7919 * k)
 
-        class _Shard(torch.utils.data.Sampler):  # rank r takes slots [r*bs, (r+1)*bs) of every global batch
-            def __iter__(self):
-                idx = list(iter(order))
-                full = len(idx) - len(idx) % (args.batch_size * world)
-                g = torch.tensor(idx[:full]).view(-1, world, args.batch_size)[:, rank].reshape(-1)
-                return iter(g.tolist())
-
-            def __len__(self):
-                return (len(pairs) // (args.batch_size * world)) * args.batch_size
-        loaders.append(torch.utils.data.DataLoader(ds, batch_size=args.batch_size, sampler=_Shard(),
+        loaders.append(torch.utils.data.DataLoader(ds, batch_size=args.batch_size, sampler=_Shard(order, len(pairs), args.batch_size, rank, world),
                                                    num_workers=args.num_workers, drop_last=True,
                                                    pin_memory=True))   # 53 GB/s host -> HBM, copies are non_blocking
     return loaders
