@@ -23,9 +23,11 @@
 //     the slabs in slice order -- deterministic -- divides by C and writes the window entries in the caller's layout
 //     (NCHW planes or position-major rows).  No second kernel, no split-K partials beyond one slab per slice.
 #include <stdlib.h>
+#include <string.h>
 #include <type_traits>
 #include <algorithm>
 #include "common.h"
+#include "corr_internal.h"
 
 namespace {
 
@@ -414,11 +416,17 @@ extern "C" size_t dtt_correlation_nhwc_workspace_bytes(int batch, int ic, int ih
 // input1 / input2: (batch, ih, iw, ic) channels-last.  Output addressing as dtt_correlation_forward_strided.  Supports
 // kernel_size 1, stride1 == stride2 = s, (max_displacement - pad_size) % s == 0, ic % 16 == 0 and max_displacement / s <= 8, or
 // 16 with a multiple-of-4 ... (four sub-windows); everything else: transpose and call dtt_correlation_forward_strided.
-extern "C" int dtt_correlation_forward_nhwc(float* output, int ob, int oc, int oh, int ow, long out_batch_stride,
-                                            long out_ch_stride, long out_px_stride, const float* input1, int ic, int ih,
-                                            int iw, const float* input2, void* workspace, size_t workspace_bytes,
-                                            int pad_size, int kernel_size, int max_displacement, int stride1, int stride2,
-                                            void* stream_) {
+static int corr_nhwc_ticket_forward(float* output, int ob, int oc, int oh, int ow, long out_batch_stride,
+                                    long out_ch_stride, long out_px_stride, const float* input1, int ic, int ih,
+                                    int iw, const float* input2, void* workspace, size_t workspace_bytes,
+                                    int pad_size, int kernel_size, int max_displacement, int stride1, int stride2,
+                                    hipStream_t stream);
+
+extern "C" int dtt_correlation_forward_nhwc_limited(float* output, int ob, int oc, int oh, int ow, long out_batch_stride,
+                                                    long out_ch_stride, long out_px_stride, const float* input1, int ic, int ih,
+                                                    int iw, const float* input2, void* workspace, size_t workspace_bytes,
+                                                    int pad_size, int kernel_size, int max_displacement, int stride1, int stride2,
+                                                    int max_workgroups, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   DTT_REQUIRE(output && input1 && input2, "correlation (channels-last): null pointer");
   int eoc, eoh, eow;
@@ -426,6 +434,36 @@ extern "C" int dtt_correlation_forward_nhwc(float* output, int ob, int oc, int o
     return 0;
   DTT_REQUIRE(ob > 0 && oc == eoc && oh == eoh && ow == eow, "correlation (channels-last): output is (%d,%d,%d,%d), expected (B,%d,%d,%d)",
               ob, oc, oh, ow, eoc, eoh, eow);
+  DTT_REQUIRE((((size_t)input1 | (size_t)input2) & 15) == 0, "correlation (channels-last): inputs must be 16-byte aligned");
+  // DTT_CORR_NHWC_IMPL=ticket: round 2's channel-split kernel with the in-launch slab reduction (developer A/B)
+  static const bool use_ticket = getenv("DTT_CORR_NHWC_IMPL") && !strcmp(getenv("DTT_CORR_NHWC_IMPL"), "ticket");
+  if (!use_ticket) {
+    DTT_REQUIRE(dtt_corr_wsplit_supported(ic, kernel_size, max_displacement, pad_size, stride1, stride2),
+                "correlation (channels-last): needs kernel_size 1, stride1 == stride2 = s, displacement and padding multiples of s, "
+                "window radius <= 16 and channels %% 16 == 0");
+    return dtt_corr_wsplit_forward(output, ob, oc, oh, ow, out_batch_stride, out_ch_stride, out_px_stride, input1, ic, ih, iw,
+                                   input2, pad_size, max_displacement, stride1, max_workgroups, stream);
+  }
+  return corr_nhwc_ticket_forward(output, ob, oc, oh, ow, out_batch_stride, out_ch_stride, out_px_stride, input1, ic, ih, iw,
+                                  input2, workspace, workspace_bytes, pad_size, kernel_size, max_displacement, stride1, stride2,
+                                  stream);
+}
+
+extern "C" int dtt_correlation_forward_nhwc(float* output, int ob, int oc, int oh, int ow, long out_batch_stride,
+                                            long out_ch_stride, long out_px_stride, const float* input1, int ic, int ih,
+                                            int iw, const float* input2, void* workspace, size_t workspace_bytes,
+                                            int pad_size, int kernel_size, int max_displacement, int stride1, int stride2,
+                                            void* stream_) {
+  return dtt_correlation_forward_nhwc_limited(output, ob, oc, oh, ow, out_batch_stride, out_ch_stride, out_px_stride, input1, ic,
+                                              ih, iw, input2, workspace, workspace_bytes, pad_size, kernel_size, max_displacement,
+                                              stride1, stride2, 0, stream_);
+}
+
+static int corr_nhwc_ticket_forward(float* output, int ob, int oc, int oh, int ow, long out_batch_stride,
+                                    long out_ch_stride, long out_px_stride, const float* input1, int ic, int ih,
+                                    int iw, const float* input2, void* workspace, size_t workspace_bytes,
+                                    int pad_size, int kernel_size, int max_displacement, int stride1, int stride2,
+                                    hipStream_t stream) {
   DTT_REQUIRE(kernel_size == 1 && stride1 == stride2, "correlation (channels-last): kernel_size 1 and stride1 == stride2 only");
   const int s = stride1, Rfull = max_displacement / s;
   DTT_REQUIRE((max_displacement - pad_size) % s == 0 && max_displacement % s == 0,

@@ -251,7 +251,7 @@ class _RFCN(nn.Module):
             off += ch
         return buf
 
-    def _launch_correlations(self, pm, maps, which, B, dev):
+    def _launch_correlations(self, pm, maps, which, B, dev, budget=0):
         """Correlations `which` (indices into conv3 / conv4 / conv5) of the frame pair, written as columns of the tracking
         head's input rows (`pm.tracking_rows`), on the current stream."""
         from .ops import correlation_forward_nhwc, correlation_forward_rows
@@ -268,9 +268,12 @@ class _RFCN(nn.Module):
         for i in which:
             l, f, c0 = jobs[i]
             if f.is_contiguous(memory_format=torch.channels_last) and not f.is_contiguous():
-                # channels-last trunk maps: the single-launch channels-last kernel, no transposes
+                # channels-last trunk maps: the single-launch window-split kernel, no transposes.  `budget` > 0: the proposal
+                # layer's kernels are resident on a few CUs beside this launch -- plan for fewer CUs (more, shorter
+                # workgroups in two rounds) instead of exactly one workgroup per CU, which would leave a few workgroups
+                # waiting for a whole second round
                 correlation_forward_nhwc(f[:B], f[B:2 * B], l.pad_size, l.kernel_size, l.max_displacement, l.stride1,
-                                         l.stride2, rows=rows, col=c0)
+                                         l.stride2, rows=rows, col=c0, max_workgroups=budget)
             else:
                 correlation_forward_rows(rows, c0, f[:B].contiguous(), f[B:2 * B].contiguous(), l.pad_size, l.kernel_size,
                                          l.max_displacement, l.stride1, l.stride2, l.corr_multiply)
@@ -297,7 +300,7 @@ class _RFCN(nn.Module):
             # that engine frees up (tools/wg_trace.py, tools/probes/wg_placement.hip): that now costs conv4 ≈ 25 us in
             # some steps instead of conv5 20 - 60.  (env DTT_CORR_ORDER: developer A/B over the order of what is left.)
             idx = [int(c) for c in os.environ.get("DTT_CORR_ORDER", "021") if int(c) not in corr_done]
-            rows = self._launch_correlations(pm, (c3, c4, c5), idx, B, dev)
+            rows = self._launch_correlations(pm, (c3, c4, c5), idx, B, dev, budget=int(os.environ.get("DTT_CORR_BUDGET", "240")))
         det, fused.det_rows = getattr(fused, "det_rows", None), None    # (n_legs*B*H*W, stride): issued by the fused trunk ...
         if det is None:
             det = head_gemm(top_rows, pm.det)                           # ... or here

@@ -13,6 +13,7 @@ The reference builds an old-style stateful autograd Function per call; these are
 torch.autograd.Function subclasses.  All ops are GPU-only and raise if the library is missing.
 """
 import ctypes
+import os
 
 import torch
 from torch import nn
@@ -95,11 +96,14 @@ def correlation_forward_rows(rows, col, input1, input2, pad_size, kernel_size, m
 _NHWC_WORKSPACES = {}
 
 
-def correlation_forward_nhwc(input1, input2, pad_size, kernel_size, max_displacement, stride1, stride2, rows=None, col=0):
+def correlation_forward_nhwc(input1, input2, pad_size, kernel_size, max_displacement, stride1, stride2, rows=None, col=0,
+                             max_workgroups=0):
     """Correlation of two channels-last (B, C, H, W)-shaped maps (memory order B, H, W, C -- the channels-last trunk's
-    own layout) without any layout change in front of the op (`dtt_correlation_forward_nhwc`).
+    own layout) without any layout change in front of the op (`dtt_correlation_forward_nhwc_limited`: the window-split
+    kernel, one launch, no workspace).
     rows is None: returns the reference's (B, D*D, oh, ow) NCHW tensor.  Otherwise writes columns [col, col + D*D) of
-    `rows`, a position-major (B*oh*ow, ld) matrix (the tracking head's GEMM input, dtt.heads)."""
+    `rows`, a position-major (B*oh*ow, ld) matrix (the tracking head's GEMM input, dtt.heads).
+    max_workgroups: 0 = plan one round over every CU; n = plan for n CUs (other kernels run beside this one)."""
     require_gpu(input1, input2)
     if input1.shape != input2.shape or input1.dim() != 4:
         raise ValueError("correlation: input shapes differ: %s vs %s" % (tuple(input1.shape), tuple(input2.shape)))
@@ -109,14 +113,16 @@ def correlation_forward_nhwc(input1, input2, pad_size, kernel_size, max_displace
     B, C, H, W = input1.shape
     oc, oh, ow = correlation_output_shape(C, H, W, pad_size, kernel_size, max_displacement, stride1, stride2)
     L = _lib.lib()
-    nbytes = L.dtt_correlation_nhwc_workspace_bytes(B, C, H, W, pad_size, kernel_size, max_displacement, stride1, stride2)
-    if nbytes == 0:
-        raise ValueError("correlation (channels-last): unsupported geometry (kernel_size 1, stride1 == stride2, C % 16 == 0)")
-    # zero-filled once, then owned by (device, stream): the kernel leaves its ticket area zeroed (C ABI workspace contract)
-    key = (input1.device, torch.cuda.current_stream(input1.device).cuda_stream, nbytes)
-    ws = _NHWC_WORKSPACES.get(key)
-    if ws is None:
-        ws = _NHWC_WORKSPACES[key] = torch.zeros((nbytes,), dtype=torch.uint8, device=input1.device)
+    ws, nbytes = None, 0
+    if os.environ.get("DTT_CORR_NHWC_IMPL") == "ticket":   # developer A/B: round 2's channel-split kernel needs its slabs
+        nbytes = L.dtt_correlation_nhwc_workspace_bytes(B, C, H, W, pad_size, kernel_size, max_displacement, stride1, stride2)
+        if nbytes == 0:
+            raise ValueError("correlation (channels-last, ticket kernel): unsupported geometry")
+        # zero-filled once, then owned by (device, stream): the kernel leaves its ticket area zeroed (C ABI workspace contract)
+        key = (input1.device, torch.cuda.current_stream(input1.device).cuda_stream, nbytes)
+        ws = _NHWC_WORKSPACES.get(key)
+        if ws is None:
+            ws = _NHWC_WORKSPACES[key] = torch.zeros((nbytes,), dtype=torch.uint8, device=input1.device)
     if rows is None:
         out = torch.empty((B, oc, oh, ow), dtype=torch.float32, device=input1.device)
         optr, sb, sc, sp, ret = ptr(out), oc * oh * ow, oh * ow, 1, out
@@ -127,9 +133,11 @@ def correlation_forward_nhwc(input1, input2, pad_size, kernel_size, max_displace
         ld = rows.stride(0)
         optr, sb, sc, sp, ret = ctypes.c_void_p(rows.data_ptr() + 4 * col), oh * ow * ld, 1, ld, rows
     with torch.cuda.device(input1.device):
-        check(L.dtt_correlation_forward_nhwc(optr, B, oc, oh, ow, sb, sc, sp, ptr(input1), C, H, W, ptr(input2), ptr(ws), nbytes,
-                                             pad_size, kernel_size, max_displacement, stride1, stride2,
-                                             stream_ptr(input1.device)), "correlation forward (channels-last)")
+        check(L.dtt_correlation_forward_nhwc_limited(optr, B, oc, oh, ow, sb, sc, sp, ptr(input1), C, H, W, ptr(input2),
+                                                     ptr(ws) if ws is not None else None, nbytes,
+                                                     pad_size, kernel_size, max_displacement, stride1, stride2,
+                                                     int(max_workgroups), stream_ptr(input1.device)),
+              "correlation forward (channels-last)")
     return ret
 
 

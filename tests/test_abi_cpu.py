@@ -69,3 +69,25 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(_lib.DttLibraryError, match="no CPU"):
         _lib.lib()
+
+
+def test_correlation_window_split_plans_without_gpu():
+    """dtt_correlation_nhwc_plan is host code: the launch plan of the window-split correlation at the benchmark shapes
+    (B = 2, 38 x 67 outputs = 10 x 17 pixel blocks; radius 8 -> 25 window blocks per pixel block)."""
+    from dtt import _lib
+    L = _lib.lib()
+
+    def plan(*a):
+        v = [ctypes.c_int() for _ in range(4)]
+        assert L.dtt_correlation_nhwc_plan(*a, *[ctypes.byref(x) for x in v]) == 1, a
+        return tuple(x.value for x in v)
+    assert plan(2, 38, 67, 8, 256)[:3] == (3, 9, 256)     # 2 x ((40 + 2) four-block tiles x 3 parts + one 2 x 1 tile x 2)
+    assert plan(2, 38, 67, 8, 240)[:3] == (5, 5, 426)     # CUs left to other kernels: more, shorter workgroups
+    assert plan(2, 38, 67, 4, 256)[:3] == (3, 3, 256)     # conv3 (stride 2: radius 4 on the lattice)
+    parts, nacc, wgs, slots = plan(1, 36, 63, 16, 256)    # BASELINE configs[4]: 81 window blocks
+    assert parts * nacc >= 81 and wgs >= 36 and slots >= 4
+    for B, oh, ow, R in ((1, 1, 1, 1), (3, 9, 11, 4), (8, 38, 67, 8), (1, 75, 134, 16), (2, 5, 4, 13)):
+        parts, nacc, wgs, slots = plan(B, oh, ow, R, 256)
+        nblk = (1 + (R + 1) // 2) ** 2
+        assert parts >= 1 and -(-nblk // parts) <= nacc and wgs >= 1 and 4 <= slots <= 8
+    assert L.dtt_correlation_nhwc_plan(1, 8, 8, 17, 0, None, None, None, None) == 0   # radius > 16: not this kernel

@@ -256,25 +256,36 @@ def test_correlation_backward_any_kernel_size_is_the_exact_adjoint(dev, case):
 
 
 NHWC_CASES = [
-    (2, 64, 38, 67, 8, 1, 8, 1, 1),     # conv4 / conv5 geometry at the 600 px map size (fewer channels)
-    (2, 2048, 38, 67, 8, 1, 8, 1, 1),   # conv5 at full size: 4 channel slices per tile, in-launch slab reduction
+    (2, 64, 38, 67, 8, 1, 8, 1, 1),     # conv4 / conv5 geometry at the 600 px map size (fewer channels): 10 x 17 pixel blocks
+    (2, 2048, 38, 67, 8, 1, 8, 1, 1),   # conv5 at full size: 3 window parts x (42 full tiles + one 2 x 1) x 2 images = 256 workgroups
     (2, 512, 75, 134, 8, 1, 8, 2, 2),   # conv3 at full size: stride 2 = the stride-1 problem on the even lattice
     (1, 48, 37, 45, 8, 1, 8, 2, 2),     # odd map sizes under stride 2
-    (1, 32, 36, 63, 16, 1, 16, 1, 1),   # config 5: R = 16 as four R = 8 sub-windows
-    (1, 32, 18, 22, 12, 1, 12, 1, 1),   # R = 12 the same way
-    (3, 16, 9, 11, 4, 1, 4, 1, 1),      # R = 4 (3 x 3 window blocks), tiny map, one chunk per slice
-    (1, 48, 21, 17, 3, 1, 3, 1, 1),     # R = 3 inside the R = 4 instantiation
-    (1, 32, 20, 27, 6, 1, 6, 1, 1),     # R = 6 inside the R = 8 instantiation
+    (1, 32, 36, 63, 16, 1, 16, 1, 1),   # config 5: R = 16 natively (9 x 9 window blocks)
+    (1, 32, 18, 22, 12, 1, 12, 1, 1),   # R = 12 (7 x 7 window blocks)
+    (3, 16, 9, 11, 4, 1, 4, 1, 1),      # R = 4 (3 x 3 window blocks), tiny map, one chunk
+    (1, 48, 21, 17, 3, 1, 3, 1, 1),     # odd radii: R = 3 ...
+    (1, 32, 20, 27, 5, 1, 5, 1, 1),     # ... 5 ...
+    (1, 16, 19, 23, 7, 1, 7, 1, 1),     # ... 7 ...
+    (2, 16, 14, 30, 13, 1, 13, 1, 1),   # ... 13
+    (1, 32, 20, 27, 6, 1, 6, 1, 1),     # R = 6
+    (1, 16, 12, 9, 1, 1, 1, 1, 1),      # R = 1 and R = 2: two window blocks per axis
+    (2, 16, 10, 13, 2, 1, 2, 1, 1),
     (1, 16, 16, 16, 6, 1, 4, 1, 1),     # pad > displacement: output pixels inside the padding
     (2, 32, 13, 19, 2, 1, 4, 1, 1),     # pad < displacement: the output is smaller than the map
-    (1, 16, 5, 4, 8, 1, 8, 1, 1),       # map smaller than one tile
+    (1, 16, 5, 4, 8, 1, 8, 1, 1),       # map smaller than one tile (2 x 1 pixel blocks)
+    (1, 16, 3, 3, 8, 1, 8, 1, 1),       # a single pixel block
+    (1, 16, 20, 4, 8, 1, 8, 1, 1),      # one block column: 4 x 1 tiles + remainder
+    (1, 16, 4, 33, 8, 1, 8, 1, 1),      # one block row, odd count: 1 x 4 tiles + a 1 x 1
+    (2, 16, 22, 26, 8, 1, 8, 1, 1),     # odd x odd block grid (6 x 7 ... 5.5 -> 6 rows, 6.5 -> 7 cols): every segment kind
 ]
 
 
 @pytest.mark.parametrize("case", NHWC_CASES)
 def test_correlation_nhwc_forward(dev, case):
-    """The channels-last kernel (dtt_correlation_forward_nhwc) against the oracle on the same values, in both output
-    layouts (NCHW tensor; columns of a position-major matrix), and run-to-run identical (the slab reduction is ordered)."""
+    """The channels-last kernel (dtt_correlation_forward_nhwc: window-split, csrc/correlation_wsplit.hip) against the oracle on
+    the same values, in both output layouts (NCHW tensor; columns of a position-major matrix), run-to-run identical, and
+    bit-identical under every plan (all CUs / a CU budget that forces more, shorter workgroups / one CU): each output is one
+    wave's fma chain over the channels in order, whatever the partition."""
     from dtt.ops import correlation_forward_nhwc
     B, C, H, W, pad, k, d, s1, s2 = case
     rng = np.random.RandomState(sum(case))
@@ -294,6 +305,28 @@ def test_correlation_nhwc_forward(dev, case):
     assert bool((rows[:, :5] == 7).all()) and bool((rows[:, 5 + oc:] == 7).all())
     for _ in range(3):
         assert torch.equal(correlation_forward_nhwc(t1, t2, pad, k, d, s1, s2), out)
+    for budget in (240, 100, 17, 1):
+        assert torch.equal(correlation_forward_nhwc(t1, t2, pad, k, d, s1, s2, max_workgroups=budget), out), budget
+
+
+def test_correlation_nhwc_plans():
+    """dtt_correlation_nhwc_plan at the shapes of the benchmark step (pure host code)."""
+    import ctypes
+    from dtt import _lib
+    L = _lib.lib()
+
+    def plan(*a):
+        v = [ctypes.c_int() for _ in range(4)]
+        assert L.dtt_correlation_nhwc_plan(*a, *[ctypes.byref(x) for x in v]) == 1, a
+        return tuple(x.value for x in v)
+    parts, nacc, wgs, slots = plan(2, 38, 67, 8, 256)
+    assert (parts, nacc, wgs) == (3, 9, 256) and slots >= 4      # 2 x (40 + 2 full tiles x 3 + one 2 x 1 tile x 2)
+    parts, nacc, wgs, slots = plan(2, 38, 67, 8, 240)            # CUs left free: more, shorter workgroups
+    assert parts == 5 and nacc == 5 and wgs == 426
+    assert plan(2, 38, 67, 4, 256)[:3] == (3, 3, 256)            # conv3
+    parts, nacc, wgs, _ = plan(1, 36, 63, 16, 256)               # BASELINE configs[4]: 81 window blocks
+    assert parts * nacc >= 81 and wgs >= 36
+    assert L.dtt_correlation_nhwc_plan(1, 8, 8, 17, 0, None, None, None, None) == 0
 
 
 def test_correlation_into_concat_slice(dev):
