@@ -77,43 +77,24 @@ int dtt_correlation_forward_strided(float* output, int ob, int oc, int oh, int o
 /* The same forward on CHANNELS-LAST inputs: input1 / input2 are (ob, ih, iw, ic) row-major, i.e. what the reference's own
  * kernel reads after its `channels_first` repack (correlation_cuda_kernel.cu:10-32, 296-340) -- callers whose trunk is
  * channels-last skip both that repack and the NHWC -> NCHW hand-over.  Output addressing as above.  ONE launch per op and
- * no partial sums anywhere (round 3, csrc/correlation_wsplit.hip): the (2R+1)^2 displacement window of a 4 x 4 pixel block is
- * dealt to `parts` waves in runs of 4 x 4 window blocks and every wave runs ALL channels for its run, so what a wave
- * accumulates is final -- no channel slices, no slabs, no tickets, no inter-workgroup communication of any kind: results
- * are bit-identical from run to run by construction and concurrent calls on different streams share nothing.
+ * no partial sums in memory (round 3, csrc/correlation_wsplit.hip): the (2R+1)^2 displacement window of a 4 x 4 pixel block
+ * is dealt to `parts` wave pairs in runs of 4 x 4 window blocks and every pair runs ALL channels for its run (its two waves
+ * take alternate 16-channel chunks and meet in LDS, even + odd, at the end) -- no channel slices across workgroups, no slabs,
+ * no tickets, no workspace, no inter-workgroup communication of any kind: a result does not depend on how the launch was
+ * partitioned, it is bit-identical from run to run by construction, and concurrent calls on different streams share nothing.
+ * (Round 2's channel-split kernel with its ticketed in-launch slab reduction -- whose ordering argument leant on ISA behaviour
+ * rather than on the HIP memory model -- is gone, and with it dtt_correlation_nhwc_workspace_bytes and the workspace arguments.)
  * Supported: kernel_size 1, stride1 == stride2 = s, pad and displacement multiples of s, ic % 16 == 0, window radius
  * max_displacement / s in 1 .. 16 (natively: d = 16 is one 33 x 33 window, not four sub-windows); 16-byte aligned inputs.
- * workspace / workspace_bytes: NOT USED by the window-split kernel (pass NULL, 0).  They remain in the signature for round 2's
- * channel-split kernel, kept behind the developer switch DTT_CORR_NHWC_IMPL=ticket: that kernel needs
- * dtt_correlation_nhwc_workspace_bytes(...) bytes, zero-filled ONCE after allocation (every call leaves its ticket area zeroed
- * again), one workspace per stream that may run it concurrently.  Its slices meet through memory as follows -- the ordering
- * argument, since it leans on ISA behaviour rather than on the HIP memory model: (1) a slice stores its slab with
- * `global_store_dwordx4 ... sc1` (write-through: the data leaves the XCD's L2 towards memory, no dirty line stays behind);
- * (2) every storing wave executes `s_waitcnt vmcnt(0)`, which on gfx950 returns only when its write-through stores have been
- * acknowledged by the memory side, then the workgroup meets at a barrier; (3) ONE lane takes the tile's ticket with a relaxed
- * agent-scope atomic add (executed at the L2 / memory side, ordered after (2) by program order + the barrier); (4) the
- * workgroup that reads ticket == slices - 1 knows that every other slice has passed (2); one lane executes an agent-scope
- * acquire fence (`buffer_inv sc1`: drops this CU's possibly stale L1 lines), a barrier follows, and only then are the slabs
- * loaded -- from L2 / memory, where step (1) put them.  A release fence in (2) would be the portable form; it writes back the
- * whole L2 (8.2 vs 3.0 us per publish, MI355X_MICROARCH.md "publish-large") and is not needed for write-through stores.
- * dtt_correlation_forward_nhwc_limited: the same with `max_workgroups` > 0 = plan the launch for that many CUs (the caller runs
- * other kernels beside it and wants them to keep theirs; the plan then uses more, shorter workgroups in several rounds
- * instead of exactly one workgroup per CU); 0 = all CUs.  dtt_correlation_nhwc_plan reports the plan (window parts,
- * accumulators per wave, workgroups, LDS ring slots) without launching anything. */
-size_t dtt_correlation_nhwc_workspace_bytes(int batch, int ic, int ih, int iw, int pad_size, int kernel_size,
-                                            int max_displacement, int stride1, int stride2);
+ * max_workgroups: 0 = plan the launch for every CU of the device (one workgroup per CU where the shape allows it: 256 at the
+ * 600 px shapes); n > 0 = plan for n CUs -- the caller runs other kernels beside this one and wants neither to wait for the
+ * other's CUs (the plan then uses more, shorter workgroups in several rounds).  dtt_correlation_nhwc_plan reports the plan
+ * (window parts, accumulators per wave, workgroups, LDS ring slots of the largest tile) without launching anything. */
 int dtt_correlation_forward_nhwc(float* output, int ob, int oc, int oh, int ow, long out_batch_stride,
                                  long out_channel_stride, long out_pixel_stride,
                                  const float* input1, int ic, int ih, int iw, const float* input2,
-                                 void* workspace, size_t workspace_bytes,
                                  int pad_size, int kernel_size, int max_displacement,
-                                 int stride1, int stride2, void* stream);
-int dtt_correlation_forward_nhwc_limited(float* output, int ob, int oc, int oh, int ow, long out_batch_stride,
-                                         long out_channel_stride, long out_pixel_stride,
-                                         const float* input1, int ic, int ih, int iw, const float* input2,
-                                         void* workspace, size_t workspace_bytes,
-                                         int pad_size, int kernel_size, int max_displacement,
-                                         int stride1, int stride2, int max_workgroups, void* stream);
+                                 int stride1, int stride2, int max_workgroups, void* stream);
 int dtt_correlation_nhwc_plan(int batch, int oh, int ow, int window_radius, int max_workgroups, int* parts,
                               int* accumulators, int* workgroups, int* ring_slots);
 /* Any kernel_size / strides (D&T itself uses kernel_size 1, rfcn.py:58-60: that case runs on the matrix cores).

@@ -28,7 +28,6 @@
 #include <type_traits>
 #include <algorithm>
 #include "common.h"
-#include "corr_internal.h"
 
 namespace {
 
@@ -553,18 +552,28 @@ int launch_ws(const WGeom& g, int items, size_t lds_bytes, hipStream_t stream) {
 
 }  // namespace
 
-int dtt_corr_wsplit_supported(int ic, int kernel_size, int max_displacement, int pad_size, int stride1, int stride2) {
-  if (kernel_size != 1 || stride1 != stride2 || stride1 < 1) return 0;
-  const int s = stride1;
-  if (max_displacement % s || (max_displacement - pad_size) % s || ic % kKC) return 0;
-  const int R = max_displacement / s;
-  return R >= 1 && R <= 16;
-}
-
-int dtt_corr_wsplit_forward(float* output, int ob, int oc, int oh, int ow, long out_batch_stride, long out_ch_stride,
-                            long out_px_stride, const float* input1, int ic, int ih, int iw, const float* input2,
-                            int pad_size, int max_displacement, int stride, int max_workgroups, hipStream_t stream) {
-  const int s = stride, R = max_displacement / s;
+// input1 / input2: (ob, ih, iw, ic) channels-last.  Output addressing as dtt_correlation_forward_strided.  Supports
+// kernel_size 1, stride1 == stride2 = s, displacement and padding multiples of s, ic % 16 == 0, window radius
+// max_displacement / s in 1 .. 16; everything else: transpose and call dtt_correlation_forward_strided.
+// max_workgroups: 0 = plan one round over every CU; n = plan for n CUs (other kernels run beside this one).
+extern "C" int dtt_correlation_forward_nhwc(float* output, int ob, int oc, int oh, int ow, long out_batch_stride,
+                                            long out_ch_stride, long out_px_stride, const float* input1, int ic, int ih,
+                                            int iw, const float* input2, int pad_size, int kernel_size, int max_displacement,
+                                            int stride1, int stride2, int max_workgroups, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  DTT_REQUIRE(output && input1 && input2, "correlation (channels-last): null pointer");
+  int eoc, eoh, eow;
+  if (!dtt_correlation_output_shape(ic, ih, iw, pad_size, kernel_size, max_displacement, stride1, stride2, &eoc, &eoh, &eow))
+    return 0;
+  DTT_REQUIRE(ob > 0 && oc == eoc && oh == eoh && ow == eow, "correlation (channels-last): output is (%d,%d,%d,%d), expected (B,%d,%d,%d)",
+              ob, oc, oh, ow, eoc, eoh, eow);
+  DTT_REQUIRE((((size_t)input1 | (size_t)input2) & 15) == 0, "correlation (channels-last): inputs must be 16-byte aligned");
+  DTT_REQUIRE(kernel_size == 1 && stride1 == stride2 && stride1 >= 1, "correlation (channels-last): kernel_size 1 and stride1 == stride2 only");
+  const int s = stride1, R = max_displacement / s;
+  DTT_REQUIRE(max_displacement % s == 0 && (max_displacement - pad_size) % s == 0,
+              "correlation (channels-last): displacement and padding must be multiples of the stride");
+  DTT_REQUIRE(ic % kKC == 0, "correlation (channels-last): channels (%d) must be a multiple of %d", ic, kKC);
+  DTT_REQUIRE(R >= 1 && R <= 16, "correlation (channels-last): window radius %d not supported (1 .. 16)", R);
   WGeom g;
   g.f1 = input1; g.f2 = input2;
   g.C = ic;
@@ -572,7 +581,6 @@ int dtt_corr_wsplit_forward(float* output, int ob, int oc, int oh, int ow, long 
   g.sx = (long)s * ic; g.sy = (long)s * iw * ic; g.sb = (long)ih * iw * ic;
   g.oh = oh; g.ow = ow; g.origin = (max_displacement - pad_size) / s;
   g.R = R; g.D = 2 * R + 1;
-  DTT_REQUIRE(oc == g.D * g.D, "correlation (window-split): %d output channels, expected %d", oc, g.D * g.D);
   DTT_REQUIRE((long)ih * iw * ic * 4 < 0xffffffffl, "correlation (window-split): one image exceeds the 32-bit DMA offset range");
   g.out = output; g.out_sb = out_batch_stride; g.out_sc = out_ch_stride; g.out_sp = out_px_stride;
   static const int ablate = getenv("DTT_CORR_WS_ABLATE") ? atoi(getenv("DTT_CORR_WS_ABLATE")) : 0;

@@ -34,7 +34,7 @@ struct PropGeom {
   int P;                   // power-of-two sort size >= topn
 };
 
-#ifdef DTT_WG_TRACE   // developer build: where and when the select / sort workgroups ran (see correlation_nhwc.hip)
+#ifdef DTT_WG_TRACE   // developer build: where and when the select / sort workgroups ran (tools/wg_trace.py)
 __device__ unsigned long long dtt_sort_trace[16 * 8 * 8];
 #define SORT_STAMP(k) do { __syncthreads(); if (threadIdx.x == 0 && blockIdx.x < 8) dtt_sort_trace[(trace_slot * 8 + blockIdx.x) * 8 + (k)] = wall_clock64(); } while (0)
 __device__ int dtt_sort_trace_launch;

@@ -93,14 +93,11 @@ def correlation_forward_rows(rows, col, input1, input2, pad_size, kernel_size, m
     return rows
 
 
-_NHWC_WORKSPACES = {}
-
-
 def correlation_forward_nhwc(input1, input2, pad_size, kernel_size, max_displacement, stride1, stride2, rows=None, col=0,
                              max_workgroups=0):
     """Correlation of two channels-last (B, C, H, W)-shaped maps (memory order B, H, W, C -- the channels-last trunk's
-    own layout) without any layout change in front of the op (`dtt_correlation_forward_nhwc_limited`: the window-split
-    kernel, one launch, no workspace).
+    own layout) without any layout change in front of the op (`dtt_correlation_forward_nhwc`: the window-split kernel,
+    one launch, no workspace).
     rows is None: returns the reference's (B, D*D, oh, ow) NCHW tensor.  Otherwise writes columns [col, col + D*D) of
     `rows`, a position-major (B*oh*ow, ld) matrix (the tracking head's GEMM input, dtt.heads).
     max_workgroups: 0 = plan one round over every CU; n = plan for n CUs (other kernels run beside this one)."""
@@ -113,16 +110,6 @@ def correlation_forward_nhwc(input1, input2, pad_size, kernel_size, max_displace
     B, C, H, W = input1.shape
     oc, oh, ow = correlation_output_shape(C, H, W, pad_size, kernel_size, max_displacement, stride1, stride2)
     L = _lib.lib()
-    ws, nbytes = None, 0
-    if os.environ.get("DTT_CORR_NHWC_IMPL") == "ticket":   # developer A/B: round 2's channel-split kernel needs its slabs
-        nbytes = L.dtt_correlation_nhwc_workspace_bytes(B, C, H, W, pad_size, kernel_size, max_displacement, stride1, stride2)
-        if nbytes == 0:
-            raise ValueError("correlation (channels-last, ticket kernel): unsupported geometry")
-        # zero-filled once, then owned by (device, stream): the kernel leaves its ticket area zeroed (C ABI workspace contract)
-        key = (input1.device, torch.cuda.current_stream(input1.device).cuda_stream, nbytes)
-        ws = _NHWC_WORKSPACES.get(key)
-        if ws is None:
-            ws = _NHWC_WORKSPACES[key] = torch.zeros((nbytes,), dtype=torch.uint8, device=input1.device)
     if rows is None:
         out = torch.empty((B, oc, oh, ow), dtype=torch.float32, device=input1.device)
         optr, sb, sc, sp, ret = ptr(out), oc * oh * ow, oh * ow, 1, out
@@ -133,10 +120,9 @@ def correlation_forward_nhwc(input1, input2, pad_size, kernel_size, max_displace
         ld = rows.stride(0)
         optr, sb, sc, sp, ret = ctypes.c_void_p(rows.data_ptr() + 4 * col), oh * ow * ld, 1, ld, rows
     with torch.cuda.device(input1.device):
-        check(L.dtt_correlation_forward_nhwc_limited(optr, B, oc, oh, ow, sb, sc, sp, ptr(input1), C, H, W, ptr(input2),
-                                                     ptr(ws) if ws is not None else None, nbytes,
-                                                     pad_size, kernel_size, max_displacement, stride1, stride2,
-                                                     int(max_workgroups), stream_ptr(input1.device)),
+        check(L.dtt_correlation_forward_nhwc(optr, B, oc, oh, ow, sb, sc, sp, ptr(input1), C, H, W, ptr(input2),
+                                             pad_size, kernel_size, max_displacement, stride1, stride2,
+                                             int(max_workgroups), stream_ptr(input1.device)),
               "correlation forward (channels-last)")
     return ret
 
