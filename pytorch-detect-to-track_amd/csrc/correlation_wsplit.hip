@@ -46,6 +46,7 @@ struct WSeg { int item0, nitems, by0, bx0, nty, ntx, th, tw, wpt; unsigned wpt_m
 struct WGeom {
   const float* f1; const float* f2;      // frame t / t+tau, channels-last
   long sy, sx, sb;                       // floats between vertically / horizontally adjacent lattice pixels, between images
+  unsigned sy4, sx4;                     // the same in bytes (one image stays below 4 GB: the DMA offsets are 32-bit)
   int C, H, W;                           // channels, lattice size
   int oh, ow, origin;                    // output size; output (y, x) <-> lattice pixel (origin + y, origin + x)
   int R, D, nbr, nblk, parts;
@@ -156,6 +157,8 @@ __global__ __launch_bounds__(kThreads) void corr_wsplit_kernel(WGeom g) {
 #pragma unroll
     for (int i = 0; i < kMaxNI; ++i) {
       const int instr = i * kNLoad + lw;            // instruction `instr` fills LDS pixels [16 instr, 16 instr + 16) of a slot
+      voff[i] = 0;
+      if (i == 0 ? instr >= nb : instr >= n_instr) continue;   // (wave-uniform)
       const int px = lane >> 2;
       int y, x, key;
       if (i == 0) {                                 // instr < 4: frame-t block `instr` (16 pixels, block-major)
@@ -170,8 +173,8 @@ __global__ __launch_bounds__(kThreads) void corr_wsplit_kernel(WGeom g) {
       }
       y = min(max(y + g.origin, 0), g.H - 1);       // out-of-image pixels: any in-bounds address (their products are discarded)
       x = min(max(x + g.origin, 0), g.W - 1);
-      voff[i] = (unsigned)(((long)y * g.sy + (long)x * g.sx) * 4 + (((lane & 3) ^ swz(key)) << 4));
-      if (i == 0 ? instr < nb : instr < n_instr) ++my_cnt;
+      voff[i] = (unsigned)y * g.sy4 + (unsigned)x * g.sx4 + (unsigned)(((lane & 3) ^ swz(key)) << 4);
+      ++my_cnt;
     }
     const char* b1 = reinterpret_cast<const char*>(g.f1 + (long)n * g.sb);
     const char* b2 = reinterpret_cast<const char*>(g.f2 + (long)n * g.sb);
@@ -399,10 +402,20 @@ __global__ __launch_bounds__(kThreads) void corr_wsplit_kernel(WGeom g) {
         if (y >= g.oh || x >= g.ow) continue;
         float* orow = ob + ((long)y * g.ow + x) * g.out_sp + (dy_lo + g.R) * g.D;
         const float* trow = lds + px * per_px;
-        for (int e = lane; e < per_px; e += 64) {
-          const int dyi = mdiv(e, g.d_magic), dxi = e - dyi * g.D;
-          const int qb = ((jy + dyi + dy_lo + g.R) >> 2) * g.nbr + ((jx + dxi) >> 2);   // the window block this entry comes from
-          if (qb >= q_lo && qb < q_hi) orow[e] = trow[e];                               // (else: another workgroup's part)
+        for (int e0 = lane; e0 < per_px; e0 += 256) {   // four entries per lane per round: the LDS reads go out together
+          float v[4];
+          bool mine[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int e = e0 + 64 * u;
+            const int dyi = mdiv(e, g.d_magic), dxi = e - dyi * g.D;
+            const int qb = ((jy + dyi + dy_lo + g.R) >> 2) * g.nbr + ((jx + dxi) >> 2);   // the window block this entry comes from
+            mine[u] = e < per_px && qb >= q_lo && qb < q_hi;                               // (else: another workgroup's part)
+            v[u] = trow[min(e, per_px - 1)];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (mine[u]) orow[e0 + 64 * u] = v[u];
         }
       }
     } else {
@@ -579,9 +592,10 @@ extern "C" int dtt_correlation_forward_nhwc(float* output, int ob, int oc, int o
   g.C = ic;
   g.H = (ih + s - 1) / s; g.W = (iw + s - 1) / s;            // lattice pixels 0, s, 2s, ...
   g.sx = (long)s * ic; g.sy = (long)s * iw * ic; g.sb = (long)ih * iw * ic;
+  DTT_REQUIRE((long)ih * iw * ic * 4 < 0xffffffffl, "correlation (channels-last): one image exceeds the 32-bit DMA offset range");
+  g.sx4 = (unsigned)(g.sx * 4); g.sy4 = (unsigned)(g.sy * 4);
   g.oh = oh; g.ow = ow; g.origin = (max_displacement - pad_size) / s;
   g.R = R; g.D = 2 * R + 1;
-  DTT_REQUIRE((long)ih * iw * ic * 4 < 0xffffffffl, "correlation (window-split): one image exceeds the 32-bit DMA offset range");
   g.out = output; g.out_sb = out_batch_stride; g.out_sc = out_ch_stride; g.out_sp = out_px_stride;
   static const int ablate = getenv("DTT_CORR_WS_ABLATE") ? atoi(getenv("DTT_CORR_WS_ABLATE")) : 0;
   g.ablate = ablate;
