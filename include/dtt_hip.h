@@ -412,6 +412,14 @@ int dtt_gemm_tune(const float* a, const float* w, const float* bias, const float
  * Same bin arithmetic and summation order as dtt_psroi_pool_vote_forward on the equivalent NCHW map: bit-identical. */
 int dtt_head_gemm(const float* x, long ldx, int M, int K, const float* w, const float* bias, int n_rows,
                   float* out, long ldc, int n_store, int passes, void* stream);
+/* The RPN's two 1x1 heads + the pairwise softmax in ONE launch of the same kernel (rpn/rpn.py:63-71: RPN_cls_score ->
+ * reshape(2) -> softmax -> reshape(2A), RPN_bbox_pred).  x: (batch * hw, K) channels-last rows of relu(RPN_Conv(.)), ldx floats
+ * between rows.  w: (n_rows, K) with the rows in the order [bg_0, fg_0, bg_1, fg_1, ..., bg_{A-1}, fg_{A-1}, box deltas
+ * 0 .. 4A-1, zero rows up to a multiple of 16] where bg_a / fg_a are RPN_cls_score's output channels a / A + a (the pair the
+ * reference's softmax normalises), bias likewise.  cls_prob (batch, 2A, h, w) and bbox_pred (batch, 4A, h, w) come out in the
+ * reference's NCHW layout -- what dtt_proposal_select_sort / dtt_proposal_decode_nms read.  num_anchors must be even. */
+int dtt_rpn_head_gemm(const float* x, long ldx, int batch, int hw, int K, const float* w, const float* bias, int n_rows,
+                      int num_anchors, float* cls_prob, float* bbox_pred, void* stream);
 int dtt_psroi_pm_forward(const float* map, long pixel_stride, int cp, int batch_size, int num_rois, int height,
                          int width, int pooled, const float* rois, float spatial_scale, int output_dim,
                          float* vote_out, float* pooled_out, void* stream);

@@ -44,6 +44,9 @@ struct DttDeviceOnce {
   }
 };
 
+// compute units of the current device, cached per device (hipGetDeviceProperties costs ~10 us of host time per call)
+int dtt_device_cus();
+
 static inline int dtt_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // XCD-aware remap of a linear workgroup id (8 XCDs; block b runs on XCD b % 8): gives each XCD a

@@ -68,3 +68,16 @@ void dtt_prof_end(const char* tag, hipStream_t stream) {
   g_prof.used++;
   g_prof.open = false;
 }
+
+int dtt_device_cus() {
+  static int cached[64] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  int& c = cached[dev & 63];
+  if (c == 0) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    c = v;
+  }
+  return c;
+}

@@ -535,19 +535,6 @@ int plan_wsplit(int batch, int oh, int ow, int R, int D, int max_wgs, WPlan* bes
   return found ? 1 : 0;
 }
 
-int device_cus() {
-  static int cached[64] = {};
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  int& c = cached[dev & 63];
-  if (c == 0) {
-    int v = 0;
-    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-    c = v;
-  }
-  return c;
-}
-
 template <int NACC>
 int launch_ws(const WGeom& g, int items, size_t lds_bytes, hipStream_t stream) {
   static DttDeviceOnce once;
@@ -599,7 +586,7 @@ extern "C" int dtt_correlation_forward_nhwc(float* output, int ob, int oc, int o
   g.out = output; g.out_sb = out_batch_stride; g.out_sc = out_ch_stride; g.out_sp = out_px_stride;
   static const int ablate = getenv("DTT_CORR_WS_ABLATE") ? atoi(getenv("DTT_CORR_WS_ABLATE")) : 0;
   g.ablate = ablate;
-  const int ncu = device_cus();
+  const int ncu = dtt_device_cus();
   const int budget = max_workgroups > 0 ? std::min(max_workgroups, ncu) : ncu;
   WPlan p;
   DTT_REQUIRE(plan_wsplit(ob, oh, ow, R, g.D, budget, &p), "correlation (window-split): no plan for %d x %d outputs, radius %d", oh, ow, R);
@@ -635,7 +622,7 @@ extern "C" int dtt_ws_trace_read(unsigned long long* host, int n) {
 extern "C" int dtt_correlation_nhwc_plan(int batch, int oh, int ow, int window_radius, int max_workgroups, int* parts,
                                          int* accumulators, int* workgroups, int* ring_slots) {
   WPlan p;
-  const int ncu = device_cus();
+  const int ncu = dtt_device_cus();
   const int budget = max_workgroups > 0 ? std::min(max_workgroups, ncu) : ncu;
   if (!plan_wsplit(batch, oh, ow, window_radius, 2 * window_radius + 1, budget, &p)) return 0;
   if (parts) *parts = p.parts;

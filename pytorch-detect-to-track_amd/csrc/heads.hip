@@ -52,6 +52,12 @@ struct HeadGeom {
   int nt_total, n_groups, strips, passes;
   int pass_len[kMaxPasses];   // channel tiles per pass (the last pass takes what is left of the group)
   int ablate;                 // developer timing experiments (DTT_HEAD_ABLATE): 1 no DMA, 2 no MFMA, 4 no stores, 8 no DMA wait, 16 no X DMA, 32 no W DMA
+  // epilogue 1 (the RPN's heads, rpn.py:63-71): emitted channels [0, 2A) are (background, foreground) score PAIRS of anchor
+  // a = channel / 2 -> softmax over the pair -> planes a and A + a of `out` = rpn_cls_prob (B, 2A, H, W); emitted channels
+  // [2A, 6A) -> planes of `out2` = rpn_bbox_pred (B, 4A, H, W).  Rows are pixels, image-major: row = b * hw + p.
+  int epilogue, A, hw;
+  unsigned hw_magic;          // (2^32 - 1) / hw + 1
+  float* out2;
 };
 
 // One LDS-DMA instruction in the scalar-base form: 16 bytes per lane from sbase + voff (per-lane byte offset) to LDS byte
@@ -177,14 +183,50 @@ __device__ __forceinline__ void head_pass(const HeadGeom& g, const float* lds, i
   for (int kc = 0; kc + 1 < KC; ++kc) { do_step(std::false_type{}, kc); pin(); }
   do_step(std::true_type{}, KC - 1);
   HEAD_STAMP(wave, 400 + 4 * (s_begin / KC));
+  if (g.epilogue == 1) {
+    // RPN heads: pairwise softmax in registers (a lane holds two whole (bg, fg) pairs), NCHW planes out -- the layout
+    // proposal_select_sort / proposal_decode read; 16 consecutive pixels per lane group = 64-byte runs
 #pragma unroll
-  for (int t = 0; t < CNT; ++t) {
-    if (t < cnt && !(g.ablate & 4)) {
-      const int col = (tile0 + t) * 16 + 4 * lg;
+    for (int t = 0; t < CNT; ++t) {
+      if (t < cnt && !(g.ablate & 4)) {
+        const int col = (tile0 + t) * 16 + 4 * lg;
 #pragma unroll
-      for (int pt = 0; pt < TPX; ++pt) {
-        const int row = p0 + pt * 16 + l15;
-        if (row < g.M && col < g.n_store) *reinterpret_cast<f32x4*>(g.out + (long)row * g.ldc + col) = acc[t][pt];
+        for (int pt = 0; pt < TPX; ++pt) {
+          const int row = p0 + pt * 16 + l15;
+          if (row >= g.M || col >= g.n_store) continue;
+          const int b = (int)__umulhi((unsigned)row, g.hw_magic), p = row - b * g.hw;
+          const f32x4 v = acc[t][pt];
+          if (col < 2 * g.A) {
+            float* o = g.out + ((long)b * 2 * g.A) * g.hw + p;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const int a = (col >> 1) + h;
+              const float m = fmaxf(v[2 * h], v[2 * h + 1]);
+              const float e0 = expf(v[2 * h] - m), e1 = expf(v[2 * h + 1] - m), inv = 1.f / (e0 + e1);
+              if (a < g.A) {
+                o[(long)a * g.hw] = e0 * inv;
+                o[(long)(g.A + a) * g.hw] = e1 * inv;
+              }
+            }
+          } else {
+            float* o = g.out2 + ((long)b * 4 * g.A + (col - 2 * g.A)) * g.hw + p;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (col - 2 * g.A + r < 4 * g.A) o[(long)r * g.hw] = v[r];
+          }
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < CNT; ++t) {
+      if (t < cnt && !(g.ablate & 4)) {
+        const int col = (tile0 + t) * 16 + 4 * lg;
+#pragma unroll
+        for (int pt = 0; pt < TPX; ++pt) {
+          const int row = p0 + pt * 16 + l15;
+          if (row < g.M && col < g.n_store) *reinterpret_cast<f32x4*>(g.out + (long)row * g.ldc + col) = acc[t][pt];
+        }
       }
     }
   }
@@ -391,14 +433,13 @@ template <int TPX, int NTW, int NLOAD, bool PIN>
 int launch_head(const HeadGeom& g, hipStream_t stream) {
   constexpr size_t lds = 3ul * (TPX * 16 + 4 * NTW * 16) * kBK * sizeof(float);
   static_assert(lds <= 160 * 1024, "three stages must fit the CU's LDS");
-  static bool raised[64] = {};
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  if (lds > 64 * 1024 && !raised[dev & 63]) {
+  static DttDeviceOnce once;
+  bool& raised_here = once.here();
+  if (lds > 64 * 1024 && !raised_here) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(head_gemm_kernel<TPX, NTW, NLOAD, PIN>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     DTT_REQUIRE(e == hipSuccess, "head_gemm: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
-    raised[dev & 63] = true;
+    raised_here = true;
   }
   dtt_prof_begin("head_gemm", stream);
   hipLaunchKernelGGL((head_gemm_kernel<TPX, NTW, NLOAD, PIN>), dim3(g.n_groups * g.strips), dim3((4 + NLOAD) * 64), lds, stream, g);
@@ -437,28 +478,19 @@ extern "C" int dtt_head_stamps_read(unsigned long long* host, int n) {
 }
 #endif
 
-// out[m][n] = sum_k x[m][k] * w[n][k] + bias[n]  for n < n_store  (the 1x1 convolution of rfcn.py:49-53 over
-// channels-last pixel rows, channels emitted in the order of w's rows).
-extern "C" int dtt_head_gemm(const float* x, long ldx, int M, int K, const float* w, const float* bias, int n_rows,
-                             float* out, long ldc, int n_store, int passes, void* stream_) {
-  hipStream_t stream = static_cast<hipStream_t>(stream_);
+static int head_gemm_launch(HeadGeom g, const float* x, long ldx, int M, int K, const float* w, const float* bias, int n_rows,
+                            float* out, long ldc, int n_store, int passes, hipStream_t stream) {
   DTT_REQUIRE(x && w && bias && out, "head_gemm: null pointer");
   DTT_REQUIRE(M > 0 && K > 0 && K % kBK == 0, "head_gemm: K (%d) must be a positive multiple of %d", K, kBK);
   DTT_REQUIRE(n_rows > 0 && n_rows % 16 == 0, "head_gemm: weight rows (%d) must be padded to a multiple of 16", n_rows);
   DTT_REQUIRE(n_store > 0 && n_store <= n_rows && n_store % 4 == 0 && ldc >= n_store && ldc % 4 == 0 && ldx % 4 == 0 && ldx >= K,
               "head_gemm: bad leading dimensions / n_store");
   DTT_REQUIRE((((size_t)x | (size_t)w | (size_t)out | (size_t)bias) & 15) == 0, "head_gemm: pointers must be 16-byte aligned");
-  HeadGeom g;
   g.x = x; g.ldx = ldx; g.w = w; g.bias = bias; g.out = out; g.ldc = ldc;
   g.M = M; g.K = K; g.n_store = n_store; g.nt_total = n_rows / 16;
-  g.ablate = getenv("DTT_HEAD_ABLATE") ? atoi(getenv("DTT_HEAD_ABLATE")) : 0;
-  int ncu = 256;
-  {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-      ncu = prop.multiProcessorCount;
-  }
+  static const int ablate = getenv("DTT_HEAD_ABLATE") ? atoi(getenv("DTT_HEAD_ABLATE")) : 0;
+  g.ablate = ablate;
+  const int ncu = dtt_device_cus();
   static const int nload = getenv("DTT_HEAD_NLOAD") ? atoi(getenv("DTT_HEAD_NLOAD")) : 4;   // developer A/B switches
   if (g.nt_total > 16) {   // more channel tiles than the narrow configuration's single pass holds
     // wide heads (31*49 classes [+ 4*49 box deltas]): pixel strips x channel groups, one workgroup per CU
@@ -492,6 +524,33 @@ extern "C" int dtt_head_gemm(const float* x, long ldx, int M, int K, const float
   g.n_groups = 1;
   plan_passes(g, g.nt_total, NTW, 1);
   return launch_head<TPX, NTW, 1, false>(g, stream);
+}
+
+// out[m][n] = sum_k x[m][k] * w[n][k] + bias[n]  for n < n_store  (the 1x1 convolution of rfcn.py:49-53 over
+// channels-last pixel rows, channels emitted in the order of w's rows).
+extern "C" int dtt_head_gemm(const float* x, long ldx, int M, int K, const float* w, const float* bias, int n_rows,
+                             float* out, long ldc, int n_store, int passes, void* stream_) {
+  HeadGeom g;
+  g.epilogue = 0; g.A = 0; g.hw = 1; g.hw_magic = 0; g.out2 = nullptr;
+  return head_gemm_launch(g, x, ldx, M, K, w, bias, n_rows, out, ldc, n_store, passes, static_cast<hipStream_t>(stream_));
+}
+
+// The RPN's two 1x1 heads + the pairwise softmax in ONE launch (rpn.py:63-71: RPN_cls_score, reshape(2) -> softmax ->
+// reshape(2A), RPN_bbox_pred).  x: (batch * hw, K) channels-last rows of relu(RPN_Conv(.)).  w: (n_rows, K), rows emitted in
+// the order [bg_0, fg_0, bg_1, fg_1, ..., bg_{A-1}, fg_{A-1}, box deltas 0 .. 4A-1, zero padding to a multiple of 16]
+// (bg_a = RPN_cls_score channel a, fg_a = channel A + a: the pair the reference's softmax normalises); bias alike.
+// cls_prob: (batch, 2A, h, w) and bbox_pred: (batch, 4A, h, w), NCHW -- what dtt_proposal_select_sort / _decode_nms read.
+extern "C" int dtt_rpn_head_gemm(const float* x, long ldx, int batch, int hw, int K, const float* w, const float* bias, int n_rows,
+                                 int num_anchors, float* cls_prob, float* bbox_pred, void* stream_) {
+  DTT_REQUIRE(cls_prob && bbox_pred, "rpn_head_gemm: null pointer");
+  DTT_REQUIRE(batch > 0 && hw > 0 && num_anchors > 0 && (long)batch * hw < (1l << 31) && n_rows >= 6 * num_anchors && num_anchors % 2 == 0,
+              "rpn_head_gemm: bad shape (an even number of anchors, weight rows >= 6 * anchors)");
+  HeadGeom g;
+  g.epilogue = 1; g.A = num_anchors; g.hw = hw; g.hw_magic = 0xffffffffu / (unsigned)hw + 1u; g.out2 = bbox_pred;
+  DTT_REQUIRE(hw > 1, "rpn_head_gemm: a map of one pixel is not supported");
+  const int n_store = 6 * num_anchors;
+  return head_gemm_launch(g, x, ldx, batch * hw, K, w, bias, n_rows, cls_prob, (long)((n_store + 3) / 4 * 4), (n_store + 3) / 4 * 4, 1,
+                          static_cast<hipStream_t>(stream_));
 }
 
 // Position-sensitive pooling + vote over a position-major map (see the header comment).  map: (batch, H, W) pixels of

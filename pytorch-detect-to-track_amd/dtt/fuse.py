@@ -505,6 +505,7 @@ class FusedTrunkNHWC:
         # take the Winograd path, and handed to _RPN.head() through `rpn_conv1`
         self.rpn_conv = _NhwcConv(model.RFCN_rpn.RPN_Conv)
         self.rpn_conv1 = None
+        self.rpn_rows = None
         self.pm_heads = False     # set by fuse_for_inference when the position-major tail is active
         self.pm_tail = None       # dtt.heads.PositionMajorTail: when set, the class + box head GEMM is issued in here
         self.top_rows = None
@@ -540,7 +541,12 @@ class FusedTrunkNHWC:
                 # squeeze in beside, the others -- 150 -> 200 us when it ran after the correlations, under the NMS sweep).
                 from .heads import head_gemm
                 self.det_rows = head_gemm(self.top_rows, self.pm_tail.det)
-        self.rpn_conv1 = _to_nchw(self.rpn_conv.act(top))
+        if self.pm_heads and self.pm_tail is not None and self.pm_tail.rpn is not None and os.environ.get("DTT_RPN_FUSED", "1") != "0":
+            # channels-last rows of relu(RPN_Conv(top)) for the one-launch RPN heads (dtt.heads.rpn_head_gemm): no
+            # NHWC -> NCHW hand-over at all
+            self.rpn_rows, self.rpn_conv1 = _rows(self.rpn_conv.act(top)), None
+        else:
+            self.rpn_rows, self.rpn_conv1 = None, _to_nchw(self.rpn_conv.act(top))
         if self.pm_heads:
             return feats[1], feats[2], feats[3], top
         return _to_nchw(feats[1]), _to_nchw(feats[2]), _to_nchw(feats[3]), _to_nchw(top)

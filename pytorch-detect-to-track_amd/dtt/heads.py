@@ -83,6 +83,49 @@ def head_gemm(x_rows, packed, out=None, passes=0):
     return out
 
 
+class PackedRPNHeads:
+    """`RPN_cls_score` + `RPN_bbox_pred` (rpn.py:63-71) as ONE weight matrix for `dtt_rpn_head_gemm`: rows in the order
+    [bg_0, fg_0, bg_1, fg_1, ..., box deltas 0 .. 4A-1, zero rows up to a multiple of 16] -- a lane of the GEMM's accumulator
+    then holds whole (background, foreground) pairs and the reference's reshape(2) -> softmax -> reshape(2A) happens in
+    registers.  Weights are only permuted; parameters, state_dict and checkpoint layout are untouched."""
+
+    def __init__(self, cls_conv, bbox_conv):
+        dev = cls_conv.weight.device
+        wc = cls_conv.weight.detach().reshape(cls_conv.weight.shape[0], -1).float()
+        wb = bbox_conv.weight.detach().reshape(bbox_conv.weight.shape[0], -1).float()
+        self.A = wc.shape[0] // 2
+        assert wc.shape[0] == 2 * self.A and wb.shape[0] == 4 * self.A and wc.shape[1] == wb.shape[1]
+        if self.A % 2:
+            raise ValueError("PackedRPNHeads: an even number of anchors is required (got %d)" % self.A)
+        pair = torch.stack([torch.arange(self.A), self.A + torch.arange(self.A)], 1).reshape(-1).to(dev)   # bg_a, fg_a
+        bc = cls_conv.bias.detach().float() if cls_conv.bias is not None else torch.zeros(2 * self.A, device=dev)
+        bb = bbox_conv.bias.detach().float() if bbox_conv.bias is not None else torch.zeros(4 * self.A, device=dev)
+        w = torch.cat([wc[pair], wb], 0)
+        b = torch.cat([bc[pair], bb], 0)
+        n16 = -(-w.shape[0] // 16) * 16
+        if n16 > w.shape[0]:
+            b = torch.cat([b, torch.zeros(n16 - w.shape[0], device=dev)], 0)
+            w = torch.cat([w, torch.zeros(n16 - w.shape[0], w.shape[1], device=dev)], 0)
+        self.w, self.bias, self.K = w.contiguous(), b.contiguous(), w.shape[1]
+
+
+def rpn_head_gemm(x_rows, packed, batch, height, width):
+    """x_rows (batch*height*width, K) channels-last rows of relu(RPN_Conv(.)) -> (rpn_cls_prob (batch, 2A, H, W),
+    rpn_bbox_pred (batch, 4A, H, W)): both 1x1 heads and the pairwise softmax in one launch (`dtt_rpn_head_gemm`)."""
+    require_gpu(x_rows)
+    require_f32_contig("x_rows", x_rows)
+    M, K = x_rows.shape
+    if K != packed.K or M != batch * height * width:
+        raise ValueError("rpn_head_gemm: rows %s do not match batch %d x %d x %d, K %d" % (tuple(x_rows.shape), batch, height, width, packed.K))
+    prob = torch.empty((batch, 2 * packed.A, height, width), dtype=torch.float32, device=x_rows.device)
+    bbox = torch.empty((batch, 4 * packed.A, height, width), dtype=torch.float32, device=x_rows.device)
+    with torch.cuda.device(x_rows.device):
+        check(_lib.lib().dtt_rpn_head_gemm(ptr(x_rows), K, batch, height * width, K, ptr(packed.w), ptr(packed.bias),
+                                           packed.w.shape[0], packed.A, ptr(prob), ptr(bbox), stream_ptr(x_rows.device)),
+              "rpn_head_gemm")
+    return prob, bbox
+
+
 def gather_column_blocks(dst, dst_col, src, src_col, rows, n_blocks, ncols):
     """dst[r, dst_col + k*ncols + c] = src[k*rows + r, src_col + c] (`dtt_gather_column_blocks`): the box-delta columns of the
     two legs side by side in the tracking head's input rows (rfcn.py:133-140's torch.cat on position-major rows)."""
@@ -139,6 +182,11 @@ class PositionMajorTail:
     """
 
     def __init__(self, model):
+        self.rpn = None
+        try:
+            self.rpn = PackedRPNHeads(model.RFCN_rpn.RPN_cls_score, model.RFCN_rpn.RPN_bbox_pred)
+        except (ValueError, AttributeError):
+            pass   # odd anchor count: the RPN heads stay library convolutions
         self.det = PackedHeads([model.RFCN_cls_net, model.RFCN_bbox_net])
         self.cls_head, self.loc_head = self.det.heads
         self.trk = None

