@@ -45,6 +45,24 @@ def _loss(out):
     return out[4].mean() + out[5].mean() + out[6].mean() + out[7].mean() + out[9].mean()   # trainval_net.py:367-368
 
 
+def _freeze_proposals(model, dev):
+    """Replace the RPN's proposal step by boxes that do not depend on the network's outputs: a last-bit difference between
+    two runs of the library convolutions can then no longer swap two near-tied proposals (and with them a sampled RoI), so
+    the two sides of the comparison sample the SAME RoIs and their gradients can be compared tensor by tensor at 3e-3."""
+    def fixed(cls_prob, bbox_pred, im_info):
+        n = cls_prob.size(0)
+        g = torch.Generator().manual_seed(4242)
+        R = 300
+        x1 = torch.rand(n, R, generator=g) * (SIZE[1] - 40)
+        y1 = torch.rand(n, R, generator=g) * (SIZE[0] - 40)
+        w = 16 + torch.rand(n, R, generator=g) * (SIZE[1] * 0.6)
+        h = 16 + torch.rand(n, R, generator=g) * (SIZE[0] * 0.6)
+        rois = torch.stack([torch.arange(n).float().view(n, 1).expand(n, R), x1, y1,
+                            (x1 + w).clamp(max=SIZE[1] - 1), (y1 + h).clamp(max=SIZE[0] - 1)], 2)
+        return rois.to(dev)
+    model.RFCN_rpn.proposals = fixed
+
+
 def _snippet(r, dev):
     from dtt.synth import make_batch
     return make_batch(1, SIZE[0], SIZE[1], seed=500 + r, device=dev)
@@ -58,6 +76,7 @@ def _worker(rank, world, port, q):
     from dtt.dist import prepare_replica
     dev = torch.device("cuda:0")
     model = _model(cfg, seed=3 + 10 * rank, dev=dev)      # rank 1 starts from other weights: the broadcast must fix that
+    _freeze_proposals(model, dev)
     runner = prepare_replica(model, world, channels_last=True)
     np.random.seed(1234 + rank)
     runner.zero_grad(set_to_none=True)
@@ -96,29 +115,29 @@ def test_two_ranks_on_one_gpu_match_sequential_snippets():
         p.join(300)
         assert p.exitcode == 0
     model = _model(cfg, seed=3, dev=dev)
+    _freeze_proposals(model, dev)
     runner = prepare_replica(model, 1, channels_last=True)
     runner.zero_grad(set_to_none=True)
     for r in range(world):
         np.random.seed(1234 + r)
         (_loss(runner(*_snippet(r, dev))) / world).backward()
     torch.cuda.synchronize()
-    checked, rels, outliers = 0, [], 0
+    checked, rels = 0, []
     for n, p in model.named_parameters():
         if not p.requires_grad or p.grad is None:
             continue
         assert n in got, n
         ref = p.grad.detach().float().cpu().numpy()
-        scale = max(float(np.abs(ref).max()), 1e-6)
-        # Not bit-reproducible: the library convolutions (forward and backward) differ in the last bits run to run, and
-        # with random-init weights a last-bit change in an RPN score can swap two near-tied proposals, i.e. one sampled
-        # RoI of 128 -- a few per cent on individual entries.  Same gradient = same direction and size per tensor.
+        # With the proposals frozen both sides sample the same RoIs (numpy's generator is seeded per snippet), so what is left
+        # between them is the run-to-run rounding of the library convolutions' backward kernels: per tensor, the averaged
+        # all-reduced gradient must equal the sequential one to 3e-3 of its norm (fp32 Winograd vs direct algorithm picks of the
+        # two processes differ by up to 1e-3 on the 3x3 RPN convolution) -- one bucket left un-reduced, reduced twice
+        # or averaged by the wrong count is off by 50 - 100 %.
         a, b = got[n].ravel().astype(np.float64), ref.ravel().astype(np.float64)
-        cos = float(a @ b / max(np.linalg.norm(a) * np.linalg.norm(b), 1e-30))
         rel = float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
-        assert cos > 0.9 and rel < 0.5, (n, cos, rel, scale)       # no tensor is off in direction or size ...
-        outliers += int(not (cos > 0.97 and rel < 0.25))
+        # (trunk tensors many layers below the losses see that rounding amplified through ReLU gates: per cents at most)
+        assert rel < (3e-3 if not n.startswith("RFCN_base") else 5e-2), (n, rel, float(np.linalg.norm(b)))
         rels.append(rel)
         checked += 1
-    assert outliers <= 3, outliers                                  # ... at most a few feel a swapped RoI by more than 25 % ...
-    assert float(np.median(rels)) < 0.03, sorted(rels)[-5:]   # ... and the bulk agrees to per cents
+    assert float(np.median(rels)) < 2e-2, sorted(rels)[-5:]   # most tensors are trunk tensors (see above); the head / RPN tensors carry the tight bound
     assert checked > 40 and set(got) == {n for n, p in model.named_parameters() if p.requires_grad and p.grad is not None}

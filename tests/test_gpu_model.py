@@ -413,10 +413,19 @@ def test_position_major_tail_matches_nchw_tail(monkeypatch):
     from dtt.fuse import fuse_for_inference
     from dtt.ops import psroi_vote
     from dtt.synth import build_model, calibrate_batchnorm_, make_batch
+    _check_pm_tail(monkeypatch, 50, ((2, 256, 352), (1, 300, 500)))
+
+
+def _check_pm_tail(monkeypatch, layers, shapes):
+    import torch.nn.functional as F
+    from dtt.config import cfg
+    from dtt.fuse import fuse_for_inference
+    from dtt.ops import psroi_vote
+    from dtt.synth import build_model, calibrate_batchnorm_, make_batch
     dev = torch.device("cuda:0")
-    model = build_model(50, cfg=cfg).to(dev).eval()
+    model = build_model(layers, cfg=cfg).to(dev).eval()
     monkeypatch.setenv("DTT_PM_HEADS", "1")
-    for shape in ((2, 256, 352), (1, 300, 500)):
+    for shape in shapes:
         B = shape[0]
         im, info, gt, nb = make_batch(B, shape[1], shape[2], seed=5, device=dev)
         calibrate_batchnorm_(model, im[:, 0])
@@ -429,6 +438,12 @@ def test_position_major_tail_matches_nchw_tail(monkeypatch):
             c3, c4, c5, top = model._im_to_head(flat)
             conv1, fused.rpn_conv1, fused.rpn_rows = fused.rpn_conv1, None, None   # (None when the one-launch RPN heads took the rows)
             _, _, rpn_prob, rpn_bbox = model.RFCN_rpn.head(top, conv1)
+            if pm.rpn is not None:   # the one-launch RPN heads (dtt_rpn_head_gemm) against the library convolutions + softmax
+                from dtt.fuse import _rows
+                from dtt.heads import rpn_head_gemm
+                p2, b2 = rpn_head_gemm(_rows(fused.rpn_conv.act(top)), pm.rpn, 2 * B, top.size(2), top.size(3))
+                assert float((p2 - rpn_prob).abs().max()) < 1e-4
+                assert float((b2 - rpn_bbox).abs().max()) < 1e-4 * max(1.0, float(rpn_bbox.abs().max()))
             info2 = info.permute(1, 0, 2).reshape(2 * B, -1).contiguous()
             all_rois = model.RFCN_rpn.proposals(rpn_prob, rpn_bbox, info2)
             side = torch.cuda.Stream(device=dev)
@@ -456,3 +471,40 @@ def test_position_major_tail_matches_nchw_tail(monkeypatch):
         with torch.no_grad():
             one = model(im[:, :1], info[:, :1], gt[:, :1], nb[:, :1])
         assert one[3].shape[0] == 0 and one[1].shape == (1, B, R, model.n_classes)
+
+
+def test_bench_step_tail_at_full_size_matches_nchw_tail(monkeypatch):
+    """The exact benchmark step (BASELINE configs[2]: fused Res-101, 600 x 1067, two frame pairs): the production tail --
+    one-launch RPN heads, window-split channels-last correlations written as columns of the tracking rows, hand-written head
+    GEMMs, position-major PSRoI pooling -- against the reference graph of rfcn.py:133-140, 166-196 (library 1x1 convolutions
+    into NCHW maps, NCHW correlation kernels, plane-stationary PSRoI) on the SAME trunk maps and RoIs, at full size."""
+    from dtt.config import apply_dataset_defaults
+    apply_dataset_defaults("imagenet_vid")
+    _check_pm_tail(monkeypatch, 101, ((2, 600, 1067),))
+
+
+def test_config0_single_frame_res50_300px_against_cpu_graph():
+    """BASELINE configs[0]: single-frame R-FCN Res-50 on one 300 x 500 image -- the GPU graph (HIP ops) against the CPU
+    graph (torch CPU convolutions + the oracle's ops, oracle/cpu_graph.py) on the same weights and frame."""
+    from dtt.config import apply_dataset_defaults, cfg
+    from dtt.synth import build_model, calibrate_batchnorm_, make_batch
+    from oracle import cpu_graph
+    apply_dataset_defaults("imagenet_vid")
+    dev = torch.device("cuda:0")
+    B, H, W = 1, 300, 500
+    model = build_model(50, cfg=cfg).eval()
+    im, info, gt, nb = make_batch(B, H, W, seed=9)
+    im, info, gt, nb = im[:, :1], info[:, :1], gt[:, :1], nb[:, :1]          # one frame
+    calibrate_batchnorm_(model, im[:, 0])
+    ref = cpu_graph.rfcn_forward_test(model, im, info, cfg)
+    model = model.to(dev)
+    with torch.no_grad():
+        out = model(im.to(dev), info.to(dev), gt.to(dev), nb.to(dev))
+    rois, cls_prob, bbox_pred, tracking_pred = (o.cpu() for o in out[:4])
+    R = cfg.TEST.RPN_POST_NMS_TOP_N
+    assert tuple(rois.shape) == (1, B, R, 5) and tuple(cls_prob.shape) == (1, B, R, 31) and tracking_pred.shape[0] == 0
+    same = (rois - ref["rois"]).abs().amax(dim=3) < 0.05
+    assert same.float().mean() > 0.9, "only %.3f of RoI rows agree" % same.float().mean()
+    d_cls = (cls_prob - ref["cls_prob"]).abs().amax(dim=3)[same]
+    d_box = (bbox_pred - ref["bbox_pred"]).abs().amax(dim=3)[same]
+    assert d_cls.max() < 1e-3 and d_box.max() < 1e-2 * max(1.0, float(ref["bbox_pred"].abs().max()))
