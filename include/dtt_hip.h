@@ -423,6 +423,14 @@ int dtt_rpn_head_gemm(const float* x, long ldx, int batch, int hw, int K, const 
 int dtt_psroi_pm_forward(const float* map, long pixel_stride, int cp, int batch_size, int num_rois, int height,
                          int width, int pooled, const float* rois, float spatial_scale, int output_dim,
                          float* vote_out, float* pooled_out, void* stream);
+/* Backward of the vote with respect to the position-major map (PSROIPoolBackward, psroi_pooling_kernel.cu:109-170, composed with
+ * the AvgPool2d of rfcn.py:62-64): grad_map[pixel][bin*cp + c] = sum over the RoIs of that image whose bin contains the pixel of
+ * grad_vote[roi][c] / pooled^2 / bin_area, added in RoI order -- map-stationary, no atomics (the reference scatters with
+ * atomicAdd), deterministic.  Every pixel's floats [0, pooled^2 * cp) are WRITTEN (zeros where no RoI reaches): no pre-zeroing.
+ * edges: caller-owned scratch, num_rois * (4 * pooled + 1) ints.  cp in {4, 32} as in the forward. */
+int dtt_psroi_pm_backward(const float* grad_vote, const float* rois, int num_rois, int batch_size, int height, int width,
+                          int pooled, float spatial_scale, int output_dim, int cp, long pixel_stride, float* grad_map,
+                          int* edges, void* stream);
 
 /* ---------------------------------------------------------------- zero-jump Viterbi tube linking
  * Replaces VideoPostProcessor._make_tubes / _zero_jump_link / _score_of_edge (lib/model/utils/tracking_utils.py:

@@ -429,6 +429,115 @@ __global__ __launch_bounds__(NW * 64) void psroi_pm_kernel(const float* __restri
   }
 }
 
+// ------------------------------------------------------------------------------------------------ pooling, backward
+// Gradient of psroi_pm_kernel's vote with respect to the position-major map (PSROIPoolBackward, psroi_pooling_kernel.cu:109-170,
+// composed with the AvgPool2d of rfcn.py:62-64):  d map[b, h, w, bin, c] = sum over the RoIs r of image b whose bin `bin`
+// contains (h, w) of  gvote[r, c] / (P * P) / area(r, bin).  The reference scatters with atomicAdd (summation order = whatever
+// the hardware does); here the map is stationary: one workgroup per PIXEL collects, in RoI order, the (RoI, bin) pairs that
+// cover it (ballot-free ordered compaction through an LDS prefix sum) and one wave per bin subset adds them in that order,
+// lanes = classes -- no atomics, no pre-zeroed output (every pixel writes its whole row segment), deterministic.
+// psroi_pm_edges_kernel first turns every RoI into its 4 * P bin edges with the forward's arithmetic (psroi_bin.h).
+__global__ void psroi_pm_edges_kernel(const float* __restrict__ rois, int num_rois, float spatial_scale, int pooled, int height,
+                                      int width, int* __restrict__ edges) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= num_rois) return;
+  float roi[5];
+#pragma unroll
+  for (int q = 0; q < 5; ++q) roi[q] = rois[(long)r * 5 + q];
+  int* e = edges + (long)r * (4 * pooled + 1);
+  e[4 * pooled] = (int)roi[0];
+  for (int k = 0; k < pooled; ++k) {
+    const Bin b = psroi_bin(roi, spatial_scale, k, k, pooled, pooled, height, width);   // rows depend on ph only, columns on pw only
+    e[k] = b.hstart; e[pooled + k] = b.hend; e[2 * pooled + k] = b.wstart; e[3 * pooled + k] = b.wend;
+  }
+}
+
+template <int CP>
+__global__ __launch_bounds__(256) void psroi_pm_bwd_kernel(const float* __restrict__ gvote, const int* __restrict__ edges, int num_rois,
+                                                           int output_dim, int pooled, int height, int width, long pixel_stride,
+                                                           float* __restrict__ gmap) {
+  constexpr int kMaxHits = 2048;                       // (RoI, bin, weight) triples per chunk of 256 RoIs: at most 4 x 4 bins each in theory,
+  __shared__ int hit_r[kMaxHits];                      // 2 x 2 in practice; a chunk that overflows is split (see below)
+  __shared__ short hit_bin[kMaxHits];
+  __shared__ float hit_w[kMaxHits];
+  __shared__ int wave_cnt[4];
+  extern __shared__ __attribute__((aligned(16))) float accum[];   // [pooled*pooled][CP]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int px = blockIdx.x;
+  const int hw = height * width;
+  const int b = px / hw, rem = px - b * hw, h = rem / width, w = rem - h * width;
+  const int nbins = pooled * pooled, E = 4 * pooled + 1;
+  for (int i = tid; i < nbins * CP; i += 256) accum[i] = 0.f;
+  const float inv_bins = 1.f / (float)nbins;
+  for (int r0 = 0; r0 < num_rois; r0 += 256) {
+    // ---- phase 1: RoI r0 + tid -> the bins of that RoI that contain this pixel
+    const int r = r0 + tid;
+    int nh = 0, ph_lo = 0, ph_hi = -1, pw_lo = 0, pw_hi = -1;
+    const int* e = edges + (long)min(r, num_rois - 1) * E;
+    if (r < num_rois && e[4 * pooled] == b) {
+      // bins are intervals with non-decreasing edges: the ph whose [hstart, hend) contains h form a contiguous run
+      ph_lo = pooled; pw_lo = pooled;
+      for (int k = 0; k < pooled; ++k) {
+        if (e[k] <= h && h < e[pooled + k]) { ph_lo = min(ph_lo, k); ph_hi = k; }
+        if (e[2 * pooled + k] <= w && w < e[3 * pooled + k]) { pw_lo = min(pw_lo, k); pw_hi = k; }
+      }
+      if (ph_hi >= 0 && pw_hi >= 0) nh = (ph_hi - ph_lo + 1) * (pw_hi - pw_lo + 1);
+    }
+    // ordered compaction: exclusive prefix of nh over the 256 RoIs of the chunk (wave scan + 4 wave totals)
+    int incl = nh;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += o;
+    }
+    if (lane == 63) wave_cnt[wave] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int k = 0; k < wave; ++k) base += wave_cnt[k];
+    const int total = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    int pos = base + incl - nh;
+    if (nh > 0 && total <= kMaxHits) {
+      for (int ph = ph_lo; ph <= ph_hi; ++ph)
+        for (int pw = pw_lo; pw <= pw_hi; ++pw) {
+          const int area = (e[pooled + ph] - e[ph]) * (e[3 * pooled + pw] - e[2 * pooled + pw]);
+          hit_r[pos] = r; hit_bin[pos] = (short)(ph * pooled + pw); hit_w[pos] = inv_bins / (float)area;
+          ++pos;
+        }
+    }
+    __syncthreads();
+    // ---- phase 2: wave v owns the bins = v (mod 4); it walks the list in order (= RoI order), lanes = classes
+    if (total <= kMaxHits) {
+      for (int i = 0; i < total; ++i) {
+        const int bin = hit_bin[i];
+        if ((bin & 3) != wave) continue;
+        if (lane < CP) {
+          const float g = lane < output_dim ? gvote[(long)hit_r[i] * output_dim + lane] : 0.f;
+          accum[bin * CP + lane] += g * hit_w[i];
+        }
+      }
+    } else {
+      // (pathological chunk: more than 8 bins per RoI on average -- every RoI handled by one thread-serial pass, still in order)
+      if (tid < 64) {
+        for (int rr = r0; rr < min(r0 + 256, num_rois); ++rr) {
+          const int* ee = edges + (long)rr * E;
+          if (ee[4 * pooled] != b) continue;
+          for (int ph = 0; ph < pooled; ++ph) {
+            if (!(ee[ph] <= h && h < ee[pooled + ph])) continue;
+            for (int pw = 0; pw < pooled; ++pw) {
+              if (!(ee[2 * pooled + pw] <= w && w < ee[3 * pooled + pw])) continue;
+              const int area = (ee[pooled + ph] - ee[ph]) * (ee[3 * pooled + pw] - ee[2 * pooled + pw]);
+              if (lane < CP) accum[(ph * pooled + pw) * CP + lane] += (lane < output_dim ? gvote[(long)rr * output_dim + lane] : 0.f) * (inv_bins / (float)area);
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  float* dst = gmap + (long)px * pixel_stride;
+  for (int i = tid; i < nbins * CP; i += 256) dst[i] = accum[i];
+}
+
 template <int TPX, int NTW, int NLOAD, bool PIN>
 int launch_head(const HeadGeom& g, hipStream_t stream) {
   constexpr size_t lds = 3ul * (TPX * 16 + 4 * NTW * 16) * kBK * sizeof(float);
@@ -551,6 +660,36 @@ extern "C" int dtt_rpn_head_gemm(const float* x, long ldx, int batch, int hw, in
   const int n_store = 6 * num_anchors;
   return head_gemm_launch(g, x, ldx, batch * hw, K, w, bias, n_rows, cls_prob, (long)((n_store + 3) / 4 * 4), (n_store + 3) / 4 * 4, 1,
                           static_cast<hipStream_t>(stream_));
+}
+
+// Backward of dtt_psroi_pm_forward's vote: grad_map (batch*height*width pixels, pixel_stride floats apart; this call writes
+// floats [bin*cp + c] for bin < pooled^2, c < cp of EVERY pixel -- zeros where no RoI reaches, so no pre-zeroing) from
+// grad_vote (num_rois, output_dim).  edges: caller-owned scratch of num_rois * (4 * pooled + 1) ints.
+extern "C" int dtt_psroi_pm_backward(const float* grad_vote, const float* rois, int num_rois, int batch_size, int height, int width,
+                                     int pooled, float spatial_scale, int output_dim, int cp, long pixel_stride, float* grad_map,
+                                     int* edges, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  DTT_REQUIRE(batch_size > 0 && height > 0 && width > 0 && pooled > 0 && output_dim > 0 && num_rois >= 0, "psroi_pm backward: bad shape");
+  DTT_REQUIRE(cp >= output_dim && (long)pooled * pooled * cp <= pixel_stride, "psroi_pm backward: %d bins x %d do not fit the pixel stride %ld",
+              pooled * pooled, cp, pixel_stride);
+  DTT_REQUIRE(grad_map && (num_rois == 0 || (grad_vote && rois && edges)), "psroi_pm backward: null pointer");
+  DTT_REQUIRE(cp == 4 || cp == 32, "psroi_pm backward: classes-per-bin padding %d not instantiated (4 or 32)", cp);
+  const size_t lds = (size_t)pooled * pooled * cp * sizeof(float);
+  DTT_REQUIRE(lds <= 32 * 1024, "psroi_pm backward: pooled size too large");
+  if (num_rois > 0) {
+    hipLaunchKernelGGL(psroi_pm_edges_kernel, dim3(dtt_cdiv(num_rois, 256)), dim3(256), 0, stream, rois, num_rois, spatial_scale, pooled,
+                       height, width, edges);
+    DTT_CHECK_LAUNCH("psroi_pm_edges");
+  }
+  const int npx = batch_size * height * width;
+  if (cp == 32)
+    hipLaunchKernelGGL((psroi_pm_bwd_kernel<32>), dim3(npx), dim3(256), lds, stream, grad_vote, edges, num_rois, output_dim, pooled, height,
+                       width, pixel_stride, grad_map);
+  else
+    hipLaunchKernelGGL((psroi_pm_bwd_kernel<4>), dim3(npx), dim3(256), lds, stream, grad_vote, edges, num_rois, output_dim, pooled, height,
+                       width, pixel_stride, grad_map);
+  DTT_CHECK_LAUNCH("psroi_pm_bwd");
+  return 1;
 }
 
 // Position-sensitive pooling + vote over a position-major map (see the header comment).  map: (batch, H, W) pixels of

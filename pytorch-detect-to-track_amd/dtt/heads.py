@@ -163,6 +163,129 @@ def psroi_pm(pm_map, head, batch, height, width, rois, spatial_scale, want_poole
     return (vote, pooled) if want_pooled else vote
 
 
+# ------------------------------------------------------------------------------------------------ training (autograd)
+def pack_heads_differentiable(convs, group=7):
+    """PackedHeads' row permutation as differentiable tensor ops on the LIVE parameters (training: the weights change every
+    step, and their gradients must flow back through the permutation): returns (w (rows16, K), bias (rows16,), heads, n_store,
+    stride) with the same meaning as PackedHeads' fields."""
+    dev = convs[0].weight.device
+    K = convs[0].weight.shape[1]
+    rows, biases, heads, off = [], [], [], 0
+    for conv in convs:
+        w = conv.weight.reshape(conv.weight.shape[0], K)
+        od = w.shape[0] // (group * group)
+        cp = 4 if od <= 4 else _pow2_at_least(max(od, 32))
+        b = conv.bias if conv.bias is not None else torch.zeros(w.shape[0], device=dev)
+        wp = w.view(od, group * group, K).permute(1, 0, 2)                       # (bin, class, K)
+        bp = b.view(od, group * group).t()
+        if cp > od:
+            wp = torch.cat([wp, wp.new_zeros(group * group, cp - od, K)], 1)
+            bp = torch.cat([bp, bp.new_zeros(group * group, cp - od)], 1)
+        rows.append(wp.reshape(-1, K))
+        biases.append(bp.reshape(-1))
+        heads.append(dict(offset=off, cp=cp, od=od, group=group))
+        off += group * group * cp
+    n16 = -(-off // 16) * 16
+    w, b = torch.cat(rows, 0), torch.cat(biases, 0)
+    if n16 > off:
+        w = torch.cat([w, w.new_zeros(n16 - off, K)], 0)
+        b = torch.cat([b, b.new_zeros(n16 - off)], 0)
+    return w.contiguous(), b.contiguous(), heads, off, -(-off // 32) * 32
+
+
+class HeadGemmFn(torch.autograd.Function):
+    """out = x_rows @ w.T + bias through `dtt_head_gemm`, with a backward on the same kernel (closes SURVEY 8 row A9 for the
+    training graph, rfcn.py:49-53): dX = gOut @ w is the head GEMM over the gradient rows with the transposed weights as
+    its "weight" operand; dW = gOut.T @ x is the head GEMM over the TRANSPOSED gradient (rows = output channels, K = pixels:
+    one workgroup accumulates a whole pixel range in registers, fixed order, no atomics); dBias is a column sum.
+    The gradient rows must have finite values in their padding columns (they are multiplied by zero weights): the
+    position-major PSRoI backward writes whole rows."""
+
+    @staticmethod
+    def forward(ctx, x_rows, w, bias, n_store, stride):
+        require_gpu(x_rows)
+        x_rows = x_rows.contiguous()
+        M, K = x_rows.shape
+        out = torch.zeros((M, stride), dtype=torch.float32, device=x_rows.device)
+        with torch.cuda.device(x_rows.device):
+            check(_lib.lib().dtt_head_gemm(ptr(x_rows), K, M, K, ptr(w), ptr(bias), w.shape[0], ptr(out), stride, n_store, 0,
+                                           stream_ptr(x_rows.device)), "head_gemm")
+        ctx.save_for_backward(x_rows, w)
+        ctx.n_store = n_store
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gout):
+        x_rows, w = ctx.saved_tensors
+        gout = gout.contiguous()
+        M, K = x_rows.shape
+        N16, stride = w.shape[0], gout.shape[1]
+        dev = x_rows.device
+        L = _lib.lib()
+        gx = gw = gb = None
+        zeros = lambda n: torch.zeros(n, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            if ctx.needs_input_grad[0]:
+                # dX (M, K) = gout (M, stride) @ Wt.T with Wt (K, stride) = w.T zero-padded: the GEMM's K is the stride (a multiple of 32)
+                wt = torch.zeros((K, stride), dtype=torch.float32, device=dev)
+                wt[:, :N16] = w.t()
+                gx = torch.empty((M, K), dtype=torch.float32, device=dev)
+                check(L.dtt_head_gemm(ptr(gout), stride, M, stride, ptr(wt), ptr(zeros(K)), K, ptr(gx), K, K, 0, stream_ptr(dev)),
+                      "head_gemm dX")
+            if ctx.needs_input_grad[1]:
+                # dW (N16, K) = gout[:, :N16].T (N16, M) @ x (M, K): rows = output channels, reduction over the pixels
+                Mp = -(-M // 32) * 32
+                gt = torch.zeros((N16, Mp), dtype=torch.float32, device=dev)
+                gt[:, :M] = gout[:, :N16].t()
+                xt = torch.zeros((K, Mp), dtype=torch.float32, device=dev)
+                xt[:, :M] = x_rows.t()
+                gw = torch.empty((N16, K), dtype=torch.float32, device=dev)
+                check(L.dtt_head_gemm(ptr(gt), Mp, N16, Mp, ptr(xt), ptr(zeros(K)), K, ptr(gw), K, K, 0, stream_ptr(dev)), "head_gemm dW")
+            if ctx.needs_input_grad[2]:
+                gb = gout[:, :N16].sum(0)
+        return gx, gw, gb, None, None
+
+
+class PsroiPmFn(torch.autograd.Function):
+    """Position-sensitive pooling + vote of SEVERAL heads of one position-major map in one autograd node (`dtt_psroi_pm_forward`
+    per head; backward `dtt_psroi_pm_backward` per head into ONE gradient map, whose remaining columns are zeroed): the
+    map-stationary backward needs no atomics and no pre-zeroed output (psroi_pooling_kernel.cu:109-170 scatters with atomicAdd)."""
+
+    @staticmethod
+    def forward(ctx, pm_map, rois, batch, height, width, spatial_scale, heads):
+        require_gpu(pm_map, rois)
+        rois = rois.detach().float().contiguous()
+        ctx.save_for_backward(rois)
+        ctx.geom = (batch, height, width, float(spatial_scale), heads, pm_map.shape[0], pm_map.stride(0))
+        votes = tuple(psroi_pm(pm_map, h, batch, height, width, rois, spatial_scale) for h in heads)
+        return votes
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, *gvotes):
+        import ctypes
+        (rois,) = ctx.saved_tensors
+        batch, height, width, scale, heads, M, stride = ctx.geom
+        dev = rois.device
+        gmap = torch.empty((M, stride), dtype=torch.float32, device=dev)
+        covered = 0
+        R = rois.shape[0]
+        with torch.cuda.device(dev):
+            for h, gv in zip(heads, gvotes):
+                G, cp, od = h["group"], h["cp"], h["od"]
+                assert h["offset"] == covered, "heads must tile the row from column 0"
+                covered += G * G * cp
+                gv = torch.zeros((R, od), dtype=torch.float32, device=dev) if gv is None else gv.contiguous()
+                edges = torch.empty((max(R, 1) * (4 * G + 1),), dtype=torch.int32, device=dev)
+                check(_lib.lib().dtt_psroi_pm_backward(ptr(gv), ptr(rois), R, batch, height, width, G, scale, od, cp, stride,
+                                                       ctypes.c_void_p(gmap.data_ptr() + 4 * h["offset"]), ptr(edges),
+                                                       stream_ptr(dev)), "psroi_pm backward")
+        if covered < stride:
+            gmap[:, covered:].zero_()
+        return gmap, None, None, None, None, None, None
+
+
 def pm_to_nchw(pm_map, head, batch, height, width):
     """The head's score map in the reference layout (batch, od*G*G, H, W) -- for tests and for callers that want the
     reference tensor."""

@@ -183,3 +183,67 @@ def test_rpn_heads_one_launch(dev, B, H, W, K, A):
         b = prop((prob, F.conv2d(x, box.weight, box.bias).contiguous(), info, "TEST"))
         assert float((a - b).abs().max()) < 1e-2          # same selection (scores identical), box deltas within rounding
         assert prop((lib_prob, bbox, info, "TEST")).shape == a.shape
+
+
+@pytest.mark.parametrize("B,H,W,K,ods", [
+    (4, 38, 67, 512, (31, 4)),     # the training step's shape: class + box heads of both legs of two frame pairs
+    (2, 13, 17, 64, (31, 4)),
+    (1, 9, 11, 96, (4,)),
+])
+def test_head_gemm_autograd_matches_conv2d_in_float64(dev, B, H, W, K, ods):
+    """HeadGemmFn (forward, dX, dW, dBias all on dtt_head_gemm) over the differentiable packing of the LIVE conv parameters,
+    against F.conv2d autograd in float64: 1e-4 relative to each tensor's largest entry (rfcn.py:49-53 in the training graph)."""
+    from dtt.heads import HeadGemmFn, pack_heads_differentiable, pm_to_nchw
+    convs = _convs(dev, K, ods, seed=B + K)
+    for c in convs:
+        c.weight.requires_grad_(True); c.bias.requires_grad_(True)
+    g = torch.Generator().manual_seed(7)
+    x = torch.relu(torch.randn(B, K, H, W, generator=g)).to(dev)
+    rows = x.permute(0, 2, 3, 1).reshape(B * H * W, K).contiguous().requires_grad_(True)
+    w, b, heads, n_store, stride = pack_heads_differentiable(convs)
+    out = HeadGemmFn.apply(rows, w, b, n_store, stride)
+    gouts = [torch.randn(B, od * 49, H, W, generator=g).to(dev) for od in ods]
+    loss = sum((pm_to_nchw(out, h, B, H, W) * go).sum() for h, go in zip(heads, gouts))
+    loss.backward()
+    x64 = x.double().requires_grad_(True)
+    ref_params = [(c.weight.detach().double().requires_grad_(True), c.bias.detach().double().requires_grad_(True)) for c in convs]
+    ref_loss = sum((F.conv2d(x64, wr, br) * go.double()).sum() for (wr, br), go in zip(ref_params, gouts))
+    ref_loss.backward()
+    rel = lambda a, r: float((a.double() - r).abs().max() / r.abs().max().clamp_min(1e-30))
+    for h, (wr, br), go in zip(heads, ref_params, gouts):
+        assert rel(pm_to_nchw(out.detach(), h, B, H, W), F.conv2d(x64.detach(), wr.detach(), br.detach())) < 1e-4
+    assert rel(rows.grad.view(B, H, W, K).permute(0, 3, 1, 2), x64.grad) < 1e-4
+    for c, (wr, br) in zip(convs, ref_params):
+        assert rel(c.weight.grad, wr.grad) < 1e-4, "dW"
+        assert rel(c.bias.grad, br.grad) < 1e-4, "dBias"
+
+
+@pytest.mark.parametrize("B,H,W,R", [(4, 38, 67, 512), (2, 20, 30, 77), (1, 6, 9, 300), (3, 12, 9, 0)])
+def test_psroi_pm_backward_matches_oracle(dev, B, H, W, R):
+    """dtt_psroi_pm_backward (map-stationary, no atomics) for the class and box heads of one map in one autograd node, against
+    the oracle's PSROIPoolBackward (psroi_pooling_kernel.cu:109-170) fed the AvgPool2d gradient (rfcn.py:62-64): 1e-5; the
+    padding columns of the gradient rows are zero; run-to-run identical (RoI order, not atomics)."""
+    from dtt.heads import PsroiPmFn, pm_to_nchw
+    rng = np.random.RandomState(B * 7 + R)
+    heads = [dict(offset=0, cp=32, od=31, group=7), dict(offset=49 * 32, cp=4, od=4, group=7)]
+    stride = 1792
+    pm = torch.from_numpy(rng.normal(size=(B * H * W, stride)).astype(np.float32)).to(dev).requires_grad_(True)
+    rois = _rois(rng, R, B, H, W) if R else np.zeros((0, 5), np.float32)
+    rt = torch.from_numpy(rois).to(dev)
+    votes = PsroiPmFn.apply(pm, rt, B, H, W, 1 / 16.0, heads)
+    gv = [rng.normal(size=tuple(v.shape)).astype(np.float32) for v in votes]
+    torch.autograd.backward(votes, [torch.from_numpy(g).to(dev) for g in gv])
+    gm = pm.grad
+    assert bool((gm[:, 49 * 36:] == 0).all())
+    for h, g in zip(heads, gv):
+        od = h["od"]
+        top_diff = np.repeat((g / np.float32(49.0)).reshape(R, od, 1, 1), 49, axis=2).reshape(R, od, 7, 7).astype(np.float32)
+        want = O.psroi_pool_backward(top_diff, rois, (B, od * 49, H, W), 7, 7, 1 / 16.0, 7, od) if R else np.zeros((B, od * 49, H, W), np.float32)
+        got = pm_to_nchw(gm, h, B, H, W).cpu().numpy()
+        np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5 * max(1.0, float(np.abs(want).max())))
+        pad = gm[:, h["offset"]:h["offset"] + 49 * h["cp"]].reshape(-1, 49, h["cp"])[:, :, od:]
+        assert bool((pad == 0).all())
+    pm.grad = None
+    votes = PsroiPmFn.apply(pm, rt, B, H, W, 1 / 16.0, heads)
+    torch.autograd.backward(votes, [torch.from_numpy(g).to(dev) for g in gv])
+    assert torch.equal(pm.grad, gm)
