@@ -230,7 +230,9 @@ class FusedTrainTrunk:
             feats.append(x)
         top = F.relu(self.model.RFCN_net(feats[3]), inplace=True)
         if self.channels_last:
-            return _to_nchw(feats[1]), _to_nchw(feats[2]), _to_nchw(feats[3]), _to_nchw(top)
+            # (the hand-written heads of the training graph read the channels-last `top` rows directly: dtt/model.py, `_train_pm`)
+            keep_top = getattr(self.model, "_train_pm", False)
+            return _to_nchw(feats[1]), _to_nchw(feats[2]), _to_nchw(feats[3]), (top if keep_top else _to_nchw(top))
         return feats[1], feats[2], feats[3], top
 
 
@@ -238,6 +240,11 @@ def fuse_for_training(model, channels_last=False):
     """Build the training-time fused trunk from the model's current (frozen) BatchNorm statistics; call again after
     loading a checkpoint."""
     model._fused_train_trunk = FusedTrainTrunk(model, channels_last=channels_last)
+    # RFCN_cls_net + RFCN_bbox_net as ONE hand-written MFMA GEMM with a hand-written backward, position-major PSRoI pooling
+    # forward / backward (dtt.heads.HeadGemmFn / PsroiPmFn): needs the channels-last `top`, class-agnostic boxes and at most
+    # 32 classes (the pooling kernel's lane layout).  DTT_TRAIN_PM=0: the library convolutions + NCHW pooling kernels.
+    model._train_pm = bool(channels_last and os.environ.get("DTT_TRAIN_PM", "1") != "0" and getattr(model, "class_agnostic", False)
+                           and getattr(model, "n_classes", 99) <= 32)
     return model
 
 

@@ -398,8 +398,27 @@ class _RFCN(nn.Module):
         if pm is not None and side is not None and n_legs <= 2 and getattr(fused, "top_rows", None) is not None:
             # hand-written heads + position-major pooling (dtt.heads): no NCHW score maps at all
             return self._inference_tail_pm(pm, fused, c3, c4, c5, all_rois, side, n_legs, B, dev, top=top, corr_done=corr_done)
-        cls_maps = self.RFCN_cls_net(top)
-        bbox_maps = self.RFCN_bbox_net(top)
+        fused_inf = getattr(self, "_fused_trunk", None)
+        if fused_inf is not None and not self.training:
+            fused_inf.top_rows = fused_inf.det_rows = fused_inf.rpn_rows = None   # (not consumed: more than two legs take the NCHW graph below)
+        train_pm = (self.training and getattr(self, "_train_pm", False) and top.is_cuda and torch.is_grad_enabled()
+                    and top.is_contiguous(memory_format=torch.channels_last) and not top.is_contiguous())
+        det = det_heads = None
+        if train_pm:
+            # training on the hand-written heads: one exact-fp32 MFMA GEMM over the channels-last `top` rows
+            # for RFCN_cls_net + RFCN_bbox_net of every image (forward, dX and dW all on dtt_head_gemm: dtt.heads.HeadGemmFn),
+            # position-major score map, lanes = classes PSRoI pooling with a map-stationary backward (PsroiPmFn)
+            from .heads import HeadGemmFn, pack_heads_differentiable, pm_to_nchw
+            rows = top.permute(0, 2, 3, 1).reshape(-1, top.size(1))
+            w_pk, b_pk, det_heads, n_store, stride = pack_heads_differentiable([self.RFCN_cls_net, self.RFCN_bbox_net])
+            det = HeadGemmFn.apply(rows, w_pk, b_pk, n_store, stride)
+            cls_maps = None
+            bbox_maps = pm_to_nchw(det, det_heads[1], n_legs * B, top.size(2), top.size(3))   # the tracking branch's NCHW concat
+        else:
+            if top.is_cuda and not top.is_contiguous():
+                top = top.contiguous()
+            cls_maps = self.RFCN_cls_net(top)
+            bbox_maps = self.RFCN_bbox_net(top)
         conv3 = [leg(c3, i) for i in range(n_legs)]
         conv4 = [leg(c4, i) for i in range(n_legs)]
         conv5 = [leg(c5, i) for i in range(n_legs)]
@@ -441,7 +460,7 @@ class _RFCN(nn.Module):
             return leg_rois, prob, pred, tracking_pred, zeros, zeros, zeros, zeros, [], zero
         for i in range(n_legs if self.training else 0):
             # training keeps the reference's per-leg order: anchor-target and RoI sampling draw from numpy's RNG
-            top_i, cls_map, bbox_map = leg(top, i), leg(cls_maps, i), rfcn_bbox[i]
+            top_i, cls_map, bbox_map = leg(top, i), (leg(cls_maps, i) if cls_maps is not None else None), rfcn_bbox[i]
             leg_rois, l_cls, l_box = self.RFCN_rpn(top_i, im_info[i], gt_boxes[i][:, :, :5], num_boxes[i])
             leg_rois, label, target, w_in, w_out = self.RFCN_proposal_target(leg_rois, gt_boxes[i][:, :, :5],
                                                                               num_boxes[i])
@@ -456,9 +475,16 @@ class _RFCN(nn.Module):
             if getattr(self._cfg, "RFCN_ROI_FEATURES", ""):
                 feats = (feats if i else []) + [self._roi_features(top_i.detach(), flat_rois)]
                 self.roi_feat = feats
-            score = self._pool_vote(self.RFCN_psroi_cls_pool, self.RFCN_cls_score, cls_map, flat_rois)
+            if det is not None:
+                from .heads import PsroiPmFn
+                rois_all = flat_rois.detach().clone()
+                rois_all[:, 0] += i * B                     # batch index inside the (n_legs * B)-image score map
+                score, pred = PsroiPmFn.apply(det, rois_all, n_legs * B, top.size(2), top.size(3),
+                                              self.RFCN_psroi_cls_pool.spatial_scale, det_heads)
+            else:
+                score = self._pool_vote(self.RFCN_psroi_cls_pool, self.RFCN_cls_score, cls_map, flat_rois)
+                pred = self._pool_vote(self.RFCN_psroi_loc_pool, self.RFCN_bbox_pred, bbox_map, flat_rois)
             prob = F.softmax(score, dim=1)
-            pred = self._pool_vote(self.RFCN_psroi_loc_pool, self.RFCN_bbox_pred, bbox_map, flat_rois)
             if not self.class_agnostic:
                 pv = pred.view(pred.size(0), int(pred.size(1) / 4), 4)
                 pred = torch.gather(pv, 1, label.view(-1, 1, 1).expand(label.size(0), 1, 4)).squeeze(1)
