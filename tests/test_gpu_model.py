@@ -437,12 +437,13 @@ def _check_pm_tail(monkeypatch, layers, shapes):
             out = model(im, info, gt, nb)                      # the production path (position-major tail inside)
             flat = im.permute(1, 0, 2, 3, 4).reshape(2 * B, *im.shape[2:])
             c3, c4, c5, top = model._im_to_head(flat)
-            conv1, fused.rpn_conv1, fused.rpn_rows = fused.rpn_conv1, None, None   # (None when the one-launch RPN heads took the rows)
-            _, _, rpn_prob, rpn_bbox = model.RFCN_rpn.head(top, conv1)
+            fused.rpn_conv1 = fused.rpn_rows = None
+            conv1_cl = fused.rpn_conv.act(top)                 # relu(RPN_Conv(top)), channels-last: the SAME map feeds both sides
+            _, _, rpn_prob, rpn_bbox = model.RFCN_rpn.head(top, conv1_cl.contiguous())
             if pm.rpn is not None:   # the one-launch RPN heads (dtt_rpn_head_gemm) against the library convolutions + softmax
                 from dtt.fuse import _rows
                 from dtt.heads import rpn_head_gemm
-                p2, b2 = rpn_head_gemm(_rows(fused.rpn_conv.act(top)), pm.rpn, 2 * B, top.size(2), top.size(3))
+                p2, b2 = rpn_head_gemm(_rows(conv1_cl), pm.rpn, 2 * B, top.size(2), top.size(3))
                 assert float((p2 - rpn_prob).abs().max()) < 1e-4
                 assert float((b2 - rpn_bbox).abs().max()) < 1e-4 * max(1.0, float(rpn_bbox.abs().max()))
             info2 = info.permute(1, 0, 2).reshape(2 * B, -1).contiguous()
