@@ -232,10 +232,9 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
-    # The tag "corr_fwd_op" brackets a whole op.  Inference on the channels-last
-    # trunk: ONE launch of corr_nhwc_kernel per op (product + in-launch slice reduction; the four sub-windows of
-    # 8 < R <= 16 (d = 12 / 16) are virtual images of the same launch).  NCHW maps (training, --nchw-trunk): banded-product
-    # kernel + slice-reduction kernel per op, and for d = 12 / 16 conv4 / conv5 are four R = 8 sub-window ops each.
+    # The tag "corr_fwd_op" brackets a whole op.  Inference on the channels-last trunk: ONE launch of corr_wsplit_kernel per
+    # op (window-split: no partial sums, d = 16 natively).  NCHW maps (training, --nchw-trunk): banded-product kernel +
+    # slice-reduction kernel per op, and for d = 12 / 16 conv4 / conv5 are four R = 8 sub-window ops each.
     nhwc_corr = args.mode == "infer" and not args.nchw_trunk and getattr(model, "_pm_tail", None) is not None
     n_sub = 4 if (args.disp in (12, 16) and not nhwc_corr) else 1
     ops_per_step = 1 + 2 * n_sub
@@ -285,7 +284,7 @@ def main():
         bytes_ = (2 * 2048 * H16 * W16 * 4 + D2 * H16 * W16 * 4) * B
         achieved = flops / (op_us * 1e-6) / 1e12 if op_us > 0 else 0.0
         hbm = bytes_ / (op_us * 1e-6) / 1e9 if op_us > 0 else 0.0
-        main_us = red_us = head_us = psroi_us = None
+        main_us = red_us = head_us = psroi_us = rpn_us = None
         assert used == ops_per_step * args.steps, "expected %d correlation ops per step, saw %d in %d steps" % (
             ops_per_step, used, args.steps)
         if args.mode == "infer":
@@ -294,20 +293,36 @@ def main():
             else:
                 main_us = extra("corr_fwd_mfma", ops_per_step, c5)
                 red_us = extra("corr_fwd_reduce", ops_per_step, c5)
-            n_head = 2      # class + box heads, then the tracking head
+            n_head = 3 if getattr(model._pm_tail, "rpn", None) is not None and os.environ.get("DTT_RPN_FUSED", "1") != "0" else 2
+            rpn_us = None   # launches per step: class + box heads, [the RPN's heads in one launch,] the tracking head
             if model._pm_tail is not None:
                 head_us = extra("head_gemm", n_head, lambda d: d[0])
+                if n_head == 3:
+                    rpn_us = extra("head_gemm", n_head, lambda d: d[1])
                 psroi_us = extra("psroi_pm", 3, lambda d: d[0])
-        # HBM bytes of the op come from a separate rocprofv3 --pmc pass over the same launch (profiles/r02_pmc_conv5.json,
-        # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes); quoted only for the shape that pass was taken on
+        # HBM bytes of the op come from separate rocprofv3 --pmc passes over the same launch (tools/profile_round.sh ->
+        # profiles/r03_pmc_conv5.json, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes).  The json records the sha256 of
+        # the libdtt_hip.so it was measured on: quoted only for that binary and for the shape the pass was taken on.
         traffic, traffic_src = None, None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_conv5.json")))
-            if (args.batch, args.height, args.width, args.disp) == (2, 600, 1067, 8):
-                traffic = pmc["traffic_bytes_per_op"]
-                traffic_src = "static: " + pmc.get("source", "profiles/r02_pmc_conv5.json")
+            import hashlib
+            from dtt import _lib
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_conv5.json")))
+            same_binary = pmc.get("library_sha256") == hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()
+            if nhwc_corr and (args.batch, args.height, args.width, args.disp) == (2, 600, 1067, 8):
+                if same_binary:
+                    traffic = pmc["traffic_bytes_per_op"]
+                    traffic_src = "static: " + pmc.get("source", "profiles/r03_pmc_conv5.json") + " (same libdtt_hip.so: sha256 checked)"
+                else:
+                    traffic_src = "profiles/r03_pmc_conv5.json was measured on another libdtt_hip.so build: not quoted (rerun tools/profile_round.sh)"
         except (OSError, ValueError, KeyError):
             pass
+        corr_us = {}
+        if nhwc_corr and args.disp <= 8 and os.environ.get("DTT_CORR5_EARLY", "1") != "0":
+            order = [int(c) for c in os.environ.get("DTT_CORR_ORDER", "021") if c != "2"]      # after conv5: conv3, conv4 by default
+            for pos, which in enumerate(order):
+                v = [durs[i + 1 + pos] for i in range(0, len(durs) - ops_per_step + 1, ops_per_step)]
+                corr_us[which] = sum(v) / max(len(v), 1)
         pairs = args.batch * world * args.steps
         out = {
             "metric": "frame-pairs/sec (600px, Res101 D&T)",
@@ -334,9 +349,9 @@ def main():
             # the dominant hot-path op: conv5 cross-frame correlation (exact-f32 MFMA banded product + slice reduction),
             # timed as ONE op with HIP events on its launch stream inside the timed region (other streams keep running
             # beside it, as in production)
-            "roofline": {"kernel": ("conv5 correlation op = %scorr_nhwc_kernel<5> (channels-last, 2048 ch, d=%d: "
-                                    "exact-f32 MFMA banded product, in-launch slice reduction; event tag corr_fwd_op)"
-                                    % ("" if args.disp <= 8 else "four 17x17 sub-windows in one launch of ", args.disp)) if nhwc_corr else
+            "roofline": {"kernel": ("conv5 correlation op = corr_wsplit_kernel (channels-last, 2048 ch, d=%d: exact-f32 MFMA banded "
+                                    "product, displacement window split over workgroups, no partial sums; event tag corr_fwd_op)"
+                                    % args.disp) if nhwc_corr else
                                    ("conv5 correlation op = %s + corr_fwd_reduce<5> (2048 ch, d=%d; event tag corr_fwd_op)"
                                     % ("corr_fwd_glds<5>" if args.disp <= 8 else "4 x corr_fwd_glds<5> sub-windows", args.disp)),
                          "bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -345,13 +360,28 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_src,
                          "op_us": round(op_us, 2), "ops_timed": len(conv5),
                          "op_us_min_median_max": [round(v, 1) for v in (min(conv5), sorted(conv5)[len(conv5) // 2], max(conv5))] if conv5 else None,
-                         "kernel_us": ({"corr_nhwc_kernel": None if main_us is None else round(main_us, 2)} if nhwc_corr else
+                         "kernel_us": ({"corr_wsplit_kernel": None if main_us is None else round(main_us, 2)} if nhwc_corr else
                                        {"banded_product": None if main_us is None else round(main_us, 2),
                                         "slice_reduction": None if red_us is None else round(red_us, 2)}),
                          "event_bracket_overhead_us": round(KernelTimer.event_pair_overhead_us(dev), 2),
                          "algorithmic_flops_per_op": flops, "algorithmic_bytes_per_op": bytes_},
         }
         sec = {}
+        for which, name, C, HWc in ((1, "corr4", 1024, H16 * W16), (0, "corr3", 512, -(-args.height // 8) * -(-args.width // 8))):
+            if which in corr_us and corr_us[which] > 0:
+                R = args.disp if which == 1 else args.disp // 2
+                Dw = (2 * R + 1) ** 2
+                fl = 2.0 * C * Dw * H16 * W16 * B
+                by = (2 * C * HWc * 4 + Dw * H16 * W16 * 4) * B
+                us = corr_us[which]
+                sec[name] = {"kernel": "conv%d correlation op = corr_wsplit_kernel (%d ch, planned for 240 CUs: it runs beside the proposal "
+                                       "layer; event tag corr_fwd_op)" % (4 if which == 1 else 3, C),
+                             "bound": "mfma" if which == 1 else "hbm", "op_us": round(us, 2),
+                             "mfma": {"achieved": round(fl / (us * 1e-6) / 1e12, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                      "frac": round(fl / (us * 1e-6) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)},
+                             "hbm": {"achieved": round(by / (us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": round(by / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)},
+                             "algorithmic_flops_per_op": fl, "algorithmic_bytes_per_op": by}
         if head_us:
             n_img = 2 * args.batch
             hf = 2.0 * n_img * H16 * W16 * 512 * (31 * 49 + 4 * 49)     # 3.96 + 0.51 GFLOP per image per leg
@@ -360,6 +390,13 @@ def main():
                             "achieved": round(hf / (head_us * 1e-6) / 1e12, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                             "frac": round(hf / (head_us * 1e-6) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4), "launch_us": round(head_us, 2),
                             "algorithmic_flops_per_launch": hf}
+        if rpn_us:
+            n_img = 2 * args.batch
+            rb = n_img * H16 * W16 * (512 + 72) * 4          # the RPN conv's rows in, 24 probabilities + 48 box deltas out
+            sec["rpn_heads"] = {"kernel": "head_gemm_kernel, RPN epilogue (RPN_cls_score + pairwise softmax + RPN_bbox_pred of %d images in one "
+                                          "launch, NCHW planes out)" % n_img, "bound": "hbm", "achieved": round(rb / (rpn_us * 1e-6) / 1e9, 1),
+                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(rb / (rpn_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                "launch_us": round(rpn_us, 2), "algorithmic_bytes_per_launch": rb}
         if psroi_us:
             n_img, od = 2 * args.batch, 31 * 49
             ps_bytes = n_img * od * H16 * W16 * 4 + n_img * cfg.TEST.RPN_POST_NMS_TOP_N * 31 * 4   # score maps in, votes out

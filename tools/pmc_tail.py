@@ -25,7 +25,7 @@ rois[:, 3] = rois[:, 1] + 200; rois[:, 4] = rois[:, 2] + 150
 with torch.no_grad():
     for _ in range(5):
         col = 2 * pm.n_box
-        for (a, b, s) in maps:
+        for (a, b, s) in maps:      # conv5, conv4, conv3 (tools/pmc_conv5_json.py relies on this order)
             correlation_forward_nhwc(a, b, 8, 1, 8, s, s)
         det = head_gemm(top, pm.det)
         trk = head_gemm(rows, pm.trk)

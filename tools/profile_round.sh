@@ -3,26 +3,32 @@
 #   tools/profile_round.sh r02
 # bench stdout (default flags), rocprofv3 kernel-trace summaries (whole run, steady state, one step launch by launch, the tail's
 # per-step overlap), separate --pmc passes over the tail's hand-written kernels, the config-4 / config-3 lines.
-R=${1:-r02}
+R=${1:-r03}
 cd ${GRAFT_REPO_ROOT:-$(dirname "$0")/..}; export TMPDIR=/tmp
 O=$PWD/gpurun_out/$R; rm -rf $O; mkdir -p $O
 timeout 900 python bench.py > $O/bench_stdout.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/trace -o bench -- python bench.py --no-cpu-baseline --steps 10 --warmup 5 > $O/prof_bench_stdout.log 2>&1
 DB=$(ls $O/trace/*.db | head -1)
 python tools/rocpd_stats.py $DB > $O/bench_kernel_stats.txt 2>&1
-python tools/rocpd_steady.py $DB 5 "corr_nhwc_kernel<3" > $O/bench_steady_state.txt 2>&1
+python tools/rocpd_steady.py $DB 5 "corr_wsplit_kernel<9" > $O/bench_steady_state.txt 2>&1
 python tools/rocpd_sequence.py $DB "psroi_pm_kernel<32" > $O/bench_step_sequence.txt 2>&1
 python tools/rocpd_tail_steps.py $DB 8 > $O/bench_tail_overlap.txt 2>&1
 rm -rf $O/trace
 for c in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE; do
   timeout 400 rocprofv3 --kernel-trace --pmc $c -d $O/pmc_$c -o p -- python tools/pmc_tail.py > $O/pmc_$c.log 2>&1
   python tools/rocpd_pmc.py $(ls $O/pmc_$c/*.db | head -1) | grep -v "at::\|Cijk\|miopen\|elementwise\|rocclr\|rocprim" >> $O/pmc_tail.txt 2>&1
-  rm -rf $O/pmc_$c $O/pmc_$c.log
+  rm -f $O/pmc_$c.log
 done
+# the traffic figure bench.py quotes: regenerated on THIS binary (the json carries the library's sha256)
+python tools/pmc_conv5_json.py $(ls $O/pmc_FETCH_SIZE/*.db | head -1) $(ls $O/pmc_WRITE_SIZE/*.db | head -1) $O/pmc_conv5.json > $O/pmc_conv5.log 2>&1 \
+  || { echo "profile_round: pmc_conv5.json not produced"; cat $O/pmc_conv5.log; exit 1; }
+[ $O/pmc_conv5.json -nt pytorch-detect-to-track_amd/lib/libdtt_hip.so ] || { echo "profile_round: pmc_conv5.json is older than libdtt_hip.so"; exit 1; }
+for c in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE; do rm -rf $O/pmc_$c; done
 timeout 600 python bench.py --no-cpu-baseline --pooling align --disp 16 --height 563 --width 1000 --batch 1 > $O/bench_config4_stdout.log 2>&1
 timeout 900 python bench.py --mode train --steps 8 --warmup 4 > $O/bench_train_stdout.log 2>&1
 timeout 600 rocprofv3 --kernel-trace -d $O/trace -o tr -- python bench.py --mode train --steps 5 --warmup 3 > $O/prof_train_stdout.log 2>&1
 python tools/rocpd_steady.py $(ls $O/trace/*.db | head -1) 3 "corr_fwd_mfma<3" > $O/train_steady_state.txt 2>&1
+python tools/rocpd_stats.py $(ls $O/trace/*.db | head -1) > $O/train_kernel_stats.txt 2>&1
 rm -rf $O/trace
 ITERS=20 timeout 300 python tools/time_corr.py > $O/corr_microbench.txt 2>&1
 B=8 ITERS=10 timeout 300 python tools/time_corr.py >> $O/corr_microbench.txt 2>&1
@@ -32,5 +38,10 @@ if [ -x tools/_variants/fetch_calib ]; then
   timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/calib -o p -- tools/_variants/fetch_calib > $O/fetch_calib.log 2>&1
   python tools/rocpd_pmc.py $O/calib/*.db > $O/fetch_calib.txt; tail -1 $O/fetch_calib.log >> $O/fetch_calib.txt; rm -rf $O/calib $O/fetch_calib.log
 fi
+if [ -x tools/_variants/write_calib ]; then
+  timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/calib -o p -- tools/_variants/write_calib > $O/write_calib.log 2>&1
+  python tools/rocpd_pmc.py $O/calib/*.db > $O/write_calib.txt; tail -1 $O/write_calib.log >> $O/write_calib.txt; rm -rf $O/calib $O/write_calib.log
+fi
 [ -f tools/_variants/wgtrace.so ] && DTT_HIP_LIBRARY=$PWD/tools/_variants/wgtrace.so timeout 600 python tools/wg_trace.py 2>&1 | grep -v "Warn\|amdgpu.ids" > $O/wg_trace.txt
+[ -f tools/_variants/wstrace.so ] && DTT_HIP_LIBRARY=$PWD/tools/_variants/wstrace.so timeout 300 python tools/ws_trace.py 2>&1 | grep -v "Warn\|amdgpu.ids" > $O/ws_trace.txt
 tail -c 1500 $O/bench_stdout.log

@@ -4,14 +4,14 @@ layer runs beside the correlations and the head GEMMs) -- shows which launches o
 import sqlite3, sys
 db = sqlite3.connect(sys.argv[1])
 rows = db.execute("select name, start, end from kernels order by start").fetchall()
-short = (("corr_nhwc_kernel<5", "corr5/4"), ("corr_nhwc_kernel<3", "corr3"), ("proposal_select_sort", "sort"), ("nms_mask", "mask"),
-         ("nms_sweep", "sweep"), ("head_gemm_kernel<10", "head"), ("head_gemm_kernel<2", "trk"), ("psroi_pm_kernel<32", "psroi"))
+short = (("corr_wsplit_kernel<9", "corr5"), ("corr_wsplit_kernel", "corr3/4"), ("proposal_select_sort", "sort"), ("nms_mask", "mask"),
+         ("nms_sweep", "sweep"), ("head_gemm_kernel<10", "head"), ("head_gemm_kernel<6", "trk/rpn"), ("psroi_pm_kernel<32", "psroi"))
 steps, cur = [], None
 for n, s, e in rows:
     tag = next((t for k, t in short if k in n), None)
     if tag is None:
         continue
-    if tag == "corr5/4" and (cur is None or any(t == "psroi" for t, _, _ in cur)):
+    if tag == "corr5" and (cur is None or any(t == "psroi" for t, _, _ in cur)):
         cur = []; steps.append(cur)
     if cur is not None:
         cur.append((tag, s, e))
