@@ -95,7 +95,7 @@ __device__ __forceinline__ int pass_begin(const HeadGeom& g, int ntg, int p) {
 // chunk s: the first operands of chunk s+1 are fetched underneath that segment, so the matrix pipe does not drain at
 // chunk boundaries.  Three LDS stages make that legal (after barrier s+1 the loaders fill stage s+2 while stages s and
 // s+1 are both still being read).
-template <int TPX, int NTW, int CNT, bool PIN>
+template <int TPX, int NTW, int CNT, bool PIN, int NSTAGE>
 __device__ __forceinline__ void head_pass(const HeadGeom& g, const float* lds, int s_begin, int tile0, int t0, int cnt,
                                           int p0, int lane, int wave) {
   constexpr int XROWS = TPX * 16;
@@ -116,7 +116,7 @@ __device__ __forceinline__ void head_pass(const HeadGeom& g, const float* lds, i
   // its slowest wave anyway, and the extra tile is never stored)
   const int xrow = l15 * kBK;
   const int wrow = (XROWS + min(t0, 4 * NTW - CNT) * 16 + l15) * kBK;
-  auto stage_of = [&](int s) { return lds + (s % 3) * STAGE; };
+  auto stage_of = [&](int s) { return lds + (s % NSTAGE) * STAGE; };
   auto read_bx = [&](f32x4 (&dst)[TPG], const float* st, int seg) {
     const int hh = seg / NG, pxg = seg % NG;
 #pragma unroll
@@ -235,7 +235,7 @@ __device__ __forceinline__ void head_pass(const HeadGeom& g, const float* lds, i
 
 // 4 compute waves (one per SIMD) + NLOAD loader waves.  Loaders move chunk s+1 global -> LDS by LDS-DMA while the compute
 // waves run the MFMAs of chunk s; one barrier per chunk, three LDS stages (see head_pass).
-template <int TPX, int NTW, int NLOAD, bool PIN>
+template <int TPX, int NTW, int NLOAD, bool PIN, int NSTAGE>
 __global__ __launch_bounds__((4 + NLOAD) * 64) void head_gemm_kernel(HeadGeom g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int XROWS = TPX * 16;
@@ -282,7 +282,7 @@ __global__ __launch_bounds__((4 + NLOAD) * 64) void head_gemm_kernel(HeadGeom g)
       auto chunk = [&](auto nw_tag) {
         constexpr int NWI = decltype(nw_tag)::value;
         for (int kc = 0; kc < KC; ++kc, ++s) {
-          const unsigned stage = lds_base + (unsigned)((s % 3) * STAGE * 4 + lw * 1024);
+          const unsigned stage = lds_base + (unsigned)((s % NSTAGE) * STAGE * 4 + lw * 1024);
           if (!(g.ablate & 1)) {
             const char* xs = uniform_ptr(xb);
 #pragma unroll
@@ -301,9 +301,21 @@ __global__ __launch_bounds__((4 + NLOAD) * 64) void head_gemm_kernel(HeadGeom g)
           xb += kBK * 4;
           wb += kBK * 4;
           HEAD_STAMP(wave, 3 * s);
-          if (!(g.ablate & 8)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          HEAD_STAMP(wave, 3 * s + 1);
-          __builtin_amdgcn_s_barrier();   // chunk s is in LDS; every compute wave has finished chunk s-2 (the stage refilled next)
+          if constexpr (NSTAGE > 3) {
+            // a fourth stage lets the loader run one chunk ahead: chunk s stays in flight while chunk s-1 is published (barrier
+            // #(s-1) comes one iteration late; the last one after the loop).  Narrow heads have so few MFMAs per chunk that the
+            // DMA latency of every chunk was exposed: 16 chunks x ~1.3 us for the RPN's heads.
+            if (s > 0) {
+              if constexpr (NWI >= 0) { if (!(g.ablate & 8)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NX + NWI) : "memory"); }
+              else { if (!(g.ablate & 8)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+              HEAD_STAMP(wave, 3 * s + 1);
+              __builtin_amdgcn_s_barrier();   // chunk s-1 is in LDS; every compute wave has finished chunk s-3
+            }
+          } else {
+            if (!(g.ablate & 8)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            HEAD_STAMP(wave, 3 * s + 1);
+            __builtin_amdgcn_s_barrier();   // chunk s is in LDS; every compute wave has finished chunk s-2 (the stage refilled next)
+          }
           HEAD_STAMP(wave, 3 * s + 2);
         }
       };
@@ -321,6 +333,12 @@ __global__ __launch_bounds__((4 + NLOAD) * 64) void head_gemm_kernel(HeadGeom g)
       }
       xb -= (long)KC * kBK * 4;
     }
+    if constexpr (NSTAGE > 3) {
+      if (s > 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();     // the last chunk
+      }
+    }
     return;
   }
 
@@ -331,7 +349,7 @@ __global__ __launch_bounds__((4 + NLOAD) * 64) void head_gemm_kernel(HeadGeom g)
     const int cmax = (L + 3) >> 2;   // workgroup-uniform tiles per wave in this pass
     const int t0 = part_begin(L, 4, wave), cnt = part_begin(L, 4, wave + 1) - t0;
     const int tile0 = nt_lo + pb + t0;
-#define DTT_HEAD_PASS(C) head_pass<TPX, NTW, C, PIN>(g, lds, s_begin, tile0, t0, cnt, p0, lane, wave)
+#define DTT_HEAD_PASS(C) head_pass<TPX, NTW, C, PIN, NSTAGE>(g, lds, s_begin, tile0, t0, cnt, p0, lane, wave)
     if constexpr (NTW >= 7) { if (cmax == 7) { DTT_HEAD_PASS(7); continue; } }
     if constexpr (NTW >= 6) { if (cmax == 6) { DTT_HEAD_PASS(6); continue; } }
     if constexpr (NTW >= 5) { if (cmax == 5) { DTT_HEAD_PASS(5); continue; } }
@@ -538,20 +556,20 @@ __global__ __launch_bounds__(256) void psroi_pm_bwd_kernel(const float* __restri
   for (int i = tid; i < nbins * CP; i += 256) dst[i] = accum[i];
 }
 
-template <int TPX, int NTW, int NLOAD, bool PIN>
+template <int TPX, int NTW, int NLOAD, bool PIN, int NSTAGE = 3>
 int launch_head(const HeadGeom& g, hipStream_t stream) {
-  constexpr size_t lds = 3ul * (TPX * 16 + 4 * NTW * 16) * kBK * sizeof(float);
+  constexpr size_t lds = (size_t)NSTAGE * (TPX * 16 + 4 * NTW * 16) * kBK * sizeof(float);
   static_assert(lds <= 160 * 1024, "three stages must fit the CU's LDS");
   static DttDeviceOnce once;
   bool& raised_here = once.here();
   if (lds > 64 * 1024 && !raised_here) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(head_gemm_kernel<TPX, NTW, NLOAD, PIN>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(head_gemm_kernel<TPX, NTW, NLOAD, PIN, NSTAGE>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     DTT_REQUIRE(e == hipSuccess, "head_gemm: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
     raised_here = true;
   }
   dtt_prof_begin("head_gemm", stream);
-  hipLaunchKernelGGL((head_gemm_kernel<TPX, NTW, NLOAD, PIN>), dim3(g.n_groups * g.strips), dim3((4 + NLOAD) * 64), lds, stream, g);
+  hipLaunchKernelGGL((head_gemm_kernel<TPX, NTW, NLOAD, PIN, NSTAGE>), dim3(g.n_groups * g.strips), dim3((4 + NLOAD) * 64), lds, stream, g);
   dtt_prof_end("head_gemm", stream);
   DTT_CHECK_LAUNCH("head_gemm");
   return 1;
@@ -619,12 +637,15 @@ static int head_gemm_launch(HeadGeom g, const float* x, long ldx, int M, int K, 
     // compute wave, one pass -- 54 strips x 4 groups = 216 workgroups at the 600 px shape: 34 us standalone (32-pixel strips with
     // all 13 tiles in one workgroup: 160 workgroups, 41 us).  80-pixel strips (256 workgroups, 51) are 29 us standalone, but a grid
     // that fills every CU leaves no room for the NMS sweep's four 1024-thread workgroups that run beside it (sweep 25 -> 50 us).
-    const int tpx = narrow_cfg == 51 ? 5 : 6;
+    // very narrow heads (the RPN's 72 channels = 5 tiles): the waves of a workgroup split CHANNEL tiles, so the per-wave MFMA
+    // chain (pixel tiles x K) is what bounds the launch -- half-length strips, twice the workgroups (two per CU)
+    const int tpx = g.nt_total <= 6 ? 3 : narrow_cfg == 51 ? 5 : 6;
     g.strips = dtt_cdiv(M, tpx * 16);
     g.n_groups = dtt_cdiv(g.nt_total, 4);
     plan_passes(g, dtt_cdiv(g.nt_total, g.n_groups), 1, 1);
-    if (tpx == 6) return launch_head<6, 1, 2, false>(g, stream);
-    return launch_head<5, 1, 2, false>(g, stream);
+    if (tpx == 3) return launch_head<3, 1, 2, false, 4>(g, stream);
+    if (tpx == 6) return launch_head<6, 1, 2, false, 4>(g, stream);
+    return launch_head<5, 1, 2, false, 4>(g, stream);
   }
   // narrow heads (4*49 box deltas alone): 32-pixel strips, every tile of the row in one pass
   constexpr int TPX = 2, NTW = 4;
