@@ -373,7 +373,7 @@ template <int CP, int LPB, int NW, int POOLED>
 __global__ __launch_bounds__(NW * 64) void psroi_pm_kernel(const float* __restrict__ map, long pixel_stride, int height,
                                                            int width, const float* __restrict__ rois,
                                                            float spatial_scale, int pooled_rt, int output_dim,
-                                                           float* __restrict__ vote, float* __restrict__ pooled_out) {
+                                                           float* __restrict__ vote, float* __restrict__ pooled_out, int batch_size) {
   extern __shared__ __attribute__((aligned(16))) float bins[];   // [pooled*pooled][CP]
   constexpr int VPL = CP / LPB, NV = VPL / 4;   // classes / 16-byte pieces per lane
   constexpr int SLOTS = NW * 64 / LPB;          // bins in flight per workgroup
@@ -385,7 +385,8 @@ __global__ __launch_bounds__(NW * 64) void psroi_pm_kernel(const float* __restri
   float roi[5];
 #pragma unroll
   for (int q = 0; q < 5; ++q) roi[q] = rois[(long)n * 5 + q];
-  const int b = (int)roi[0];
+  // a batch index outside the map (a caller's bug: the reference reads out of bounds there) pools image 0 instead of wild memory
+  const int b = min(max((int)roi[0], 0), batch_size - 1);
   const int nbins = pooled * pooled;
   const float* img = map + (long)b * height * width * pixel_stride + cq * VPL;
   for (int bin = slot; bin < nbins; bin += SLOTS) {
@@ -732,7 +733,7 @@ extern "C" int dtt_psroi_pm_forward(const float* map, long pixel_stride, int cp,
   dtt_prof_begin("psroi_pm", stream);
 #define DTT_PM_LAUNCH(CPV, LPBV, NWV, PV)                                                                                   \
   hipLaunchKernelGGL((psroi_pm_kernel<CPV, LPBV, NWV, PV>), dim3(num_rois), dim3(NWV * 64), lds, stream, map, pixel_stride, \
-                     height, width, rois, spatial_scale, pooled, output_dim, vote_out, pooled_out)
+                     height, width, rois, spatial_scale, pooled, output_dim, vote_out, pooled_out, batch_size)
   if (cp == 32) {
     if (pooled == 7) DTT_PM_LAUNCH(32, 4, 4, 7); else DTT_PM_LAUNCH(32, 4, 4, 0);
   } else if (cp == 4) {

@@ -98,6 +98,14 @@ class _ProposalTargetLayer(nn.Module):
         self.last_status = status
         return rois, labels, targets, inside, outside
 
+    def check_status(self):
+        """proposal_target_layer_cascade.py:186 raises when an image has neither foreground nor background candidates.  The
+        "device" sampler cannot raise inside the step without reading the device (the kernel fills candidate 0 and flags the
+        image instead): call this where the caller synchronises anyway (trainval_net.py does, once per logged loss)."""
+        st = self.last_status
+        if st is not None and bool((st != 0).any().item()):
+            raise ValueError("bg_num_rois = 0 and fg_num_rois = 0, this should not happen!")
+
 
 class _TrackingProposalTargetLayer(nn.Module):
     """forward(gt_boxes (2,B,G,6) [x1,y1,x2,y2,cls,track_id], num_boxes (2,B,1)) ->

@@ -199,7 +199,8 @@ def main(argv=None):
             loss.backward()
             runner.finish_gradients()
             optimizer.step()
-            loss_temp += float(loss.detach())
+            loss_temp += float(loss.detach())   # (the step's one host read)
+            model.RFCN_proposal_target.check_status()   # the reference's "no fg and no bg RoIs" ValueError, deferred to this sync
             if (step + 1) % args.disp_interval == 0 and rank == 0:
                 n = args.disp_interval
                 fg = int((out[8] != 0).sum())
