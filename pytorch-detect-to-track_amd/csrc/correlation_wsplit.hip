@@ -38,7 +38,8 @@ constexpr int kPPX = 64;                 // frame-t pixels per slot: up to four 
 constexpr int kNComp = 8, kNLoad = 4, kThreads = (kNComp + kNLoad) * 64;   // 2 compute waves + 1 loader per SIMD
 constexpr int kMaxNI = 12;               // DMA instructions per loader per chunk (4 loaders x 12 x 1 KB = 48 KB per slot)
 constexpr int kMaxSeg = 6;
-constexpr int kLdsMax = 160 * 1024;
+constexpr int kLdsMax = 144 * 1024;       // 16 KB of the CU's 160 stay free: small kernels of other streams (the NMS mask kernel's
+                                          // one-wave workgroups with 1 KB of LDS) can still become resident beside a correlation workgroup
 constexpr double kDmaBytesPerClk = 32.0;   // planning figure: LDS-DMA into one CU beside a running MFMA stream
 
 struct WSeg { int item0, nitems, by0, bx0, nty, ntx, th, tw, wpt; unsigned wpt_magic, tiles_magic, nty_magic; };   // magics: 2^32 / d + 1
@@ -394,28 +395,35 @@ __global__ __launch_bounds__(kThreads) void corr_wsplit_kernel(WGeom g) {
     float* ob = g.out + (long)n * g.out_sb;
     if (g.out_sc == 1) {
       // position-major rows: the entries of a pixel are one contiguous run of its row, (dy + R) * D + dx + R = e + (dy_lo + R) * D.
-      // A wave takes whole pixels (pixel coordinates and the row pointer are wave-uniform), its lanes walk the run:
-      // consecutive lanes write consecutive floats (minus the entries that belong to the tile's other window parts).
-      for (int px = wave; px < npx; px += kThreads / 64) {
-        const int bi = px >> 4, jy = (px >> 2) & 3, jx = px & 3;
-        const int y = Y0 + 4 * (bi >> tw_shift) + jy, x = X0 + 4 * (bi & (tw - 1)) + jx;
-        if (y >= g.oh || x >= g.ow) continue;
-        float* orow = ob + ((long)y * g.ow + x) * g.out_sp + (dy_lo + g.R) * g.D;
-        const float* trow = lds + px * per_px;
-        for (int e0 = lane; e0 < per_px; e0 += 256) {   // four entries per lane per round: the LDS reads go out together
-          float v[4];
+      // Which entries of a run belong to THIS workgroup's window parts depends only on the pixel's position inside its 4 x 4
+      // block, so a wave takes one in-block position (jy, jx), works the ownership test out once per lane (four entries
+      // e = lane + 64 u per round) and then streams that position's pixel of every block of the tile: consecutive lanes
+      // write consecutive floats.
+      for (int pos = wave; pos < 16; pos += kThreads / 64) {
+        const int jy = pos >> 2, jx = pos & 3;
+        for (int e0 = lane; e0 < per_px; e0 += 256) {
           bool mine[4];
+          int eo[4];
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             const int e = e0 + 64 * u;
             const int dyi = mdiv(e, g.d_magic), dxi = e - dyi * g.D;
             const int qb = ((jy + dyi + dy_lo + g.R) >> 2) * g.nbr + ((jx + dxi) >> 2);   // the window block this entry comes from
             mine[u] = e < per_px && qb >= q_lo && qb < q_hi;                               // (else: another workgroup's part)
-            v[u] = trow[min(e, per_px - 1)];
+            eo[u] = min(e, per_px - 1);
           }
+          for (int bi = 0; bi < nb; ++bi) {
+            const int y = Y0 + 4 * (bi >> tw_shift) + jy, x = X0 + 4 * (bi & (tw - 1)) + jx;
+            if (y >= g.oh || x >= g.ow) continue;
+            float* orow = ob + ((long)y * g.ow + x) * g.out_sp + (dy_lo + g.R) * g.D;
+            const float* trow = lds + (bi * 16 + pos) * per_px;
+            float v[4];
 #pragma unroll
-          for (int u = 0; u < 4; ++u)
-            if (mine[u]) orow[e0 + 64 * u] = v[u];
+            for (int u = 0; u < 4; ++u) v[u] = trow[eo[u]];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+              if (mine[u]) orow[eo[u]] = v[u];
+          }
         }
       }
     } else {
@@ -522,7 +530,7 @@ int plan_wsplit(int batch, int oh, int ow, int R, int D, int max_wgs, WPlan* bes
     p.items = (int)items;
     p.slot_bytes = (kPPX + max_hpx) * kKC * 4;
     p.nslot = std::min(8, kLdsMax / p.slot_bytes);
-    if (p.nslot < 4 || max_tile > (size_t)kLdsMax) continue;
+    if (p.nslot < 3 || max_tile > (size_t)kLdsMax) continue;   // (3 slots: no run-ahead beyond the chunk being awaited -- legal, slow)
     p.lds_bytes = kLdsMax;   // one workgroup per CU (12 waves at 3 per SIMD): the ring takes the whole LDS; the output tile
                              // (max_tile) and the phase exchange (4 * nacc KB) reuse it after the loop
     // time ~ rounds x the slower of a chunk's MFMAs (4 k-steps x nacc x 32 cycles on each SIMD) and its LDS-DMA (pixels x 64 B

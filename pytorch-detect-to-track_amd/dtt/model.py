@@ -308,11 +308,16 @@ class _RFCN(nn.Module):
             gather_column_blocks(rows, 0, det, pm.loc_head["offset"], B * hw, n_legs, pm.n_box)   # box deltas of both legs
             trk = head_gemm(rows, pm.trk)                           # (B*H*W, stride)
         R = all_rois.size(1)
-        with torch.cuda.stream(side):   # the per-leg copy of the RoIs rides on the side stream, which has slack
+        # The poolings need the RoIs as the NMS epilogue wrote them (image index inside the n_legs * B batch): they start as soon
+        # as the proposal layer is done.  The per-leg copy the caller gets back (batch index within the leg) is made on the side
+        # stream BESIDE them -- it used to sit, with its two small launches and a stream hop, between the NMS and the first pooling.
+        rois_ready = torch.cuda.Event()
+        rois_ready.record(side)
+        with torch.cuda.stream(side):
             leg_rois = all_rois.view(n_legs, B, R, 5).clone()
             for i in range(1, n_legs):
                 leg_rois[i, :, :, 0] -= i * B  # batch index within the leg
-        cur.wait_stream(side)
+        cur.wait_event(rois_ready)
         all_rois.record_stream(cur); leg_rois.record_stream(cur)
         flat_rois = all_rois.view(-1, 5)
         scale = self.RFCN_psroi_cls_pool.spatial_scale
@@ -324,7 +329,9 @@ class _RFCN(nn.Module):
         zeros = torch.zeros(n_legs, 1, device=dev)
         tracking_pred = torch.zeros(0, 4, device=dev)
         if trk is not None:
-            tracking_pred = psroi_pm(trk, pm.trk_head, B, H, W, leg_rois[0].view(-1, 5), scale)   # frame-t RoIs (rfcn.py:192)
+            # frame-t RoIs (rfcn.py:192): leg 0 of all_rois -- its batch indices are already leg-local
+            tracking_pred = psroi_pm(trk, pm.trk_head, B, H, W, all_rois[:B].reshape(-1, 5), scale)
+        cur.wait_stream(side)   # leg_rois
         return leg_rois, prob, pred, tracking_pred, zeros, zeros, zeros, zeros, [], zeros[0]
 
     def forward(self, im_data, im_info, gt_boxes, num_boxes):

@@ -276,6 +276,7 @@ NHWC_CASES = [
     (1, 16, 3, 3, 8, 1, 8, 1, 1),       # a single pixel block
     (1, 16, 20, 4, 8, 1, 8, 1, 1),      # one block column: 4 x 1 tiles + remainder
     (1, 16, 4, 33, 8, 1, 8, 1, 1),      # one block row, odd count: 1 x 4 tiles + a 1 x 1
+    (1, 16, 14, 34, 16, 1, 16, 1, 1),   # R = 16 with a 4 x 1 edge tile: 40 KB ring slots, only three fit (found by tests/fuzz_ops.py)
     (2, 16, 22, 26, 8, 1, 8, 1, 1),     # odd x odd block grid (6 x 7 ... 5.5 -> 6 rows, 6.5 -> 7 cols): every segment kind
 ]
 
