@@ -97,6 +97,9 @@ int dtt_correlation_forward_nhwc(float* output, int ob, int oc, int oh, int ow, 
                                  int stride1, int stride2, int max_workgroups, void* stream);
 int dtt_correlation_nhwc_plan(int batch, int oh, int ow, int window_radius, int max_workgroups, int* parts,
                               int* accumulators, int* workgroups, int* ring_slots);
+/* Host-only self-check of that plan: replays every work item through the kernel's own item decode and returns 1 iff every
+ * (image, 4 x 4 pixel block, window block) triple is owned by exactly one wave and every workgroup's halo fits its LDS-DMA budget. */
+int dtt_correlation_nhwc_plan_check(int batch, int oh, int ow, int window_radius, int max_workgroups);
 /* Any kernel_size / strides (D&T itself uses kernel_size 1, rfcn.py:58-60: that case runs on the matrix cores).
  * gradInput1/2 are fully written (no pre-zeroing needed).  The gradients are the mathematically exact adjoint of
  * dtt_correlation_forward.  The reference's own backward departs from its forward in two places, which are NOT

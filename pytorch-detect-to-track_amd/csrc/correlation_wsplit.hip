@@ -27,6 +27,7 @@
 #include <stdlib.h>
 #include <type_traits>
 #include <algorithm>
+#include <vector>
 #include "common.h"
 
 namespace {
@@ -91,14 +92,55 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
 }
 
 // n / d for 0 <= n < 65536 with magic = 65536 / d + 1 (exact while n * (magic * d - 65536) < 65536: the host checks the range)
-__device__ __forceinline__ int mdiv(int n, unsigned magic) { return (int)(((unsigned)n * magic) >> 16); }
+__host__ __device__ __forceinline__ int mdiv(int n, unsigned magic) { return (int)(((unsigned)n * magic) >> 16); }
 // n / d with magic = (2^32 - 1) / d + 1 (which wraps to 0 for d == 1): exact while n * d < 2^32 (host-checked)
-__device__ __forceinline__ int mdiv32(int n, unsigned magic) { return magic ? (int)__umulhi((unsigned)n, magic) : n; }
+__host__ __device__ __forceinline__ int mdiv32(int n, unsigned magic) {
+  return magic ? (int)(((unsigned long long)(unsigned)n * magic) >> 32) : n;
+}
 
 __device__ __forceinline__ void wg_barrier() {
   asm volatile("" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
+}
+
+// What one workgroup does, worked out from its item number and the plan in the kernel arguments (wave-uniform; the same code
+// runs on the host in dtt_correlation_nhwc_plan_check, which replays every item of a plan and counts who computes what).
+struct WItem {
+  int n;                    // image
+  int Y0, X0;               // tile origin, output pixels
+  int th, tw, nb, nb_shift, tw_shift;
+  int jw;                   // workgroup jw of its tile: wave task t = 4 * jw + wave -> pixel block t % nb, window part t / nb
+  int q_lo, q_hi;           // window blocks [q_lo, q_hi) of every pixel block of the tile belong to this workgroup
+  int r0, r1;               // the window block rows they lie in
+  int hrows, HC;            // halo pixels staged per chunk: hrows x HC
+};
+
+__host__ __device__ __forceinline__ int ws_q0(const WGeom& g, int p) { return mdiv32(g.nblk * p, g.parts_magic); }
+
+__host__ __device__ __forceinline__ WItem ws_decode(const WGeom& g, int item) {
+  WSeg sg = g.seg[0];
+#pragma unroll
+  for (int i = 1; i < kMaxSeg; ++i)
+    if (i < g.nseg && item >= g.seg[i].item0) sg = g.seg[i];
+  WItem w;
+  const int local = item - sg.item0;
+  const int ntiles = sg.nty * sg.ntx;
+  // (divisions by plan constants through host-made multipliers: the set-up sits in front of the first DMA)
+  const int wt = mdiv32(local, sg.wpt_magic);
+  w.jw = local - wt * sg.wpt;
+  w.n = mdiv32(wt, sg.tiles_magic);
+  const int tile = wt - w.n * ntiles;
+  const int txi = mdiv32(tile, sg.nty_magic), tyi = tile - txi * sg.nty;         // column-major: an XCD's run of items is a vertical strip
+  w.th = sg.th; w.tw = sg.tw; w.nb = sg.th * sg.tw;
+  w.nb_shift = w.nb == 4 ? 2 : w.nb == 2 ? 1 : 0;                                // nb, tw in {1, 2, 4}
+  w.tw_shift = w.tw == 4 ? 2 : w.tw == 2 ? 1 : 0;
+  w.Y0 = 4 * (sg.by0 + tyi * sg.th); w.X0 = 4 * (sg.bx0 + txi * sg.tw);
+  const int p_lo = (4 * w.jw) >> w.nb_shift, p_hi = min(g.parts - 1, (4 * w.jw + 3) >> w.nb_shift);
+  w.q_lo = ws_q0(g, p_lo); w.q_hi = ws_q0(g, p_hi + 1);
+  w.r0 = mdiv(w.q_lo, g.nbr_magic); w.r1 = mdiv(w.q_hi - 1, g.nbr_magic);
+  w.hrows = 4 * (w.r1 - w.r0 + sg.th); w.HC = 4 * (g.nbr - 1 + sg.tw);
+  return w;
 }
 
 #ifdef DTT_WS_TRACE   // developer build (tools/build_ws_trace.sh): shader-clock stamps of every workgroup's waves 0 / 4 / 8
@@ -119,24 +161,10 @@ __global__ __launch_bounds__(kThreads) void corr_wsplit_kernel(WGeom g) {
   const int item = dtt_xcd_remap(blockIdx.x, gridDim.x);
 
   // ---- which tile, which run of window parts (all wave-uniform)
-  WSeg sg = g.seg[0];
-#pragma unroll
-  for (int i = 1; i < kMaxSeg; ++i)
-    if (i < g.nseg && item >= g.seg[i].item0) sg = g.seg[i];
-  const int local = item - sg.item0;
-  const int ntiles = sg.nty * sg.ntx;
-  // (divisions by plan constants through host-made multipliers: the set-up sits in front of the first DMA)
-  const int wt = mdiv32(local, sg.wpt_magic), jw = local - wt * sg.wpt;           // workgroup jw of its tile
-  const int n = mdiv32(wt, sg.tiles_magic), tile = wt - n * ntiles;
-  const int txi = mdiv32(tile, sg.nty_magic), tyi = tile - txi * sg.nty;         // column-major: an XCD's run of items is a vertical strip
-  const int nb = sg.th * sg.tw, tw = sg.tw;
-  const int nb_shift = nb == 4 ? 2 : nb == 2 ? 1 : 0, tw_shift = tw == 4 ? 2 : tw == 2 ? 1 : 0;   // nb, tw in {1, 2, 4}
-  const int Y0 = 4 * (sg.by0 + tyi * sg.th), X0 = 4 * (sg.bx0 + txi * sg.tw);   // tile origin, output pixels
-  auto q0 = [&](int p) { return mdiv32(g.nblk * p, g.parts_magic); };           // window blocks [q0(p), q0(p+1)) belong to part p
-  const int p_lo = (4 * jw) >> nb_shift, p_hi = min(g.parts - 1, (4 * jw + 3) >> nb_shift);
-  const int q_lo = q0(p_lo), q_hi = q0(p_hi + 1);
-  const int r0 = mdiv(q_lo, g.nbr_magic), r1 = mdiv(q_hi - 1, g.nbr_magic);     // window block rows this workgroup touches
-  const int hrows = 4 * (r1 - r0 + sg.th), HC = 4 * (g.nbr - 1 + tw);
+  const WItem wi = ws_decode(g, item);
+  const int jw = wi.jw, n = wi.n, nb = wi.nb, tw = wi.tw, nb_shift = wi.nb_shift, tw_shift = wi.tw_shift;
+  const int Y0 = wi.Y0, X0 = wi.X0, q_lo = wi.q_lo, q_hi = wi.q_hi, r0 = wi.r0, r1 = wi.r1, hrows = wi.hrows, HC = wi.HC;
+  auto q0 = [&](int p) { return ws_q0(g, p); };                                  // window blocks [q0(p), q0(p+1)) belong to part p
   const int n_instr = (kPPX + hrows * HC) / 16;
   const int slot_bytes = (kPPX + hrows * HC) * kKC * 4, nslot = min(8, g.ring_bytes / slot_bytes);
   const int nch = g.C / kKC;
@@ -558,6 +586,17 @@ int launch_ws(const WGeom& g, int items, size_t lds_bytes, hipStream_t stream) {
   return 1;
 }
 
+// the plan's part of the kernel arguments (g.R / g.D set by the caller)
+void plan_into_geom(const WPlan& p, WGeom* g) {
+  g->nbr = p.nbr; g->nblk = p.nbr * p.nbr; g->parts = p.parts;
+  g->nbr_magic = 65536u / (unsigned)p.nbr + 1u;     // x < 81
+  g->d_magic = 65536u / (unsigned)g->D + 1u;        // e < 19 * 33
+  g->parts_magic = 0xffffffffu / (unsigned)p.parts + 1u;
+  g->nseg = p.nseg;
+  for (int i = 0; i < kMaxSeg; ++i) g->seg[i] = i < p.nseg ? p.seg[i] : WSeg{0x7fffffff, 0, 0, 0, 1, 1, 1, 1, 1, 0u, 0u, 0u};
+  g->ring_bytes = (int)p.lds_bytes;
+}
+
 }  // namespace
 
 // input1 / input2: (ob, ih, iw, ic) channels-last.  Output addressing as dtt_correlation_forward_strided.  Supports
@@ -598,13 +637,7 @@ extern "C" int dtt_correlation_forward_nhwc(float* output, int ob, int oc, int o
   const int budget = max_workgroups > 0 ? std::min(max_workgroups, ncu) : ncu;
   WPlan p;
   DTT_REQUIRE(plan_wsplit(ob, oh, ow, R, g.D, budget, &p), "correlation (window-split): no plan for %d x %d outputs, radius %d", oh, ow, R);
-  g.nbr = p.nbr; g.nblk = p.nbr * p.nbr; g.parts = p.parts;
-  g.nbr_magic = 65536u / (unsigned)p.nbr + 1u;     // x < 81
-  g.d_magic = 65536u / (unsigned)g.D + 1u;         // e < 19 * 33
-  g.parts_magic = 0xffffffffu / (unsigned)p.parts + 1u;
-  g.nseg = p.nseg;
-  for (int i = 0; i < kMaxSeg; ++i) g.seg[i] = i < p.nseg ? p.seg[i] : WSeg{0x7fffffff, 0, 0, 0, 1, 1, 1, 1, 1, 0u, 0u, 0u};
-  g.ring_bytes = (int)p.lds_bytes;
+  plan_into_geom(p, &g);
   dtt_prof_begin("corr_fwd_op", stream);
   dtt_prof_begin("corr_nhwc", stream);
   int ok = 0;
@@ -625,6 +658,46 @@ extern "C" int dtt_ws_trace_read(unsigned long long* host, int n) {
   return hipMemcpyFromSymbol(host, HIP_SYMBOL(dtt_ws_trace), sizeof(unsigned long long) * n) == hipSuccess;
 }
 #endif
+
+// Test hook (pure host code): replays EVERY work item of the plan the launcher would use through the kernel's own item decode
+// (ws_decode: the same magic-number divisions) and counts, per (image, 4 x 4 pixel block, window block), how many waves own it.
+// Returns 1 iff every pair inside the output is owned exactly once, every workgroup's halo fits its DMA budget and at least three
+// ring slots, and no wave is given more window blocks than the kernel instantiation holds.
+extern "C" int dtt_correlation_nhwc_plan_check(int batch, int oh, int ow, int window_radius, int max_workgroups) {
+  WPlan p;
+  const int ncu = dtt_device_cus();
+  const int budget = max_workgroups > 0 ? std::min(max_workgroups, ncu) : ncu;
+  const int R = window_radius;
+  if (!plan_wsplit(batch, oh, ow, R, 2 * R + 1, budget, &p)) return 0;
+  WGeom g = {};
+  g.R = R; g.D = 2 * R + 1;
+  plan_into_geom(p, &g);
+  const int GH = (oh + 3) / 4, GW = (ow + 3) / 4;
+  std::vector<unsigned char> owned((size_t)batch * GH * GW * g.nblk, 0);
+  for (int item = 0; item < p.items; ++item) {
+    const WItem w = ws_decode(g, item);
+    if (w.n < 0 || w.n >= batch || w.q_lo >= w.q_hi || w.r0 > w.r1) return 0;
+    const int slot_bytes = (kPPX + w.hrows * w.HC) * kKC * 4;
+    if ((kPPX + w.hrows * w.HC) / 16 > kMaxNI * kNLoad || g.ring_bytes / slot_bytes < 3) return 0;
+    for (int wave = 0; wave < 4; ++wave) {
+      const int t = 4 * w.jw + wave, bi = t & (w.nb - 1), part = t >> w.nb_shift;
+      if (part >= g.parts) continue;
+      const int a0 = ws_q0(g, part), a1 = ws_q0(g, part + 1);
+      if (a1 - a0 > p.nacc || a0 < w.q_lo || a1 > w.q_hi) return 0;
+      const int by = w.Y0 / 4 + (bi >> w.tw_shift), bx = w.X0 / 4 + (bi & (w.tw - 1));
+      if (by >= GH || bx >= GW) return 0;
+      for (int qb = a0; qb < a1; ++qb) {
+        if (mdiv(qb, g.nbr_magic) != qb / g.nbr) return 0;
+        unsigned char& c = owned[(((size_t)w.n * GH + by) * GW + bx) * g.nblk + qb];
+        if (c) return 0;
+        c = 1;
+      }
+    }
+  }
+  for (unsigned char c : owned)
+    if (!c) return 0;
+  return 1;
+}
 
 // developer / test hook: the plan the launcher would use (parts, accumulators per wave, workgroups, ring slots)
 extern "C" int dtt_correlation_nhwc_plan(int batch, int oh, int ow, int window_radius, int max_workgroups, int* parts,

@@ -30,6 +30,7 @@ SIGNATURES = {
     "dtt_correlation_forward": (_I, [_P, _I, _I, _I, _I, _L, _P, _I, _I, _I, _P, _P, _Z, _I, _I, _I, _I, _I, _I, _P]),
     "dtt_correlation_forward_strided": (_I, [_P, _I, _I, _I, _I, _L, _L, _L, _P, _I, _I, _I, _P, _P, _Z, _I, _I, _I, _I, _I, _I, _P]),
     "dtt_correlation_forward_nhwc": (_I, [_P, _I, _I, _I, _I, _L, _L, _L, _P, _I, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "dtt_correlation_nhwc_plan_check": (_I, [_I, _I, _I, _I, _I]),
     "dtt_correlation_nhwc_plan": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "dtt_correlation_backward": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "dtt_psroi_pool_forward": (_I, [_P, _F, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P, _P, _P]),

@@ -91,3 +91,20 @@ def test_correlation_window_split_plans_without_gpu():
         nblk = (1 + (R + 1) // 2) ** 2
         assert parts >= 1 and -(-nblk // parts) <= nacc and wgs >= 1 and 3 <= slots <= 8
     assert L.dtt_correlation_nhwc_plan(1, 8, 8, 17, 0, None, None, None, None) == 0   # radius > 16: not this kernel
+
+
+def test_correlation_window_split_plans_cover_every_pair_exactly_once():
+    """dtt_correlation_nhwc_plan_check replays every work item of a plan through the kernel's own item decode (the same
+    magic-number divisions, compiled for the host) and counts the owners of every (image, pixel block, window block) triple:
+    exactly one, for the benchmark shapes and a sweep of odd sizes, radii and CU budgets (pure host code)."""
+    from dtt import _lib
+    L = _lib.lib()
+    cases = [(2, 38, 67, 8, 0), (2, 38, 67, 8, 240), (2, 38, 67, 4, 0), (2, 38, 67, 4, 240), (1, 36, 63, 16, 0), (8, 38, 67, 8, 0),
+             (1, 14, 34, 16, 0), (1, 1, 1, 1, 0), (3, 9, 11, 4, 7), (1, 75, 134, 16, 0), (2, 5, 4, 13, 1), (1, 4, 33, 8, 0), (1, 20, 4, 8, 0)]
+    import numpy as np
+    rs = np.random.RandomState(0)
+    for _ in range(120):
+        cases.append((int(rs.randint(1, 5)), int(rs.randint(1, 80)), int(rs.randint(1, 140)), int(rs.randint(1, 17)),
+                      int(rs.choice([0, 1, 17, 64, 240, 252]))))
+    for c in cases:
+        assert L.dtt_correlation_nhwc_plan_check(*c) == 1, c
