@@ -128,14 +128,23 @@ __global__ __launch_bounds__(kSweepThreads) void nms_sweep_kernel(
     if (state[0] != 0ULL) return;   // the first phase finished this image (and wrote its outputs)
     const int kept_so_far = (int)state[1];
     const int w_first = sc_begin * kSuperWords;   // first column block the first phase did not have
-    for (int j = tid; j < col_blocks; j += kSweepThreads) {
-      unsigned long long r = state[2 + j];
-      if (j >= w_first && j < cb) {               // replay: every row kept in phase 1 suppresses across the new columns
-        for (int k = 0; k < kept_so_far; ++k) r |= m[(long)keep[k] * col_blocks + j];
-      }
-      remv[j] = r;
-    }
+    for (int j = tid; j < col_blocks; j += kSweepThreads) remv[j] = state[2 + j];
     if (tid == 0) { ctl[0] = 0; ctl[1] = kept_so_far; ctl[2] = 0; }
+    // replay: every row kept in phase 1 suppresses across the columns computed since.  The kept rows are dealt to as many
+    // thread slices per column as the workgroup has threads for (a column alone would walk up to max_keep rows serially:
+    // ADVICE r2) and the slices meet with an LDS atomic OR -- order-free, so still deterministic.
+    const int ncol = cb - w_first;
+    if (ncol > 0 && kept_so_far > 0) {
+      __syncthreads();
+      const int nsl = max(1, kSweepThreads / ncol);
+      const int c = tid % ncol, sl = tid / ncol;
+      if (sl < nsl) {
+        const int j = w_first + c;
+        unsigned long long r = 0ULL;
+        for (int k = sl; k < kept_so_far; k += nsl) r |= m[(long)keep[k] * col_blocks + j];
+        if (r) atomicOr(&remv[j], r);
+      }
+    }
   } else {
     for (int j = tid; j < col_blocks; j += kSweepThreads) remv[j] = 0;
     if (tid == 0) { ctl[0] = 0; ctl[1] = 0; ctl[2] = 0; }

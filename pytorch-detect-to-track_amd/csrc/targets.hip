@@ -131,8 +131,8 @@ __global__ __launch_bounds__(256) void pt_sample(const float* __restrict__ all_r
                                                  const double* __restrict__ u_bg, PtParams P, float* __restrict__ rois_out,
                                                  float* __restrict__ labels_out, float* __restrict__ targets_out,
                                                  float* __restrict__ inside_out, float* __restrict__ outside_out,
-                                                 int* __restrict__ status) {
-  extern __shared__ int sel[];   // n_out candidate indices
+                                                 int* __restrict__ status, int stage_keys) {
+  extern __shared__ int sel[];   // n_out candidate indices (+ R + G staged keys when stage_keys)
   const int b = blockIdx.x, tid = threadIdx.x;
   const int N = R + G, n = P.n_out;
   const int fg_cnt = counts[b * 2], bg_cnt = counts[b * 2 + 1];
@@ -148,10 +148,19 @@ __global__ __launch_bounds__(256) void pt_sample(const float* __restrict__ all_r
     if (fg_cnt > 0 && bg_cnt > 0) {
       fg_n = min(P.fg_per_image, fg_cnt);
       // the fg_n smallest keys of the foreground list (ties by position): a uniform subset without replacement
+      // (the fg_cnt keys are staged in LDS once -- ADVICE r2: every thread used to re-read them from global memory in its
+      // O(fg_cnt) ranking loop; the launch reserves N doubles behind the n_out selection slots)
+      const double* ufs = uf;
+      if (stage_keys) {
+        double* st = reinterpret_cast<double*>(sel + ((n + 1) & ~1));
+        for (int k = tid; k < fg_cnt; k += blockDim.x) st[k] = uf[k];
+        __syncthreads();
+        ufs = st;
+      }
       for (int k = tid; k < fg_cnt; k += blockDim.x) {
-        const double key = uf[k];
+        const double key = ufs[k];
         int rank = 0;
-        for (int m = 0; m < fg_cnt; ++m) rank += (uf[m] < key) || (uf[m] == key && m < k);
+        for (int m = 0; m < fg_cnt; ++m) rank += (ufs[m] < key) || (ufs[m] == key && m < k);
         if (rank < fg_n) sel[rank] = fl[k];
       }
       for (int j = fg_n + tid; j < n; j += blockDim.x) sel[j] = bl[min((int)floor(ub[j - fg_n] * (double)bg_cnt), bg_cnt - 1)];
@@ -302,9 +311,12 @@ extern "C" int dtt_proposal_target_sample(const float* all_rois, const float* gt
   DTT_REQUIRE((pos && fg_n) || (!pos && !fg_n && u_fg && u_bg), "proposal_target_sample: pass positions + fg_n, or the two uniform arrays");
   DTT_REQUIRE(images > 0 && n_out > 0 && n_out <= 8192 && num_gt > 0 && num_gt <= kMaxGt, "proposal_target_sample: bad shape");
   const PtParams P = make_params(mean4_host, std4_host, inside4_host, normalize, fg_per_image, n_out);
-  hipLaunchKernelGGL(pt_sample, dim3(images), dim3(256), n_out * sizeof(int), stream, all_rois, gt_boxes, num_rois, num_gt,
+  const size_t sel_bytes = (size_t)((n_out + 1) & ~1) * sizeof(int);
+  const size_t key_bytes = (size_t)(num_rois + num_gt) * sizeof(double);
+  const int stage_keys = !pos && sel_bytes + key_bytes <= 60 * 1024;
+  hipLaunchKernelGGL(pt_sample, dim3(images), dim3(256), sel_bytes + (stage_keys ? key_bytes : 0), stream, all_rois, gt_boxes, num_rois, num_gt,
                      gt_stride, assign, fg_list, bg_list, counts, pos, fg_n, u_fg, u_bg, P, rois_out, labels_out, targets_out,
-                     inside_out, outside_out, status);
+                     inside_out, outside_out, status, stage_keys);
   DTT_CHECK_LAUNCH("pt_sample");
   return 1;
 }
