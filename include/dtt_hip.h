@@ -154,7 +154,8 @@ int dtt_psroi_vote_forward(const float* bottom_data, float spatial_scale, int ba
  * max_keep > 0 lets the sweep stop after max_keep survivors (the proposal layer keeps only the
  * first post_nms_topN, proposal_layer.py:151-152); 0 = keep all (reference behaviour).  With max_keep << boxes_num the
  * IoU bit matrix is computed in two stream-ordered phases -- the rows the sweep needs first, the rest only if the keep list
- * is still short -- with the same keep list (the workspace holds the matrix plus the parked sweep state).
+ * is still short -- with the same keep list (the workspace holds the matrix, the parked sweep state, and one word per box:
+ * the overlaps with the earlier boxes of its own 64-box chunk, from which the sweep settles a chunk in a few wave-wide steps).
  */
 size_t dtt_nms_workspace_bytes(int boxes_num);
 int dtt_nms(int* keep_out, int* num_out, const float* boxes, int boxes_num, int boxes_dim,
@@ -239,8 +240,11 @@ int dtt_proposal_forward(const float* cls_prob, const float* bbox_pred, const fl
  * a side stream right after the RPN softmax, while the box-delta convolution still runs on the main stream):
  *   dtt_proposal_select_sort  reads the scores only: per image, the pre_nms_topN best (score, anchor) keys in order -> workspace
  *   dtt_proposal_decode_nms   decodes + clips those anchors' boxes (bbox_pred, im_info, anchors), NMS, writes rois_out / num_out
- * Both take the geometry arguments and the workspace of dtt_proposal_forward (which is exactly phase 1 + phase 2 on one
- * stream); the workspace carries the selection from one to the other. */
+ * Both take the geometry arguments and the workspace of dtt_proposal_forward; the workspace carries the selection from one to
+ * the other.  dtt_proposal_forward gives the same RoIs with fewer launches: having the box deltas at hand, the kernel that
+ * ranks the selected anchors also decodes their boxes.
+ * The selection runs on many workgroups (runs of 1024 anchors sorted in LDS, then ranked against each other: exact
+ * (score desc, anchor index asc) order, no atomics) when K*A <= 38912; larger maps take one workgroup per image. */
 int dtt_proposal_select_sort(const float* cls_prob, int batch, int num_anchors, int height, int width, int pre_nms_topN,
                              void* workspace, size_t workspace_bytes, void* stream);
 int dtt_proposal_decode_nms(const float* bbox_pred, const float* im_info, const float* anchors, int batch, int num_anchors,

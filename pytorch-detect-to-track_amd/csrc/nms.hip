@@ -1,4 +1,4 @@
-// NMS for gfx950: 64x64 IoU bitmask tiles (one wave64 per tile, one uint64 per row) + an on-device
+// NMS for gfx950: 64x64 IoU bitmask tiles (four wave64s per tile, one uint64 per row) + an on-device
 // greedy sweep, so nothing returns to the host.
 //
 // Replaces nms_kernel + nms_cuda_compute (reference nms/src/nms_cuda_kernel.cu:41-161).  The IoU
@@ -27,36 +27,51 @@ __device__ __forceinline__ float dev_iou(const float a0, const float a1, const f
   return interS / (Sa + Sb - interS);
 }
 
-// grid (col_blocks, row_blocks, batch), block 64.  Only tiles with col >= row are produced: the sweep
-// never reads words left of a row's own block (nms_cuda_kernel.cu:139 starts at j = nblock).
+constexpr int kMaskWaves = 4;      // waves per 64 x 64 tile: each takes 16 of the tile's 64 columns
+constexpr int kMaskThreads = kMaskWaves * kTile;
+constexpr int kStateWords = 8;     // sweep state parked behind the bit matrix: [0] done, [1] survivors, [2 ..) removal words
+
+// Words per image behind the n_max x col_blocks bit matrix: the parked sweep state, then one "lower" word per box --
+// the bits of the box's own 64-box chunk BELOW its own position (bit i of lower[r]: box chunk(r) * 64 + i, i < r % 64,
+// overlaps box r; devIoU is symmetric bit for bit, so this is column r of the diagonal tile).  The sweep settles a chunk
+// from these with a few wave-wide steps instead of one scalar step per box.
+__host__ __device__ inline long mask_state_offset(int n_max, int col_blocks) { return (long)n_max * col_blocks; }
+__host__ __device__ inline long mask_lower_offset(int n_max, int col_blocks) { return (long)n_max * col_blocks + col_blocks + kStateWords; }
+
+// grid (col_blocks, row_blocks, batch), block 256 = 4 waves: wave q of a tile computes columns 16q .. 16q+15 of every row
+// and stores its 16 bits of the row's word (the serial column loop is what bounds a tile: 64 dependent IoUs with a true
+// division each).  Only tiles with col >= row are produced: the sweep never reads words left of a row's own block
+// (nms_cuda_kernel.cu:139 starts at j = nblock).
 // A workgroup owns column block col_block0 + blockIdx.x and the row blocks row_block0 + blockIdx.y, + gridDim.y, ... < row_block_end
 // (one tile per workgroup in the usual launch; the second phase of a two-phase NMS uses a short grid that loops, so that
 // the images the first phase finished cost a few hundred workgroup exits instead of tens of thousands).
-__global__ __launch_bounds__(kTile) void nms_mask_kernel(const float* __restrict__ boxes, int boxes_dim,
-                                                          long box_batch_stride, const int* __restrict__ n_per_image,
-                                                          int n_max, float thresh, unsigned long long* __restrict__ mask,
-                                                          long mask_batch_stride, int col_blocks, int row_block0,
-                                                          int row_block_end, int col_block0, int check_done) {
+__global__ __launch_bounds__(kMaskThreads) void nms_mask_kernel(const float* __restrict__ boxes, int boxes_dim,
+                                                                long box_batch_stride, const int* __restrict__ n_per_image,
+                                                                int n_max, float thresh, unsigned long long* __restrict__ mask,
+                                                                long mask_batch_stride, int col_blocks, int row_block0,
+                                                                int row_block_end, int col_block0, int check_done) {
   const int col_start = blockIdx.x + col_block0, img = blockIdx.z;
   // second phase of a two-phase NMS: nothing to do for an image whose sweep already has max_keep survivors
-  if (check_done && mask[img * mask_batch_stride + (long)n_max * col_blocks] != 0ULL) return;
+  if (check_done && mask[img * mask_batch_stride + mask_state_offset(n_max, col_blocks)] != 0ULL) return;
   const int n_boxes = n_per_image ? n_per_image[img] : n_max;
   if (col_start * kTile >= n_boxes) return;
   const float* b = boxes + img * box_batch_stride;
   unsigned long long* m = mask + img * mask_batch_stride;
+  unsigned long long* lower = m + mask_lower_offset(n_max, col_blocks);
   const int col_size = min(n_boxes - col_start * kTile, kTile);
   __shared__ float bb[kTile * 4];
-  const int t = threadIdx.x;
+  const int t = threadIdx.x & (kTile - 1), q = threadIdx.x >> 6;
+  const int i0 = q * (kTile / kMaskWaves), i1 = min(i0 + kTile / kMaskWaves, col_size);
   bool staged = false;
   for (int row_start = row_block0 + blockIdx.y; row_start < row_block_end && row_start <= col_start; row_start += gridDim.y) {
     if (row_start * kTile >= n_boxes) break;
-    if (!staged) {   // (uniform: the loop bounds do not depend on the lane)
-      if (t < col_size) {
-        const float* p = b + (long)(kTile * col_start + t) * boxes_dim;
-        bb[t * 4 + 0] = p[0];
-        bb[t * 4 + 1] = p[1];
-        bb[t * 4 + 2] = p[2];
-        bb[t * 4 + 3] = p[3];
+    if (!staged) {   // (uniform: the loop bounds do not depend on the thread)
+      if (threadIdx.x < col_size) {
+        const float* p = b + (long)(kTile * col_start + threadIdx.x) * boxes_dim;
+        bb[threadIdx.x * 4 + 0] = p[0];
+        bb[threadIdx.x * 4 + 1] = p[1];
+        bb[threadIdx.x * 4 + 2] = p[2];
+        bb[threadIdx.x * 4 + 3] = p[3];
       }
       __syncthreads();
       staged = true;
@@ -66,13 +81,23 @@ __global__ __launch_bounds__(kTile) void nms_mask_kernel(const float* __restrict
       const int cur = kTile * row_start + t;
       const float* p = b + (long)cur * boxes_dim;
       const float a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3];
-      unsigned long long bits = 0;
-      const int start = (row_start == col_start) ? t + 1 : 0;
-      for (int i = start; i < col_size; ++i) {
+      unsigned bits = 0;
+      for (int i = i0; i < i1; ++i) {
         if (dev_iou(a0, a1, a2, a3, bb[i * 4 + 0], bb[i * 4 + 1], bb[i * 4 + 2], bb[i * 4 + 3]) > thresh)
-          bits |= 1ULL << i;
+          bits |= 1u << (i - i0);
       }
-      m[(long)cur * col_blocks + col_start] = bits;
+      unsigned short* word = reinterpret_cast<unsigned short*>(m + (long)cur * col_blocks + col_start);
+      if (row_start == col_start) {
+        // diagonal tile: the row's word keeps the bits above its own position (.cu:98 starts at threadIdx.x + 1), the bits
+        // below go to the box's "lower" word
+        const unsigned long long full = (unsigned long long)bits << i0;
+        const unsigned long long above = (t == kTile - 1) ? 0ULL : (~0ULL << (t + 1));
+        const unsigned long long below = (1ULL << t) - 1ULL;
+        word[q] = (unsigned short)((full & above) >> i0);
+        reinterpret_cast<unsigned short*>(lower + cur)[q] = (unsigned short)((full & below) >> i0);
+      } else {
+        word[q] = (unsigned short)bits;
+      }
     }
   }
 }
@@ -118,7 +143,8 @@ __global__ __launch_bounds__(kSweepThreads) void nms_sweep_kernel(
   const int img = blockIdx.x;
   const int n = n_per_image ? n_per_image[img] : n_max;
   const unsigned long long* m = mask + img * mask_batch_stride;
-  unsigned long long* state = mask + img * mask_batch_stride + (long)n_max * col_blocks;   // [0] done, [1] total, [2..] remv
+  unsigned long long* state = mask + img * mask_batch_stride + mask_state_offset(n_max, col_blocks);   // [0] done, [1] total, [2..] remv
+  const unsigned long long* lower = mask + img * mask_batch_stride + mask_lower_offset(n_max, col_blocks);
   int* keep = keep_out ? keep_out + img * keep_batch_stride : nullptr;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int cb = (n + kTile - 1) / kTile;
@@ -158,20 +184,21 @@ __global__ __launch_bounds__(kSweepThreads) void nms_sweep_kernel(
     const int rows = min(kSuper, n - base);
     const int w0 = sc * kSuperWords;
     const int nw = min(kSuperWords, cb - w0);
-    // ---- A: stage the diagonal super-block (unconditional loads, 4 in flight per thread; words left
+    // ---- A: stage the diagonal super-block (unconditional loads, 16 in flight per thread; words left
     //         of a row's own block were never written by the mask kernel and are replaced by 0)
     {
       const int total = rows * nw;
-      for (int i0 = tid; i0 < total; i0 += 4 * kSweepThreads) {
-        unsigned long long v[4];
+      constexpr int NL = 16;   // loads in flight per thread: a full 1024 x 16-word super-block is ONE round trip
+      for (int i0 = tid; i0 < total; i0 += NL * kSweepThreads) {
+        unsigned long long v[NL];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < NL; ++u) {
           const int idx = min(i0 + u * kSweepThreads, total - 1);
           const int r = idx / nw, j = idx - r * nw;
           v[u] = m[(long)(base + r) * col_blocks + w0 + j];
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < NL; ++u) {
           const int idx = i0 + u * kSweepThreads;
           if (idx < total) {
             const int r = idx / nw, j = idx - r * nw;
@@ -181,30 +208,32 @@ __global__ __launch_bounds__(kSweepThreads) void nms_sweep_kernel(
       }
     }
     __syncthreads();
-    // ---- B: serial part, wave 0 only.  Lanes 0..15 hold the removal words of this super-chunk in a
-    //         register (R); per chunk the keep decision only iterates over alive boxes whose diagonal
-    //         word is non-zero (a box that suppresses nothing inside its chunk cannot change the outcome
-    //         of its neighbours), then lane j ORs the kept rows' word j into R with plain LDS reads.
+    // ---- B: serial part, wave 0 only.  Lanes 0..15 hold the removal words of this super-chunk in a register (R).  A chunk
+    //         of 64 boxes is settled from the boxes' "lower" words L (bit i of L[j]: box i < j of the chunk overlaps box j):
+    //         kept = alive & ~{ j : L[j] & kept != 0 } iterated from kept = alive.  The dependence only runs from lower to
+    //         higher positions, so after k steps the first k positions are final and a repeated value is THE greedy answer
+    //         (nms_cuda_kernel.cu:131-144); it takes as many steps as the longest chain of boxes that flip each other
+    //         (a handful) instead of one scalar step per alive box.  Then lane (j, quarter) ORs word j of the kept rows of
+    //         its quarter of the chunk (LDS reads, 4 in flight) and the quarters meet in lane j.
     if (wave == 0) {
       int total = __builtin_amdgcn_readfirstlane(ctl[1]);
       int nk = 0;
       bool done = false;
       unsigned long long R = (lane < nw) ? remv[w0 + lane] : 0ULL;
+      unsigned long long Lnext = lane < rows ? lower[base + lane] : 0ULL;
       for (int c = 0; c < nw && !done; ++c) {
         const unsigned long long r = readlane64(R, c);
         const int rows_c = min(kTile, rows - c * kTile);
         const unsigned long long valid = rows_c == kTile ? ~0ULL : ((1ULL << rows_c) - 1ULL);
-        const unsigned long long d = (lane < rows_c) ? sb[(c * kTile + lane) * kRowStride + c] : 0ULL;
-        const unsigned long long nz = __ballot(d != 0ULL);
-        unsigned long long alive = ~r & valid;
-        unsigned long long cand = alive & nz;
-        while (cand != 0) {
-          const int i = __builtin_ctzll(cand);
-          alive &= ~readlane64(d, i);  // d_i only has bits above i (mask kernel starts at t + 1)
-          const unsigned long long above = (i == 63) ? 0ULL : (~0ULL << (i + 1));
-          cand = alive & nz & above;
-        }
+        const unsigned long long L = Lnext;
+        if (c + 1 < nw) Lnext = ((c + 1) * kTile + lane < rows) ? lower[base + (c + 1) * kTile + lane] : 0ULL;   // in flight during this chunk
+        const unsigned long long alive = ~r & valid;
         unsigned long long kept = alive;
+        for (;;) {
+          const unsigned long long next = alive & ~__ballot((L & kept) != 0ULL);
+          if (next == kept) break;
+          kept = next;
+        }
         const int room = limit - total;
         for (int extra = __builtin_popcountll(kept) - room; extra > 0; --extra)
           kept &= ~(1ULL << (63 - __builtin_clzll(kept)));
@@ -218,22 +247,26 @@ __global__ __launch_bounds__(kSweepThreads) void nms_sweep_kernel(
         total += nkept;
         if (total >= limit) done = true;
         if (!done && c + 1 < nw) {
-          const bool owner = lane > c && lane < nw;
-          const unsigned long long* col = sb + (size_t)(c * kTile) * kRowStride + (owner ? lane : 0);
-          unsigned long long kk = kept, accw = 0;
-          while (kk != 0) {
+          const int j = lane & 15, quarter = lane >> 4;
+          const bool owner = j > c && j < nw;
+          const unsigned long long* col = sb + (size_t)(c * kTile + quarter * 16) * kRowStride + (owner ? j : 0);
+          unsigned kk = (unsigned)(kept >> (quarter * 16)) & 0xFFFFu;
+          unsigned long long accw = 0;
+          while (__any(kk != 0)) {
             unsigned long long v[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
               if (kk != 0) {
-                const int i = __builtin_ctzll(kk);
+                const int i = __builtin_ctz(kk);
                 kk &= kk - 1;
                 v[u] = col[i * kRowStride];
               }
             }
             accw |= (v[0] | v[1]) | (v[2] | v[3]);
           }
-          if (owner) R |= accw;
+          accw |= __shfl_xor(accw, 16);
+          accw |= __shfl_xor(accw, 32);
+          if (owner && quarter == 0) R |= accw;
         }
       }
       if (lane == 0) { ctl[0] = nk; ctl[1] = total; ctl[2] = done ? 1 : 0; }
@@ -312,7 +345,8 @@ size_t sweep_lds_bytes(int col_blocks) {
 size_t dtt_nms_mask_bytes(int boxes_num) {
   const long cb = (boxes_num + kTile - 1) / kTile;
   // the bit matrix + the parked sweep state of a two-phase run (done flag, survivor count, removal words)
-  return ((size_t)(boxes_num > 0 ? boxes_num : 1) * (size_t)(cb > 0 ? cb : 1) + (size_t)(cb > 0 ? cb : 1) + 8) * sizeof(unsigned long long);
+  const size_t n = boxes_num > 0 ? boxes_num : 1, c = cb > 0 ? cb : 1;
+  return (n * c + c + kStateWords + n) * sizeof(unsigned long long);
 }
 
 // Two phases when few survivors are wanted (the proposal layer keeps 300 of 6000): the sweep visits boxes in score order
@@ -358,7 +392,7 @@ int dtt_nms_phase1(const float* boxes, int boxes_dim, long box_batch_stride, con
   const int n_super = (n_max + kSuper - 1) / kSuper;
   const int rb1 = split ? min(cb, split * kSuperWords) : cb;   // row AND column blocks of the first mask launch
   dtt_prof_begin("nms_mask", stream);
-  hipLaunchKernelGGL(nms_mask_kernel, dim3(rb1, rb1, batch), dim3(kTile), 0, stream, boxes, boxes_dim, box_batch_stride,
+  hipLaunchKernelGGL(nms_mask_kernel, dim3(rb1, rb1, batch), dim3(kMaskThreads), 0, stream, boxes, boxes_dim, box_batch_stride,
                      n_per_image, n_max, thresh, mask, mask_batch_stride, cb, 0, rb1, 0, 0);
   dtt_prof_end("nms_mask", stream);
   DTT_CHECK_LAUNCH("nms_mask_kernel");
@@ -382,7 +416,7 @@ int dtt_nms_phase2(const float* boxes, int boxes_dim, long box_batch_stride, con
   const int n_super = (n_max + kSuper - 1) / kSuper;
   const int rb1 = min(cb, split * kSuperWords);
   if (cb > rb1) {   // column blocks rb1 .. cb-1, all their rows (a short grid that loops over the row blocks)
-    hipLaunchKernelGGL(nms_mask_kernel, dim3(cb - rb1, 8, batch), dim3(kTile), 0, stream, boxes, boxes_dim, box_batch_stride,
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(cb - rb1, 8, batch), dim3(kMaskThreads), 0, stream, boxes, boxes_dim, box_batch_stride,
                        n_per_image, n_max, thresh, mask, mask_batch_stride, cb, 0, cb, rb1, 1);
     DTT_CHECK_LAUNCH("nms_mask_kernel (phase 2)");
   }

@@ -67,11 +67,11 @@ __host__ __device__ constexpr int sort_slots(int P) { return P + (P >> 3); }
 // NST consecutive stages (j = jlow << (NST-1), ..., 2*jlow, jlow) of bitonic phase k in ONE pass over LDS: a thread loads
 // the 2^NST keys that only exchange among themselves in these stages, runs the compare-exchanges in registers and stores
 // them back -- 35 barrier-separated passes for 8192 keys instead of 91.
-template <int NST>
+template <int NST, int NT = kThreads>
 __device__ __forceinline__ void bitonic_pass(unsigned long long* __restrict__ buf, int P, int k, int jlow, int tid) {
   constexpr int G = 1 << NST;
   const int plow = __builtin_ctz(jlow);
-  for (int gi = tid; gi < (P >> NST); gi += kThreads) {
+  for (int gi = tid; gi < (P >> NST); gi += NT) {
     const int base = ((gi >> plow) << (plow + NST)) | (gi & (jlow - 1));
     const bool up = (base & k) == 0;
     unsigned long long v[G];
@@ -270,20 +270,9 @@ __global__ __launch_bounds__(kThreads) void proposal_select_sort(const float* __
 #endif
 }
 
-// Decode + clip the survivors (bbox_transform.py:108-134, 156-173), one thread per (image, rank).
-// Ranks [r0, r1) of every image; with `done` (the NMS's per-image flags, `done_stride` words apart) images whose NMS has
-// finished are skipped (second half of a two-phase run).
-__global__ __launch_bounds__(256) void proposal_decode(const unsigned* __restrict__ order, const float* __restrict__ bbox_pred,
-                                                       const float* __restrict__ im_info, const float* __restrict__ anchors,
-                                                       PropGeom g, float* __restrict__ boxes_out, int r0, int r1,
-                                                       const unsigned long long* __restrict__ done, long done_stride) {
-  const int b = blockIdx.y, r = r0 + blockIdx.x * 256 + threadIdx.x;
-  if (r >= r1) return;
-  if (done && done[b * done_stride] != 0ULL) return;
-  const float im_h = im_info[b * 3 + 0], im_w = im_info[b * 3 + 1];
-  const float xmax = im_w - 1.0f, ymax = im_h - 1.0f;
-  const float* dl = bbox_pred + (long)b * 4 * g.A * g.K;
-  const unsigned t = order[(long)b * g.topn + r];
+// Decode + clip one box (bbox_transform.py:108-134, 156-173): flattened anchor index t = k * A + a of image b.
+__device__ __forceinline__ float4 decode_box(unsigned t, const float* __restrict__ dl, const float* __restrict__ anchors,
+                                             const PropGeom& g, float xmax, float ymax) {
   const int k = t / g.A, a = t - k * g.A;
   const int h = k / g.W, w = k - h * g.W;
   const float sx = (float)(w * g.feat_stride), sy = (float)(h * g.feat_stride);
@@ -301,7 +290,174 @@ __global__ __launch_bounds__(256) void proposal_decode(const unsigned* __restric
   o.y = fminf(fmaxf(pcy - 0.5f * ph, 0.f), ymax);
   o.z = fminf(fmaxf(pcx + 0.5f * pw, 0.f), xmax);
   o.w = fminf(fmaxf(pcy + 0.5f * ph, 0.f), ymax);
-  reinterpret_cast<float4*>(boxes_out)[(long)b * g.topn + r] = o;
+  return o;
+}
+
+// Decode + clip the survivors, one thread per (image, rank).
+// Ranks [r0, r1) of every image; with `done` (the NMS's per-image flags, `done_stride` words apart) images whose NMS has
+// finished are skipped (second half of a two-phase run).
+__global__ __launch_bounds__(256) void proposal_decode(const unsigned* __restrict__ order, const float* __restrict__ bbox_pred,
+                                                       const float* __restrict__ im_info, const float* __restrict__ anchors,
+                                                       PropGeom g, float* __restrict__ boxes_out, int r0, int r1,
+                                                       const unsigned long long* __restrict__ done, long done_stride) {
+  const int b = blockIdx.y, r = r0 + blockIdx.x * 256 + threadIdx.x;
+  if (r >= r1) return;
+  if (done && done[b * done_stride] != 0ULL) return;
+  const float im_h = im_info[b * 3 + 0], im_w = im_info[b * 3 + 1];
+  const unsigned t = order[(long)b * g.topn + r];
+  reinterpret_cast<float4*>(boxes_out)[(long)b * g.topn + r] =
+      decode_box(t, bbox_pred + (long)b * 4 * g.A * g.K, anchors, g, im_w - 1.0f, im_h - 1.0f);
+}
+
+// ---- The selection on many workgroups (round 3): runs of 1024 keys sorted locally, then ranked against each other.
+//
+// The one-workgroup-per-image kernel above takes 85 us for 30552 anchors (32 bisection rounds + a 8192-key bitonic sort on 4
+// CUs of 256).  Here the image's keys are cut into runs of kRun CONSECUTIVE FLATTENED ANCHOR INDICES t (so that the tie-break
+// "lower t first" between two runs is just "lower run first", and within a run "lower position first"):
+//   proposal_sort_runs     one 256-thread workgroup per run: keys (descending score) + position sorted in LDS, written as
+//                          32-bit keys and the t they belong to;
+//   proposal_rank_scatter  every workgroup stages ALL sorted runs' keys of its image in LDS (4 B x n <= 152 KB) and ranks two
+//                          run: rank = own position + sum over the other runs of a binary search (count of keys <= mine in earlier
+//                          runs, < mine in later runs) -- the exact position in the (score desc, t asc) order.  A lane stops
+//                          as soon as its rank reaches topn (most anchors: the lanes of a wave hold neighbours of one sorted
+//                          run, so they stop together).  Ranks below topn write order[rank] = t and, when the box deltas are
+//                          at hand, the decoded box.
+// No atomics, no cross-workgroup protocol: the second kernel only reads what the first wrote.
+constexpr int kRun = 1024;
+constexpr int kRunThreads = 256;
+constexpr int kMaxRuns = 38;   // kMaxRuns * kRun * 4 B of LDS in proposal_rank_scatter
+
+__global__ __launch_bounds__(kRunThreads) void proposal_sort_runs(const float* __restrict__ cls_prob, PropGeom g, int nruns,
+                                                                  unsigned* __restrict__ rkeys, unsigned* __restrict__ rts) {
+  __shared__ unsigned long long buf[sort_slots(kRun)];
+  const int w = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const float* sc = cls_prob + ((long)b * 2 * g.A + g.A) * g.K;  // fg scores: channels A .. 2A-1
+#pragma unroll
+  for (int e = 0; e < kRun / kRunThreads; ++e) {
+    const int i = tid + e * kRunThreads;
+    const int t = w * kRun + i;
+    unsigned key = 0xFFFFFFFFu;
+    if (t < g.n) {
+      const int k = t / g.A, a = t - k * g.A;
+      key = desc_key(sc[(long)a * g.K + k]);
+    }
+    buf[sort_slot(i)] = ((unsigned long long)key << 32) | (unsigned)(t < g.n ? i : 0xFFFFFFFFu);
+  }
+  __syncthreads();
+  for (int k = 2; k <= kRun; k <<= 1) {
+    int j = k >> 1;
+    while (j > 0) {
+      if (j >= 4) { bitonic_pass<3, kRunThreads>(buf, kRun, k, j >> 2, tid); j >>= 3; }
+      else if (j == 2) { bitonic_pass<2, kRunThreads>(buf, kRun, k, 1, tid); j = 0; }
+      else { bitonic_pass<1, kRunThreads>(buf, kRun, k, 1, tid); j = 0; }
+      __syncthreads();
+    }
+  }
+  unsigned* ko = rkeys + ((long)b * nruns + w) * kRun;
+  unsigned* to = rts + ((long)b * nruns + w) * kRun;
+#pragma unroll
+  for (int e = 0; e < kRun / kRunThreads; ++e) {
+    const int i = tid + e * kRunThreads;
+    const unsigned long long v = buf[sort_slot(i)];
+    const unsigned lo = (unsigned)v;
+    ko[i] = (unsigned)(v >> 32);
+    to[i] = lo == 0xFFFFFFFFu ? 0xFFFFFFFFu : (unsigned)(w * kRun) + lo;
+  }
+}
+
+constexpr int kRankThreads = 1024;  // one position of each of the workgroup's runs per thread
+constexpr int kRunsPerWg = 2;       // few, fat workgroups.  Alone on the chip one run per workgroup is faster (16 us against 24), but
+                                    // the layer runs BESIDE the conv4 correlation (two rounds of workgroups on 240 CUs): 60 waiting
+                                    // rank workgroups take the CUs its second round needs (conv4 60 -> 72 us), 30 do not
+
+constexpr int kRunsInFlight = 8;    // independent binary searches per thread (the search is a chain of dependent LDS reads)
+
+template <bool DECODE>
+__global__ __launch_bounds__(kRankThreads) void proposal_rank_scatter(const unsigned* __restrict__ rkeys, const unsigned* __restrict__ rts,
+                                                                      PropGeom g, int nruns, unsigned* __restrict__ order,
+                                                                      const float* __restrict__ bbox_pred,
+                                                                      const float* __restrict__ im_info,
+                                                                      const float* __restrict__ anchors, float* __restrict__ boxes) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned* lk = reinterpret_cast<unsigned*>(smem);   // [nruns][kRun]
+  const int b = blockIdx.y, tid = threadIdx.x, pos = tid;
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(rkeys + (long)b * nruns * kRun);
+    uint4* dst = reinterpret_cast<uint4*>(lk);
+    const int total = nruns * (kRun / 4);
+    for (int i0 = tid; i0 < total; i0 += 8 * kRankThreads) {   // 8 loads in flight per thread: the whole image in one round trip
+      uint4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = src[min(i0 + u * kRankThreads, total - 1)];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (i0 + u * kRankThreads < total) dst[i0 + u * kRankThreads] = v[u];
+    }
+  }
+  __syncthreads();
+  int w[kRunsPerWg], rank[kRunsPerWg];
+  unsigned key[kRunsPerWg];
+#pragma unroll
+  for (int q = 0; q < kRunsPerWg; ++q) {
+    w[q] = blockIdx.x * kRunsPerWg + q;
+    const bool have = w[q] < nruns;
+    key[q] = have ? lk[w[q] * kRun + pos] : 0u;
+    rank[q] = have ? 0 : g.topn;   // (a run past the end: never live)
+  }
+#pragma unroll 1
+  for (int r0 = 0; r0 < nruns; r0 += kRunsInFlight) {
+    bool live = false;
+#pragma unroll
+    for (int q = 0; q < kRunsPerWg; ++q) live = live || rank[q] < g.topn;
+    if (!__any(live)) break;
+#pragma unroll
+    for (int q = 0; q < kRunsPerWg; ++q) {
+      // count of keys that precede mine in runs r0 .. r0+7: x <= key in an earlier run, x < key in a later one, my own
+      // position in my own run
+      const unsigned* a[kRunsInFlight];
+      bool le[kRunsInFlight];
+      int lo[kRunsInFlight];
+#pragma unroll
+      for (int u = 0; u < kRunsInFlight; ++u) {
+        const int r = min(r0 + u, nruns - 1);
+        a[u] = lk + r * kRun;
+        le[u] = r < w[q];
+        lo[u] = 0;
+      }
+#pragma unroll
+      for (int s = kRun / 2; s > 0; s >>= 1) {
+        unsigned x[kRunsInFlight];
+#pragma unroll
+        for (int u = 0; u < kRunsInFlight; ++u) x[u] = a[u][lo[u] + s - 1];
+#pragma unroll
+        for (int u = 0; u < kRunsInFlight; ++u) lo[u] += (x[u] < key[q] || (le[u] && x[u] == key[q])) ? s : 0;
+      }
+      {
+        unsigned x[kRunsInFlight];
+#pragma unroll
+        for (int u = 0; u < kRunsInFlight; ++u) x[u] = a[u][lo[u]];
+#pragma unroll
+        for (int u = 0; u < kRunsInFlight; ++u) lo[u] += (x[u] < key[q] || (le[u] && x[u] == key[q])) ? 1 : 0;
+      }
+#pragma unroll
+      for (int u = 0; u < kRunsInFlight; ++u) {
+        const int r = r0 + u;
+        rank[q] += r >= nruns ? 0 : (r == w[q] ? pos : lo[u]);
+      }
+    }
+  }
+  float xmax = 0.f, ymax = 0.f;
+  if constexpr (DECODE) { ymax = im_info[b * 3 + 0] - 1.0f; xmax = im_info[b * 3 + 1] - 1.0f; }
+#pragma unroll
+  for (int q = 0; q < kRunsPerWg; ++q) {
+    if (rank[q] >= g.topn) continue;
+    const unsigned t = rts[((long)b * nruns + w[q]) * kRun + pos];
+    if (t == 0xFFFFFFFFu) continue;   // padding of the last run
+    order[(long)b * g.topn + rank[q]] = t;
+    if constexpr (DECODE)
+      reinterpret_cast<float4*>(boxes)[(long)b * g.topn + rank[q]] =
+          decode_box(t, bbox_pred + (long)b * 4 * g.A * g.K, anchors, g, xmax, ymax);
+  }
 }
 
 int next_pow2(int v) {
@@ -332,7 +488,8 @@ namespace {
 // workspace: boxes (B, topn, 4) | NMS mask | keep | num | order (B, topn)
 struct PropPlan {
   PropGeom g;
-  size_t off_mask, off_keep, off_num, off_order, total, mask_per_image;
+  size_t off_mask, off_keep, off_num, off_order, off_rkeys, off_rts, total, mask_per_image;
+  int nruns;   // > 0: the selection runs on many workgroups (proposal_sort_runs + proposal_rank_scatter)
 };
 
 PropPlan plan_proposal(int batch, int num_anchors, int height, int width, int feat_stride, int pre_nms_topN) {
@@ -348,6 +505,12 @@ PropPlan plan_proposal(int batch, int num_anchors, int height, int width, int fe
   p.off_num = p.off_keep + align_up((size_t)batch * g.topn * sizeof(int), 256);
   p.off_order = p.off_num + 256;
   p.total = p.off_order + align_up((size_t)batch * g.topn * sizeof(unsigned), 256);
+  static const bool one_wg = getenv("DTT_PROPOSAL_ONE_WG") != nullptr;   // developer A/B switch: the one-workgroup-per-image selection
+  const int nruns = (g.n + kRun - 1) / kRun;
+  p.nruns = (nruns <= kMaxRuns && g.P <= kMaxSort && !one_wg) ? nruns : 0;
+  p.off_rkeys = p.total;
+  p.off_rts = p.off_rkeys + align_up((size_t)batch * nruns * kRun * sizeof(unsigned), 256);
+  p.total = p.off_rts + align_up((size_t)batch * nruns * kRun * sizeof(unsigned), 256);
   return p;
 }
 
@@ -356,6 +519,39 @@ PropPlan plan_proposal(int batch, int num_anchors, int height, int width, int fe
 extern "C" size_t dtt_proposal_workspace_bytes(int batch, int num_anchors, int height, int width,
                                                int pre_nms_topN) {
   return plan_proposal(batch, num_anchors, height, width, 1, pre_nms_topN).total;
+}
+
+// The selection on many workgroups; with bbox_pred also decodes the selected boxes into the workspace.
+static int select_runs(const PropPlan& p, const float* cls_prob, const float* bbox_pred, const float* im_info, const float* anchors,
+                       int batch, unsigned char* w, hipStream_t stream) {
+  const PropGeom& g = p.g;
+  unsigned* order = reinterpret_cast<unsigned*>(w + p.off_order);
+  unsigned* rkeys = reinterpret_cast<unsigned*>(w + p.off_rkeys);
+  unsigned* rts = reinterpret_cast<unsigned*>(w + p.off_rts);
+  float* boxes = reinterpret_cast<float*>(w);
+  const size_t lds = (size_t)p.nruns * kRun * sizeof(unsigned);
+  static DttDeviceOnce attr_once;
+  bool& attr = attr_once.here();
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(proposal_rank_scatter<true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(proposal_rank_scatter<false>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    DTT_REQUIRE(e == hipSuccess && e2 == hipSuccess, "proposal: cannot raise dynamic LDS limit");
+    attr = true;
+  }
+  dtt_prof_begin("proposal_select_sort", stream);
+  hipLaunchKernelGGL(proposal_sort_runs, dim3(p.nruns, batch), dim3(kRunThreads), 0, stream, cls_prob, g, p.nruns, rkeys, rts);
+  DTT_CHECK_LAUNCH("proposal_sort_runs");
+  if (bbox_pred)
+    hipLaunchKernelGGL(proposal_rank_scatter<true>, dim3((p.nruns + kRunsPerWg - 1) / kRunsPerWg, batch), dim3(kRankThreads), lds, stream, rkeys, rts, g, p.nruns,
+                       order, bbox_pred, im_info, anchors, boxes);
+  else
+    hipLaunchKernelGGL(proposal_rank_scatter<false>, dim3((p.nruns + kRunsPerWg - 1) / kRunsPerWg, batch), dim3(kRankThreads), lds, stream, rkeys, rts, g, p.nruns,
+                       order, nullptr, nullptr, nullptr, nullptr);
+  dtt_prof_end("proposal_select_sort", stream);
+  DTT_CHECK_LAUNCH("proposal_rank_scatter");
+  return 1;
 }
 
 // Phase 1 of the proposal layer: per image, the pre_nms_topN best (score, anchor) keys in order -> workspace.  Reads the
@@ -369,6 +565,8 @@ extern "C" int dtt_proposal_select_sort(const float* cls_prob, int batch, int nu
   const PropGeom& g = p.g;
   DTT_REQUIRE(g.P <= kMaxSort, "proposal: %d boxes per image exceed the %d-entry LDS sort", g.topn, kMaxSort);
   DTT_REQUIRE(workspace && workspace_bytes >= p.total, "proposal: workspace too small (%zu < %zu)", workspace_bytes, p.total);
+  DTT_REQUIRE(batch <= 65535, "proposal: more than 65535 images in one call");
+  if (p.nruns) return select_runs(p, cls_prob, nullptr, nullptr, nullptr, batch, static_cast<unsigned char*>(workspace), stream);
   unsigned* order = reinterpret_cast<unsigned*>(static_cast<unsigned char*>(workspace) + p.off_order);
   const size_t lds = (size_t)sort_slots(g.P) * 8 + (96 + 8) * 4;
   static DttDeviceOnce attr_once;
@@ -392,10 +590,10 @@ extern "C" int dtt_proposal_select_sort(const float* cls_prob, int batch, int nu
 }
 
 // Phase 2: decode + clip the boxes phase 1 selected (same geometry arguments, same workspace), NMS, RoI tensor.
-extern "C" int dtt_proposal_decode_nms(const float* bbox_pred, const float* im_info, const float* anchors, int batch,
-                                       int num_anchors, int height, int width, int feat_stride, int pre_nms_topN,
-                                       int post_nms_topN, float nms_thresh, float* rois_out, int* num_out, void* workspace,
-                                       size_t workspace_bytes, void* stream_) {
+static int decode_nms(const float* bbox_pred, const float* im_info, const float* anchors, int batch,
+                      int num_anchors, int height, int width, int feat_stride, int pre_nms_topN,
+                      int post_nms_topN, float nms_thresh, float* rois_out, int* num_out, void* workspace,
+                      size_t workspace_bytes, void* stream_, bool boxes_ready) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   DTT_REQUIRE(bbox_pred && im_info && anchors && rois_out, "proposal: null pointer");
   DTT_REQUIRE(batch > 0 && num_anchors > 0 && height > 0 && width > 0 && feat_stride > 0, "proposal: bad shape");
@@ -416,15 +614,17 @@ extern "C" int dtt_proposal_decode_nms(const float* bbox_pred, const float* im_i
   const long mask_stride = (long)(p.mask_per_image / sizeof(unsigned long long));
   const int split = dtt_nms_split(g.topn, post_nms_topN, 1);
   const int first = split ? min(g.topn, split * 1024) : g.topn;
-  hipLaunchKernelGGL(proposal_decode, dim3((first + 255) / 256, batch), dim3(256), 0, stream, order, bbox_pred, im_info, anchors, g,
-                     boxes, 0, first, nullptr, 0L);
-  DTT_CHECK_LAUNCH("proposal_decode");
+  if (!boxes_ready) {
+    hipLaunchKernelGGL(proposal_decode, dim3((first + 255) / 256, batch), dim3(256), 0, stream, order, bbox_pred, im_info, anchors, g,
+                       boxes, 0, first, nullptr, 0L);
+    DTT_CHECK_LAUNCH("proposal_decode");
+  }
   int* nout = num_out ? num_out : num_ws;
   if (!dtt_nms_phase1(boxes, 4, (long)g.topn * 4, nullptr, g.topn, batch, nms_thresh, post_nms_topN, mask, mask_stride, keep, g.topn,
                       nout, rois_out, post_nms_topN, split, stream))
     return 0;
   if (!split) return 1;
-  if (g.topn > first) {
+  if (g.topn > first && !boxes_ready) {
     const long cbw = (g.topn + 63) / 64;
     hipLaunchKernelGGL(proposal_decode, dim3((g.topn - first + 255) / 256, batch), dim3(256), 0, stream, order, bbox_pred, im_info,
                        anchors, g, boxes, first, g.topn, mask + (long)g.topn * cbw, mask_stride);
@@ -434,6 +634,14 @@ extern "C" int dtt_proposal_decode_nms(const float* bbox_pred, const float* im_i
                         nout, rois_out, post_nms_topN, split, stream);
 }
 
+extern "C" int dtt_proposal_decode_nms(const float* bbox_pred, const float* im_info, const float* anchors, int batch,
+                                       int num_anchors, int height, int width, int feat_stride, int pre_nms_topN,
+                                       int post_nms_topN, float nms_thresh, float* rois_out, int* num_out, void* workspace,
+                                       size_t workspace_bytes, void* stream_) {
+  return decode_nms(bbox_pred, im_info, anchors, batch, num_anchors, height, width, feat_stride, pre_nms_topN, post_nms_topN,
+                    nms_thresh, rois_out, num_out, workspace, workspace_bytes, stream_, false);
+}
+
 extern "C" int dtt_proposal_forward(const float* cls_prob, const float* bbox_pred, const float* im_info,
                                     const float* anchors, int batch, int num_anchors, int height, int width,
                                     int feat_stride, int pre_nms_topN, int post_nms_topN, float nms_thresh,
@@ -441,6 +649,18 @@ extern "C" int dtt_proposal_forward(const float* cls_prob, const float* bbox_pre
                                     void* stream_) {
   DTT_REQUIRE(cls_prob && bbox_pred && im_info && anchors && rois_out, "proposal: null pointer");
   DTT_REQUIRE(post_nms_topN > 0, "proposal: post_nms_topN must be > 0");
+  DTT_REQUIRE(batch > 0 && num_anchors > 0 && height > 0 && width > 0 && feat_stride > 0, "proposal: bad shape");
+  const PropPlan p = plan_proposal(batch, num_anchors, height, width, feat_stride, pre_nms_topN);
+  if (p.nruns) {
+    // scores and box deltas both at hand: the ranking kernel decodes the boxes it selects (no decode launches)
+    DTT_REQUIRE(workspace && workspace_bytes >= p.total, "proposal: workspace too small (%zu < %zu)", workspace_bytes, p.total);
+    DTT_REQUIRE(batch <= 65535, "proposal: more than 65535 images in one call");
+    if (!select_runs(p, cls_prob, bbox_pred, im_info, anchors, batch, static_cast<unsigned char*>(workspace),
+                     static_cast<hipStream_t>(stream_)))
+      return 0;
+    return decode_nms(bbox_pred, im_info, anchors, batch, num_anchors, height, width, feat_stride, pre_nms_topN, post_nms_topN,
+                      nms_thresh, rois_out, num_out, workspace, workspace_bytes, stream_, true);
+  }
   if (!dtt_proposal_select_sort(cls_prob, batch, num_anchors, height, width, pre_nms_topN, workspace, workspace_bytes, stream_))
     return 0;
   return dtt_proposal_decode_nms(bbox_pred, im_info, anchors, batch, num_anchors, height, width, feat_stride, pre_nms_topN,

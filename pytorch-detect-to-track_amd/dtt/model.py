@@ -388,8 +388,8 @@ class _RFCN(nn.Module):
                 rpn_prob, rpn_bbox = rpn_head_gemm(rpn_rows, pm_early.rpn, n_legs * B, top.size(2), top.size(3))
                 side.wait_stream(cur)
                 with torch.cuda.stream(side):
-                    selection = rpn.RPN_proposal.select(rpn_prob, "TEST")
-                    all_rois = rpn.RPN_proposal.finish(selection, rpn_bbox, im_info.view(n_legs * B, -1), "TEST")
+                    # scores and box deltas arrive together: one dtt_proposal_forward (the ranking kernel decodes the boxes)
+                    all_rois = rpn.RPN_proposal((rpn_prob, rpn_bbox, im_info.view(n_legs * B, -1), "TEST"))
             else:
                 conv1, rpn_prob = rpn.head_scores(top, conv1)
                 side.wait_stream(cur)
