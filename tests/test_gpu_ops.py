@@ -483,6 +483,31 @@ def test_proposal_layer_vs_oracle(dev, B, H, W, pre, post):
     np.testing.assert_array_equal(rois.cpu().numpy(), ref)  # bit-exact rows, order and zero padding
 
 
+@pytest.mark.parametrize("H,W,pre,post,quant", [
+    (16, 16, 6000, 300, 16),     # n = 3072 = 3 full runs of 1024, scores on a 1/16 grid: ties within and across runs
+    (2, 43, 700, 100, 8),        # n = 1032: the second run holds 8 keys + padding
+    (38, 67, 6000, 300, 64),     # the benchmark map, ~470 anchors per distinct score
+    (38, 67, 12000, 2000, 0),    # quant 0: every score equal -- the order is the anchor index alone
+    (5, 7, 6000, 300, 4),        # n = 420 < one run, pre_nms_topN > n
+    (60, 60, 6000, 300, 32),     # n = 43200 > 38 runs: the one-workgroup-per-image selection
+])
+def test_proposal_selection_ties_and_run_edges(dev, H, W, pre, post, quant):
+    """The selection's total order is (score descending, flattened anchor index ascending).  The many-workgroup path gets
+    it from sorted runs of 1024 consecutive anchor indices ranked against each other (<= against earlier runs, < against
+    later ones): scores with massive ties across runs, runs that end exactly at n / hold a few keys, a single short run and a
+    map past the LDS capacity must all give the oracle's RoIs bit for bit."""
+    from dtt.rpn import generate_anchors, proposal_forward
+    rng = np.random.RandomState(H * 100 + W + quant)
+    base = generate_anchors(scales=(4, 8, 16, 32))
+    A = base.shape[0]
+    prob, bbox, info = _proposal_inputs(rng, 2, A, H, W)
+    prob = (np.round(prob * quant) / quant if quant else np.full_like(prob, 0.5)).astype(np.float32)
+    ref, nref = ro.proposal_layer(prob, bbox, info, base, 16, pre, post, 0.7, O.nms)
+    rois, num = proposal_forward(cu(prob, dev), cu(bbox, dev), cu(info, dev), torch.from_numpy(base).float(), 16, pre, post, 0.7)
+    np.testing.assert_array_equal(num.cpu().numpy(), nref)
+    np.testing.assert_array_equal(rois.cpu().numpy(), ref)
+
+
 def test_proposal_layer_two_phases_across_streams(dev):
     """_ProposalLayer.select (scores only, side stream) + .finish (box deltas, after a stream dependency) -- the split
     dtt/model.py uses to start the sort under the RPN's box-delta convolution -- is the one-call layer, bit for bit."""
