@@ -372,6 +372,13 @@ int dtt_winograd_output_transform(const float* mm, const float* bias, float* y, 
  * the channels-last trunk and the NCHW maps the operators above read (NHWC -> NCHW: rows = H*W, cols = C), which the
  * reference never needs because its trunk is NCHW throughout (faster_rcnn/resnet.py:325-343).  in != out. */
 int dtt_transpose_batched(const float* in, float* out, int batch, int rows, int cols, void* stream);
+/* n independent row scalings in as few launches as the kernel-argument space allows (48 tensors each):
+ * dst[i][r][c] = src[i][r][c] * scale[i][r], tensor i being rows[i] x cols[i], dense, row-major in memory order (a (K, C, kh, kw)
+ * convolution filter in either NCHW or channels-last memory is K rows of C*kh*kw).  src / scale / dst / rows / cols are HOST
+ * arrays of n entries holding device pointers / extents.  The training trunk folds the frozen BatchNorm scales into ~100
+ * filters per step with it (dtt/fuse.py: _FoldScalesFn, forward and backward), instead of ~100 launch-bound multiplies. */
+int dtt_scale_rows_batch(int n, const float* const* src, const float* const* scale, float* const* dst, const int* rows,
+                         const int* cols, void* stream);
 
 /* Column blocks of a row-major matrix gathered side by side: dst[r][k * ncols + c] = src[k * src_block_rows + r][c] for
  * k < n_blocks, r < rows, c < ncols (dst / src point at the first column of interest; leading dimensions in floats).

@@ -226,6 +226,84 @@ extern "C" int dtt_transpose_batched(const float* in, float* out, int batch, int
   return 1;
 }
 
+namespace {
+
+// ---- many small row-scalings in one launch
+// dst_i[r][c] = src_i[r][c] * scale_i[r] for i < n tensors (rows_i x cols_i, dense, row-major in MEMORY order).  The training
+// trunk folds the frozen BatchNorm scale of every trainable convolution into its filter each step, forward (w * s) and
+// backward (grad * s): ~100 filters of 16 K .. 2.4 M elements.  As one PyTorch multiply each they are ~100 launch-bound
+// kernels per direction (torch._foreach_mul takes its per-tensor slow path for broadcast operands); here the pointers ride
+// in the kernel arguments, kFoldMax tensors per launch, and a workgroup finds its tensor from the prefix sums of the
+// per-tensor workgroup counts.
+constexpr int kFoldMax = 48;
+constexpr int kFoldElems = kThreads * 16;   // elements per workgroup
+struct FoldBatch {
+  const float* src[kFoldMax];
+  const float* scale[kFoldMax];
+  float* dst[kFoldMax];
+  int cols[kFoldMax];
+  long total[kFoldMax];
+  int block0[kFoldMax + 1];
+  int n;
+};
+
+__global__ __launch_bounds__(kThreads) void scale_rows_batch_kernel(FoldBatch fb) {
+  int i = 0;
+  while (i + 1 < fb.n && (int)blockIdx.x >= fb.block0[i + 1]) ++i;   // (uniform: scalar loop)
+  const float* __restrict__ src = fb.src[i];
+  const float* __restrict__ scale = fb.scale[i];
+  float* __restrict__ dst = fb.dst[i];
+  const int cols = fb.cols[i];
+  const long total = fb.total[i];
+  const long e0 = (long)((int)blockIdx.x - fb.block0[i]) * kFoldElems;
+  const bool vec = (cols & 3) == 0 && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
+  if (vec) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long e = e0 + ((long)u * kThreads + threadIdx.x) * 4;
+      if (e < total) {   // (cols % 4 == 0: a float4 never straddles two rows, total % 4 == 0)
+        const float sc = scale[e / cols];
+        float4 v = *reinterpret_cast<const float4*>(src + e);
+        v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+        *reinterpret_cast<float4*>(dst + e) = v;
+      }
+    }
+  } else {
+    for (int u = 0; u < 16; ++u) {
+      const long e = e0 + (long)u * kThreads + threadIdx.x;
+      if (e < total) dst[e] = src[e] * scale[e / cols];
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int dtt_scale_rows_batch(int n, const float* const* src, const float* const* scale, float* const* dst,
+                                    const int* rows, const int* cols, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  DTT_REQUIRE(n >= 0 && (n == 0 || (src && scale && dst && rows && cols)), "scale_rows_batch: null pointer");
+  for (int i0 = 0; i0 < n; i0 += kFoldMax) {
+    FoldBatch fb;
+    fb.n = n - i0 < kFoldMax ? n - i0 : kFoldMax;
+    int blocks = 0;
+    for (int i = 0; i < fb.n; ++i) {
+      DTT_REQUIRE(src[i0 + i] && scale[i0 + i] && dst[i0 + i] && rows[i0 + i] > 0 && cols[i0 + i] > 0,
+                  "scale_rows_batch: tensor %d: null pointer or empty shape", i0 + i);
+      fb.src[i] = src[i0 + i]; fb.scale[i] = scale[i0 + i]; fb.dst[i] = dst[i0 + i];
+      fb.cols[i] = cols[i0 + i];
+      fb.total[i] = (long)rows[i0 + i] * cols[i0 + i];
+      fb.block0[i] = blocks;
+      const long nb = (fb.total[i] + kFoldElems - 1) / kFoldElems;
+      DTT_REQUIRE(nb < (1L << 24) && blocks + nb < (1L << 30), "scale_rows_batch: tensor %d too large", i0 + i);
+      blocks += (int)nb;
+    }
+    fb.block0[fb.n] = blocks;
+    hipLaunchKernelGGL(scale_rows_batch_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, fb);
+    DTT_CHECK_LAUNCH("scale_rows_batch_kernel");
+  }
+  return 1;
+}
+
 // Tracking-head input assembly (rfcn.py:133-140 `torch.cat` of the two legs' box-delta maps, on position-major rows):
 // dst[r][k * ncols + c] = src[k * src_block_rows + r][c] for k < n_blocks, r < rows, c < ncols.  dst / src point at the
 // first column of interest; leading dimensions in floats; everything 16-byte aligned, ncols % 4 == 0.

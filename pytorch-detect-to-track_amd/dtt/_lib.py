@@ -59,6 +59,7 @@ SIGNATURES = {
     "dtt_bias_act_inplace": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "dtt_bias_act_nhwc_inplace": (_I, [_P, _P, _P, _L, _I, _I, _P]),
     "dtt_transpose_batched": (_I, [_P, _P, _I, _I, _I, _P]),
+    "dtt_scale_rows_batch": (_I, [_I, _P, _P, _P, _P, _P, _P]),
     "dtt_gather_column_blocks": (_I, [_P, _L, _P, _L, _L, _I, _L, _I, _P]),
     "dtt_maxpool3s2_bias_relu_nhwc": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "dtt_gemm_batched": (_I, [_P, _P, _P, _I, _L, _I, _I, _P, _Z, _P]),

@@ -102,6 +102,26 @@ cfg = AttrDict({
 })
 
 
+import copy as _copy
+
+_DEFAULTS = _copy.deepcopy(cfg)
+
+
+def reset_cfg():
+    """Put the process-wide cfg back to its import-time values, in place (every module holds a reference to the same
+    object).  For processes that run several independent configurations one after the other -- the test suite."""
+    def put(live, saved):
+        for k in [k for k in live if k not in saved]:
+            del live[k]
+        for k, v in saved.items():
+            if isinstance(v, AttrDict) and isinstance(live.get(k), AttrDict):
+                put(live[k], v)
+            else:
+                live[k] = _copy.deepcopy(v)
+    put(cfg, _DEFAULTS)
+    return cfg
+
+
 def _merge(src, dst, path=""):
     for k, v in src.items():
         if k not in dst:

@@ -128,23 +128,56 @@ class _BiasActFn(torch.autograd.Function):
         return gi, None, (gi if ctx.has_res else None)
 
 
+def _dense_rows(t):
+    """(rows, cols) of a tensor whose MEMORY is `size(0)` dense rows (contiguous or channels-last), else None."""
+    if t.dim() >= 1 and (t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last))):
+        return t.size(0), t.numel() // max(t.size(0), 1)
+    return None
+
+
+def scale_rows_batch(tensors, scales):
+    """[t_i * s_i] for per-row scales s_i (size(0) entries, any shape) in ONE launch per 48 tensors (dtt_scale_rows_batch);
+    results keep each tensor's memory format.  Falls back to a PyTorch multiply per tensor off the GPU / for layouts that
+    are not dense rows."""
+    import ctypes
+    if not tensors:
+        return []
+    ok = all(t.is_cuda and t.dtype == torch.float32 and s.is_cuda and s.dtype == torch.float32 and s.is_contiguous() and
+             s.numel() == t.size(0) and _dense_rows(t) is not None and t.numel() > 0 for t, s in zip(tensors, scales))
+    if not ok or os.environ.get("DTT_FOLD_BATCH", "1") == "0":   # (env: developer A/B switch)
+        return [t * s for t, s in zip(tensors, scales)]
+    n = len(tensors)
+    outs = [torch.empty_like(t) for t in tensors]   # (preserves contiguous / channels-last strides)
+    if any(o.stride() != t.stride() for o, t in zip(outs, tensors)):
+        return [t * s for t, s in zip(tensors, scales)]
+    P, I = ctypes.c_void_p * n, ctypes.c_int * n
+    shapes = [_dense_rows(t) for t in tensors]
+    dev = tensors[0].device
+    with torch.cuda.device(dev):
+        check(_lib.lib().dtt_scale_rows_batch(n, P(*[t.data_ptr() for t in tensors]), P(*[s.data_ptr() for s in scales]),
+                                              P(*[o.data_ptr() for o in outs]), I(*[r for r, _ in shapes]),
+                                              I(*[c for _, c in shapes]), stream_ptr(dev)), "scale_rows_batch")
+    return outs
+
+
 class _FoldScalesFn(torch.autograd.Function):
-    """(w_1 .. w_n, s_1 .. s_n) -> (w_1 * s_1, .. , w_n * s_n) with multi-tensor launches in both directions; the
-    scales are frozen-BatchNorm constants (no gradient)."""
+    """(w_1 .. w_n, s_1 .. s_n) -> (w_1 * s_1, .. , w_n * s_n) with one launch per 48 filters in both directions
+    (dtt_scale_rows_batch; torch._foreach_mul takes its per-tensor path for broadcast operands: ~100 launch-bound multiplies
+    per direction, 1.6 ms of a 44 ms step); the scales are frozen-BatchNorm constants (no gradient)."""
 
     @staticmethod
     def forward(ctx, *tensors):
         n = len(tensors) // 2
         ctx.scales = tensors[n:]
-        return tuple(torch._foreach_mul(list(tensors[:n]), list(tensors[n:])))
+        return tuple(scale_rows_batch([t.detach() for t in tensors[:n]], list(tensors[n:])))
 
     @staticmethod
     def backward(ctx, *grads):
         n = len(grads)
-        if all(g is not None for g in grads):
-            out = torch._foreach_mul(list(grads), list(ctx.scales))
-        else:
-            out = [None if g is None else g * s for g, s in zip(grads, ctx.scales)]
+        idx = [i for i, g in enumerate(grads) if g is not None]
+        out = [None] * n
+        for i, o in zip(idx, scale_rows_batch([grads[i] for i in idx], [ctx.scales[i] for i in idx])):
+            out[i] = o
         return tuple(out) + (None,) * n
 
 

@@ -27,7 +27,8 @@ def _free_port():
 
 def _setup():
     sys.path[:0] = [ROOT, os.path.join(ROOT, "pytorch-detect-to-track_amd")]
-    from dtt.config import apply_dataset_defaults, cfg
+    from dtt.config import apply_dataset_defaults, cfg, reset_cfg
+    reset_cfg()   # (tests that ran before this one in the same process may have loaded a yml: the spawned ranks start from defaults)
     apply_dataset_defaults("imagenet_vid")
     return cfg
 

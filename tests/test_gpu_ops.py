@@ -458,6 +458,32 @@ def test_layout_transposes(dev):
     assert torch.equal(xl.grad, gy)
 
 
+def test_scale_rows_batch_and_fold_scales(dev):
+    """dtt_scale_rows_batch (one launch per 48 tensors) == a PyTorch multiply per tensor, bit for bit: NCHW and channels-last
+    filters, a row length that is not a multiple of 4, more tensors than one launch holds; _FoldScalesFn's gradient."""
+    from dtt.fuse import _FoldScalesFn, scale_rows_batch
+    g = torch.Generator().manual_seed(11)
+    shapes = [(64, 64, 1, 1), (64, 64, 3, 3), (256, 64, 1, 1), (5, 3, 7, 7), (512, 128, 3, 3), (7, 1, 1, 1), (33, 5, 3, 3)]
+    ws, ss = [], []
+    for i in range(60):
+        k, c, kh, kw = shapes[i % len(shapes)]
+        w = torch.randn(k, c, kh, kw, generator=g).to(dev)
+        if i % 2:
+            w = w.contiguous(memory_format=torch.channels_last)
+        ws.append(w)
+        ss.append((torch.rand(k, generator=g) + 0.5).view(-1, 1, 1, 1).to(dev))
+    outs = scale_rows_batch(ws, ss)
+    for w, s_, o in zip(ws, ss, outs):
+        assert o.stride() == w.stride()
+        assert torch.equal(o, w * s_)
+    params = [w.clone().requires_grad_(True) for w in ws[:9]]
+    folded = _FoldScalesFn.apply(*params, *ss[:9])
+    gs = [torch.randn(p.shape, generator=g).to(dev) for p in params]
+    torch.autograd.backward(folded, gs)
+    for p, s_, g_ in zip(params, ss, gs):
+        assert torch.equal(p.grad, g_ * s_)
+
+
 # ------------------------------------------------------------------------------------ proposal layer
 def _proposal_inputs(rng, B, A, H, W):
     logits = rng.normal(0, 2, size=(B, 2, A * H, W)).astype(np.float32)
