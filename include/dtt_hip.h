@@ -113,6 +113,15 @@ int dtt_correlation_backward(const float* gradOutput, int gob, int goc, int goh,
                              int pad_size, int kernel_size, int max_displacement,
                              int stride1, int stride2, int corr_type_multiply,
                              void* stream);
+/* The same gradients for channels-last inputs (gob, ih, iw, ic) and channels-last gradInput1/2 -- the layout of a channels-last
+ * training trunk (dtt/ops.py: CorrelationNHWCFunction; forward = dtt_correlation_forward_nhwc with the NCHW output strides).
+ * gradOutput stays the reference's (gob, D*D, oh, ow).  Matrix-core path only: kernel_size 1, stride1 == stride2,
+ * max_displacement / stride <= 8, ic % 16 == 0 (every correlation D&T trains, rfcn.py:58-60); anything else fails with an error
+ * string and the caller converts to NCHW for dtt_correlation_backward.  Same MFMA sequence as the NCHW instantiation:
+ * bit-identical gradients (tests/test_gpu_ops.py). */
+int dtt_correlation_backward_nhwc(const float* gradOutput, int gob, int goc, int goh, int gow, const float* input1, int ic,
+                                  int ih, int iw, const float* input2, float* gradInput1, float* gradInput2, int pad_size,
+                                  int kernel_size, int max_displacement, int stride1, int stride2, void* stream);
 
 /* ---------------------------------------------------------------- PSRoI pooling
  * Replaces PSROIPoolForwardLauncher  (psroi_pooling/src/psroi_pooling_kernel.cu:82-106)

@@ -877,7 +877,12 @@ __global__ void corr_bwd_simple(const float* __restrict__ gout, const float* __r
 // channel, so every wave gathers its NB*4 band words from gradOut ONCE into registers (the MFMA B operand)
 // and then streams channel chunks of the other frame through LDS (A operand) -- no split-K, no atomics, each
 // gradient element is written exactly once.  WRT2 selects which gradient (and hence which gather rule).
-template <int NBR, bool WRT2, int MINW>
+// NHWC: `other` and `grad` are channels-last (n, y, x, c) -- the training trunk's layout: a halo pixel's 16-channel chunk is one
+// 64-byte piece whatever the lattice stride (so conv3 gets the pipelined 16-byte staging too), LDS holds the halo pixel-major
+// ([pixel][16 channels]: the A read of 16 channels x 4 neighbouring pixels is 64 consecutive floats, conflict free) and a lane
+// stores its four channels of a target pixel as one float4.  Same MFMA sequence, so the gradients are bit-identical to the
+// NCHW instantiation's.
+template <int NBR, bool WRT2, int MINW, bool NHWC = false>
 __global__ __launch_bounds__(kThreads, MINW) void corr_bwd_mfma(const float* __restrict__ gout,
                                                                 const float* __restrict__ other,
                                                                 float* __restrict__ grad, FastGeom g, int cgroups,
@@ -998,58 +1003,110 @@ __global__ __launch_bounds__(kThreads, MINW) void corr_bwd_mfma(const float* __r
     }
   };
 
+  // channels-last staging: piece f = (halo pixel, 16-byte quarter of its 64-byte chunk row)
+  constexpr int NP = NHWC ? (K::HR * K::HR * 4 + kThreads - 1) / kThreads : 1;
+  long goffp[NP];
+  int loffp[NP];
+  bool okp[NP];
+  f32x4 stp[NP];
+  if constexpr (NHWC) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int f = tid + i * kThreads;
+      const bool live = f < K::HR * K::HR * 4;
+      const int pi = live ? f >> 2 : 0, piece = f & 3;
+      const int hr = pi / K::HR, hc = pi - hr * K::HR;
+      const int gy = g.origin + (ty0 - g.R + hr) * g.s, gx = g.origin + (tx0 - g.R + hc) * g.s;
+      okp[i] = live && gy >= 0 && gy < g.H && gx >= 0 && gx < g.W;
+      goffp[i] = okp[i] ? ((long)gy * g.W + gx) * g.C + piece * 4 : 0;
+      loffp[i] = live ? pi * KB + piece * 4 : K::HR * K::HR * KB;   // (idle lanes: the spare slot behind the image)
+    }
+  }
+  auto stage_nhwc = [&](int c0, bool issue, bool write) {
+    if (issue) {
+#pragma unroll
+      for (int i = 0; i < NP; ++i) stp[i] = load16(src + goffp[i] + c0);
+    }
+    if (write) {
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        f32x4 o = stp[i];
+        if (!okp[i]) o = f32x4{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(lds + loffp[i]) = o;
+      }
+    }
+  };
+  const int a_off_p = ((my * 4) * K::HR + mx * 4 + kx) * KB + (lane & 15);   // A[i = channel][k = halo column kx], pixel-major
+
   // target pixel of this lane's D column (j = lane & 15) and validity of the write
   const int wy = g.origin + (ty0 + my * 4 + tyi) * g.s, wx = g.origin + (tx0 + mx * 4 + txi) * g.s;
   const bool w_ok = wy >= 0 && wy < g.H && wx >= 0 && wx < g.W;
 
   if (c_begin >= c_end) return;   // more channel groups than 16-channel chunks (small C): nothing to do, and no staging --
                                   // the prologue below would read past the end of the tensor (found by tools/fuzz_ops.py)
-  if (vec4) { stage_vec(c_begin, true, true); } else { stage_scalar(c_begin); }
+  if constexpr (NHWC) { stage_nhwc(c_begin, true, true); }
+  else if (vec4) { stage_vec(c_begin, true, true); } else { stage_scalar(c_begin); }
   __syncthreads();
   for (int c0 = c_begin; c0 < c_end; c0 += KB) {
     const bool more = c0 + KB < c_end;
-    if (vec4 && more) stage_vec(c0 + KB, true, false);
+    if constexpr (NHWC) { if (more) stage_nhwc(c0 + KB, true, false); }
+    else if (vec4 && more) stage_vec(c0 + KB, true, false);
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < K::NB * 4; t += 2) {
       const int nb0 = t >> 2, jy0 = t & 3, nb1 = (t + 1) >> 2, jy1 = (t + 1) & 3;
-      const float a0 = lds[a_off + ((nb0 / NBR) * 4 + jy0) * K::HRS + (nb0 % NBR) * 4];
-      const float a1 = lds[a_off + ((nb1 / NBR) * 4 + jy1) * K::HRS + (nb1 % NBR) * 4];
+      float a0, a1;
+      if constexpr (NHWC) {
+        a0 = lds[a_off_p + (((nb0 / NBR) * 4 + jy0) * K::HR + (nb0 % NBR) * 4) * KB];
+        a1 = lds[a_off_p + (((nb1 / NBR) * 4 + jy1) * K::HR + (nb1 % NBR) * 4) * KB];
+      } else {
+        a0 = lds[a_off + ((nb0 / NBR) * 4 + jy0) * K::HRS + (nb0 % NBR) * 4];
+        a1 = lds[a_off + ((nb1 / NBR) * 4 + jy1) * K::HRS + (nb1 % NBR) * 4];
+      }
       acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, band[t], acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, band[t + 1], acc1, 0, 0, 0);
     }
     // D[i = channel (lane>>4)*4 + reg][j = target pixel]
     if (w_ok) {
+      if constexpr (NHWC) {
+        f32x4 o;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int c = c0 + (lane >> 4) * 4 + r;
-        if (c < c_end) dst[(long)c * plane + wy * g.W + wx] = (acc0[r] + acc1[r]) / nelems;
+        for (int r = 0; r < 4; ++r) o[r] = (acc0[r] + acc1[r]) / nelems;
+        *reinterpret_cast<f32x4*>(dst + ((long)wy * g.W + wx) * g.C + c0 + (lane >> 4) * 4) = o;   // (C % 16 == 0: no channel tail)
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = c0 + (lane >> 4) * 4 + r;
+          if (c < c_end) dst[(long)c * plane + wy * g.W + wx] = (acc0[r] + acc1[r]) / nelems;
+        }
       }
     }
     __syncthreads();
     if (more) {
-      if (vec4) stage_vec(0, false, true); else stage_scalar(c0 + KB);
+      if constexpr (NHWC) stage_nhwc(0, false, true);
+      else if (vec4) stage_vec(0, false, true); else stage_scalar(c0 + KB);
       __syncthreads();
     }
   }
 }
 
-template <int NBR>
+template <int NBR, bool NHWC>
 size_t bwd_lds_bytes() {
   using K = Cfg<NBR>;
+  if (NHWC) return (size_t)(K::HR * K::HR * 16 + 4) * sizeof(float);
   return (size_t)(16 * (((K::HR * K::HRS + 31) / 32) * 32 + 2) + 4) * sizeof(float);
 }
 
-template <int NBR, int MINW>
+template <int NBR, int MINW, bool NHWC>
 int launch_bwd(const float* gout, const float* in1, const float* in2, float* g1, float* g2, const FastGeom& g,
                int batch, hipStream_t stream) {
-  const size_t lds = bwd_lds_bytes<NBR>();
+  const size_t lds = bwd_lds_bytes<NBR, NHWC>();
   static DttDeviceOnce attr_once;
   bool& attr = attr_once.here();   // the attribute is per device, not per process
   if (!attr) {
-    hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(corr_bwd_mfma<NBR, false, MINW>),
+    hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(corr_bwd_mfma<NBR, false, MINW, NHWC>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(corr_bwd_mfma<NBR, true, MINW>),
+    hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(corr_bwd_mfma<NBR, true, MINW, NHWC>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     DTT_REQUIRE(e1 == hipSuccess && e2 == hipSuccess, "correlation backward: cannot raise dynamic LDS limit");
     attr = true;
@@ -1062,7 +1119,7 @@ int launch_bwd(const float* gout, const float* in1, const float* in2, float* g1,
   // gradInput1: targets = output pixels (lattice 0 .. oh-1)
   {
     const int ty = g.tiles_y, tx = g.tiles_x;
-    hipLaunchKernelGGL((corr_bwd_mfma<NBR, false, MINW>), dim3(ty * tx * g.ksplit * batch), dim3(kThreads), lds, stream,
+    hipLaunchKernelGGL((corr_bwd_mfma<NBR, false, MINW, NHWC>), dim3(ty * tx * g.ksplit * batch), dim3(kThreads), lds, stream,
                        gout, in2, g1, g, g.ksplit, (float)g.C, 0, 0, ty, tx);
     DTT_CHECK_LAUNCH("corr_bwd_mfma<input1>");
   }
@@ -1074,7 +1131,7 @@ int launch_bwd(const float* gout, const float* in1, const float* in2, float* g1,
     const int hi_y = qhi_y < g.oh - 1 + g.R ? qhi_y : g.oh - 1 + g.R, hi_x = qhi_x < g.ow - 1 + g.R ? qhi_x : g.ow - 1 + g.R;
     if (hi_y >= lo_y && hi_x >= lo_x) {
       const int ty = (hi_y - lo_y + kTile) / kTile, tx = (hi_x - lo_x + kTile) / kTile;
-      hipLaunchKernelGGL((corr_bwd_mfma<NBR, true, MINW>), dim3(ty * tx * g.ksplit * batch), dim3(kThreads), lds,
+      hipLaunchKernelGGL((corr_bwd_mfma<NBR, true, MINW, NHWC>), dim3(ty * tx * g.ksplit * batch), dim3(kThreads), lds,
                          stream, gout, in1, g2, g, g.ksplit, (float)g.C, lo_y, lo_x, ty, tx);
       DTT_CHECK_LAUNCH("corr_bwd_mfma<input2>");
     }
@@ -1313,8 +1370,8 @@ extern "C" int dtt_correlation_backward(const float* gradOutput, int gob, int go
   int nbr;
   if (fast_path(kernel_size, stride1, stride2, max_displacement, &nbr) && nbr <= 5 && ic % 16 == 0) {
     const FastGeom g = make_geom(gob, ic, ih, iw, goc, goh, gow, pad_size, max_displacement, stride1);
-    return nbr == 3 ? launch_bwd<3, 2>(gradOutput, input1, input2, gradInput1, gradInput2, g, gob, stream)
-                    : launch_bwd<5, 2>(gradOutput, input1, input2, gradInput1, gradInput2, g, gob, stream);
+    return nbr == 3 ? launch_bwd<3, 2, false>(gradOutput, input1, input2, gradInput1, gradInput2, g, gob, stream)
+                    : launch_bwd<5, 2, false>(gradOutput, input1, input2, gradInput1, gradInput2, g, gob, stream);
   }
   const long total = (long)gob * ic * ih * iw;
   hipLaunchKernelGGL(corr_bwd_simple, dim3(min(dtt_cdiv(total, 256), 1 << 20)), dim3(256), 0, stream, gradOutput,
@@ -1322,4 +1379,28 @@ extern "C" int dtt_correlation_backward(const float* gradOutput, int gob, int go
                      max_displacement, stride1, stride2);
   DTT_CHECK_LAUNCH("corr_bwd_simple");
   return 1;
+}
+
+// The same gradients for channels-last inputs (n, ih, iw, ic) and channels-last gradInputs; gradOutput stays the reference's
+// (n, D*D, oh, ow).  The matrix-core path only (kernel_size 1, stride1 == stride2, max_displacement / stride <= 8, ic % 16 == 0
+// -- every correlation D&T trains): other geometries fail here and the caller converts to NCHW for dtt_correlation_backward.
+extern "C" int dtt_correlation_backward_nhwc(const float* gradOutput, int gob, int goc, int goh, int gow,
+                                             const float* input1, int ic, int ih, int iw, const float* input2,
+                                             float* gradInput1, float* gradInput2, int pad_size, int kernel_size,
+                                             int max_displacement, int stride1, int stride2, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  DTT_REQUIRE(gradOutput && input1 && input2 && gradInput1 && gradInput2, "correlation backward: null pointer");
+  int eoc, eoh, eow;
+  if (!dtt_correlation_output_shape(ic, ih, iw, pad_size, kernel_size, max_displacement, stride1, stride2, &eoc, &eoh, &eow))
+    return 0;
+  DTT_REQUIRE(gob > 0 && goc == eoc && goh == eoh && gow == eow, "correlation backward: gradOutput shape mismatch");
+  int nbr = 0;
+  DTT_REQUIRE(fast_path(kernel_size, stride1, stride2, max_displacement, &nbr) && nbr <= 5 && ic % 16 == 0,
+              "correlation backward (channels-last): needs kernel_size 1, stride1 == stride2, max_displacement / stride <= 8 and "
+              "channels %% 16 == 0 (got k=%d s1=%d s2=%d d=%d C=%d)", kernel_size, stride1, stride2, max_displacement, ic);
+  DTT_REQUIRE(((reinterpret_cast<uintptr_t>(input1) | reinterpret_cast<uintptr_t>(input2) | reinterpret_cast<uintptr_t>(gradInput1) |
+                reinterpret_cast<uintptr_t>(gradInput2)) & 15) == 0, "correlation backward (channels-last): pointers must be 16-byte aligned");
+  const FastGeom g = make_geom(gob, ic, ih, iw, goc, goh, gow, pad_size, max_displacement, stride1);
+  return nbr == 3 ? launch_bwd<3, 2, true>(gradOutput, input1, input2, gradInput1, gradInput2, g, gob, stream)
+                  : launch_bwd<5, 2, true>(gradOutput, input1, input2, gradInput1, gradInput2, g, gob, stream);
 }

@@ -33,6 +33,7 @@ SIGNATURES = {
     "dtt_correlation_nhwc_plan_check": (_I, [_I, _I, _I, _I, _I]),
     "dtt_correlation_nhwc_plan": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "dtt_correlation_backward": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "dtt_correlation_backward_nhwc": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "dtt_psroi_pool_forward": (_I, [_P, _F, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P, _P, _P]),
     "dtt_psroi_pool_backward": (_I, [_P, _P, _I, _I, _F, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     "dtt_psroi_pool_vote_forward": (_I, [_P, _F, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P, _P, _P]),

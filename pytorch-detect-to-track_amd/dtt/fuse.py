@@ -265,6 +265,10 @@ class FusedTrainTrunk:
         if self.channels_last:
             # (the hand-written heads of the training graph read the channels-last `top` rows directly: dtt/model.py, `_train_pm`)
             keep_top = getattr(self.model, "_train_pm", False)
+            if os.environ.get("DTT_TRAIN_CORR_CL", "1") != "0":   # (env: developer A/B switch)
+                # the correlations read channels-last maps and hand channels-last gradients back (dtt.ops.Correlation ->
+                # CorrelationNHWCFunction): no NHWC -> NCHW copies of conv3 / conv4 / conv5, none of their gradients
+                return feats[1], feats[2], feats[3], (top if keep_top else _to_nchw(top))
             return _to_nchw(feats[1]), _to_nchw(feats[2]), _to_nchw(feats[3]), (top if keep_top else _to_nchw(top))
         return feats[1], feats[2], feats[3], top
 

@@ -225,9 +225,11 @@ class _RFCN(nn.Module):
             raise ValueError("cfg.RFCN_ROI_FEATURES must be '', 'align', 'pool' or 'crop' (got %r)" % (mode,))
         return self.roi_feat
 
-    def _tracking_features(self, rfcn_bbox, conv3, conv4, conv5):
+    def _tracking_features(self, rfcn_bbox, conv3, conv4, conv5, whole=None):
         """cat([bbox_t, bbox_t+tau, corr3, corr4, corr5], 1) (rfcn.py:166-174).  Without autograd the
-        correlations write directly into their channel slices of the concat buffer."""
+        correlations write directly into their channel slices of the concat buffer.  `whole`: the three un-sliced
+        (n_legs * B, C, H, W) maps the per-leg lists were cut from -- a channels-last training trunk's maps stay whole under
+        autograd (dtt.ops.Correlation.pair)."""
         layers = (self.conv3_corr_layer, self.conv4_corr_layer, self.conv5_corr_layer)
         feats = (conv3, conv4, conv5)
         need_grad = torch.is_grad_enabled() and any(f.requires_grad for pair in feats for f in pair)
@@ -236,7 +238,10 @@ class _RFCN(nn.Module):
             n = len(rfcn_bbox)
             for i in range(n - 1):
                 for j in range(i + 1, n):
-                    out += [l(f[i], f[j]) for l, f in zip(layers, feats)]
+                    if whole is not None:
+                        out += [l.pair(m, conv3[0].size(0), i, j) for l, m in zip(layers, whole)]
+                    else:
+                        out += [l(f[i], f[j]) for l, f in zip(layers, feats)]
             return torch.cat(out, dim=1)
         B, cb, H, W = rfcn_bbox[0].shape
         chans = [correlation_output_shape(f[0].size(1), f[0].size(2), f[0].size(3), l.pad_size, l.kernel_size,
@@ -439,7 +444,7 @@ class _RFCN(nn.Module):
             # inference: RPN, proposal layer and PSRoI pooling also run once for all n_legs*B images
             if side is not None:
                 if not single_frame:
-                    tracking_reg = self.corr_bbox_net(self._tracking_features(rfcn_bbox, conv3, conv4, conv5))
+                    tracking_reg = self.corr_bbox_net(self._tracking_features(rfcn_bbox, conv3, conv4, conv5, whole=(c3, c4, c5)))
                 torch.cuda.current_stream(dev).wait_stream(side)
                 all_rois.record_stream(torch.cuda.current_stream(dev))
             else:
@@ -460,7 +465,7 @@ class _RFCN(nn.Module):
             tracking_pred = torch.zeros(0, 4, device=dev)
             if not single_frame:
                 if tracking_reg is None:
-                    tracking_reg = self.corr_bbox_net(self._tracking_features(rfcn_bbox, conv3, conv4, conv5))
+                    tracking_reg = self.corr_bbox_net(self._tracking_features(rfcn_bbox, conv3, conv4, conv5, whole=(c3, c4, c5)))
                 # tracking RoIs = frame-t RoIs (rfcn.py:192)
                 tracking_pred = self._pool_vote(self.RFCN_psroi_loc_pool, self.RFCN_tracking_pred, tracking_reg,
                                                 leg_rois[0].view(-1, 5))
@@ -509,7 +514,7 @@ class _RFCN(nn.Module):
                     torch.stack(rpn_loss_cls, 0), torch.stack(rpn_loss_bbox, 0), torch.stack(loss_cls, 0),
                     torch.stack(loss_bbox, 0), rois_label, zero)
         if tracking_reg is None:
-            tracking_reg = self.corr_bbox_net(self._tracking_features(rfcn_bbox, conv3, conv4, conv5))
+            tracking_reg = self.corr_bbox_net(self._tracking_features(rfcn_bbox, conv3, conv4, conv5, whole=(c3, c4, c5)))
         if self.training:
             trk_rois, trk_label, trk_target, trk_in, trk_out = self.RFCN_tracking_proposal_target(gt_boxes, num_boxes)
             trk_target = trk_target.view(-1, trk_target.size(2))

@@ -157,8 +157,86 @@ class CorrelationFunction(Function):
         return g1, g2, None, None, None, None, None, None
 
 
+def _is_channels_last(t):
+    return t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last) and not t.is_contiguous()
+
+
+class CorrelationNHWCFunction(Function):
+    """The same op on channels-last maps, for a channels-last training trunk: forward = the window-split kernel
+    (`dtt_correlation_forward_nhwc`, NCHW output as the reference's), backward = the matrix-core gradients reading and
+    writing channels-last (`dtt_correlation_backward_nhwc`) -- no layout conversion of the feature maps or of their
+    gradients in either direction.  Geometry: kernel_size 1, stride1 == stride2, max_displacement / stride <= 8,
+    channels % 16 == 0 (`Correlation.forward` routes everything else through the NCHW functions)."""
+
+    @staticmethod
+    def supports(input1, input2, kernel_size, max_displacement, stride1, stride2):
+        return (input1.is_cuda and input1.dtype == torch.float32 and input1.shape == input2.shape and
+                _is_channels_last(input1) and _is_channels_last(input2) and kernel_size == 1 and stride1 == stride2 and
+                stride2 > 0 and 1 <= max_displacement // stride2 <= 8 and input1.size(1) % 16 == 0)
+
+    @staticmethod
+    def forward(ctx, input1, input2, pad_size, kernel_size, max_displacement, stride1, stride2):
+        ctx.save_for_backward(input1, input2)
+        ctx.params = (pad_size, kernel_size, max_displacement, stride1, stride2)
+        return correlation_forward_nhwc(input1, input2, pad_size, kernel_size, max_displacement, stride1, stride2)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        input1, input2 = ctx.saved_tensors
+        pad_size, kernel_size, max_displacement, stride1, stride2 = ctx.params
+        grad_output = grad_output.contiguous()
+        B, C, H, W = input1.shape
+        g1 = torch.empty_like(input1)   # (channels-last, as the inputs)
+        g2 = torch.empty_like(input2)
+        assert _is_channels_last(g1) and _is_channels_last(g2)
+        with torch.cuda.device(input1.device):
+            check(_lib.lib().dtt_correlation_backward_nhwc(ptr(grad_output), grad_output.shape[0], grad_output.shape[1],
+                                                           grad_output.shape[2], grad_output.shape[3], ptr(input1), C, H, W,
+                                                           ptr(input2), ptr(g1), ptr(g2), pad_size, kernel_size,
+                                                           max_displacement, stride1, stride2, stream_ptr(input1.device)),
+                  "correlation backward (channels-last)")
+        return g1, g2, None, None, None, None, None
+
+
+class CorrelationPairNHWCFunction(Function):
+    """CorrelationNHWCFunction for two legs of ONE channels-last batch tensor `maps` (n_legs * B, C, H, W): images
+    [i*B, (i+1)*B) against images [j*B, (j+1)*B).  Slicing the batch under autograd would hand the trunk an NCHW zeros
+    tensor with the channels-last gradient copied in (SliceBackward does not keep the memory format: a strided copy of the
+    whole map per leg and NCHW gradients into a channels-last trunk); here the gradient of `maps` is allocated channels-last
+    once and the two gradient kernels write their legs of it in place."""
+
+    @staticmethod
+    def forward(ctx, maps, B, i, j, pad_size, kernel_size, max_displacement, stride1, stride2):
+        ctx.save_for_backward(maps)
+        ctx.params = (B, i, j, pad_size, kernel_size, max_displacement, stride1, stride2)
+        return correlation_forward_nhwc(maps[i * B:(i + 1) * B], maps[j * B:(j + 1) * B], pad_size, kernel_size,
+                                        max_displacement, stride1, stride2)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        (maps,) = ctx.saved_tensors
+        B, i, j, pad_size, kernel_size, max_displacement, stride1, stride2 = ctx.params
+        grad_output = grad_output.contiguous()
+        n, C, H, W = maps.shape
+        # (two legs: every image's gradient is written by one of the two kernels, which zero-fill their outputs themselves)
+        g = torch.empty_like(maps) if n == 2 * B else torch.zeros_like(maps)
+        assert _is_channels_last(g) or n == 1
+        g1, g2 = g[i * B:(i + 1) * B], g[j * B:(j + 1) * B]
+        in1, in2 = maps[i * B:(i + 1) * B], maps[j * B:(j + 1) * B]
+        with torch.cuda.device(maps.device):
+            check(_lib.lib().dtt_correlation_backward_nhwc(ptr(grad_output), grad_output.shape[0], grad_output.shape[1],
+                                                           grad_output.shape[2], grad_output.shape[3], ptr(in1), C, H, W,
+                                                           ptr(in2), ptr(g1), ptr(g2), pad_size, kernel_size,
+                                                           max_displacement, stride1, stride2, stream_ptr(maps.device)),
+                  "correlation backward (channels-last)")
+        return g, None, None, None, None, None, None, None, None
+
+
 class Correlation(nn.Module):
-    """correlation/modules/correlation.py:5-13 (same argument order and defaults)."""
+    """correlation/modules/correlation.py:5-13 (same argument order and defaults).  Channels-last inputs (a channels-last
+    trunk) take the channels-last kernels when the geometry allows; the result is the same NCHW tensor either way."""
 
     def __init__(self, pad_size=0, kernel_size=0, max_displacement=0, stride1=1, stride2=2, corr_multiply=1):
         super().__init__()
@@ -170,8 +248,24 @@ class Correlation(nn.Module):
         self.corr_multiply = corr_multiply
 
     def forward(self, input1, input2):
+        if CorrelationNHWCFunction.supports(input1, input2, self.kernel_size, self.max_displacement, self.stride1, self.stride2):
+            return CorrelationNHWCFunction.apply(input1, input2, self.pad_size, self.kernel_size, self.max_displacement,
+                                                 self.stride1, self.stride2)
+        if input1.is_cuda and not input1.is_contiguous():
+            input1 = input1.contiguous()
+        if input2.is_cuda and not input2.is_contiguous():
+            input2 = input2.contiguous()
         return CorrelationFunction.apply(input1, input2, self.pad_size, self.kernel_size, self.max_displacement,
                                          self.stride1, self.stride2, self.corr_multiply)
+
+    def pair(self, maps, B, i, j):
+        """Legs i and j of a (n_legs * B, C, H, W) batch tensor; channels-last maps stay whole under autograd
+        (CorrelationPairNHWCFunction), anything else is sliced and goes through forward()."""
+        a, b = maps[i * B:(i + 1) * B], maps[j * B:(j + 1) * B]
+        if i != j and CorrelationNHWCFunction.supports(a, b, self.kernel_size, self.max_displacement, self.stride1, self.stride2):
+            return CorrelationPairNHWCFunction.apply(maps, B, i, j, self.pad_size, self.kernel_size, self.max_displacement,
+                                                     self.stride1, self.stride2)
+        return self.forward(a, b)
 
     def extra_repr(self):
         return "pad_size=%d, kernel_size=%d, max_displacement=%d, stride1=%d, stride2=%d" % (

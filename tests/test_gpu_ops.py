@@ -207,6 +207,88 @@ def test_correlation_backward(dev, case):
     np.testing.assert_allclose(t2.grad.cpu().numpy(), g2, rtol=0, atol=1e-4)
 
 
+CORR_CL_CASES = [
+    # B, C, H, W, pad, k, d, s1, s2 -- geometries of the channels-last training path (kernel 1, stride1 == stride2, R <= 8, C % 16 == 0)
+    (2, 64, 20, 27, 8, 1, 8, 1, 1),     # conv4 / conv5 geometry
+    (1, 48, 37, 45, 8, 1, 8, 2, 2),     # conv3 geometry: lattice stride 2, R = 4
+    (1, 16, 16, 16, 6, 1, 4, 1, 1),     # pad > displacement
+    (1, 32, 21, 17, 3, 1, 3, 1, 1),     # R = 3
+    (2, 16, 9, 11, 4, 1, 4, 1, 1),      # tiny map, one chunk
+    (1, 80, 38, 67, 8, 1, 8, 1, 1),     # the 600 px map, five chunks
+    (3, 16, 5, 4, 8, 1, 8, 1, 1),       # map narrower than the window
+]
+
+
+@pytest.mark.parametrize("case", CORR_CL_CASES)
+def test_correlation_channels_last_autograd(dev, case):
+    """dtt.ops.Correlation on channels-last maps (CorrelationNHWCFunction: window-split forward, channels-last matrix-core
+    backward): output and both gradients against the oracle at the north-star tolerance, gradients channels-last, and
+    bit-identical to the NCHW functions' (same MFMA sequence)."""
+    from dtt.ops import Correlation, CorrelationNHWCFunction
+    B, C, H, W, pad, k, d, s1, s2 = case
+    rng = np.random.RandomState(sum(case) + 7)
+    x1 = rng.normal(size=(B, C, H, W)).astype(np.float32)
+    x2 = rng.normal(size=(B, C, H, W)).astype(np.float32)
+    layer = Correlation(pad, k, d, s1, s2)
+    t1 = cu(x1, dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    t2 = cu(x2, dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    assert CorrelationNHWCFunction.supports(t1, t2, k, d, s1, s2)
+    out = layer(t1, t2)
+    assert out.is_contiguous()
+    ref = O.correlation_forward(x1, x2, pad, k, d, s1, s2)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref, rtol=0, atol=1e-4)
+    gout = rng.normal(size=tuple(out.shape)).astype(np.float32)
+    out.backward(cu(gout, dev))
+    for t in (t1, t2):
+        assert t.grad.is_contiguous(memory_format=torch.channels_last) and t.grad.shape == t.shape
+    g1, g2 = O.correlation_backward(gout, x1, x2, pad, k, d, s1, s2)
+    np.testing.assert_allclose(t1.grad.cpu().numpy(), g1, rtol=0, atol=1e-4)
+    np.testing.assert_allclose(t2.grad.cpu().numpy(), g2, rtol=0, atol=1e-4)
+    n1, n2 = cu(x1, dev).requires_grad_(True), cu(x2, dev).requires_grad_(True)
+    layer(n1, n2).backward(cu(gout, dev))
+    assert torch.equal(n1.grad, t1.grad) and torch.equal(n2.grad, t2.grad)
+
+
+def test_correlation_pair_keeps_a_channels_last_batch_whole(dev):
+    """Correlation.pair(maps, B, 0, 1) on the (2B, C, H, W) channels-last batch of both legs: same output as slicing, and the
+    gradient of `maps` comes back channels-last in one piece (legs written in place), equal to the sliced path's."""
+    from dtt.ops import Correlation
+    rng = np.random.RandomState(21)
+    B, C, H, W = 2, 32, 19, 23
+    x = rng.normal(size=(2 * B, C, H, W)).astype(np.float32)
+    for (pad, k, d, s1, s2) in [(8, 1, 8, 1, 1), (8, 1, 8, 2, 2)]:
+        layer = Correlation(pad, k, d, s1, s2)
+        m = cu(x, dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        out = layer.pair(m, B, 0, 1)
+        gout = torch.from_numpy(rng.normal(size=tuple(out.shape)).astype(np.float32)).to(dev)
+        out.backward(gout)
+        assert m.grad.is_contiguous(memory_format=torch.channels_last)
+        a = cu(x[:B], dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        b = cu(x[B:], dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        ref = layer(a, b)
+        ref.backward(gout)
+        assert torch.equal(out, ref)
+        assert torch.equal(m.grad[:B], a.grad) and torch.equal(m.grad[B:], b.grad)
+
+
+def test_correlation_channels_last_falls_back_outside_its_geometry(dev):
+    """R = 16 and C % 16 != 0 on channels-last maps: the module converts to NCHW and takes the reference-layout functions."""
+    from dtt.ops import Correlation, CorrelationNHWCFunction
+    rng = np.random.RandomState(5)
+    for (B, C, H, W, pad, k, d, s1, s2) in [(1, 16, 18, 22, 16, 1, 16, 1, 1), (1, 20, 12, 13, 4, 1, 4, 1, 1)]:
+        x1 = rng.normal(size=(B, C, H, W)).astype(np.float32)
+        x2 = rng.normal(size=(B, C, H, W)).astype(np.float32)
+        t1 = cu(x1, dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        t2 = cu(x2, dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        assert not CorrelationNHWCFunction.supports(t1, t2, k, d, s1, s2)
+        out = Correlation(pad, k, d, s1, s2)(t1, t2)
+        gout = rng.normal(size=tuple(out.shape)).astype(np.float32)
+        out.backward(cu(gout, dev))
+        g1, g2 = O.correlation_backward(gout, x1, x2, pad, k, d, s1, s2)
+        np.testing.assert_allclose(t1.grad.cpu().numpy(), g1, rtol=0, atol=1e-4)
+        np.testing.assert_allclose(t2.grad.cpu().numpy(), g2, rtol=0, atol=1e-4)
+
+
 def _corr_autograd_f64(x1, x2, pad, k, d, s1, s2):
     """Independent formulation of the forward (correlation_cuda_kernel.cu:34-106: k x k patches anchored at their top-left
     corner (oy*s1 + d, ox*s1 + d) in padded coordinates, displaced by multiples of s2, mean over k*k*C) in float64 torch
