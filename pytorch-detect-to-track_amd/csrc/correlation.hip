@@ -1112,9 +1112,12 @@ int launch_bwd(const float* gout, const float* in1, const float* in2, float* g1,
     attr = true;
   }
   const size_t bytes = (size_t)batch * g.C * g.H * g.W * sizeof(float);
-  // pixels that no lattice point maps to (stride > 1, pad != displacement) keep a zero gradient
-  DTT_REQUIRE(hipMemsetAsync(g1, 0, bytes, stream) == hipSuccess && hipMemsetAsync(g2, 0, bytes, stream) == hipSuccess,
-              "correlation backward: memset failed");
+  // pixels that no lattice point maps to (stride > 1, pad != displacement) keep a zero gradient; on the dense lattice of
+  // conv4 / conv5 (stride 1, pad == displacement: output pixel = input pixel) both kernels write every element themselves
+  const bool every_pixel_is_a_target = g.s == 1 && g.origin == 0 && g.oh == g.H && g.ow == g.W;
+  if (!every_pixel_is_a_target)
+    DTT_REQUIRE(hipMemsetAsync(g1, 0, bytes, stream) == hipSuccess && hipMemsetAsync(g2, 0, bytes, stream) == hipSuccess,
+                "correlation backward: memset failed");
   auto cdiv_floor = [](int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); };
   // gradInput1: targets = output pixels (lattice 0 .. oh-1)
   {

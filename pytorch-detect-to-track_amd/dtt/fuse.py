@@ -253,7 +253,9 @@ class FusedTrainTrunk:
         ws = _FoldScalesFn.apply(*[c.weight for c in self.convs], *self.scales)
         if self.channels_last:
             # MIOpen's fp32 backward kernels are NHWC implicit GEMMs; feeding them NCHW costs a transpose on each side
-            x = x.contiguous(memory_format=torch.channels_last)
+            # (the frozen stages' output crosses over once, through the tiled transpose: the strided copy behind
+            #  .contiguous(memory_format=...) moves the 164 MB of a 600 px batch at 1.4 TB/s)
+            x = nchw_to_nhwc(x) if x.is_cuda and x.is_contiguous() else x.contiguous(memory_format=torch.channels_last)
         k = 0
         for blocks in self.live:
             for blk in blocks:
