@@ -27,8 +27,13 @@ for c in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_LDS_BA
 timeout 600 python bench.py --no-cpu-baseline --pooling align --disp 16 --height 563 --width 1000 --batch 1 > $O/bench_config4_stdout.log 2>&1
 timeout 900 python bench.py --mode train --steps 8 --warmup 4 > $O/bench_train_stdout.log 2>&1
 timeout 600 rocprofv3 --kernel-trace -d $O/trace -o tr -- python bench.py --mode train --steps 5 --warmup 3 > $O/prof_train_stdout.log 2>&1
-python tools/rocpd_steady.py $(ls $O/trace/*.db | head -1) 3 "corr_fwd_mfma<3" > $O/train_steady_state.txt 2>&1
+python tools/rocpd_steady.py $(ls $O/trace/*.db | head -1) 3 "corr_wsplit_kernel<3" > $O/train_steady_state.txt 2>&1
 python tools/rocpd_stats.py $(ls $O/trace/*.db | head -1) > $O/train_kernel_stats.txt 2>&1
+rm -rf $O/trace
+# the proposal layer alone (B = 2: one frame pair, the bench step; B = 4: two pairs), per-kernel split of the B = 4 call
+for b in 2 4; do echo "== B=$b" >> $O/proposal_microbench.txt; B=$b timeout 300 python tools/time_proposal.py 2>&1 | grep -v "Warn\|amdgpu.ids\|capture_end" >> $O/proposal_microbench.txt; done
+B=4 TEST_ONLY=1 timeout 300 rocprofv3 --kernel-trace -d $O/trace -o prop -- python tools/time_proposal.py > /dev/null 2>&1
+python tools/rocpd_stats.py $(ls $O/trace/*.db | head -1) | head -6 >> $O/proposal_microbench.txt 2>&1
 rm -rf $O/trace
 ITERS=20 timeout 300 python tools/time_corr.py > $O/corr_microbench.txt 2>&1
 B=8 ITERS=10 timeout 300 python tools/time_corr.py >> $O/corr_microbench.txt 2>&1
