@@ -443,6 +443,16 @@ int dtt_head_gemm(const float* x, long ldx, int M, int K, const float* w, const 
  * reference's NCHW layout -- what dtt_proposal_select_sort / dtt_proposal_decode_nms read.  num_anchors must be even. */
 int dtt_rpn_head_gemm(const float* x, long ldx, int batch, int hw, int K, const float* w, const float* bias, int n_rows,
                       int num_anchors, float* cls_prob, float* bbox_pred, void* stream);
+
+/* Weight gradient of the packed 1x1 heads (training graph, rfcn.py:49-53): dw[n][k] = sum_m gout[m][n] * x[m][k] for n < N,
+ * k < K over the M pixel rows of the position-major maps -- gout (M, g_cols >= N columns readable, row stride ldg floats; the
+ * columns N .. g_cols only have to be finite), x (M, K) with row stride ldx, dw (N, K) dense.  Exact-f32 MFMA; both operands
+ * are read as they lie (no transposes); the pixel rows are split over workgroups whose partial tiles meet in `workspace`
+ * (dtt_head_gemm_dw_workspace_bytes) and are added in a fixed order: deterministic, no atomics.  K, g_cols, ldg, ldx % 4 == 0,
+ * 16-byte aligned pointers. */
+size_t dtt_head_gemm_dw_workspace_bytes(int M, int N, int K);
+int dtt_head_gemm_dw(const float* gout, long ldg, int g_cols, const float* x, long ldx, int M, int N, int K, float* dw,
+                     void* workspace, size_t workspace_bytes, void* stream);
 int dtt_psroi_pm_forward(const float* map, long pixel_stride, int cp, int batch_size, int num_rois, int height,
                          int width, int pooled, const float* rois, float spatial_scale, int output_dim,
                          float* vote_out, float* pooled_out, void* stream);

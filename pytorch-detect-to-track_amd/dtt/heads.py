@@ -196,8 +196,8 @@ def pack_heads_differentiable(convs, group=7):
 class HeadGemmFn(torch.autograd.Function):
     """out = x_rows @ w.T + bias through `dtt_head_gemm`, with a backward on the same kernel (closes SURVEY 8 row A9 for the
     training graph, rfcn.py:49-53): dX = gOut @ w is the head GEMM over the gradient rows with the transposed weights as
-    its "weight" operand; dW = gOut.T @ x is the head GEMM over the TRANSPOSED gradient (rows = output channels, K = pixels:
-    one workgroup accumulates a whole pixel range in registers, fixed order, no atomics); dBias is a column sum.
+    its "weight" operand; dW = gOut.T @ x is `dtt_head_gemm_dw` (both operands read as they lie, pixel rows split over
+    workgroups, partial tiles added in a fixed order: no atomics); dBias is a column sum.
     The gradient rows must have finite values in their padding columns (they are multiplied by zero weights): the
     position-major PSRoI backward writes whole rows."""
 
@@ -234,21 +234,13 @@ class HeadGemmFn(torch.autograd.Function):
                 check(L.dtt_head_gemm(ptr(gout), stride, M, stride, ptr(wt), ptr(zeros(K)), K, ptr(gx), K, K, 0, stream_ptr(dev)),
                       "head_gemm dX")
             if ctx.needs_input_grad[1]:
-                # dW (N16, K) = gout[:, :N16].T @ x: rows = output channels, reduction over the pixels.  Both operands are
-                # transposed with the tiled LDS transpose (dtt_transpose_batched: 5 TB/s against 1.4 for a strided copy); the
-                # GEMM's K must be a multiple of 32, so the last M % 32 pixels are a small matrix product on the side.
-                Mk = M // 32 * 32
+                # dW (N16, K) = gout[:, :N16].T @ x: its own kernel (dtt_head_gemm_dw) -- an MFMA step wants 16 outputs x 4 pixels
+                # of gout and 4 pixels x 16 inputs of x, i.e. 64-byte runs of the rows as they lie: nothing is transposed
                 gw = torch.empty((N16, K), dtype=torch.float32, device=dev)
-                if Mk > 0:
-                    gt = torch.empty((stride, Mk), dtype=torch.float32, device=dev)
-                    xt = torch.empty((K, Mk), dtype=torch.float32, device=dev)
-                    check(L.dtt_transpose_batched(ptr(gout), ptr(gt), 1, Mk, stride, stream_ptr(dev)), "transpose gOut")
-                    check(L.dtt_transpose_batched(ptr(x_rows), ptr(xt), 1, Mk, K, stream_ptr(dev)), "transpose x")
-                    check(L.dtt_head_gemm(ptr(gt), Mk, N16, Mk, ptr(xt), ptr(zeros(K)), K, ptr(gw), K, K, 0, stream_ptr(dev)), "head_gemm dW")
-                else:
-                    gw.zero_()
-                if Mk < M:
-                    gw.addmm_(gout[Mk:, :N16].t(), x_rows[Mk:])
+                nb = L.dtt_head_gemm_dw_workspace_bytes(M, N16, K)
+                ws = torch.empty((nb,), dtype=torch.uint8, device=dev)
+                check(L.dtt_head_gemm_dw(ptr(gout), stride, stride, ptr(x_rows), K, M, N16, K, ptr(gw), ptr(ws), nb, stream_ptr(dev)),
+                      "head_gemm dW")
             if ctx.needs_input_grad[2]:
                 gb = gout[:, :N16].sum(0)
         return gx, gw, gb, None, None

@@ -247,3 +247,31 @@ def test_psroi_pm_backward_matches_oracle(dev, B, H, W, R):
     votes = PsroiPmFn.apply(pm, rt, B, H, W, 1 / 16.0, heads)
     torch.autograd.backward(votes, [torch.from_numpy(g).to(dev) for g in gv])
     assert torch.equal(pm.grad, gm)
+
+
+@pytest.mark.parametrize("M,N,K,g_cols", [(10184, 1776, 512, 1792), (1000, 100, 36, 128), (33, 17, 4, 20), (4097, 300, 132, 320),
+                                          (31, 256, 128, 256)])
+def test_head_gemm_dw_kernel(M, N, K, g_cols):
+    """dtt_head_gemm_dw: dW = gOut[:, :N].T @ x in exact f32 on the matrix cores, operands read as they lie, pixel rows split
+    over workgroups and added in a fixed order.  Against a float64 product at 1e-4 of the largest entry; bit-identical from run
+    to run; padding columns of the gradient (finite garbage) do not leak into the stored rows; ragged M / N / K."""
+    from dtt import _lib
+    from dtt._lib import check, ptr, stream_ptr
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(M + N)
+    gout = torch.randn(M, g_cols, generator=g).to(dev)
+    gout[:, N:] = 1e3                       # padding columns: finite, large
+    x = torch.randn(M, K, generator=g).to(dev)
+    L = _lib.lib()
+    nb = L.dtt_head_gemm_dw_workspace_bytes(M, N, K)
+    outs = []
+    for _ in range(2):
+        ws = torch.full((nb,), 255, dtype=torch.uint8, device=dev)     # NaN-filled workspace: every word read must have been written
+        dw = torch.empty(N, K, device=dev)
+        with torch.cuda.device(dev):
+            check(L.dtt_head_gemm_dw(ptr(gout), g_cols, g_cols, ptr(x), K, M, N, K, ptr(dw), ptr(ws), nb, stream_ptr(dev)), "dw")
+        outs.append(dw)
+    assert torch.equal(outs[0], outs[1])
+    ref = gout[:, :N].double().t() @ x.double()
+    err = (outs[0].double() - ref).abs().max().item()
+    assert err < 1e-4 * max(1.0, ref.abs().max().item()), err
