@@ -27,7 +27,7 @@ for c in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_LDS_BA
 timeout 600 python bench.py --no-cpu-baseline --pooling align --disp 16 --height 563 --width 1000 --batch 1 > $O/bench_config4_stdout.log 2>&1
 timeout 900 python bench.py --mode train --steps 8 --warmup 4 > $O/bench_train_stdout.log 2>&1
 timeout 600 rocprofv3 --kernel-trace -d $O/trace -o tr -- python bench.py --mode train --steps 5 --warmup 3 > $O/prof_train_stdout.log 2>&1
-python tools/rocpd_steady.py $(ls $O/trace/*.db | head -1) 3 "corr_wsplit_kernel<3" > $O/train_steady_state.txt 2>&1
+python tools/rocpd_steady.py $(ls $O/trace/*.db | head -1) 3 "corr_wsplit_kernel<3" 400 > $O/train_steady_state.txt 2>&1
 python tools/rocpd_stats.py $(ls $O/trace/*.db | head -1) > $O/train_kernel_stats.txt 2>&1
 rm -rf $O/trace
 # the proposal layer alone (B = 2: one frame pair, the bench step; B = 4: two pairs), per-kernel split of the B = 4 call
