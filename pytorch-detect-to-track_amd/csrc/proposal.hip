@@ -3,13 +3,17 @@
 // Replaces _ProposalLayer.forward (reference rpn/proposal_layer.py:49-161): numpy meshgrid + H2D every
 // call, decode/clip of all K*A anchors, a full torch.sort of the B x K*A scores, then a Python loop of
 // per-image NMS round trips.  Here:
-//   1. proposal_select_sort (one 1024-thread workgroup per image): select the pre_nms_topN best
-//      (score, index) keys straight from the NCHW score map (exact bisection on the key bits, keys cached in
-//      registers) and bitonic-sort just those in LDS.  Keys are (descending score, ascending anchor index), a total
-//      order, so the result is deterministic.  Needs the SCORES only: callers that overlap the proposal layer with
-//      other work start it as soon as the softmax is done, while the box-delta convolution still runs
-//      (dtt_proposal_select_sort / dtt_proposal_decode_nms).
-//   2. proposal_decode (all CUs): decode + clip only the survivors (bbox_transform.py:108-134, 156-173).
+//   1. the selection: the pre_nms_topN best (score, index) keys of every image straight from the NCHW score map, in order.
+//      Keys are (descending score, ascending anchor index), a total order, so the result is deterministic.
+//        * proposal_sort_runs + proposal_rank_scatter (maps up to 38 912 anchors, i.e. every D&T shape): runs of 1024
+//          consecutive anchor indices sorted in LDS by one workgroup each, then every key ranked against the other runs by
+//          binary search with all sorted keys of the image staged in LDS -- the whole chip instead of one CU per image;
+//        * proposal_select_sort (larger maps): one 1024-thread workgroup per image, exact bisection on the key bits
+//          (keys cached in registers) + a bitonic sort of the selected keys in LDS.
+//      Needs the SCORES only: callers that overlap the proposal layer with other work can start it as soon as the softmax
+//      is done, while the box-delta convolution still runs (dtt_proposal_select_sort / dtt_proposal_decode_nms).
+//   2. decode + clip of only the survivors (bbox_transform.py:108-134, 156-173): by the ranking kernel itself when the box
+//      deltas are at hand (dtt_proposal_forward), else by proposal_decode (all CUs).
 //   3. the batched NMS of nms.hip (mask tiles + on-device sweep) whose epilogue writes the zero-padded
 //      (B, post_nms_topN, 5) RoI tensor (proposal_layer.py:151-159).
 #include "common.h"
