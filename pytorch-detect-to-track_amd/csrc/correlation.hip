@@ -1119,11 +1119,21 @@ int launch_bwd(const float* gout, const float* in1, const float* in2, float* g1,
     DTT_REQUIRE(hipMemsetAsync(g1, 0, bytes, stream) == hipSuccess && hipMemsetAsync(g2, 0, bytes, stream) == hipSuccess,
                 "correlation backward: memset failed");
   auto cdiv_floor = [](int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); };
+  // channel groups of the gradient kernels: MINW workgroups are resident per CU, so tiles x groups x batch is kept within ONE
+  // round of resident workgroups (the forward's 720-workgroup split is 1.4 rounds here: a second, 40 %-full round as long as
+  // the first)
+  static const int ks_env = getenv("DTT_CORR_BWD_KSPLIT") ? atoi(getenv("DTT_CORR_BWD_KSPLIT")) : 0;   // developer A/B switch
+  auto groups_for = [&](int tiles) {
+    int ks = ks_env > 0 ? ks_env : (MINW * dtt_device_cus()) / (tiles * batch > 0 ? tiles * batch : 1);
+    const int max_ks = (g.C + 15) / 16;
+    ks = ks > max_ks ? max_ks : ks;
+    return ks < 1 ? 1 : ks;
+  };
   // gradInput1: targets = output pixels (lattice 0 .. oh-1)
   {
-    const int ty = g.tiles_y, tx = g.tiles_x;
-    hipLaunchKernelGGL((corr_bwd_mfma<NBR, false, MINW, NHWC>), dim3(ty * tx * g.ksplit * batch), dim3(kThreads), lds, stream,
-                       gout, in2, g1, g, g.ksplit, (float)g.C, 0, 0, ty, tx);
+    const int ty = g.tiles_y, tx = g.tiles_x, ks = groups_for(ty * tx);
+    hipLaunchKernelGGL((corr_bwd_mfma<NBR, false, MINW, NHWC>), dim3(ty * tx * ks * batch), dim3(kThreads), lds, stream,
+                       gout, in2, g1, g, ks, (float)g.C, 0, 0, ty, tx);
     DTT_CHECK_LAUNCH("corr_bwd_mfma<input1>");
   }
   // gradInput2: targets = displaced pixels q = p + disp that fall inside the image
@@ -1133,9 +1143,9 @@ int launch_bwd(const float* gout, const float* in1, const float* in2, float* g1,
     const int lo_y = qlo_y > -g.R ? qlo_y : -g.R, lo_x = qlo_x > -g.R ? qlo_x : -g.R;
     const int hi_y = qhi_y < g.oh - 1 + g.R ? qhi_y : g.oh - 1 + g.R, hi_x = qhi_x < g.ow - 1 + g.R ? qhi_x : g.ow - 1 + g.R;
     if (hi_y >= lo_y && hi_x >= lo_x) {
-      const int ty = (hi_y - lo_y + kTile) / kTile, tx = (hi_x - lo_x + kTile) / kTile;
-      hipLaunchKernelGGL((corr_bwd_mfma<NBR, true, MINW, NHWC>), dim3(ty * tx * g.ksplit * batch), dim3(kThreads), lds,
-                         stream, gout, in1, g2, g, g.ksplit, (float)g.C, lo_y, lo_x, ty, tx);
+      const int ty = (hi_y - lo_y + kTile) / kTile, tx = (hi_x - lo_x + kTile) / kTile, ks = groups_for(ty * tx);
+      hipLaunchKernelGGL((corr_bwd_mfma<NBR, true, MINW, NHWC>), dim3(ty * tx * ks * batch), dim3(kThreads), lds,
+                         stream, gout, in1, g2, g, ks, (float)g.C, lo_y, lo_x, ty, tx);
       DTT_CHECK_LAUNCH("corr_bwd_mfma<input2>");
     }
   }
