@@ -13,7 +13,7 @@
 //     are padded by 16 floats so that the four pixel rows of a fragment read fall on the two halves of the banks: 2 cycles
 //     per ds_read_b32, the minimum for 64 lanes;
 //   * the pixel rows are split over `slices` workgroups per tile so that tiles x slices fills the chip in ONE round (7 x 4 tiles x
-//     4 slices = 224 workgroups at the D&T shape; five slices would be 280: a second, nearly empty round as long as the first --
+//     9 slices = 252 workgroups at the D&T shape; ten slices would be 280: a second, nearly empty round as long as the first --
 //     283 us against 164); the slices' partial tiles go to a workspace and a second kernel adds them IN SLICE ORDER:
 //     deterministic, no atomics, no tickets.
 // Measured (training step at 600 px, rocprofv3): 164 + 6 us = 113 TFLOP/s, 0.72 of the fp32 MFMA peak.

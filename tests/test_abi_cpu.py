@@ -46,6 +46,9 @@ def test_shape_and_workspace_queries_run_without_gpu():
         correlation_output_shape(8, 4, 4, 0, 1, 8, 1, 1)  # empty output -> error string, not exit()
     assert "empty output" in _lib.last_error()
     L = _lib.lib()
+    # head weight gradient: slices x 7 padded 256-row tile rows x 512 inputs; no pixel rows -> nothing
+    dw = L.dtt_head_gemm_dw_workspace_bytes(10184, 1776, 512)
+    assert dw > 0 and dw % (7 * 256 * 512 * 4) == 0 and L.dtt_head_gemm_dw_workspace_bytes(0, 1776, 512) == 0
     assert L.dtt_nms_workspace_bytes(6000) == (6000 * 94 + 94 + 8 + 6000) * 8   # bit matrix + parked two-phase sweep state + one "lower" word per box
     assert L.dtt_proposal_workspace_bytes(2, 12, 38, 67, 6000) > 2 * 6000 * 94 * 8
     assert L.dtt_correlation_forward_workspace_bytes(2, 2048, 38, 67, 8, 1, 8, 1, 1) > 0
