@@ -115,13 +115,41 @@ int dtt_correlation_backward(const float* gradOutput, int gob, int goc, int goh,
                              void* stream);
 /* The same gradients for channels-last inputs (gob, ih, iw, ic) and channels-last gradInput1/2 -- the layout of a channels-last
  * training trunk (dtt/ops.py: CorrelationNHWCFunction; forward = dtt_correlation_forward_nhwc with the NCHW output strides).
- * gradOutput stays the reference's (gob, D*D, oh, ow).  Matrix-core path only: kernel_size 1, stride1 == stride2,
- * max_displacement / stride <= 8, ic % 16 == 0 (every correlation D&T trains, rfcn.py:58-60); anything else fails with an error
- * string and the caller converts to NCHW for dtt_correlation_backward.  Same MFMA sequence as the NCHW instantiation:
- * bit-identical gradients (tests/test_gpu_ops.py). */
+ * Matrix-core paths only: kernel_size 1, stride1 == stride2, max_displacement / stride <= 8 (every correlation D&T trains,
+ * rfcn.py:58-60); anything else fails with an error string and the caller converts to NCHW for dtt_correlation_backward.
+ * Replace Correlation_backward_input1 / _input2 (correlation_cuda_kernel.cu:108-290) and their launcher (:371-473).
+ *
+ * dtt_correlation_backward_nhwc_strided (ic % 64 == 0: conv3 / conv4 / conv5; dtt_correlation_backward_stream_supported):
+ * band-stationary, halo-streamed kernels (csrc/correlation_bwd.hip) -- the gradient band of a 4 x 4 target block stays in
+ * registers, the other frame's halo streams through an LDS-DMA ring 64 channels wide, one ds_read_b128 per four exact-f32 MFMAs,
+ * float4 stores straight from the accumulators; fixed summation order, no atomics, no partial sums.  gradOut[n, d, p] is read at
+ * gradOutput[n * g_batch_stride + d * g_ch_stride + p * g_px_stride], p = oy * ow + ox: contiguous planes (D*D*oh*ow, oh*ow, 1)
+ * or columns of position-major rows (g_ch_stride = 1, g_px_stride = row length: the gradient of the tracking head's input
+ * rows, no copy).  which: 1 = gradInput1 only, 2 = gradInput2 only, 3 = both.  workspace: caller-owned,
+ * dtt_correlation_backward_workspace_bytes(...) bytes (the band words in register order, written by a small first launch).
+ *
+ * dtt_correlation_backward_nhwc (ic % 16 == 0): round 1's kernel in its channels-last instantiation; gradOutput contiguous
+ * (gob, D*D, oh, ow), both gradients, no workspace. */
 int dtt_correlation_backward_nhwc(const float* gradOutput, int gob, int goc, int goh, int gow, const float* input1, int ic,
                                   int ih, int iw, const float* input2, float* gradInput1, float* gradInput2, int pad_size,
                                   int kernel_size, int max_displacement, int stride1, int stride2, void* stream);
+int dtt_correlation_backward_nhwc_strided(const float* gradOutput, long g_batch_stride, long g_ch_stride, long g_px_stride, int gob,
+                                          int goc, int goh, int gow, const float* input1, int ic, int ih, int iw, const float* input2,
+                                          float* gradInput1, float* gradInput2, int pad_size, int kernel_size, int max_displacement,
+                                          int stride1, int stride2, int which, void* workspace, size_t workspace_bytes, void* stream);
+size_t dtt_correlation_backward_workspace_bytes(int batch, int ic, int ih, int iw, int pad_size, int kernel_size,
+                                                int max_displacement, int stride1, int stride2);
+/* 1 if the streamed gradient kernels cover the geometry (kernel_size 1, stride1 == stride2 | max_displacement, radius <= 8,
+ * ic % 64 == 0). */
+int dtt_correlation_backward_stream_supported(int ic, int kernel_size, int max_displacement, int stride1, int stride2);
+/* Test hooks (pure host code).  _plan_check replays every work item of the plan the launcher would use for `batch` images of
+ * target_h x target_w target pixels on `compute_units` CUs through the kernel's own item decode: 1 iff every (image, 4 x 4 target
+ * block, 64-channel group) is owned by exactly one wave, the dispatch order is a permutation of the items and every tile shape fits
+ * its LDS ring.  _plan reports the plan (work items, channel groups per item, dynamic LDS bytes, whether the order rides in the
+ * kernel arguments). */
+int dtt_correlation_backward_plan_check(int batch, int target_h, int target_w, int window_radius, int channels, int compute_units);
+int dtt_correlation_backward_plan(int batch, int target_h, int target_w, int window_radius, int channels, int compute_units,
+                                  int* items, int* chunk, int* lds_bytes, int* table);
 
 /* ---------------------------------------------------------------- PSRoI pooling
  * Replaces PSROIPoolForwardLauncher  (psroi_pooling/src/psroi_pooling_kernel.cu:82-106)

@@ -1394,26 +1394,71 @@ extern "C" int dtt_correlation_backward(const float* gradOutput, int gob, int go
   return 1;
 }
 
-// The same gradients for channels-last inputs (n, ih, iw, ic) and channels-last gradInputs; gradOutput stays the reference's
-// (n, D*D, oh, ow).  The matrix-core path only (kernel_size 1, stride1 == stride2, max_displacement / stride <= 8, ic % 16 == 0
-// -- every correlation D&T trains): other geometries fail here and the caller converts to NCHW for dtt_correlation_backward.
+// Band-stationary, halo-streamed gradient kernels for channels-last maps (correlation_bwd.hip)
+int dtt_corr_bwd_stream(const float* gradOutput, long g_sb, long g_sc, long g_sp, int gob, int goh, int gow, const float* input1, int ic,
+                        int ih, int iw, const float* input2, float* gradInput1, float* gradInput2, int pad_size, int max_displacement,
+                        int stride, int which, void* workspace, size_t workspace_bytes, hipStream_t stream);
+extern "C" int dtt_correlation_backward_stream_supported(int ic, int kernel_size, int max_displacement, int stride1, int stride2);
+
+static int backward_nhwc_checks(const float* gradOutput, int gob, int goc, int goh, int gow, const float* input1, int ic, int ih, int iw,
+                                const float* input2, const float* gradInput1, const float* gradInput2, int pad_size, int kernel_size,
+                                int max_displacement, int stride1, int stride2, int* nbr) {
+  DTT_REQUIRE(gradOutput && input1 && input2, "correlation backward: null pointer");
+  int eoc, eoh, eow;
+  if (!dtt_correlation_output_shape(ic, ih, iw, pad_size, kernel_size, max_displacement, stride1, stride2, &eoc, &eoh, &eow))
+    return 0;
+  DTT_REQUIRE(gob > 0 && goc == eoc && goh == eoh && gow == eow, "correlation backward: gradOutput shape mismatch");
+  DTT_REQUIRE(fast_path(kernel_size, stride1, stride2, max_displacement, nbr) && *nbr <= 5 && ic % 16 == 0,
+              "correlation backward (channels-last): needs kernel_size 1, stride1 == stride2, max_displacement / stride <= 8 and "
+              "channels %% 16 == 0 (got k=%d s1=%d s2=%d d=%d C=%d)", kernel_size, stride1, stride2, max_displacement, ic);
+  DTT_REQUIRE(((reinterpret_cast<uintptr_t>(input1) | reinterpret_cast<uintptr_t>(input2) | reinterpret_cast<uintptr_t>(gradInput1) |
+                reinterpret_cast<uintptr_t>(gradInput2)) & 15) == 0, "correlation backward (channels-last): pointers must be 16-byte aligned");
+  return 1;
+}
+
+// Both gradients for channels-last inputs (n, ih, iw, ic) and channels-last gradInputs on the band-stationary streamed kernels
+// (correlation_bwd.hip; kernel_size 1, stride1 == stride2, max_displacement / stride <= 8, ic % 64 == 0 -- conv3 / conv4 / conv5 of
+// D&T; dtt_correlation_backward_stream_supported).  gradOut[n, d, p] is read at gradOutput[n * g_batch_stride + d * g_ch_stride +
+// p * g_px_stride] (p = oy * ow + ox): the reference's (n, D*D, oh, ow) planes (strides D*D*oh*ow, oh*ow, 1) or columns of
+// position-major rows (g_ch_stride = 1, g_px_stride = the row length).  which: 1 = gradInput1 only, 2 = gradInput2 only, 3 = both.
+// workspace: dtt_correlation_backward_workspace_bytes(...) bytes, caller-owned, overwritten.
+extern "C" int dtt_correlation_backward_nhwc_strided(const float* gradOutput, long g_batch_stride, long g_ch_stride, long g_px_stride,
+                                                     int gob, int goc, int goh, int gow, const float* input1, int ic, int ih, int iw,
+                                                     const float* input2, float* gradInput1, float* gradInput2, int pad_size,
+                                                     int kernel_size, int max_displacement, int stride1, int stride2, int which,
+                                                     void* workspace, size_t workspace_bytes, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  DTT_REQUIRE(which >= 1 && which <= 3 && ((which & 1) == 0 || gradInput1) && ((which & 2) == 0 || gradInput2),
+              "correlation backward: null gradient pointer / bad selector");
+  int nbr = 0;
+  if (!backward_nhwc_checks(gradOutput, gob, goc, goh, gow, input1, ic, ih, iw, input2, gradInput1, gradInput2, pad_size, kernel_size,
+                            max_displacement, stride1, stride2, &nbr))
+    return 0;
+  DTT_REQUIRE(dtt_correlation_backward_stream_supported(ic, kernel_size, max_displacement, stride1, stride2),
+              "correlation backward (channels-last, streamed): needs channels %% 64 == 0 (got %d); use dtt_correlation_backward_nhwc", ic);
+  dtt_prof_begin("corr_bwd_op", stream);
+  const int ok = dtt_corr_bwd_stream(gradOutput, g_batch_stride, g_ch_stride, g_px_stride, gob, goh, gow, input1, ic, ih, iw, input2,
+                                     gradInput1, gradInput2, pad_size, max_displacement, stride1, which, workspace, workspace_bytes, stream);
+  dtt_prof_end("corr_bwd_op", stream);
+  return ok;
+}
+
+// Round 1's channels-last gradient kernels (corr_bwd_mfma<.., NHWC = true>): gradOutput the reference's contiguous (n, D*D, oh, ow),
+// both gradients, no workspace; ic % 16 == 0.  The fallback for channel counts the streamed kernels do not take, and their A/B.
 extern "C" int dtt_correlation_backward_nhwc(const float* gradOutput, int gob, int goc, int goh, int gow,
                                              const float* input1, int ic, int ih, int iw, const float* input2,
                                              float* gradInput1, float* gradInput2, int pad_size, int kernel_size,
                                              int max_displacement, int stride1, int stride2, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  DTT_REQUIRE(gradOutput && input1 && input2 && gradInput1 && gradInput2, "correlation backward: null pointer");
-  int eoc, eoh, eow;
-  if (!dtt_correlation_output_shape(ic, ih, iw, pad_size, kernel_size, max_displacement, stride1, stride2, &eoc, &eoh, &eow))
-    return 0;
-  DTT_REQUIRE(gob > 0 && goc == eoc && goh == eoh && gow == eow, "correlation backward: gradOutput shape mismatch");
+  DTT_REQUIRE(gradInput1 && gradInput2, "correlation backward: null pointer");
   int nbr = 0;
-  DTT_REQUIRE(fast_path(kernel_size, stride1, stride2, max_displacement, &nbr) && nbr <= 5 && ic % 16 == 0,
-              "correlation backward (channels-last): needs kernel_size 1, stride1 == stride2, max_displacement / stride <= 8 and "
-              "channels %% 16 == 0 (got k=%d s1=%d s2=%d d=%d C=%d)", kernel_size, stride1, stride2, max_displacement, ic);
-  DTT_REQUIRE(((reinterpret_cast<uintptr_t>(input1) | reinterpret_cast<uintptr_t>(input2) | reinterpret_cast<uintptr_t>(gradInput1) |
-                reinterpret_cast<uintptr_t>(gradInput2)) & 15) == 0, "correlation backward (channels-last): pointers must be 16-byte aligned");
+  if (!backward_nhwc_checks(gradOutput, gob, goc, goh, gow, input1, ic, ih, iw, input2, gradInput1, gradInput2, pad_size, kernel_size,
+                            max_displacement, stride1, stride2, &nbr))
+    return 0;
   const FastGeom g = make_geom(gob, ic, ih, iw, goc, goh, gow, pad_size, max_displacement, stride1);
-  return nbr == 3 ? launch_bwd<3, 2, true>(gradOutput, input1, input2, gradInput1, gradInput2, g, gob, stream)
-                  : launch_bwd<5, 2, true>(gradOutput, input1, input2, gradInput1, gradInput2, g, gob, stream);
+  dtt_prof_begin("corr_bwd_op", stream);
+  const int ok = nbr == 3 ? launch_bwd<3, 2, true>(gradOutput, input1, input2, gradInput1, gradInput2, g, gob, stream)
+                          : launch_bwd<5, 2, true>(gradOutput, input1, input2, gradInput1, gradInput2, g, gob, stream);
+  dtt_prof_end("corr_bwd_op", stream);
+  return ok;
 }

@@ -1,0 +1,652 @@
+// Cross-frame correlation, BACKWARD on channels-last maps, band-stationary / halo-streamed form (gfx950): both gradients of
+// Correlation_backward_input1 / _input2 (correlation/src/correlation_cuda_kernel.cu:108-290) for kernel_size 1,
+// stride1 == stride2, max_displacement / stride <= 8, channels % 64 == 0 -- the three correlations D&T trains (rfcn.py:58-60).
+//
+//   With G[p, q] = gradOut[p, q - p] (p: output pixel, q: displaced pixel, zero outside the window or the image)
+//       gradInput1[p, c] = 1/C * sum_q G[p, q] * f2[q, c]          gradInput2[q, c] = 1/C * sum_p G[p, q] * f1[p, c]
+//   i.e. for a 4 x 4 block of TARGET pixels a [16 targets x 4 halo pixels] x [4 halo pixels x 16 channel quads] product per
+//   step of the exact-f32 v_mfma_f32_16x16x4_f32, the reduction running over the (4 + 2R)^2 halo of the OTHER frame.
+//   The band does not depend on the channel: a wave keeps the NBR^2 * 4 band words of its block in registers (MFMA A
+//   operand) for its whole life.  The contraction runs over PIXELS, so one ds_read_b128 of a lane (4 consecutive channels of
+//   one halo pixel) feeds FOUR MFMAs when a chunk is 64 channels wide -- each MFMA takes the channels = s (mod 4) as its 16
+//   columns -- and the lane then holds, per target pixel, four consecutive channels: the result leaves as float4 stores
+//   straight from the accumulators.  No LDS epilogue, no exchange, no partial sums, every gradient element written once.
+//
+//   * Workgroup = 8 waves = a tile of th x tw target blocks (2 x 4; 4 x 1 / 2 x 1 ... along odd map edges), every wave
+//     also issues its share of the LDS-DMA (global_load_lds_dwordx4, scalar base): no loader waves, so two waves per SIMD
+//     may use 256 registers each (band 100 + accumulators 16 + operands).
+//   * The halo of a 64-channel group is streamed as BLOCK ROWS (4 halo rows x the tile's halo width x 64 channels = one ring
+//     slot, 32 KB for a 2 x 4 tile): wave row wy consumes block rows wy .. wy + NBR - 1 of a group, i.e. it runs `wy` ring
+//     positions ahead of wave row 0 -- every wave has NBR steps of work per group although the tile's halo has th + NBR - 1
+//     block rows (a lock-step schedule would idle (th - 1) / (th + NBR - 1) of the matrix pipe).  One barrier per step
+//     (80 MFMAs per wave at R = 8).
+//   * Work items = (tile, run of channel groups), laid out by a host-side plan: the chunk length is chosen by simulating the
+//     dispatch (longest first) over the CUs; the item order rides in the kernel arguments so that every XCD gets its share of
+//     long and short items and the items that are resident together on an XCD are neighbouring tiles working on the SAME
+//     channel groups (their halos overlap: L2 serves the overlap).
+//   * The band words are laid out once per op by a small kernel (corr_bwd_band_kernel) in the caller's workspace, in MFMA
+//     register order [direction][image][block][entry][lane] with the validity (window, image borders, output range) folded
+//     in -- gradOut may lie as the reference's (n, D*D, oh, ow) planes or as columns of position-major rows.  A wave then
+//     fetches its band with NBR^2 * 4 fully coalesced loads while the first ring positions are already in flight.  (Gathering
+//     the band inside the main kernel -- directly or staged through LDS -- costs 1.5 - 3 k vector instructions per wave on
+//     the critical path of every workgroup: first version of this file.)
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <mutex>
+#include <vector>
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kGC = 64;                       // channels per group
+constexpr int kWaves = 8, kThreads = kWaves * 64;
+constexpr int kLdsMax = 144 * 1024;           // 16 KB of the CU's 160 stay free for small kernels of other streams
+constexpr int kMaxNI = 6;                     // DMA instructions per wave per ring position (halo width <= 48 pixels)
+constexpr int kMaxSeg = 8;
+constexpr int kTable = 1536;                  // work-item order in the kernel arguments (16-bit item numbers)
+
+struct BSeg { int tile0, by0, bx0, nty, ntx, th, tw; };
+
+struct BGeom {
+  const float* other;                  // the frame the window runs over (frame t+tau for gradInput1, frame t for gradInput2), channels-last
+  float* grad;                         // gradient of the target frame, channels-last
+  const float* band;                   // this direction's band words [image][block row][block column][NBR^2 * 4][64 lanes]
+  int gh, gw;                          // its grid of 4 x 4 target blocks
+  long sb;                             // floats between images of other / grad
+  unsigned sy4, sx4;                   // bytes between vertically / horizontally adjacent lattice pixels
+  int C, H, W;                         // channels, lattice size
+  int oh, ow, origin;                  // output size; output (y, x) <-> lattice pixel (origin + y, origin + x)
+  int R, D, D2;
+  unsigned d2_magic;                   // 2^32 / D2 + 1
+  int lo_y, lo_x, hi_y, hi_x;          // targets, in output coordinates (inclusive)
+  float inv;                           // 1 / C
+  int nseg, tiles_per_image, tiles_total;
+  BSeg seg[kMaxSeg];
+  int chunk, ngroups;                  // item -> (chunk index = item / tiles_total, tile = item % tiles_total); groups [ci * chunk, ...)
+  int ahead;                           // ring positions in flight beyond the ones being read
+  int use_table;
+  int ablate;                          // developer timing experiments (DTT_CORR_BWD_ABLATE): 1 no DMA, 2 no MFMA, 4 no stores, 8 no band loads
+  unsigned short table[kTable];
+};
+static_assert(sizeof(BGeom) <= 4096, "kernel arguments are limited to 4 KB");
+
+__device__ __forceinline__ void dma16b(const char* sbase, unsigned voff, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+               :
+               : "s"(lds_addr), "v"(voff), "s"(sbase)
+               : "memory", "m0");
+}
+__device__ __forceinline__ const char* uptrb(const char* p) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)), lo = (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+  return (const char*)(((unsigned long long)hi << 32) | (unsigned long long)lo);
+}
+__device__ __forceinline__ void wait_vmcnt_b(int n) {   // s_waitcnt vmcnt(n), n wave-uniform at run time
+#define DTT_W1(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+  switch (n) {
+    DTT_W1(0) DTT_W1(1) DTT_W1(2) DTT_W1(3) DTT_W1(4) DTT_W1(5) DTT_W1(6) DTT_W1(7) DTT_W1(8) DTT_W1(9) DTT_W1(10) DTT_W1(11)
+    DTT_W1(12) DTT_W1(13) DTT_W1(14) DTT_W1(15) DTT_W1(16) DTT_W1(17) DTT_W1(18) DTT_W1(19) DTT_W1(20) DTT_W1(21) DTT_W1(22)
+    DTT_W1(23) DTT_W1(24)
+    default: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;   // (a stricter wait than asked, never a looser one)
+  }
+#undef DTT_W1
+}
+__device__ __forceinline__ void wg_barrier_b() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+__host__ __device__ __forceinline__ int mdiv32b(int n, unsigned magic) {
+  return magic ? (int)(((unsigned long long)(unsigned)n * magic) >> 32) : n;
+}
+
+struct BItem { int n, th, tw, Y0, X0, g0, ng; };   // image, tile shape (blocks), tile origin (output coordinates), channel groups
+
+__host__ __device__ __forceinline__ BItem bw_decode(const BGeom& g, int item) {
+  BItem it;
+  const int ci = item / g.tiles_total, tile = item - ci * g.tiles_total;
+  it.n = tile / g.tiles_per_image;
+  const int r = tile - it.n * g.tiles_per_image;
+  BSeg sg = g.seg[0];
+#pragma unroll
+  for (int i = 1; i < kMaxSeg; ++i)
+    if (i < g.nseg && r >= g.seg[i].tile0) sg = g.seg[i];
+  const int local = r - sg.tile0;
+  const int tyi = local / sg.ntx, txi = local - tyi * sg.ntx;
+  it.th = sg.th; it.tw = sg.tw;
+  it.Y0 = g.lo_y + 4 * (sg.by0 + tyi * sg.th);
+  it.X0 = g.lo_x + 4 * (sg.bx0 + txi * sg.tw);
+  it.g0 = ci * g.chunk;
+  it.ng = min(g.chunk, g.ngroups - it.g0);
+  return it;
+}
+
+template <int NBR>
+__global__ __launch_bounds__(kThreads) void corr_bwd_stream_kernel(BGeom g) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int NB4 = NBR * NBR * 4;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int bid = blockIdx.x;
+  const int item = g.use_table ? (int)g.table[bid] : dtt_xcd_remap(bid, gridDim.x);
+  const BItem it = bw_decode(g, item);
+  const int th = it.th, tw = it.tw, nwv = th * tw;
+  const bool active = wave < nwv;
+  const int wy = active ? wave / tw : 0, wx = active ? wave - wy * tw : 0;
+  const int HC = 4 * (tw + NBR - 1);                  // halo width of the tile, pixels
+  const int slot_bytes = 4 * HC * kGC * 4;            // one halo block row of one channel group
+  const int NH = th + NBR - 1;                        // halo block rows per group
+  const int S = th + g.ahead;                         // ring slots
+  const int npos = it.ng * NH;
+  const unsigned lds0 = (unsigned)(unsigned long)(const __attribute__((address_space(3))) float*)lds;
+  const long img = (long)it.n * g.sb;
+
+  // ---------------------------------------------------------------- LDS-DMA descriptors: instruction j = wave + 8 i of a position
+  // fills slot pixels [4 j, 4 j + 4) (x 64 channels = 1 KB): halo row (4 j) / HC of the block row, columns (4 j) % HC + lane / 16
+  unsigned voff[kMaxNI];
+  int row_of[kMaxNI];
+  int ni = 0;
+#pragma unroll
+  for (int i = 0; i < kMaxNI; ++i) {
+    const int j = wave + kWaves * i;
+    voff[i] = 0; row_of[i] = 0;
+    if (j < HC) {
+      const int t = (4 * j) / HC, c = 4 * j - t * HC + (lane >> 4);
+      const int x = min(max(g.origin + it.X0 - g.R + c, 0), g.W - 1);    // out-of-image pixels: any in-bounds address (their band words are zero)
+      voff[i] = (unsigned)x * g.sx4 + (unsigned)((lane & 15) << 4);
+      row_of[i] = t;
+      ++ni;
+    }
+  }
+  if (g.ablate & 1) ni = 0;
+  const char* obase = reinterpret_cast<const char*>(g.other + img);
+  int issued = 0;
+  auto issue_position = [&](int P) {
+    const int gi = P / NH, hr = P - gi * NH;
+    const unsigned dst = lds0 + (unsigned)((P % S) * slot_bytes + wave * 1024);
+    const char* gbase = obase + (long)(it.g0 + gi) * (kGC * 4);
+#pragma unroll
+    for (int i = 0; i < kMaxNI; ++i)
+      if (i < ni) {
+        const int y = min(max(g.origin + it.Y0 - g.R + 4 * hr + row_of[i], 0), g.H - 1);
+        dma16b(uptrb(gbase + (unsigned long long)((unsigned)y * g.sy4)), voff[i], dst + (unsigned)(i * kWaves * 1024));
+      }
+  };
+
+  // the ring is filled first (positions 0 .. th - 1 are read in step 0); the band loads queue up behind it
+  for (; issued < min(S, npos); ++issued) issue_position(issued);
+
+  // ---------------------------------------------------------------- band: NBR^2 * 4 words per lane, in register order
+  float band[NB4];
+  {
+    const int by = (it.Y0 - g.lo_y) / 4 + wy, bx = (it.X0 - g.lo_x) / 4 + wx;
+    const float* bp = g.band + ((((long)it.n * g.gh + by) * g.gw + bx) * NB4) * 64 + lane;
+#pragma unroll
+    for (int b = 0; b < NB4; ++b) band[b] = (active && !(g.ablate & 8)) ? bp[b * 64] : 0.f;
+  }
+  // nothing of the compiler's is outstanding when the loop starts: its own waits then never sit inside the loop, where a
+  // vmcnt(0) would also drain the ring positions in flight
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+
+  // ---------------------------------------------------------------- store descriptors: lane -> target row tyi = lane / 16, columns r = 0 .. 3
+  unsigned st_off[4];
+  bool st_ok[4];
+  {
+    const int ty = it.Y0 + 4 * wy + (lane >> 4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int tx = it.X0 + 4 * wx + r;
+      const int ly = ty + g.origin, lx = tx + g.origin;
+      st_ok[r] = active && ty >= g.lo_y && ty <= g.hi_y && tx >= g.lo_x && tx <= g.hi_x && ly >= 0 && ly < g.H && lx >= 0 && lx < g.W &&
+                 !(g.ablate & 4);
+      st_off[r] = st_ok[r] ? (unsigned)ly * g.sy4 + (unsigned)lx * g.sx4 + (unsigned)((lane & 15) << 4) : 0u;
+    }
+  }
+  char* gbase = reinterpret_cast<char*>(g.grad + img);
+
+  // ---------------------------------------------------------------- main loop: one step = one halo block row of one group
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+  const char* lb = reinterpret_cast<const char*>(lds);
+  const unsigned rd_lane = (unsigned)(wx * 1024 + lane * 16);
+  const bool do_mfma = active && !(g.ablate & 2);
+  for (int gi = 0; gi < it.ng; ++gi) {
+#pragma unroll
+    for (int qi = 0; qi < NBR; ++qi) {
+      const int base = gi * NH + qi;
+      // positions <= base + th - 1 must have landed; mine of the later ones may still fly (loads return in order)
+      const int need = min(base + th - 1, npos - 1);
+      wait_vmcnt_b(max(issued - 1 - need, 0) * ni);
+      wg_barrier_b();      // everybody's share has landed; everybody is done with the positions below `base`
+      const int upto = min(base + th - 1 + g.ahead, npos - 1);
+      for (; issued <= upto; ++issued) issue_position(issued);
+      if (do_mfma) {
+        // One burst of NBR ds_read_b128 per halo row t (the row's NBR window blocks: 4 MFMAs each), issued one row ahead of the
+        // MFMAs that consume it; sched_barrier pins burst-then-MFMA order (hipcc otherwise sinks every read next to its MFMAs
+        // and waits for it there: a lone LDS read between two MFMAs costs the pipe ~36 cycles, tools/probes/mfma_lds.hip).
+        const char* sp = lb + ((base + wy) % S) * slot_bytes + rd_lane;
+        f32x4 bv[2][NBR];
+        auto rd = [&](int t, int buf) {
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int qj = 0; qj < NBR; ++qj) bv[buf][qj] = *reinterpret_cast<const f32x4*>(sp + (t * HC + 4 * qj) * (kGC * 4));
+          __builtin_amdgcn_sched_barrier(0);
+        };
+        auto mm = [&](int t, int buf) {
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int qj = 0; qj < NBR; ++qj) {
+            const float a = band[(qi * NBR + qj) * 4 + t];
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[buf][qj][0], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[buf][qj][1], acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[buf][qj][2], acc2, 0, 0, 0);
+            acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[buf][qj][3], acc3, 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        };
+        rd(0, 0); rd(1, 1);
+        mm(0, 0); rd(2, 0);
+        mm(1, 1); rd(3, 1);
+        mm(2, 0);
+        mm(3, 1);
+      }
+    }
+    // the group is complete: D[m = 4 * (lane / 16) + r][n = lane % 16] of accumulator s is channel 4 n + s of target pixel m
+    char* dst = gbase + (long)(it.g0 + gi) * (kGC * 4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (st_ok[r]) {
+        const f32x4 o = {acc0[r] * g.inv, acc1[r] * g.inv, acc2[r] * g.inv, acc3[r] * g.inv};
+        *reinterpret_cast<f32x4*>(dst + st_off[r]) = o;
+      }
+    acc0 = acc1 = acc2 = acc3 = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ the band, once per op
+// band[dir][n][by][bx][(qi * NBR + qj) * 4 + t][lane]: what lane (m = lane % 16: target pixel (m / 4, m % 4) of block (by, bx);
+// k = lane / 16) of the wave that owns the block feeds the MFMA of window block (qi, qj), step t as its A operand = the gradient
+// that couples target m with the other frame's halo pixel (4 qi + t, 4 qj + k) of the block's halo -- zero where the pair lies
+// outside the window, the output range or the image.  One workgroup per (direction, image, block); thread = (lane, t).
+struct BandGeom {
+  const float* gout; long g_sb, g_sc, g_sp;
+  float* band;
+  int oh, ow, origin, H, W, R, D;
+  int lo_y[2], lo_x[2], gh[2], gw[2];
+  long dir_off[2];                     // floats from `band` to a direction's words
+  int batch;
+};
+
+template <int NBR>
+__global__ __launch_bounds__(256) void corr_bwd_band_kernel(BandGeom g) {
+  constexpr int NB4 = NBR * NBR * 4;
+  int blk = blockIdx.x;
+  const int n0 = g.batch * g.gh[0] * g.gw[0];
+  const int dir = blk >= n0 ? 1 : 0;
+  blk -= dir ? n0 : 0;
+  const int gw = g.gw[dir], gh = g.gh[dir];
+  const int bx = blk % gw, by = (blk / gw) % gh, n = blk / (gw * gh);
+  const int lane = threadIdx.x & 63, t = threadIdx.x >> 6;
+  const int m = lane & 15, k = lane >> 4, tyi = m >> 2, txi = m & 3;
+  const int ty = g.lo_y[dir] + 4 * by + tyi, tx = g.lo_x[dir] + 4 * bx + txi;     // target pixel, output coordinates
+  const float* go = g.gout + (long)n * g.g_sb;
+  float* out = g.band + g.dir_off[dir] + (((long)n * gh + by) * gw + bx) * NB4 * 64 + t * 64 + lane;
+  auto in_img = [&](int y, int x) { return y + g.origin >= 0 && y + g.origin < g.H && x + g.origin >= 0 && x + g.origin < g.W; };
+#pragma unroll
+  for (int qi = 0; qi < NBR; ++qi)
+#pragma unroll
+    for (int qj = 0; qj < NBR; ++qj) {
+      const int hy = 4 * qi + t - tyi, hx = 4 * qj + k - txi;                    // halo pixel - target pixel + R
+      const int tj = dir ? 2 * g.R - hy : hy, ti = dir ? 2 * g.R - hx : hx;     // displacement index of the pair
+      const int dy = tj - g.R, dx = ti - g.R;
+      const int py = dir ? ty - dy : ty, px = dir ? tx - dx : tx;               // p: output pixel;  q = p + d: displaced pixel
+      const int qy = py + dy, qx = px + dx;
+      const bool ok = tj >= 0 && tj < g.D && ti >= 0 && ti < g.D && py >= 0 && py < g.oh && px >= 0 && px < g.ow && in_img(py, px) &&
+                      in_img(qy, qx);
+      const long off = ok ? (long)(tj * g.D + ti) * g.g_sc + ((long)py * g.ow + px) * g.g_sp : 0;
+      const float v = go[off];
+      out[(qi * NBR + qj) * 4 * 64] = ok ? v : 0.f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side: the plan
+struct BPlan {
+  int nseg, tiles_per_image, tiles_total, chunk, ngroups, items, ahead, use_table;
+  size_t lds_bytes;
+  BSeg seg[kMaxSeg];
+  std::vector<unsigned short> table;
+};
+
+// ring slots a tile shape can afford: th + ahead, ahead = 3 .. 1 positions in flight beyond the ones being read
+bool tile_lds(int th, int tw, int nbr, int* ahead, size_t* bytes) {
+  const size_t slot = (size_t)4 * 4 * (tw + nbr - 1) * kGC * 4;
+  for (int a = 3; a >= 1; --a)
+    if ((th + a) * slot <= (size_t)kLdsMax) { *ahead = a; *bytes = (th + a) * slot; return true; }
+  return false;
+}
+
+// Tiles over GH x GW target blocks: 2 x 4 in the body; the odd columns at the right edge as 4 x w / 2 x w strips (a 4 x 1 tile
+// keeps four waves busy where a 2 x 1 tile has two), an odd last row as 1 x 4 / 1 x w tiles.
+int bw_segments(int GH, int GW, BSeg* seg) {
+  int ns = 0, t0 = 0;
+  auto add = [&](int by0, int bx0, int nty, int ntx, int th, int tw) {
+    if (nty > 0 && ntx > 0 && ns < kMaxSeg) { seg[ns++] = BSeg{t0, by0, bx0, nty, ntx, th, tw}; t0 += nty * ntx; }
+  };
+  const int eh = GH / 2 * 2, ew = GW / 4 * 4, rw = GW - ew;
+  add(0, 0, eh / 2, ew / 4, 2, 4);
+  if (rw == 3) add(0, ew, eh / 2, 1, 2, 3);
+  if (rw == 1 || rw == 2) {
+    add(0, ew, eh / 4, 1, 4, rw);
+    if (eh % 4) add(eh / 4 * 4, ew, 1, 1, 2, rw);
+  }
+  if (GH & 1) {
+    add(eh, 0, 1, ew / 4, 1, 4);
+    if (rw) add(eh, ew, 1, 1, 1, rw);
+  }
+  return ns;
+}
+
+// makespan of `dur` (sorted descending) dealt greedily to `ncu` machines
+double makespan(const std::vector<double>& dur, int ncu) {
+  std::vector<double> heap(ncu, 0.0);   // min-heap of machine finish times
+  auto cmp = [](double a, double b) { return a > b; };
+  for (double d : dur) {
+    std::pop_heap(heap.begin(), heap.end(), cmp);
+    heap.back() += d;
+    std::push_heap(heap.begin(), heap.end(), cmp);
+  }
+  return *std::max_element(heap.begin(), heap.end());
+}
+
+bool plan_bwd(int batch, int eh, int ew, int nbr, int ngroups, int ncu, BPlan* out) {
+  const int GH = (eh + 3) / 4, GW = (ew + 3) / 4;
+  BPlan p;
+  p.nseg = bw_segments(GH, GW, p.seg);
+  if (p.nseg == 0 || ncu < 1) return false;
+  p.tiles_per_image = 0;
+  int ahead = 3;
+  for (int s = 0; s < p.nseg; ++s) {
+    p.tiles_per_image += p.seg[s].nty * p.seg[s].ntx;
+    int a; size_t b;
+    if (!tile_lds(p.seg[s].th, p.seg[s].tw, nbr, &a, &b)) return false;
+    ahead = std::min(ahead, a);
+  }
+  size_t lds = 0;   // (one `ahead` for the launch)
+  for (int s = 0; s < p.nseg; ++s) lds = std::max(lds, (size_t)(p.seg[s].th + ahead) * 4 * 4 * (p.seg[s].tw + nbr - 1) * kGC * 4);
+  p.ahead = ahead; p.lds_bytes = lds;
+  p.tiles_total = p.tiles_per_image * batch;
+  p.ngroups = ngroups;
+  // cost of one (tile, group) unit in matrix-pipe time: the waves of a tile sit ceil(waves / 4) deep on a SIMD; a workgroup pays
+  // a set-up (ring fill, band fetch) worth about a third of a two-deep unit
+  std::vector<double> tile_cost;
+  for (int s = 0; s < p.nseg; ++s)
+    for (int i = 0; i < p.seg[s].nty * p.seg[s].ntx; ++i) tile_cost.push_back((p.seg[s].th * p.seg[s].tw + 3) / 4);
+  const double setup = 0.6;
+  double best = 1e30;
+  int best_chunk = ngroups;
+  std::vector<double> dur;
+  for (int chunk = ngroups; chunk >= 1; --chunk) {
+    const int nchunks = (ngroups + chunk - 1) / chunk;
+    if ((long)nchunks * p.tiles_total > 65535) break;                          // (16-bit item numbers; more items than that never pay)
+    if (nchunks > 1 && (ngroups + nchunks - 1) / nchunks != chunk) continue;   // (the same chunk count with a smaller chunk is more even)
+    dur.clear();
+    for (int ci = 0; ci < nchunks; ++ci) {
+      const int len = std::min(chunk, ngroups - ci * chunk);
+      for (int b = 0; b < batch; ++b)
+        for (double c : tile_cost) dur.push_back(setup + len * c);
+    }
+    std::sort(dur.begin(), dur.end(), [](double a, double b) { return a > b; });
+    const double ms = makespan(dur, ncu);
+    if (ms < best - 1e-9) { best = ms; best_chunk = chunk; }
+  }
+  p.chunk = best_chunk;
+  const int nchunks = (ngroups + p.chunk - 1) / p.chunk;
+  p.items = nchunks * p.tiles_total;
+  // ---- dispatch order.  Block b runs on XCD b % 8 and the blocks of an XCD start in order: every XCD's queue gets its share
+  // of each duration class, longest first; within a class an XCD's share is a contiguous run of (chunk, tile) = neighbouring
+  // tiles working on the same channel groups.
+  p.use_table = p.items <= kTable ? 1 : 0;
+  if (p.use_table) {
+    struct It { double dur; int id; };
+    std::vector<It> its(p.items);
+    for (int ci = 0; ci < nchunks; ++ci) {
+      const int len = std::min(p.chunk, ngroups - ci * p.chunk);
+      for (int t = 0; t < p.tiles_total; ++t) its[ci * p.tiles_total + t] = It{setup + len * tile_cost[t % p.tiles_per_image], ci * p.tiles_total + t};
+    }
+    std::stable_sort(its.begin(), its.end(), [](const It& a, const It& b) { return a.dur > b.dur; });
+    std::vector<std::vector<int>> q(8);
+    for (size_t lo = 0; lo < its.size();) {
+      size_t hi = lo;
+      while (hi < its.size() && its[hi].dur == its[lo].dur) ++hi;
+      const size_t n = hi - lo;
+      for (int x = 0; x < 8; ++x)
+        for (size_t i = lo + n * x / 8; i < lo + n * (x + 1) / 8; ++i) q[x].push_back(its[i].id);
+      lo = hi;
+    }
+    // the hardware's queue lengths: XCD x runs blocks x, x + 8, ... -> items / 8 (+ 1 for x < items % 8)
+    for (;;) {
+      int lng = -1, sht = -1;
+      for (int x = 0; x < 8; ++x) {
+        const int want = p.items / 8 + (x < p.items % 8 ? 1 : 0);
+        if ((int)q[x].size() > want && lng < 0) lng = x;
+        if ((int)q[x].size() < want && sht < 0) sht = x;
+      }
+      if (lng < 0 || sht < 0) break;
+      q[sht].push_back(q[lng].back());
+      q[lng].pop_back();
+    }
+    p.table.assign(p.items, 0);
+    for (int x = 0; x < 8; ++x)
+      for (size_t k = 0; k < q[x].size(); ++k) p.table[x + 8 * k] = (unsigned short)q[x][k];
+  }
+  *out = p;
+  return true;
+}
+
+struct PlanKey { int batch, eh, ew, nbr, ngroups, ncu; };
+bool operator==(const PlanKey& a, const PlanKey& b) { return memcmp(&a, &b, sizeof(PlanKey)) == 0; }
+
+const BPlan* cached_plan(const PlanKey& k) {
+  static std::mutex mu;
+  static std::vector<std::pair<PlanKey, BPlan*>> cache;   // a handful of shapes per process; entries live as long as the process
+  std::lock_guard<std::mutex> lock(mu);
+  for (auto& e : cache)
+    if (e.first == k) return e.second;
+  BPlan* p = new BPlan();
+  if (!plan_bwd(k.batch, k.eh, k.ew, k.nbr, k.ngroups, k.ncu, p)) { delete p; p = nullptr; }
+  cache.emplace_back(k, p);
+  return p;
+}
+
+template <int NBR>
+int launch_stream(const BGeom& g, int items, size_t lds_bytes, hipStream_t stream) {
+  static DttDeviceOnce once;
+  bool& done = once.here();
+  if (!done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(corr_bwd_stream_kernel<NBR>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMax);
+    DTT_REQUIRE(e == hipSuccess, "correlation backward (streamed): cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
+    done = true;
+  }
+  hipLaunchKernelGGL((corr_bwd_stream_kernel<NBR>), dim3(items), dim3(kThreads), lds_bytes, stream, g);
+  DTT_CHECK_LAUNCH("corr_bwd_stream_kernel");
+  return 1;
+}
+
+// target ranges of the two directions in output coordinates (inclusive); false: empty
+bool target_range(bool wrt2, int oh, int ow, int H, int W, int origin, int R, int* lo, int* hi_y, int* hi_x) {
+  if (!wrt2) {   // output pixels whose lattice pixel lies inside the image
+    *lo = std::max(0, -origin);
+    *hi_y = std::min(oh - 1, H - 1 - origin); *hi_x = std::min(ow - 1, W - 1 - origin);
+  } else {       // displaced pixels q = p + d that fall inside the image
+    *lo = std::max(-origin, -R);
+    *hi_y = std::min(H - 1 - origin, oh - 1 + R); *hi_x = std::min(W - 1 - origin, ow - 1 + R);
+  }
+  return *hi_y >= *lo && *hi_x >= *lo;
+}
+
+}  // namespace
+
+// 1 if the band-stationary streamed kernels cover this geometry (else the caller takes the round-1 kernels)
+extern "C" int dtt_correlation_backward_stream_supported(int ic, int kernel_size, int max_displacement, int stride1, int stride2) {
+  if (kernel_size != 1 || stride1 != stride2 || stride1 < 1 || max_displacement % stride1 != 0) return 0;
+  const int R = max_displacement / stride1;
+  return R >= 1 && R <= 8 && ic % kGC == 0;
+}
+
+// bytes of workspace dtt_correlation_backward_nhwc_strided needs for this geometry (the band words of both directions); 0 where the
+// streamed kernels do not apply
+extern "C" size_t dtt_correlation_backward_workspace_bytes(int batch, int ic, int ih, int iw, int pad_size, int kernel_size,
+                                                           int max_displacement, int stride1, int stride2) {
+  if (!dtt_correlation_backward_stream_supported(ic, kernel_size, max_displacement, stride1, stride2) || batch < 1) return 0;
+  if ((max_displacement - pad_size) % stride1 != 0) return 0;
+  int oc, oh, ow;
+  if (!dtt_correlation_output_shape(ic, ih, iw, pad_size, kernel_size, max_displacement, stride1, stride2, &oc, &oh, &ow)) return 0;
+  const int s = stride1, R = max_displacement / s, nbr = R <= 4 ? 3 : 5;
+  const int H = (ih + s - 1) / s, W = (iw + s - 1) / s, origin = (max_displacement - pad_size) / s;
+  size_t total = 0;
+  for (int dir = 0; dir < 2; ++dir) {
+    int lo, hy, hx;
+    if (!target_range(dir == 1, oh, ow, H, W, origin, R, &lo, &hy, &hx)) continue;
+    total += (size_t)batch * ((hy - lo + 4) / 4) * ((hx - lo + 4) / 4) * nbr * nbr * 4 * 64 * sizeof(float);
+  }
+  return total;
+}
+
+// Both gradients, channels-last inputs and gradients; gradOut[n, d, p] at gradOutput[n * g_sb + d * g_sc + p * g_sp].
+// which: 1 = gradInput1 only, 2 = gradInput2 only, 3 = both.
+int dtt_corr_bwd_stream(const float* gradOutput, long g_sb, long g_sc, long g_sp, int gob, int goh, int gow, const float* input1, int ic,
+                        int ih, int iw, const float* input2, float* gradInput1, float* gradInput2, int pad_size, int max_displacement,
+                        int stride, int which, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  const int s = stride, R = max_displacement / s;
+  DTT_REQUIRE((max_displacement - pad_size) % s == 0, "correlation backward (channels-last): displacement - padding must be a multiple of the stride");
+  DTT_REQUIRE((long)ih * iw * ic * 4 < 0xffffffffl, "correlation backward (channels-last): one image exceeds the 32-bit offset range");
+  const size_t ws_need = dtt_correlation_backward_workspace_bytes(gob, ic, ih, iw, pad_size, 1, max_displacement, s, s);
+  DTT_REQUIRE(workspace && workspace_bytes >= ws_need && (reinterpret_cast<uintptr_t>(workspace) & 3) == 0,
+              "correlation backward (channels-last): workspace of %zu bytes needed (dtt_correlation_backward_workspace_bytes), got %zu",
+              ws_need, workspace ? workspace_bytes : (size_t)0);
+  BGeom g;
+  memset(&g, 0, sizeof(g));
+  g.C = ic;
+  g.H = (ih + s - 1) / s; g.W = (iw + s - 1) / s;
+  g.sb = (long)ih * iw * ic;
+  g.sx4 = (unsigned)((long)s * ic * 4); g.sy4 = (unsigned)((long)s * iw * ic * 4);
+  g.oh = goh; g.ow = gow; g.origin = (max_displacement - pad_size) / s;
+  g.R = R; g.D = 2 * R + 1;
+  g.inv = 1.f / (float)ic;
+  static const int ablate = getenv("DTT_CORR_BWD_ABLATE") ? atoi(getenv("DTT_CORR_BWD_ABLATE")) : 0;
+  g.ablate = ablate;
+  const int nbr = R <= 4 ? 3 : 5;
+  const int ncu = dtt_device_cus();
+
+  // ---- the band words of both directions: one small launch
+  BandGeom bg;
+  memset(&bg, 0, sizeof(bg));
+  bg.gout = gradOutput; bg.g_sb = g_sb; bg.g_sc = g_sc; bg.g_sp = g_sp;
+  bg.band = static_cast<float*>(workspace);
+  bg.oh = goh; bg.ow = gow; bg.origin = g.origin; bg.H = g.H; bg.W = g.W; bg.R = R; bg.D = g.D; bg.batch = gob;
+  int lo[2], hy[2], hx[2];
+  bool live[2];
+  long off = 0;
+  int band_blocks = 0;
+  for (int dir = 0; dir < 2; ++dir) {
+    live[dir] = target_range(dir == 1, goh, gow, g.H, g.W, g.origin, R, &lo[dir], &hy[dir], &hx[dir]);
+    bg.lo_y[dir] = bg.lo_x[dir] = live[dir] ? lo[dir] : 0;
+    bg.gh[dir] = live[dir] ? (hy[dir] - lo[dir] + 4) / 4 : 0;
+    bg.gw[dir] = live[dir] ? (hx[dir] - lo[dir] + 4) / 4 : 0;
+    bg.dir_off[dir] = off;
+    off += (long)gob * bg.gh[dir] * bg.gw[dir] * nbr * nbr * 4 * 64;
+    band_blocks += gob * bg.gh[dir] * bg.gw[dir];
+  }
+  if (band_blocks > 0) {
+    if (nbr == 3) hipLaunchKernelGGL((corr_bwd_band_kernel<3>), dim3(band_blocks), dim3(256), 0, stream, bg);
+    else hipLaunchKernelGGL((corr_bwd_band_kernel<5>), dim3(band_blocks), dim3(256), 0, stream, bg);
+    DTT_CHECK_LAUNCH("corr_bwd_band_kernel");
+  }
+
+  const size_t bytes = (size_t)gob * ic * ih * iw * sizeof(float);
+  // pixels that no lattice point maps to (stride > 1, pad != displacement) keep a zero gradient; on the dense lattice of conv4 /
+  // conv5 (stride 1, pad == displacement) both kernels write every element themselves
+  const bool dense = s == 1 && g.origin == 0 && goh == g.H && gow == g.W;
+  for (int dir = 0; dir < 2; ++dir) {
+    const bool wrt2 = dir == 1;
+    if (!(which & (wrt2 ? 2 : 1))) continue;
+    float* grad = wrt2 ? gradInput2 : gradInput1;
+    if (!dense) DTT_REQUIRE(hipMemsetAsync(grad, 0, bytes, stream) == hipSuccess, "correlation backward: memset failed");
+    if (!live[dir]) continue;
+    g.lo_y = g.lo_x = lo[dir]; g.hi_y = hy[dir]; g.hi_x = hx[dir];
+    g.gh = bg.gh[dir]; g.gw = bg.gw[dir];
+    g.band = bg.band + bg.dir_off[dir];
+    const PlanKey key{gob, g.hi_y - g.lo_y + 1, g.hi_x - g.lo_x + 1, nbr, ic / kGC, ncu};
+    const BPlan* p = cached_plan(key);
+    DTT_REQUIRE(p != nullptr, "correlation backward (streamed): no plan for %d x %d targets, radius %d", key.eh, key.ew, R);
+    g.other = wrt2 ? input1 : input2;
+    g.grad = grad;
+    g.nseg = p->nseg; g.tiles_per_image = p->tiles_per_image; g.tiles_total = p->tiles_total;
+    for (int i = 0; i < kMaxSeg; ++i) g.seg[i] = i < p->nseg ? p->seg[i] : BSeg{0x7fffffff, 0, 0, 1, 1, 1, 1};
+    g.chunk = p->chunk; g.ngroups = p->ngroups; g.ahead = p->ahead; g.use_table = p->use_table;
+    if (p->use_table) memcpy(g.table, p->table.data(), sizeof(unsigned short) * p->items);
+    int ok;
+    // (one kernel for both directions: which gradient a launch computes is a matter of its band words and of `other`)
+    ok = nbr == 3 ? launch_stream<3>(g, p->items, p->lds_bytes, stream) : launch_stream<5>(g, p->items, p->lds_bytes, stream);
+    if (!ok) return 0;
+  }
+  return 1;
+}
+
+// Test hook (pure host code): replays every work item of the plan the launcher would use through the kernel's own item decode and
+// counts, per (image, target block, channel group), how many waves own it.  Returns 1 iff each is owned exactly once, the dispatch
+// table is a permutation of the items, and every tile shape fits its ring.
+extern "C" int dtt_correlation_backward_plan_check(int batch, int target_h, int target_w, int window_radius, int channels,
+                                                   int compute_units) {
+  if (window_radius < 1 || window_radius > 8 || channels % kGC != 0 || batch < 1 || target_h < 1 || target_w < 1) return 0;
+  const int R = window_radius, nbr = R <= 4 ? 3 : 5;
+  BPlan p;
+  if (!plan_bwd(batch, target_h, target_w, nbr, channels / kGC, compute_units > 0 ? compute_units : 256, &p)) return 0;
+  BGeom g;
+  memset(&g, 0, sizeof(g));
+  g.nseg = p.nseg; g.tiles_per_image = p.tiles_per_image; g.tiles_total = p.tiles_total;
+  for (int i = 0; i < kMaxSeg; ++i) g.seg[i] = i < p.nseg ? p.seg[i] : BSeg{0x7fffffff, 0, 0, 1, 1, 1, 1};
+  g.chunk = p.chunk; g.ngroups = p.ngroups;
+  const int GH = (target_h + 3) / 4, GW = (target_w + 3) / 4, NG = channels / kGC;
+  std::vector<unsigned char> owned((size_t)batch * GH * GW * NG, 0);
+  std::vector<unsigned char> seen(p.items, 0);
+  if (p.lds_bytes > (size_t)kLdsMax) return 0;
+  for (int b = 0; b < p.items; ++b) {
+    const int item = p.use_table ? (int)p.table[b] : b;
+    if (item < 0 || item >= p.items || seen[item]) return 0;
+    seen[item] = 1;
+    const BItem it = bw_decode(g, item);
+    if (it.n < 0 || it.n >= batch || it.ng < 1 || it.g0 + it.ng > NG || it.th * it.tw > kWaves) return 0;
+    if (4 * (it.tw + nbr - 1) > kMaxNI * kWaves) return 0;
+    if ((size_t)(it.th + p.ahead) * 4 * 4 * (it.tw + nbr - 1) * kGC * 4 > p.lds_bytes || p.ahead < 1) return 0;
+    for (int w = 0; w < it.th * it.tw; ++w) {
+      const int by = it.Y0 / 4 + w / it.tw, bx = it.X0 / 4 + w % it.tw;
+      if (by >= GH || bx >= GW) return 0;
+      for (int gi = it.g0; gi < it.g0 + it.ng; ++gi) {
+        unsigned char& c = owned[(((size_t)it.n * GH + by) * GW + bx) * NG + gi];
+        if (c) return 0;
+        c = 1;
+      }
+    }
+  }
+  for (unsigned char c : owned)
+    if (!c) return 0;
+  return 1;
+}
+
+// developer / test hook: the plan's shape (work items, channel groups per item, LDS bytes, whether the order rides in the arguments)
+extern "C" int dtt_correlation_backward_plan(int batch, int target_h, int target_w, int window_radius, int channels, int compute_units,
+                                             int* items, int* chunk, int* lds_bytes, int* table) {
+  if (window_radius < 1 || window_radius > 8 || channels % kGC != 0) return 0;
+  const int R = window_radius, nbr = R <= 4 ? 3 : 5;
+  BPlan p;
+  if (!plan_bwd(batch, target_h, target_w, nbr, channels / kGC, compute_units > 0 ? compute_units : 256, &p)) return 0;
+  if (items) *items = p.items;
+  if (chunk) *chunk = p.chunk;
+  if (lds_bytes) *lds_bytes = (int)p.lds_bytes;
+  if (table) *table = p.use_table;
+  return 1;
+}

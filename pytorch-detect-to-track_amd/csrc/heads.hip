@@ -457,14 +457,14 @@ __global__ __launch_bounds__(NW * 64) void psroi_pm_kernel(const float* __restri
 // lanes = classes -- no atomics, no pre-zeroed output (every pixel writes its whole row segment), deterministic.
 // psroi_pm_edges_kernel first turns every RoI into its 4 * P bin edges with the forward's arithmetic (psroi_bin.h).
 __global__ void psroi_pm_edges_kernel(const float* __restrict__ rois, int num_rois, float spatial_scale, int pooled, int height,
-                                      int width, int* __restrict__ edges) {
+                                      int width, int batch_size, int* __restrict__ edges) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= num_rois) return;
   float roi[5];
 #pragma unroll
   for (int q = 0; q < 5; ++q) roi[q] = rois[(long)r * 5 + q];
   int* e = edges + (long)r * (4 * pooled + 1);
-  e[4 * pooled] = (int)roi[0];
+  e[4 * pooled] = min(max((int)roi[0], 0), batch_size - 1);   // the forward's clamp (psroi_pm_kernel): both directions agree on the image
   for (int k = 0; k < pooled; ++k) {
     const Bin b = psroi_bin(roi, spatial_scale, k, k, pooled, pooled, height, width);   // rows depend on ph only, columns on pw only
     e[k] = b.hstart; e[pooled + k] = b.hend; e[2 * pooled + k] = b.wstart; e[3 * pooled + k] = b.wend;
@@ -569,9 +569,10 @@ int launch_head(const HeadGeom& g, hipStream_t stream) {
     DTT_REQUIRE(e == hipSuccess, "head_gemm: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
     raised_here = true;
   }
-  dtt_prof_begin("head_gemm", stream);
+  const char* tag = g.epilogue == 1 ? "rpn_head_gemm" : "head_gemm";   // (the RPN launch carries its own timing tag)
+  dtt_prof_begin(tag, stream);
   hipLaunchKernelGGL((head_gemm_kernel<TPX, NTW, NLOAD, PIN, NSTAGE>), dim3(g.n_groups * g.strips), dim3((4 + NLOAD) * 64), lds, stream, g);
-  dtt_prof_end("head_gemm", stream);
+  dtt_prof_end(tag, stream);
   DTT_CHECK_LAUNCH("head_gemm");
   return 1;
 }
@@ -679,6 +680,9 @@ extern "C" int dtt_rpn_head_gemm(const float* x, long ldx, int batch, int hw, in
   HeadGeom g;
   g.epilogue = 1; g.A = num_anchors; g.hw = hw; g.hw_magic = 0xffffffffu / (unsigned)hw + 1u; g.out2 = bbox_pred;
   DTT_REQUIRE(hw > 1, "rpn_head_gemm: a map of one pixel is not supported");
+  // the epilogue splits a row index into (image, pixel) with __umulhi(row, 2^32 / hw + 1): exact while row * hw < 2^32
+  DTT_REQUIRE((unsigned long long)batch * hw * hw < (1ull << 32), "rpn_head_gemm: batch * hw^2 = %llu exceeds the 32-bit range of the "
+              "row -> (image, pixel) split", (unsigned long long)batch * hw * hw);
   const int n_store = 6 * num_anchors;
   return head_gemm_launch(g, x, ldx, batch * hw, K, w, bias, n_rows, cls_prob, (long)((n_store + 3) / 4 * 4), (n_store + 3) / 4 * 4, 1,
                           static_cast<hipStream_t>(stream_));
@@ -700,7 +704,7 @@ extern "C" int dtt_psroi_pm_backward(const float* grad_vote, const float* rois, 
   DTT_REQUIRE(lds <= 32 * 1024, "psroi_pm backward: pooled size too large");
   if (num_rois > 0) {
     hipLaunchKernelGGL(psroi_pm_edges_kernel, dim3(dtt_cdiv(num_rois, 256)), dim3(256), 0, stream, rois, num_rois, spatial_scale, pooled,
-                       height, width, edges);
+                       height, width, batch_size, edges);
     DTT_CHECK_LAUNCH("psroi_pm_edges");
   }
   const int npx = batch_size * height * width;

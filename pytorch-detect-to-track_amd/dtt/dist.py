@@ -12,7 +12,10 @@ bucketed gradient all-reduce that overlaps with the rest of backward:
     is all-reduced asynchronously as soon as its last gradient has been accumulated;
   * `finish_gradients()` waits for the outstanding handles and divides by the world size.
 Inference needs no communication at all (results stay per rank).
-With world_size == 1 everything degenerates to a plain module call.
+With world_size == 1 everything degenerates to a plain module call -- unless `force_buckets` is set: then the hooks, the flat
+buckets and the asynchronous all-reduces run exactly as on N ranks (over a 1-rank process group when one is initialised).
+That is how the RCCL path is exercised on a single-GPU box: two ranks cannot share one GPU under RCCL, a 1-rank `nccl`
+group can carry the buckets (tests/test_gpu_dist.py, `bench.py --mode train` -> `allreduce_ms`).
 """
 import torch
 import torch.distributed as dist
@@ -30,17 +33,19 @@ def _bucket_view(flat, off, p):
 
 
 class DataParallelSnippets(nn.Module):
-    def __init__(self, module, world_size=None, bucket_bytes=32 << 20, process_group=None):
+    def __init__(self, module, world_size=None, bucket_bytes=32 << 20, process_group=None, force_buckets=False):
         super().__init__()
         self.module = module
         self.group = process_group
         self.world = world_size if world_size is not None else (dist.get_world_size() if dist.is_initialized() else 1)
+        self.bucketed = self.world > 1 or bool(force_buckets)
         self._handles = []
         self._buckets = []
         self._views = []
         self._pending = {}
         if self.world > 1:
             self._sync_initial_state()
+        if self.bucketed:
             self._build_buckets(bucket_bytes)
 
     # ------------------------------------------------------------------ setup
@@ -110,7 +115,8 @@ class DataParallelSnippets(nn.Module):
             p.grad = v
         if dst:
             torch._foreach_copy_(dst, src)
-        self._handles.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        if dist.is_initialized():   # (force_buckets without a process group: buckets and hooks only)
+            self._handles.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def _make_hook(self, bucket_index):
         def hook(param):
@@ -126,7 +132,7 @@ class DataParallelSnippets(nn.Module):
     def zero_grad(self, set_to_none=True):
         """Drop the gradients (default) so that backward hands fresh tensors over instead of running one add per
         parameter; set_to_none=False keeps the tensors and zeroes them."""
-        if self.world == 1:
+        if not self.bucketed:
             self.module.zero_grad(set_to_none=set_to_none)
             return
         for flat, grp in self._buckets:
@@ -139,7 +145,7 @@ class DataParallelSnippets(nn.Module):
     def finish_gradients(self):
         """Wait for the in-flight bucket all-reduces and average.  Parameters that received no gradient this
         step (unused branches) still have their bucket reduced so all ranks stay in lockstep."""
-        if self.world == 1:
+        if not self.bucketed:
             return
         for bi, left in self._pending.items():
             if left > 0:
@@ -147,10 +153,36 @@ class DataParallelSnippets(nn.Module):
         for h in self._handles:
             h.wait()
         self._handles = []
-        inv = 1.0 / self.world
-        for flat, _ in self._buckets:
-            flat.mul_(inv)
+        if self.world > 1:
+            inv = 1.0 / self.world
+            for flat, _ in self._buckets:
+                flat.mul_(inv)
         self._reset_pending()
+
+    def bucket_bytes_total(self):
+        return sum(flat.numel() * flat.element_size() for flat, _ in self._buckets)
+
+    def time_allreduce_ms(self, repeats=5):
+        """The bucket all-reduces alone (every flat bucket once, back to back, as finish_gradients waits for them), median of
+        `repeats`; None without buckets or a process group.  Leaves the buckets' values untouched up to the sum over ranks
+        being re-applied -- call it outside a training step."""
+        if not self._buckets or not dist.is_initialized():
+            return None
+        import time
+        dev = self._buckets[0][0].device
+        saved = [flat.clone() for flat, _ in self._buckets]
+        times = []
+        for _ in range(repeats):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            hs = [dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True) for flat, _ in self._buckets]
+            for h in hs:
+                h.wait()
+            torch.cuda.synchronize(dev)
+            times.append((time.perf_counter() - t0) * 1e3)
+        for (flat, _), s in zip(self._buckets, saved):
+            flat.copy_(s)
+        return sorted(times)[len(times) // 2]
 
     def state_dict(self, *a, **k):  # checkpoints hold the bare module's keys (trainval_net.py:422 unwraps too)
         return self.module.state_dict(*a, **k)
@@ -172,7 +204,7 @@ def broadcast_module_state(module, process_group=None, src=0):
     return module
 
 
-def prepare_replica(model, world, channels_last=True, process_group=None):
+def prepare_replica(model, world, channels_last=True, process_group=None, force_buckets=False):
     """The start-up order of a training replica: broadcast rank 0's state -> fold the frozen constants
     (fuse_for_training, which also moves the trainable filters to channels-last memory) -> lay out the gradient buckets
     (DataParallelSnippets) after that.  Returns the runner."""
@@ -180,7 +212,7 @@ def prepare_replica(model, world, channels_last=True, process_group=None):
     if world > 1:
         broadcast_module_state(model, process_group)
     fuse_for_training(model, channels_last=channels_last)
-    return DataParallelSnippets(model, world, process_group=process_group)
+    return DataParallelSnippets(model, world, process_group=process_group, force_buckets=force_buckets)
 
 
 def shard_snippets(n_snippets, rank, world):

@@ -161,6 +161,48 @@ def _is_channels_last(t):
     return t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last) and not t.is_contiguous()
 
 
+def correlation_backward_nhwc(grad_output, input1, input2, g1, g2, pad_size, kernel_size, max_displacement, stride1, stride2,
+                              rows=None, col=0):
+    """Both correlation gradients on channels-last maps, written into the channels-last tensors g1 / g2 (either may be None).
+    grad_output: the reference's (B, D*D, oh, ow) tensor -- or, with `rows`, columns [col, col + D*D) of a position-major
+    (B*oh*ow, ld) matrix (the gradient of the tracking head's input rows: read where it lies).  Channels % 64 == 0: the
+    band-stationary streamed kernels (`dtt_correlation_backward_nhwc_strided`, workspace from the caching allocator); other
+    channel counts: round 1's kernels (`dtt_correlation_backward_nhwc`; contiguous grad_output, both gradients)."""
+    L = _lib.lib()
+    B, C, H, W = input1.shape
+    oc, oh, ow = correlation_output_shape(C, H, W, pad_size, kernel_size, max_displacement, stride1, stride2)
+    dev = input1.device
+    streamed = bool(L.dtt_correlation_backward_stream_supported(C, kernel_size, max_displacement, stride1, stride2)) and \
+        os.environ.get("DTT_CORR_BWD_STREAM", "1") != "0"
+    with torch.cuda.device(dev):
+        if not streamed:
+            if rows is not None or g1 is None or g2 is None:
+                raise ValueError("correlation backward (channels-last): %d channels take the round-1 kernels, which need a contiguous "
+                                 "gradOutput tensor and both gradient outputs" % C)
+            grad_output = grad_output.contiguous()
+            check(L.dtt_correlation_backward_nhwc(ptr(grad_output), B, oc, oh, ow, ptr(input1), C, H, W, ptr(input2), ptr(g1), ptr(g2),
+                                                  pad_size, kernel_size, max_displacement, stride1, stride2, stream_ptr(dev)),
+                  "correlation backward (channels-last)")
+            return
+        if rows is None:
+            grad_output = grad_output.contiguous()
+            gptr, sb, sc, sp = ptr(grad_output), oc * oh * ow, oh * ow, 1
+        else:
+            if rows.dim() != 2 or rows.dtype != torch.float32 or rows.stride(1) != 1 or rows.shape[0] != B * oh * ow \
+                    or col < 0 or col + oc > rows.shape[1]:
+                raise ValueError("correlation backward: rows must be float32 (%d, >= %d) with unit column stride" % (B * oh * ow, col + oc))
+            ld = rows.stride(0)
+            gptr, sb, sc, sp = ctypes.c_void_p(rows.data_ptr() + 4 * col), oh * ow * ld, 1, ld
+        nbytes = int(L.dtt_correlation_backward_workspace_bytes(B, C, H, W, pad_size, kernel_size, max_displacement, stride1, stride2))
+        ws = torch.empty((max(nbytes, 4) + 3) // 4, dtype=torch.float32, device=dev)
+        which = (1 if g1 is not None else 0) | (2 if g2 is not None else 0)
+        check(L.dtt_correlation_backward_nhwc_strided(gptr, sb, sc, sp, B, oc, oh, ow, ptr(input1), C, H, W, ptr(input2),
+                                                      ptr(g1) if g1 is not None else None, ptr(g2) if g2 is not None else None,
+                                                      pad_size, kernel_size, max_displacement, stride1, stride2, which,
+                                                      ptr(ws), ws.numel() * 4, stream_ptr(dev)),
+              "correlation backward (channels-last, streamed)")
+
+
 class CorrelationNHWCFunction(Function):
     """The same op on channels-last maps, for a channels-last training trunk: forward = the window-split kernel
     (`dtt_correlation_forward_nhwc`, NCHW output as the reference's), backward = the matrix-core gradients reading and
@@ -168,11 +210,21 @@ class CorrelationNHWCFunction(Function):
     gradients in either direction.  Geometry: kernel_size 1, stride1 == stride2, max_displacement / stride <= 8,
     channels % 16 == 0 (`Correlation.forward` routes everything else through the NCHW functions)."""
 
+    MAX_RADIUS = 8   # window radius max_displacement / stride the channels-last gradient kernels take
+
     @staticmethod
-    def supports(input1, input2, kernel_size, max_displacement, stride1, stride2):
-        return (input1.is_cuda and input1.dtype == torch.float32 and input1.shape == input2.shape and
+    def supports(input1, input2, kernel_size, max_displacement, stride1, stride2, pad_size=None):
+        """The geometries both channels-last kernels take (dtt_correlation_forward_nhwc / _backward_nhwc*): everything else goes
+        through `.contiguous()` + CorrelationFunction.  pad_size None: the caller's padding is not checked (legacy callers)."""
+        if not (input1.is_cuda and input1.dtype == torch.float32 and input1.shape == input2.shape and
                 _is_channels_last(input1) and _is_channels_last(input2) and kernel_size == 1 and stride1 == stride2 and
-                stride2 > 0 and 1 <= max_displacement // stride2 <= 8 and input1.size(1) % 16 == 0)
+                stride2 > 0 and 1 <= max_displacement // stride2 <= CorrelationNHWCFunction.MAX_RADIUS and
+                input1.size(1) % 16 == 0):
+            return False
+        # the kernels address the stride lattice: displacement and (displacement - padding) must be multiples of the stride
+        if max_displacement % stride2 != 0 or (pad_size is not None and (max_displacement - pad_size) % stride2 != 0):
+            return False
+        return True
 
     @staticmethod
     def forward(ctx, input1, input2, pad_size, kernel_size, max_displacement, stride1, stride2):
@@ -190,12 +242,7 @@ class CorrelationNHWCFunction(Function):
         g1 = torch.empty_like(input1)   # (channels-last, as the inputs)
         g2 = torch.empty_like(input2)
         assert _is_channels_last(g1) and _is_channels_last(g2)
-        with torch.cuda.device(input1.device):
-            check(_lib.lib().dtt_correlation_backward_nhwc(ptr(grad_output), grad_output.shape[0], grad_output.shape[1],
-                                                           grad_output.shape[2], grad_output.shape[3], ptr(input1), C, H, W,
-                                                           ptr(input2), ptr(g1), ptr(g2), pad_size, kernel_size,
-                                                           max_displacement, stride1, stride2, stream_ptr(input1.device)),
-                  "correlation backward (channels-last)")
+        correlation_backward_nhwc(grad_output, input1, input2, g1, g2, pad_size, kernel_size, max_displacement, stride1, stride2)
         return g1, g2, None, None, None, None, None
 
 
@@ -225,12 +272,7 @@ class CorrelationPairNHWCFunction(Function):
         assert _is_channels_last(g) or n == 1
         g1, g2 = g[i * B:(i + 1) * B], g[j * B:(j + 1) * B]
         in1, in2 = maps[i * B:(i + 1) * B], maps[j * B:(j + 1) * B]
-        with torch.cuda.device(maps.device):
-            check(_lib.lib().dtt_correlation_backward_nhwc(ptr(grad_output), grad_output.shape[0], grad_output.shape[1],
-                                                           grad_output.shape[2], grad_output.shape[3], ptr(in1), C, H, W,
-                                                           ptr(in2), ptr(g1), ptr(g2), pad_size, kernel_size,
-                                                           max_displacement, stride1, stride2, stream_ptr(maps.device)),
-                  "correlation backward (channels-last)")
+        correlation_backward_nhwc(grad_output, in1, in2, g1, g2, pad_size, kernel_size, max_displacement, stride1, stride2)
         return g, None, None, None, None, None, None, None, None
 
 
@@ -248,7 +290,8 @@ class Correlation(nn.Module):
         self.corr_multiply = corr_multiply
 
     def forward(self, input1, input2):
-        if CorrelationNHWCFunction.supports(input1, input2, self.kernel_size, self.max_displacement, self.stride1, self.stride2):
+        if CorrelationNHWCFunction.supports(input1, input2, self.kernel_size, self.max_displacement, self.stride1, self.stride2,
+                                            self.pad_size):
             return CorrelationNHWCFunction.apply(input1, input2, self.pad_size, self.kernel_size, self.max_displacement,
                                                  self.stride1, self.stride2)
         if input1.is_cuda and not input1.is_contiguous():
@@ -262,7 +305,8 @@ class Correlation(nn.Module):
         """Legs i and j of a (n_legs * B, C, H, W) batch tensor; channels-last maps stay whole under autograd
         (CorrelationPairNHWCFunction), anything else is sliced and goes through forward()."""
         a, b = maps[i * B:(i + 1) * B], maps[j * B:(j + 1) * B]
-        if i != j and CorrelationNHWCFunction.supports(a, b, self.kernel_size, self.max_displacement, self.stride1, self.stride2):
+        if i != j and CorrelationNHWCFunction.supports(a, b, self.kernel_size, self.max_displacement, self.stride1, self.stride2,
+                                                       self.pad_size):
             return CorrelationPairNHWCFunction.apply(maps, B, i, j, self.pad_size, self.kernel_size, self.max_displacement,
                                                      self.stride1, self.stride2)
         return self.forward(a, b)

@@ -111,3 +111,43 @@ def test_correlation_window_split_plans_cover_every_pair_exactly_once():
                       int(rs.choice([0, 1, 17, 64, 240, 252]))))
     for c in cases:
         assert L.dtt_correlation_nhwc_plan_check(*c) == 1, c
+
+
+def test_correlation_streamed_backward_plans_without_gpu():
+    """dtt_correlation_backward_plan / _plan_check are host code: the launch plans of the band-stationary streamed correlation
+    gradient kernels (csrc/correlation_bwd.hip).  Every (image, 4 x 4 target block, 64-channel group) must be owned by exactly one
+    wave of exactly one work item, the dispatch table must be a permutation of the items and every tile shape must fit its LDS
+    ring -- for the training shapes and a sweep of map sizes, radii, channel counts and CU counts."""
+    import numpy as np
+    from dtt import _lib
+    L = _lib.lib()
+
+    def plan(*a):
+        v = [ctypes.c_int() for _ in range(4)]
+        assert L.dtt_correlation_backward_plan(*a, *[ctypes.byref(x) for x in v]) == 1, a
+        return tuple(x.value for x in v)
+    # the 600 px training step, B = 2: 2 x (20 tiles of 2 x 4 blocks + the 17th block column as two 4 x 1 and one 2 x 1) = 46 tiles
+    items, chunk, lds, table = plan(2, 38, 67, 8, 2048, 256)
+    assert items % 46 == 0 and items == 46 * -(-32 // chunk) and lds <= 144 * 1024 and table == 1
+    # one round of workgroups (longest first) must beat the naive one-workgroup-per-tile plan by far: <= 7 two-deep units of a CU
+    assert 4 <= chunk <= 8, chunk
+    items4, chunk4, _, _ = plan(2, 38, 67, 8, 1024, 256)
+    assert items4 == 46 * -(-16 // chunk4) and 2 <= chunk4 <= 4
+    assert plan(2, 38, 67, 4, 512, 256)[0] >= 46                 # conv3 (radius 4 on the stride-2 lattice)
+    cases = [(2, 38, 67, 8, 2048, 256), (2, 38, 67, 8, 1024, 256), (2, 38, 67, 4, 512, 256), (8, 38, 67, 8, 2048, 256), (1, 36, 63, 8, 1024, 256),
+             (1, 1, 1, 1, 64, 256), (3, 9, 11, 4, 64, 7), (1, 4, 33, 8, 128, 1), (1, 20, 4, 8, 64, 256), (2, 5, 4, 8, 64, 304), (16, 38, 67, 8, 2048, 256),
+             (1, 75, 134, 8, 512, 256)]
+    rs = np.random.RandomState(0)
+    for _ in range(150):
+        cases.append((int(rs.randint(1, 5)), int(rs.randint(1, 80)), int(rs.randint(1, 140)), int(rs.randint(1, 9)),
+                      64 * int(rs.randint(1, 33)), int(rs.choice([1, 8, 64, 104, 240, 256, 304]))))
+    for c in cases:
+        assert L.dtt_correlation_backward_plan_check(*c) == 1, c
+    assert L.dtt_correlation_backward_plan_check(1, 8, 8, 9, 64, 256) == 0      # radius > 8: not these kernels
+    assert L.dtt_correlation_backward_plan_check(1, 8, 8, 4, 48, 256) == 0      # channels % 64 != 0: round 1's kernels
+    assert L.dtt_correlation_backward_stream_supported(2048, 1, 8, 1, 1) == 1 and L.dtt_correlation_backward_stream_supported(512, 1, 8, 2, 2) == 1
+    assert L.dtt_correlation_backward_stream_supported(80, 1, 8, 1, 1) == 0 and L.dtt_correlation_backward_stream_supported(64, 3, 8, 1, 1) == 0
+    assert L.dtt_correlation_backward_stream_supported(64, 1, 16, 1, 1) == 0
+    # workspace: the band words of both directions, NBR^2 * 4 * 64 floats per 4 x 4 target block
+    assert L.dtt_correlation_backward_workspace_bytes(2, 2048, 38, 67, 8, 1, 8, 1, 1) == 2 * 2 * 10 * 17 * 100 * 64 * 4
+    assert L.dtt_correlation_backward_workspace_bytes(2, 80, 38, 67, 8, 1, 8, 1, 1) == 0

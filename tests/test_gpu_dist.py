@@ -46,7 +46,7 @@ def _loss(out):
     return out[4].mean() + out[5].mean() + out[6].mean() + out[7].mean() + out[9].mean()   # trainval_net.py:367-368
 
 
-def _freeze_proposals(model, dev):
+def _freeze_proposals(model, dev, SIZE=SIZE):
     """Replace the RPN's proposal step by boxes that do not depend on the network's outputs: a last-bit difference between
     two runs of the library convolutions can then no longer swap two near-tied proposals (and with them a sampled RoI), so
     the two sides of the comparison sample the SAME RoIs and their gradients can be compared tensor by tensor at 3e-3."""
@@ -142,3 +142,92 @@ def test_two_ranks_on_one_gpu_match_sequential_snippets():
         checked += 1
     assert float(np.median(rels)) < 2e-2, sorted(rels)[-5:]   # most tensors are trunk tensors (see above); the head / RPN tensors carry the tight bound
     assert checked > 40 and set(got) == {n for n, p in model.named_parameters() if p.requires_grad and p.grad is not None}
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# RCCL on the hardware at hand: a ONE-rank `nccl` process group carrying the real gradient buckets (two ranks cannot share
+# a GPU under RCCL, so this is the only form in which RCCL moves the training step's device buffers on a 1-GPU box).
+def _nccl_one_rank_worker(port, q, full_size):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    cfg = _setup()
+    from dtt.dist import prepare_replica
+    from dtt.synth import build_model, calibrate_batchnorm_, make_batch
+    dev = torch.device("cuda:0")
+    layers, B, H, W = (101, 2, 600, 1067) if full_size else (50, 1, SIZE[0], SIZE[1])
+    batch = make_batch(B, H, W, seed=3, device=dev)
+
+    def replica(force):
+        model = build_model(layers, cfg=cfg, seed=3).to(dev)
+        calibrate_batchnorm_(model, batch[0][:, 0])
+        model.train()
+        _freeze_proposals(model, dev, (H, W))   # both replicas then sample the same RoIs whatever the last bits of the RPN outputs
+        return model, prepare_replica(model, 1, channels_last=True, force_buckets=force)
+
+    def step(runner):
+        np.random.seed(1234)
+        runner.zero_grad(set_to_none=True)
+        _loss(runner(*batch)).backward()
+        runner.finish_gradients()
+        torch.cuda.synchronize()
+
+    def grads(model):
+        return {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.requires_grad and p.grad is not None}
+
+    m_plain, r_plain = replica(False)
+    step(r_plain)                       # throw-away: the libraries pick / cache their kernels on the first step
+    step(r_plain); g_a = grads(m_plain)
+    step(r_plain); g_b = grads(m_plain)   # same step again: which tensors are run-to-run bit-identical at all?
+    m_buck, r_buck = replica(True)
+    assert r_buck.bucketed and len(r_buck._buckets) >= 2 and not r_plain.bucketed
+    step(r_buck)
+    step(r_buck); g_c = grads(m_buck)
+    ar_ms = r_buck.time_allreduce_ms(3)
+    res = {"n": len(g_a), "keys_equal": set(g_a) == set(g_c), "bucket_bytes": r_buck.bucket_bytes_total(),
+           "n_buckets": len(r_buck._buckets), "allreduce_ms": ar_ms, "backend": dist.get_backend(),
+           "in_bucket": all(any(p.grad.data_ptr() >= f.data_ptr() and p.grad.data_ptr() < f.data_ptr() + f.numel() * 4
+                                for f, _ in r_buck._buckets)
+                            for p in m_buck.parameters() if p.requires_grad and p.grad is not None),
+           "rows": []}
+    for n in g_a:
+        det = bool(torch.equal(g_a[n], g_b[n]))
+        same = bool(torch.equal(g_a[n], g_c[n]))
+        nrm = float(g_a[n].double().norm())
+        rel = float((g_a[n].double() - g_c[n].double()).norm() / max(nrm, 1e-30))
+        rel_rr = float((g_a[n].double() - g_b[n].double()).norm() / max(nrm, 1e-30))
+        res["rows"].append((n, det, same, rel, rel_rr))
+    q.put(res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("full_size", [False, True], ids=["res50_small", "configs3_per_rank_step"])
+def test_one_rank_nccl_group_carries_the_gradient_buckets(full_size):
+    """force_buckets: hooks + flat buckets + asynchronous all-reduces over a 1-rank RCCL communicator, on the real `_RFCN`
+    training step (full_size: BASELINE configs[3]'s per-rank workload, Res-101 600 x 1067, 2 frame pairs).  Every gradient
+    tensor that the plain step reproduces bit for bit from run to run must come out of the bucketed step bit-identical
+    (an all-reduce over one rank is the identity; a bucket reduced twice, skipped, mis-sliced or averaged is not); tensors the
+    libraries' atomics make run-to-run noisy must agree as closely as two plain runs do."""
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    p = ctx.Process(target=_nccl_one_rank_worker, args=(_free_port(), q, full_size))
+    p.start()
+    res = q.get()
+    p.join(300)
+    assert p.exitcode == 0
+    assert res["backend"] == "nccl" and res["keys_equal"] and res["in_bucket"] and res["n"] > 40
+    assert res["n_buckets"] >= 2 and res["bucket_bytes"] > (150 << 20 if full_size else 50 << 20)
+    assert res["allreduce_ms"] is not None and res["allreduce_ms"] > 0
+    n_det = 0
+    for n, det, same, rel, rel_rr in res["rows"]:
+        if det:
+            assert same, ("deterministic tensor differs between the plain and the bucketed step", n, rel)
+            n_det += 1
+        else:
+            assert rel <= max(10 * rel_rr, 1e-6), (n, rel, rel_rr)
+    assert n_det >= 10, "no run-to-run deterministic gradient tensors to pin the bucket path on (%d)" % n_det
+    print("1-rank RCCL: %d tensors (%d run-to-run deterministic, all bit-identical through the buckets), %d buckets / %.1f MB, "
+          "all-reduce %.3f ms" % (res["n"], n_det, res["n_buckets"], res["bucket_bytes"] / 1e6, res["allreduce_ms"]))

@@ -216,6 +216,16 @@ CORR_CL_CASES = [
     (2, 16, 9, 11, 4, 1, 4, 1, 1),      # tiny map, one chunk
     (1, 80, 38, 67, 8, 1, 8, 1, 1),     # the 600 px map, five chunks
     (3, 16, 5, 4, 8, 1, 8, 1, 1),       # map narrower than the window
+    # channels % 64 == 0: the band-stationary streamed gradient kernels (csrc/correlation_bwd.hip)
+    (1, 128, 37, 45, 8, 1, 8, 2, 2),    # conv3 geometry: lattice stride 2, R = 4, two channel groups
+    (1, 64, 16, 16, 6, 1, 4, 1, 1),     # pad > displacement: outputs beyond the map
+    (1, 64, 30, 30, 2, 1, 4, 1, 1),     # pad < displacement: the border pixels are no targets of gradInput1
+    (1, 64, 21, 17, 3, 1, 3, 1, 1),     # R = 3, odd block row, one odd block column (4 x 1 / 1 x 1 tiles)
+    (2, 64, 9, 11, 4, 1, 4, 1, 1),      # tiny map: 2 x 3 and 1 x 3 tiles only
+    (1, 128, 38, 67, 8, 1, 8, 1, 1),    # the 600 px map: 2 x 4 tiles + the 17th block column as 4 x 1 / 2 x 1
+    (1, 192, 24, 40, 8, 1, 8, 1, 1),    # two odd block columns (4 x 2 / 2 x 2 tiles), three channel groups
+    (3, 64, 5, 4, 8, 1, 8, 1, 1),       # map narrower than the window
+    (2, 320, 17, 29, 8, 1, 8, 1, 1),    # five groups, odd rows and three odd columns (2 x 3 tiles)
 ]
 
 
@@ -246,7 +256,38 @@ def test_correlation_channels_last_autograd(dev, case):
     np.testing.assert_allclose(t2.grad.cpu().numpy(), g2, rtol=0, atol=1e-4)
     n1, n2 = cu(x1, dev).requires_grad_(True), cu(x2, dev).requires_grad_(True)
     layer(n1, n2).backward(cu(gout, dev))
-    assert torch.equal(n1.grad, t1.grad) and torch.equal(n2.grad, t2.grad)
+    if C % 64:
+        # round 1's kernel in its channels-last instantiation: the NCHW instantiation's MFMA sequence
+        assert torch.equal(n1.grad, t1.grad) and torch.equal(n2.grad, t2.grad)
+    else:
+        # the streamed kernels sum the window in another (fixed) order: same values to rounding, identical from run to run
+        assert float((n1.grad - t1.grad).abs().max()) < 1e-5 and float((n2.grad - t2.grad).abs().max()) < 1e-5
+        r1 = t1.detach().clone().requires_grad_(True)
+        r2 = t2.detach().clone().requires_grad_(True)
+        layer(r1, r2).backward(cu(gout, dev))
+        assert torch.equal(r1.grad, t1.grad) and torch.equal(r2.grad, t2.grad)
+
+
+@pytest.mark.parametrize("case", [c for c in CORR_CL_CASES if c[1] % 64 == 0])
+def test_correlation_streamed_backward_rows_layout_and_single_gradients(dev, case):
+    """dtt_correlation_backward_nhwc_strided reading gradOut as columns of position-major rows (the gradient of the tracking
+    head's input rows, read where it lies) and computing one gradient at a time: bit-identical to the planes layout / both."""
+    from dtt.ops import correlation_backward_nhwc, correlation_output_shape
+    B, C, H, W, pad, k, d, s1, s2 = case
+    rng = np.random.RandomState(sum(case) + 11)
+    cl = lambda a: cu(a, dev).contiguous(memory_format=torch.channels_last)
+    t1, t2 = cl(rng.normal(size=(B, C, H, W)).astype(np.float32)), cl(rng.normal(size=(B, C, H, W)).astype(np.float32))
+    oc, oh, ow = correlation_output_shape(C, H, W, pad, k, d, s1, s2)
+    gout = cu(rng.normal(size=(B, oc, oh, ow)).astype(np.float32), dev)
+    ga, gb = torch.empty_like(t1), torch.empty_like(t2)
+    correlation_backward_nhwc(gout, t1, t2, ga, gb, pad, k, d, s1, s2)
+    ld, col = oc + 37, 13
+    rows = torch.full((B * oh * ow, ld), float("nan"), device=dev)
+    rows[:, col:col + oc] = gout.permute(0, 2, 3, 1).reshape(-1, oc)
+    ra, rb = torch.full_like(t1, float("nan")), torch.full_like(t2, float("nan"))
+    correlation_backward_nhwc(None, t1, t2, ra, None, pad, k, d, s1, s2, rows=rows, col=col)
+    correlation_backward_nhwc(None, t1, t2, None, rb, pad, k, d, s1, s2, rows=rows, col=col)
+    assert torch.equal(ra, ga) and torch.equal(rb, gb)
 
 
 def test_correlation_pair_keeps_a_channels_last_batch_whole(dev):
