@@ -472,6 +472,13 @@ int dtt_head_gemm(const float* x, long ldx, int M, int K, const float* w, const 
 int dtt_rpn_head_gemm(const float* x, long ldx, int batch, int hw, int K, const float* w, const float* bias, int n_rows,
                       int num_anchors, float* cls_prob, float* bbox_pred, void* stream);
 
+/* Backward of dtt_rpn_head_gemm's epilogue (training graph, rpn.py:63-71): the gradients with respect to cls_prob (batch, 2A, h, w)
+ * and bbox_pred (batch, 4A, h, w) -- either may be NULL = zero -- become the (batch * hw, ld) rows of the packed GEMM's output
+ * gradient, columns [bg_0, fg_0, ..., bg_{A-1}, fg_{A-1}, box deltas 0 .. 4A-1, zeros up to ld], with the adjoint of the pairwise
+ * softmax applied (cls_prob: the forward's probabilities).  dX and dW then are dtt_head_gemm / dtt_head_gemm_dw over these rows. */
+int dtt_rpn_head_grad_rows(const float* grad_cls_prob, const float* grad_bbox_pred, const float* cls_prob, int batch, int hw,
+                           int num_anchors, float* rows, long ld, void* stream);
+
 /* Weight gradient of the packed 1x1 heads (training graph, rfcn.py:49-53): dw[n][k] = sum_m gout[m][n] * x[m][k] for n < N,
  * k < K over the M pixel rows of the position-major maps -- gout (M, g_cols >= N columns readable, row stride ldg floats; the
  * columns N .. g_cols only have to be finite), x (M, K) with row stride ldx, dw (N, K) dense.  Exact-f32 MFMA; both operands

@@ -34,6 +34,7 @@
 #include <string.h>
 #include <algorithm>
 #include <mutex>
+#include <type_traits>
 #include <vector>
 #include "common.h"
 
@@ -48,7 +49,7 @@ constexpr int kMaxNI = 6;                     // DMA instructions per wave per r
 constexpr int kMaxSeg = 8;
 constexpr int kTable = 1536;                  // work-item order in the kernel arguments (16-bit item numbers)
 
-struct BSeg { int tile0, by0, bx0, nty, ntx, th, tw; };
+struct BSeg { int tile0, by0, bx0, nty, ntx, th, tw, ahead; };   // ahead: ring slots beyond the th being read
 
 struct BGeom {
   const float* other;                  // the frame the window runs over (frame t+tau for gradInput1, frame t for gradInput2), channels-last
@@ -66,7 +67,6 @@ struct BGeom {
   int nseg, tiles_per_image, tiles_total;
   BSeg seg[kMaxSeg];
   int chunk, ngroups;                  // item -> (chunk index = item / tiles_total, tile = item % tiles_total); groups [ci * chunk, ...)
-  int ahead;                           // ring positions in flight beyond the ones being read
   int use_table;
   int ablate;                          // developer timing experiments (DTT_CORR_BWD_ABLATE): 1 no DMA, 2 no MFMA, 4 no stores, 8 no band loads
   unsigned short table[kTable];
@@ -103,7 +103,18 @@ __host__ __device__ __forceinline__ int mdiv32b(int n, unsigned magic) {
   return magic ? (int)(((unsigned long long)(unsigned)n * magic) >> 32) : n;
 }
 
-struct BItem { int n, th, tw, Y0, X0, g0, ng; };   // image, tile shape (blocks), tile origin (output coordinates), channel groups
+// s_waitcnt lgkmcnt(LEFT) that names a burst's registers as read-write operands: all but the LEFT youngest LDS reads have
+// returned, and nothing that consumes those registers can be scheduled in front of the wait
+template <int LEFT>
+__device__ __forceinline__ void landed5(f32x4& a, f32x4& b, f32x4& c, f32x4& d, f32x4& e) {
+  asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e) : "n"(LEFT));
+}
+template <int LEFT>
+__device__ __forceinline__ void landed3(f32x4& a, f32x4& b, f32x4& c) {
+  asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(LEFT));
+}
+
+struct BItem { int n, th, tw, ahead, Y0, X0, g0, ng; };   // image, tile shape (blocks), ring depth, tile origin (output coordinates), channel groups
 
 __host__ __device__ __forceinline__ BItem bw_decode(const BGeom& g, int item) {
   BItem it;
@@ -116,7 +127,7 @@ __host__ __device__ __forceinline__ BItem bw_decode(const BGeom& g, int item) {
     if (i < g.nseg && r >= g.seg[i].tile0) sg = g.seg[i];
   const int local = r - sg.tile0;
   const int tyi = local / sg.ntx, txi = local - tyi * sg.ntx;
-  it.th = sg.th; it.tw = sg.tw;
+  it.th = sg.th; it.tw = sg.tw; it.ahead = sg.ahead;
   it.Y0 = g.lo_y + 4 * (sg.by0 + tyi * sg.th);
   it.X0 = g.lo_x + 4 * (sg.bx0 + txi * sg.tw);
   it.g0 = ci * g.chunk;
@@ -139,7 +150,7 @@ __global__ __launch_bounds__(kThreads) void corr_bwd_stream_kernel(BGeom g) {
   const int HC = 4 * (tw + NBR - 1);                  // halo width of the tile, pixels
   const int slot_bytes = 4 * HC * kGC * 4;            // one halo block row of one channel group
   const int NH = th + NBR - 1;                        // halo block rows per group
-  const int S = th + g.ahead;                         // ring slots
+  const int S = th + it.ahead;                        // ring slots
   const int npos = it.ng * NH;
   const unsigned lds0 = (unsigned)(unsigned long)(const __attribute__((address_space(3))) float*)lds;
   const long img = (long)it.n * g.sb;
@@ -209,33 +220,48 @@ __global__ __launch_bounds__(kThreads) void corr_bwd_stream_kernel(BGeom g) {
 
   // ---------------------------------------------------------------- main loop: one step = one halo block row of one group
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
-  const char* lb = reinterpret_cast<const char*>(lds);
-  const unsigned rd_lane = (unsigned)(wx * 1024 + lane * 16);
+  const unsigned rd_lane = lds0 + (unsigned)(wx * 1024 + lane * 16);
   const bool do_mfma = active && !(g.ablate & 2);
+  // Operand reads are inline asm the compiler does not track, released by ONE hand-counted s_waitcnt per burst (LDS returns in
+  // order): hipcc's own bookkeeping puts a counted wait in front of every group of four MFMAs, and stray issue slots inside
+  // an MFMA stream cost the pipe tens of cycles each (first version of this loop: 20 waits per step, 7.0 k cycles per step
+  // against the 5.1 k of its 160 MFMAs per SIMD).  The wait lists the burst's registers as read-write operands, so the MFMAs
+  // that consume them cannot be moved in front of it.
+  f32x4 bv[2][NBR];
+  auto rd = [&](unsigned addr, int buf) {
+#pragma unroll
+    for (int qj = 0; qj < NBR; ++qj)
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bv[buf][qj]) : "v"(addr), "n"(qj * 4 * kGC * 4));
+  };
+#define DTT_LANDED(buf, LEFT)                                                                                          \
+  do {                                                                                                                \
+    if constexpr (NBR == 5) landed5<LEFT>(bv[buf][0], bv[buf][1], bv[buf][2], bv[buf][NBR - 2], bv[buf][NBR - 1]);      \
+    else landed3<LEFT>(bv[buf][0], bv[buf][1], bv[buf][2]);                                                            \
+  } while (0)
   for (int gi = 0; gi < it.ng; ++gi) {
 #pragma unroll
     for (int qi = 0; qi < NBR; ++qi) {
       const int base = gi * NH + qi;
-      // positions <= base + th - 1 must have landed; mine of the later ones may still fly (loads return in order)
+      // Positions <= base + th - 1 are read in this step.  After the barrier the ring is refilled as far as it goes: position
+      // P's slot is free once everybody is done with position P - S < base.
       const int need = min(base + th - 1, npos - 1);
-      wait_vmcnt_b(max(issued - 1 - need, 0) * ni);
-      wg_barrier_b();      // everybody's share has landed; everybody is done with the positions below `base`
-      const int upto = min(base + th - 1 + g.ahead, npos - 1);
-      for (; issued <= upto; ++issued) issue_position(issued);
+      const int fill = min(base + S - 1, npos - 1);
+      if (issued - 1 >= need) {
+        wait_vmcnt_b((issued - 1 - need) * ni);   // mine of the later positions may still fly (loads return in order)
+        wg_barrier_b();                           // everybody's share has landed; everybody is done with the positions below `base`
+        for (; issued <= fill; ++issued) issue_position(issued);
+      } else {
+        // a tall tile at a group boundary (th rows step into fresh positions at once, the ring holds fewer than 2 th): the slots
+        // only come free now -- fill, drain, meet again
+        wg_barrier_b();
+        for (; issued <= fill; ++issued) issue_position(issued);
+        wait_vmcnt_b(0);
+        wg_barrier_b();
+      }
       if (do_mfma) {
-        // One burst of NBR ds_read_b128 per halo row t (the row's NBR window blocks: 4 MFMAs each), issued one row ahead of the
-        // MFMAs that consume it; sched_barrier pins burst-then-MFMA order (hipcc otherwise sinks every read next to its MFMAs
-        // and waits for it there: a lone LDS read between two MFMAs costs the pipe ~36 cycles, tools/probes/mfma_lds.hip).
-        const char* sp = lb + ((base + wy) % S) * slot_bytes + rd_lane;
-        f32x4 bv[2][NBR];
-        auto rd = [&](int t, int buf) {
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int qj = 0; qj < NBR; ++qj) bv[buf][qj] = *reinterpret_cast<const f32x4*>(sp + (t * HC + 4 * qj) * (kGC * 4));
-          __builtin_amdgcn_sched_barrier(0);
-        };
+        const unsigned sp = rd_lane + (unsigned)(((base + wy) % S) * slot_bytes);
+        const unsigned row = (unsigned)(HC * kGC * 4);
         auto mm = [&](int t, int buf) {
-          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int qj = 0; qj < NBR; ++qj) {
             const float a = band[(qi * NBR + qj) * 4 + t];
@@ -244,13 +270,20 @@ __global__ __launch_bounds__(kThreads) void corr_bwd_stream_kernel(BGeom g) {
             acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[buf][qj][2], acc2, 0, 0, 0);
             acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[buf][qj][3], acc3, 0, 0, 0);
           }
-          __builtin_amdgcn_sched_barrier(0);
         };
-        rd(0, 0); rd(1, 1);
-        mm(0, 0); rd(2, 0);
-        mm(1, 1); rd(3, 1);
-        mm(2, 0);
-        mm(3, 1);
+        // one burst of NBR ds_read_b128 per halo row t (4 MFMAs per read), issued one row ahead of the MFMAs that consume it
+        __builtin_amdgcn_sched_barrier(0);
+        rd(sp, 0); rd(sp + row, 1);
+        DTT_LANDED(0, NBR); mm(0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        rd(sp + 2 * row, 0);
+        DTT_LANDED(1, NBR); mm(1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        rd(sp + 3 * row, 1);
+        DTT_LANDED(0, NBR); mm(2, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        DTT_LANDED(1, 0); mm(3, 1);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     // the group is complete: D[m = 4 * (lane / 16) + r][n = lane % 16] of accumulator s is channel 4 n + s of target pixel m
@@ -264,6 +297,7 @@ __global__ __launch_bounds__(kThreads) void corr_bwd_stream_kernel(BGeom g) {
     acc0 = acc1 = acc2 = acc3 = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 }
+#undef DTT_LANDED
 
 // ------------------------------------------------------------------------------------------------ the band, once per op
 // band[dir][n][by][bx][(qi * NBR + qj) * 4 + t][lane]: what lane (m = lane % 16: target pixel (m / 4, m % 4) of block (by, bx);
@@ -319,10 +353,11 @@ struct BPlan {
   std::vector<unsigned short> table;
 };
 
-// ring slots a tile shape can afford: th + ahead, ahead = 3 .. 1 positions in flight beyond the ones being read
+// ring slots a tile shape can afford: th + ahead, ahead = 4 .. 1 positions beyond the th being read (2 th slots or more keep a
+// tall tile from draining the ring at group boundaries)
 bool tile_lds(int th, int tw, int nbr, int* ahead, size_t* bytes) {
   const size_t slot = (size_t)4 * 4 * (tw + nbr - 1) * kGC * 4;
-  for (int a = 3; a >= 1; --a)
+  for (int a = 4; a >= 1; --a)
     if ((th + a) * slot <= (size_t)kLdsMax) { *ahead = a; *bytes = (th + a) * slot; return true; }
   return false;
 }
@@ -332,7 +367,7 @@ bool tile_lds(int th, int tw, int nbr, int* ahead, size_t* bytes) {
 int bw_segments(int GH, int GW, BSeg* seg) {
   int ns = 0, t0 = 0;
   auto add = [&](int by0, int bx0, int nty, int ntx, int th, int tw) {
-    if (nty > 0 && ntx > 0 && ns < kMaxSeg) { seg[ns++] = BSeg{t0, by0, bx0, nty, ntx, th, tw}; t0 += nty * ntx; }
+    if (nty > 0 && ntx > 0 && ns < kMaxSeg) { seg[ns++] = BSeg{t0, by0, bx0, nty, ntx, th, tw, 1}; t0 += nty * ntx; }
   };
   const int eh = GH / 2 * 2, ew = GW / 4 * 4, rw = GW - ew;
   add(0, 0, eh / 2, ew / 4, 2, 4);
@@ -366,16 +401,15 @@ bool plan_bwd(int batch, int eh, int ew, int nbr, int ngroups, int ncu, BPlan* o
   p.nseg = bw_segments(GH, GW, p.seg);
   if (p.nseg == 0 || ncu < 1) return false;
   p.tiles_per_image = 0;
-  int ahead = 3;
+  size_t lds = 0;
   for (int s = 0; s < p.nseg; ++s) {
     p.tiles_per_image += p.seg[s].nty * p.seg[s].ntx;
     int a; size_t b;
     if (!tile_lds(p.seg[s].th, p.seg[s].tw, nbr, &a, &b)) return false;
-    ahead = std::min(ahead, a);
+    p.seg[s].ahead = a;
+    lds = std::max(lds, b);
   }
-  size_t lds = 0;   // (one `ahead` for the launch)
-  for (int s = 0; s < p.nseg; ++s) lds = std::max(lds, (size_t)(p.seg[s].th + ahead) * 4 * 4 * (p.seg[s].tw + nbr - 1) * kGC * 4);
-  p.ahead = ahead; p.lds_bytes = lds;
+  p.ahead = 0; p.lds_bytes = lds;
   p.tiles_total = p.tiles_per_image * batch;
   p.ngroups = ngroups;
   // cost of one (tile, group) unit in matrix-pipe time: the waves of a tile sit ceil(waves / 4) deep on a SIMD; a workgroup pays
@@ -402,6 +436,11 @@ bool plan_bwd(int batch, int eh, int ew, int nbr, int ngroups, int ncu, BPlan* o
     if (ms < best - 1e-9) { best = ms; best_chunk = chunk; }
   }
   p.chunk = best_chunk;
+  if (const char* e = getenv("DTT_CORR_BWD_CHUNK")) {   // developer / test switch: force the channel groups per work item
+    const int c = atoi(e);
+    if (c >= 1) p.chunk = std::min(c, ngroups);
+    while ((long)((ngroups + p.chunk - 1) / p.chunk) * p.tiles_total > 65535) ++p.chunk;
+  }
   const int nchunks = (ngroups + p.chunk - 1) / p.chunk;
   p.items = nchunks * p.tiles_total;
   // ---- dispatch order.  Block b runs on XCD b % 8 and the blocks of an XCD start in order: every XCD's queue gets its share
@@ -445,7 +484,7 @@ bool plan_bwd(int batch, int eh, int ew, int nbr, int ngroups, int ncu, BPlan* o
   return true;
 }
 
-struct PlanKey { int batch, eh, ew, nbr, ngroups, ncu; };
+struct PlanKey { int batch, eh, ew, nbr, ngroups, ncu, forced_chunk; };
 bool operator==(const PlanKey& a, const PlanKey& b) { return memcmp(&a, &b, sizeof(PlanKey)) == 0; }
 
 const BPlan* cached_plan(const PlanKey& k) {
@@ -579,14 +618,14 @@ int dtt_corr_bwd_stream(const float* gradOutput, long g_sb, long g_sc, long g_sp
     g.lo_y = g.lo_x = lo[dir]; g.hi_y = hy[dir]; g.hi_x = hx[dir];
     g.gh = bg.gh[dir]; g.gw = bg.gw[dir];
     g.band = bg.band + bg.dir_off[dir];
-    const PlanKey key{gob, g.hi_y - g.lo_y + 1, g.hi_x - g.lo_x + 1, nbr, ic / kGC, ncu};
+    const PlanKey key{gob, g.hi_y - g.lo_y + 1, g.hi_x - g.lo_x + 1, nbr, ic / kGC, ncu, getenv("DTT_CORR_BWD_CHUNK") ? atoi(getenv("DTT_CORR_BWD_CHUNK")) : 0};
     const BPlan* p = cached_plan(key);
     DTT_REQUIRE(p != nullptr, "correlation backward (streamed): no plan for %d x %d targets, radius %d", key.eh, key.ew, R);
     g.other = wrt2 ? input1 : input2;
     g.grad = grad;
     g.nseg = p->nseg; g.tiles_per_image = p->tiles_per_image; g.tiles_total = p->tiles_total;
-    for (int i = 0; i < kMaxSeg; ++i) g.seg[i] = i < p->nseg ? p->seg[i] : BSeg{0x7fffffff, 0, 0, 1, 1, 1, 1};
-    g.chunk = p->chunk; g.ngroups = p->ngroups; g.ahead = p->ahead; g.use_table = p->use_table;
+    for (int i = 0; i < kMaxSeg; ++i) g.seg[i] = i < p->nseg ? p->seg[i] : BSeg{0x7fffffff, 0, 0, 1, 1, 1, 1, 1};
+    g.chunk = p->chunk; g.ngroups = p->ngroups; g.use_table = p->use_table;
     if (p->use_table) memcpy(g.table, p->table.data(), sizeof(unsigned short) * p->items);
     int ok;
     // (one kernel for both directions: which gradient a launch computes is a matter of its band words and of `other`)
@@ -608,7 +647,7 @@ extern "C" int dtt_correlation_backward_plan_check(int batch, int target_h, int 
   BGeom g;
   memset(&g, 0, sizeof(g));
   g.nseg = p.nseg; g.tiles_per_image = p.tiles_per_image; g.tiles_total = p.tiles_total;
-  for (int i = 0; i < kMaxSeg; ++i) g.seg[i] = i < p.nseg ? p.seg[i] : BSeg{0x7fffffff, 0, 0, 1, 1, 1, 1};
+  for (int i = 0; i < kMaxSeg; ++i) g.seg[i] = i < p.nseg ? p.seg[i] : BSeg{0x7fffffff, 0, 0, 1, 1, 1, 1, 1};
   g.chunk = p.chunk; g.ngroups = p.ngroups;
   const int GH = (target_h + 3) / 4, GW = (target_w + 3) / 4, NG = channels / kGC;
   std::vector<unsigned char> owned((size_t)batch * GH * GW * NG, 0);
@@ -621,7 +660,7 @@ extern "C" int dtt_correlation_backward_plan_check(int batch, int target_h, int 
     const BItem it = bw_decode(g, item);
     if (it.n < 0 || it.n >= batch || it.ng < 1 || it.g0 + it.ng > NG || it.th * it.tw > kWaves) return 0;
     if (4 * (it.tw + nbr - 1) > kMaxNI * kWaves) return 0;
-    if ((size_t)(it.th + p.ahead) * 4 * 4 * (it.tw + nbr - 1) * kGC * 4 > p.lds_bytes || p.ahead < 1) return 0;
+    if ((size_t)(it.th + it.ahead) * 4 * 4 * (it.tw + nbr - 1) * kGC * 4 > p.lds_bytes || it.ahead < 1) return 0;
     for (int w = 0; w < it.th * it.tw; ++w) {
       const int by = it.Y0 / 4 + w / it.tw, bx = it.X0 / 4 + w % it.tw;
       if (by >= GH || bx >= GW) return 0;

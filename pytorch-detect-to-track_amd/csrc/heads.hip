@@ -688,6 +688,58 @@ extern "C" int dtt_rpn_head_gemm(const float* x, long ldx, int batch, int hw, in
                           static_cast<hipStream_t>(stream_));
 }
 
+// Backward of the RPN epilogue (training graph, rpn.py:63-71): the gradients of the probabilities and box deltas, which arrive as
+// the reference's NCHW tensors, become the rows of the packed GEMM's output gradient -- columns [bg_0, fg_0, bg_1, fg_1, ...,
+// box deltas 0 .. 4A-1, zeros up to `ld`] -- with the adjoint of the pairwise softmax applied on the way:
+//   d/ds_bg = p_bg * (g_bg - (g_bg p_bg + g_fg p_fg)),   d/ds_fg = p_fg * (g_fg - (g_bg p_bg + g_fg p_fg)).
+// One thread per pixel row: plane reads are coalesced across the threads of a wave, a thread writes its row as 16-byte pieces.
+namespace {
+__global__ __launch_bounds__(256) void rpn_head_grad_rows_kernel(const float* __restrict__ g_prob, const float* __restrict__ g_bbox,
+                                                                 const float* __restrict__ prob, int batch, int hw, int A,
+                                                                 float* __restrict__ rows, long ld) {
+  const long m = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= (long)batch * hw) return;
+  const int b = (int)(m / hw), p = (int)(m - (long)b * hw);
+  float* out = rows + m * ld;
+  const float* pp = prob + (long)b * 2 * A * hw + p;
+  const float* gp = g_prob ? g_prob + (long)b * 2 * A * hw + p : nullptr;
+  const float* gb = g_bbox ? g_bbox + (long)b * 4 * A * hw + p : nullptr;
+  for (int a = 0; a < A; a += 2) {      // two (background, foreground) pairs = one 16-byte piece (A is even)
+    float4 o;
+    float* ov = reinterpret_cast<float*>(&o);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const float pb = pp[(long)(a + u) * hw], pf = pp[(long)(A + a + u) * hw];
+      const float g0 = gp ? gp[(long)(a + u) * hw] : 0.f, g1 = gp ? gp[(long)(A + a + u) * hw] : 0.f;
+      const float dot = g0 * pb + g1 * pf;
+      ov[2 * u] = pb * (g0 - dot);
+      ov[2 * u + 1] = pf * (g1 - dot);
+    }
+    *reinterpret_cast<float4*>(out + 2 * a) = o;
+  }
+  for (int j = 0; j < 4 * A; j += 4) {
+    float4 o;
+    o.x = gb ? gb[(long)j * hw] : 0.f; o.y = gb ? gb[(long)(j + 1) * hw] : 0.f;
+    o.z = gb ? gb[(long)(j + 2) * hw] : 0.f; o.w = gb ? gb[(long)(j + 3) * hw] : 0.f;
+    *reinterpret_cast<float4*>(out + 2 * A + j) = o;
+  }
+  for (long j = 6 * A; j < ld; j += 4) *reinterpret_cast<float4*>(out + j) = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+}  // namespace
+
+extern "C" int dtt_rpn_head_grad_rows(const float* grad_cls_prob, const float* grad_bbox_pred, const float* cls_prob, int batch, int hw,
+                                      int num_anchors, float* rows, long ld, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  DTT_REQUIRE(cls_prob && rows && batch > 0 && hw > 0 && num_anchors > 0 && num_anchors % 2 == 0, "rpn_head_grad_rows: bad arguments");
+  DTT_REQUIRE(ld >= 6 * num_anchors && ld % 4 == 0 && (reinterpret_cast<uintptr_t>(rows) & 15) == 0,
+              "rpn_head_grad_rows: rows need a 16-byte aligned base and a row length (%ld) that is a multiple of 4 >= %d", ld, 6 * num_anchors);
+  const long M = (long)batch * hw;
+  hipLaunchKernelGGL(rpn_head_grad_rows_kernel, dim3(dtt_cdiv(M, 256)), dim3(256), 0, stream, grad_cls_prob, grad_bbox_pred, cls_prob, batch,
+                     hw, num_anchors, rows, ld);
+  DTT_CHECK_LAUNCH("rpn_head_grad_rows");
+  return 1;
+}
+
 // Backward of dtt_psroi_pm_forward's vote: grad_map (batch*height*width pixels, pixel_stride floats apart; this call writes
 // floats [bin*cp + c] for bin < pooled^2, c < cp of EVERY pixel -- zeros where no RoI reaches, so no pre-zeroing) from
 // grad_vote (num_rois, output_dim).  edges: caller-owned scratch of num_rois * (4 * pooled + 1) ints.

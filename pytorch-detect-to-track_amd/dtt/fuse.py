@@ -531,6 +531,17 @@ class _NhwcBottleneck:
         return _from_rows(y, n, hh, ww)
 
 
+class TrunkExtras:
+    """What the channels-last inference trunk computes on the way for the position-major tail, handed to `_RFCN.forward` as a
+    return value (not as attributes that outlive the call): `top_rows` / `top_hw` the channels-last rows of `top` and its map size,
+    `det_rows` the class + box head GEMM's output when it was issued inside the trunk, `rpn_rows` the channels-last rows of
+    relu(RPN_Conv(top)) for the one-launch RPN heads, or `rpn_conv1` the same map in NCHW for the library heads."""
+    __slots__ = ("top_rows", "top_hw", "det_rows", "rpn_rows", "rpn_conv1")
+
+    def __init__(self):
+        self.top_rows = self.top_hw = self.det_rows = self.rpn_rows = self.rpn_conv1 = None
+
+
 class FusedTrunkNHWC:
     """Inference trunk in channels-last layout.  Same folded weights as FusedTrunk; the 1x1 convolutions (two thirds
     of the layers) become GEMMs whose epilogue already applies bias + ReLU, the residual add is the GEMM's beta * C
@@ -550,13 +561,8 @@ class FusedTrunkNHWC:
         # the RPN's 3x3 convolution + ReLU (rpn.py:60-61) reads the same channels-last map: computed here, where it can
         # take the Winograd path, and handed to _RPN.head() through `rpn_conv1`
         self.rpn_conv = _NhwcConv(model.RFCN_rpn.RPN_Conv)
-        self.rpn_conv1 = None
-        self.rpn_rows = None
         self.pm_heads = False     # set by fuse_for_inference when the position-major tail is active
         self.pm_tail = None       # dtt.heads.PositionMajorTail: when set, the class + box head GEMM is issued in here
-        self.top_rows = None
-        self.det_rows = None
-        self.top_hw = None
 
     @torch.no_grad()
     def __call__(self, x):
@@ -577,25 +583,26 @@ class FusedTrunkNHWC:
                 x = blk(x)
             feats.append(x)
         top = self.top.act(feats[3])
+        ex = TrunkExtras()
         if self.pm_heads:
             # the position-major tail reads channels-last memory directly (head GEMM over the `top` rows, channels-last
             # correlation kernel over conv3 / conv4 / conv5): no layout hand-over at all
-            self.top_rows, self.top_hw = _rows(top), (top.shape[2], top.shape[3])
+            ex.top_rows, ex.top_hw = _rows(top), (top.shape[2], top.shape[3])
             if self.pm_tail is not None and os.environ.get("DTT_DET_EARLY", "1") != "0":   # (developer A/B switch)
                 # The class + box head GEMM runs HERE, ahead of the RPN: its grid is one workgroup on every CU, so it
                 # cannot share the chip with the proposal layer's kernels (256 + 4 workgroups: the last 4 wait for, or
                 # squeeze in beside, the others -- 150 -> 200 us when it ran after the correlations, under the NMS sweep).
                 from .heads import head_gemm
-                self.det_rows = head_gemm(self.top_rows, self.pm_tail.det)
+                ex.det_rows = head_gemm(ex.top_rows, self.pm_tail.det)
         if self.pm_heads and self.pm_tail is not None and self.pm_tail.rpn is not None and os.environ.get("DTT_RPN_FUSED", "1") != "0":
             # channels-last rows of relu(RPN_Conv(top)) for the one-launch RPN heads (dtt.heads.rpn_head_gemm): no
             # NHWC -> NCHW hand-over at all
-            self.rpn_rows, self.rpn_conv1 = _rows(self.rpn_conv.act(top)), None
+            ex.rpn_rows = _rows(self.rpn_conv.act(top))
         else:
-            self.rpn_rows, self.rpn_conv1 = None, _to_nchw(self.rpn_conv.act(top))
+            ex.rpn_conv1 = _to_nchw(self.rpn_conv.act(top))
         if self.pm_heads:
-            return feats[1], feats[2], feats[3], top
-        return _to_nchw(feats[1]), _to_nchw(feats[2]), _to_nchw(feats[3]), _to_nchw(top)
+            return feats[1], feats[2], feats[3], top, ex
+        return _to_nchw(feats[1]), _to_nchw(feats[2]), _to_nchw(feats[3]), _to_nchw(top), ex
 
 
 def fuse_for_inference(model, channels_last=True):

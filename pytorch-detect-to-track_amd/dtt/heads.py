@@ -164,15 +164,21 @@ def psroi_pm(pm_map, head, batch, height, width, rois, spatial_scale, want_poole
 
 
 # ------------------------------------------------------------------------------------------------ training (autograd)
-def pack_heads_differentiable(convs, group=7):
+def pack_heads_differentiable(convs, group=7, k_pad=None, in_perm=None):
     """PackedHeads' row permutation as differentiable tensor ops on the LIVE parameters (training: the weights change every
     step, and their gradients must flow back through the permutation): returns (w (rows16, K), bias (rows16,), heads, n_store,
-    stride) with the same meaning as PackedHeads' fields."""
+    stride) with the same meaning as PackedHeads' fields.  in_perm / k_pad as in PackedHeads (input channels permuted, then
+    zero-padded to k_pad)."""
     dev = convs[0].weight.device
-    K = convs[0].weight.shape[1]
+    K0 = convs[0].weight.shape[1]
+    K = K0 if k_pad is None else int(k_pad)
     rows, biases, heads, off = [], [], [], 0
     for conv in convs:
-        w = conv.weight.reshape(conv.weight.shape[0], K)
+        w = conv.weight.reshape(conv.weight.shape[0], K0)
+        if in_perm is not None:
+            w = w[:, in_perm.to(dev)]
+        if K > K0:
+            w = torch.cat([w, w.new_zeros(w.shape[0], K - K0)], 1)
         od = w.shape[0] // (group * group)
         cp = 4 if od <= 4 else _pow2_at_least(max(od, 32))
         b = conv.bias if conv.bias is not None else torch.zeros(w.shape[0], device=dev)
@@ -252,12 +258,18 @@ class PsroiPmFn(torch.autograd.Function):
     map-stationary backward needs no atomics and no pre-zeroed output (psroi_pooling_kernel.cu:109-170 scatters with atomicAdd)."""
 
     @staticmethod
-    def forward(ctx, pm_map, rois, batch, height, width, spatial_scale, heads):
+    def forward(ctx, pm_map, rois, batch, height, width, spatial_scale, heads, extract=None):
+        """extract = (first column, columns): additionally returns a compact copy of those columns of the map (the box deltas the
+        tracking branch concatenates, rfcn.py:166-169) as one more output -- its gradient is ADDED into the one gradient map this
+        node hands back, so the map has a single consumer under autograd (two consumers = two dense 73 MB gradients + an add)."""
         require_gpu(pm_map, rois)
         rois = rois.detach().float().contiguous()
         ctx.save_for_backward(rois)
         ctx.geom = (batch, height, width, float(spatial_scale), heads, pm_map.shape[0], pm_map.stride(0))
+        ctx.extract = extract
         votes = tuple(psroi_pm(pm_map, h, batch, height, width, rois, spatial_scale) for h in heads)
+        if extract is not None:
+            return votes + (pm_map[:, extract[0]:extract[0] + extract[1]].contiguous(),)
         return votes
 
     @staticmethod
@@ -271,7 +283,7 @@ class PsroiPmFn(torch.autograd.Function):
         covered = 0
         R = rois.shape[0]
         with torch.cuda.device(dev):
-            for h, gv in zip(heads, gvotes):
+            for h, gv in zip(heads, gvotes[:len(heads)]):
                 G, cp, od = h["group"], h["cp"], h["od"]
                 assert h["offset"] == covered, "heads must tile the row from column 0"
                 covered += G * G * cp
@@ -282,7 +294,142 @@ class PsroiPmFn(torch.autograd.Function):
                                                        stream_ptr(dev)), "psroi_pm backward")
         if covered < stride:
             gmap[:, covered:].zero_()
-        return gmap, None, None, None, None, None, None
+        if ctx.extract is not None and gvotes[len(heads)] is not None:
+            c0, nc = ctx.extract
+            gmap[:, c0:c0 + nc] += gvotes[len(heads)]
+        return gmap, None, None, None, None, None, None, None
+
+
+class TrackingRowsFn(torch.autograd.Function):
+    """The tracking head's input under autograd, assembled in place as position-major rows (rfcn.py:166-174's torch.cat):
+        rows[p] = [box deltas(t) | box deltas(t+tau) | corr3 | corr4 | corr5 | zero padding]      (B*H*W, k_pad)
+    loc_cols: (2*B*H*W, n_box) compact box-delta columns of both legs (PsroiPmFn's `extract` output, position-major order);
+    conv3 / conv4 / conv5: the whole channels-last (2*B, C, h, w) trunk maps, leg 0 = frame t.  The three correlations write their
+    columns straight into the rows (window-split forward kernel); backward: the correlation gradient kernels read THEIR columns of
+    the rows' gradient where they lie and write both legs of one channels-last gradient per map -- no 1051-channel NCHW tensor, no
+    concat, no slices, no layout copies in either direction."""
+
+    @staticmethod
+    def forward(ctx, loc_cols, conv3, conv4, conv5, B, geoms, k_pad):
+        from .ops import correlation_forward_nhwc, correlation_output_shape
+        require_gpu(loc_cols, conv3, conv4, conv5)
+        n_box = loc_cols.shape[1]
+        maps = (conv3, conv4, conv5)
+        oshape = [correlation_output_shape(m.size(1), m.size(2), m.size(3), *g) for m, g in zip(maps, geoms)]
+        oh, ow = oshape[0][1], oshape[0][2]
+        assert all(o[1:] == (oh, ow) for o in oshape) and loc_cols.shape[0] == 2 * B * oh * ow
+        cols = [2 * n_box]
+        for o in oshape:
+            cols.append(cols[-1] + o[0])
+        assert cols[-1] <= k_pad
+        rows = torch.empty((B * oh * ow, k_pad), dtype=torch.float32, device=loc_cols.device)
+        if cols[-1] < k_pad:
+            rows[:, cols[-1]:].zero_()
+        gather_column_blocks(rows, 0, loc_cols, 0, B * oh * ow, 2, n_box)
+        for m, g, c0 in zip(maps, geoms, cols):
+            correlation_forward_nhwc(m[:B], m[B:2 * B], *g, rows=rows, col=c0)
+        ctx.save_for_backward(conv3, conv4, conv5)
+        ctx.cfg = (B, geoms, cols, n_box, oh * ow)
+        return rows
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grows):
+        from .ops import correlation_backward_nhwc
+        maps = ctx.saved_tensors
+        B, geoms, cols, n_box, hw = ctx.cfg
+        grows = grows.contiguous()
+        g_loc = None
+        if ctx.needs_input_grad[0]:
+            g_loc = torch.cat([grows[:, :n_box], grows[:, n_box:2 * n_box]], 0)
+        gmaps = []
+        for i, (m, g, c0) in enumerate(zip(maps, geoms, cols)):
+            if not ctx.needs_input_grad[1 + i]:
+                gmaps.append(None)
+                continue
+            # (two legs: every image's gradient is written by one of the two kernels, which zero-fill where they have to)
+            gm = torch.empty_like(m) if m.size(0) == 2 * B else torch.zeros_like(m)
+            correlation_backward_nhwc(None, m[:B], m[B:2 * B], gm[:B], gm[B:2 * B], *g, rows=grows, col=c0)
+            gmaps.append(gm)
+        return (g_loc, *gmaps, None, None, None)
+
+
+def pack_rpn_heads_differentiable(cls_conv, bbox_conv):
+    """PackedRPNHeads' row order as differentiable tensor ops on the live parameters: (w (rows16, K), bias (rows16,), A)."""
+    K = cls_conv.weight.shape[1]
+    wc = cls_conv.weight.reshape(cls_conv.weight.shape[0], K)
+    wb = bbox_conv.weight.reshape(bbox_conv.weight.shape[0], K)
+    A = wc.shape[0] // 2
+    if A % 2 or wc.shape[0] != 2 * A or wb.shape[0] != 4 * A:
+        raise ValueError("pack_rpn_heads_differentiable: an even number of anchors is required (got %d score channels)" % wc.shape[0])
+    dev = wc.device
+    pair = torch.stack([torch.arange(A), A + torch.arange(A)], 1).reshape(-1).to(dev)   # bg_a, fg_a
+    bc = cls_conv.bias if cls_conv.bias is not None else wc.new_zeros(2 * A)
+    bb = bbox_conv.bias if bbox_conv.bias is not None else wb.new_zeros(4 * A)
+    w = torch.cat([wc[pair], wb], 0)
+    b = torch.cat([bc[pair], bb], 0)
+    n16 = -(-w.shape[0] // 16) * 16
+    if n16 > w.shape[0]:
+        b = torch.cat([b, b.new_zeros(n16 - w.shape[0])], 0)
+        w = torch.cat([w, w.new_zeros(n16 - w.shape[0], K)], 0)
+    return w.contiguous(), b.contiguous(), A
+
+
+class RpnHeadFn(torch.autograd.Function):
+    """`RPN_cls_score` + reshape(2) -> softmax -> reshape(2A) + `RPN_bbox_pred` (rpn.py:63-71) as ONE launch of the hand-written
+    GEMM (`dtt_rpn_head_gemm`) under autograd: x_rows (batch*H*W, K) channels-last rows of relu(RPN_Conv(.)), packed weights ->
+    (cls_prob (batch, 2A, H, W), bbox_pred (batch, 4A, H, W)).  Backward: one small kernel turns the two NCHW gradients into the
+    rows of the packed output's gradient, applying the adjoint of the pairwise softmax (`dtt_rpn_head_grad_rows`); dX is the head
+    GEMM over those rows with the transposed weights, dW `dtt_head_gemm_dw`, dBias a column sum."""
+
+    @staticmethod
+    def forward(ctx, x_rows, w, bias, A, batch, height, width):
+        require_gpu(x_rows)
+        x_rows = x_rows.contiguous()
+        M, K = x_rows.shape
+        if M != batch * height * width or K != w.shape[1]:
+            raise ValueError("RpnHeadFn: rows %s do not match batch %d x %d x %d, K %d" % (tuple(x_rows.shape), batch, height, width, w.shape[1]))
+        prob = torch.empty((batch, 2 * A, height, width), dtype=torch.float32, device=x_rows.device)
+        bbox = torch.empty((batch, 4 * A, height, width), dtype=torch.float32, device=x_rows.device)
+        with torch.cuda.device(x_rows.device):
+            check(_lib.lib().dtt_rpn_head_gemm(ptr(x_rows), K, batch, height * width, K, ptr(w), ptr(bias), w.shape[0], A, ptr(prob),
+                                               ptr(bbox), stream_ptr(x_rows.device)), "rpn_head_gemm")
+        ctx.save_for_backward(x_rows, w, prob)
+        ctx.cfg = (A, batch, height * width)
+        return prob, bbox
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_prob, g_bbox):
+        x_rows, w, prob = ctx.saved_tensors
+        A, batch, hw = ctx.cfg
+        M, K = x_rows.shape
+        N16 = w.shape[0]
+        dev = x_rows.device
+        L = _lib.lib()
+        g_prob = None if g_prob is None else g_prob.contiguous()
+        g_bbox = None if g_bbox is None else g_bbox.contiguous()
+        gx = gw = gb = None
+        LG = -(-N16 // 32) * 32                                          # the head GEMM's K granularity
+        with torch.cuda.device(dev):
+            grows = torch.empty((M, LG), dtype=torch.float32, device=dev)   # (columns >= 6 A are written as zeros)
+            check(L.dtt_rpn_head_grad_rows(ptr(g_prob) if g_prob is not None else None, ptr(g_bbox) if g_bbox is not None else None,
+                                           ptr(prob), batch, hw, A, ptr(grows), LG, stream_ptr(dev)), "rpn_head_grad_rows")
+            if ctx.needs_input_grad[0]:
+                wt = torch.zeros((K, LG), dtype=torch.float32, device=dev)    # dX (M, K) = grows (M, LG) @ wt.T
+                wt[:, :N16] = w.t()
+                gx = torch.empty((M, K), dtype=torch.float32, device=dev)
+                check(L.dtt_head_gemm(ptr(grows), LG, M, LG, ptr(wt), ptr(torch.zeros(K, dtype=torch.float32, device=dev)), K, ptr(gx),
+                                      K, K, 0, stream_ptr(dev)), "rpn head dX")
+            if ctx.needs_input_grad[1]:
+                gw = torch.empty((N16, K), dtype=torch.float32, device=dev)
+                nb = L.dtt_head_gemm_dw_workspace_bytes(M, N16, K)
+                ws = torch.empty((nb,), dtype=torch.uint8, device=dev)
+                check(L.dtt_head_gemm_dw(ptr(grows), LG, LG, ptr(x_rows), K, M, N16, K, ptr(gw), ptr(ws), nb, stream_ptr(dev)),
+                      "rpn head dW")
+            if ctx.needs_input_grad[2]:
+                gb = grows[:, :N16].sum(0)
+        return gx, gw, gb, None, None, None, None
 
 
 def pm_to_nchw(pm_map, head, batch, height, width):

@@ -160,6 +160,21 @@ class _RPN(nn.Module):
             self.rpn_loss_box = _smooth_l1_loss(bbox_pred, tgt, w_in, w_out, sigma=3, dim=[1, 2, 3])
         return rois, self.rpn_loss_cls, self.rpn_loss_box
 
+    def losses_from_probabilities(self, cls_prob, bbox_pred, gt_boxes, im_info, num_boxes):
+        """rpn.py:74-107 for one leg when the heads come out of the one-launch GEMM, whose epilogue has already applied the
+        pairwise softmax (dtt.heads.RpnHeadFn): the cross-entropy of rpn.py:97 over the sampled anchors is -log of the label's
+        probability (the same number to rounding; the softmax's adjoint is applied in RpnHeadFn.backward)."""
+        B = cls_prob.size(0)
+        labels, tgt, w_in, w_out = self.RPN_anchor_target((cls_prob.detach(), gt_boxes, im_info, num_boxes))
+        prob = self.reshape(cls_prob, 2).permute(0, 2, 3, 1).contiguous().view(-1, 2)
+        label = labels.view(-1)
+        keep = label.ne(-1).nonzero().view(-1)
+        prob = torch.index_select(prob, 0, keep)
+        label = torch.index_select(label, 0, keep).long()
+        self.rpn_loss_cls = F.nll_loss(torch.log(prob.clamp_min(1e-37)), label)
+        self.rpn_loss_box = _smooth_l1_loss(bbox_pred, tgt, w_in, w_out, sigma=3, dim=[1, 2, 3])
+        return self.rpn_loss_cls, self.rpn_loss_box
+
 
 # ------------------------------------------------------------------------------------------ RFCN
 class _RFCN(nn.Module):
@@ -284,29 +299,29 @@ class _RFCN(nn.Module):
                                          l.max_displacement, l.stride1, l.stride2, l.corr_multiply)
         return rows
 
-    def _inference_tail_pm(self, pm, fused, c3, c4, c5, all_rois, side, n_legs, B, dev, top=None, corr_done=()):
+    def _inference_tail_pm(self, pm, ex, c3, c4, c5, all_rois, side, n_legs, B, dev, top=None, corr_done=()):
         """rfcn.py:133-140, 166-196 at inference on the position-major layout: one MFMA GEMM for the class + box heads of
         every image (`dtt_head_gemm`), lanes = classes PSRoI pooling + vote (`dtt_psroi_pm_forward`), the tracking
-        head's input rows assembled in place (box-delta columns copied, correlations written by their reduce kernels)."""
+        head's input rows assembled in place (box-delta columns copied, correlations written by their kernels).
+        ex: the fused trunk's TrunkExtras (channels-last `top` rows, the early head GEMM's output)."""
         from .heads import gather_column_blocks, head_gemm, psroi_pm
-        top_rows, (H, W) = fused.top_rows, fused.top_hw
-        fused.top_rows = None
+        top_rows, (H, W) = ex.top_rows, ex.top_hw
         cur = torch.cuda.current_stream(dev)
         single_frame = n_legs == 1
         trk = rows = None
         hw = H * W
         if not single_frame:
-            # The correlations only need the trunk maps.  conv5 (117 us, the largest) has been issued ahead of the RPN's 1x1
-            # heads (forward()), i.e. before the side stream had anything to run: it is dispatched onto an empty chip.  The
-            # kernels that DO run beside the proposal layer are the short ones -- conv3 (24 us) and conv4 (77 us) -- whose
-            # chain with the tracking head (≈ 155 us) is as long as the side stream's (select / sort, decode, NMS ≈ 150 us),
+            # The correlations only need the trunk maps.  conv5 (the largest) has been issued ahead of the RPN's 1x1
+            # heads (_infer_proposals), i.e. before the side stream had anything to run: it is dispatched onto an empty chip.  The
+            # kernels that DO run beside the proposal layer are the short ones -- conv3 and conv4 -- whose
+            # chain with the tracking head is as long as the side stream's (selection, decode, NMS),
             # so nothing is lost by taking conv5 out of the overlap.  A one-workgroup-per-CU kernel dispatched while a
             # foreign workgroup sits on one of "its" shader engines has, in some steps, one workgroup parked until a CU of
             # that engine frees up (tools/wg_trace.py, tools/probes/wg_placement.hip): that now costs conv4 ≈ 25 us in
             # some steps instead of conv5 20 - 60.  (env DTT_CORR_ORDER: developer A/B over the order of what is left.)
             idx = [int(c) for c in os.environ.get("DTT_CORR_ORDER", "021") if int(c) not in corr_done]
             rows = self._launch_correlations(pm, (c3, c4, c5), idx, B, dev, budget=int(os.environ.get("DTT_CORR_BUDGET", "240")))
-        det, fused.det_rows = getattr(fused, "det_rows", None), None    # (n_legs*B*H*W, stride): issued by the fused trunk ...
+        det = ex.det_rows                                               # (n_legs*B*H*W, stride): issued by the fused trunk ...
         if det is None:
             det = head_gemm(top_rows, pm.det)                           # ... or here
         if not single_frame:
@@ -339,6 +354,12 @@ class _RFCN(nn.Module):
         cur.wait_stream(side)   # leg_rois
         return leg_rois, prob, pred, tracking_pred, zeros, zeros, zeros, zeros, [], zeros[0]
 
+    # ------------------------------------------------------------------------------------------------ forward: four graphs
+    # `forward` flattens the legs, runs the trunk and picks one of four graph builders (rfcn.py:66-250 is the contract of all):
+    #   _infer_proposals + _inference_tail_pm    inference, channels-last fused trunk, hand-written heads, position-major pooling
+    #   _infer_proposals + _inference_tail_nchw  inference on NCHW maps (plain / NCHW-fused trunk, more than two legs, CPU)
+    #   _forward_train_pm                        training on the hand-written heads (channels-last fused training trunk)
+    #   _forward_train_nchw                      training, the reference's graph on library convolutions + the NCHW operators
     def forward(self, im_data, im_info, gt_boxes, num_boxes):
         B, n_legs = im_data.size(0), im_data.size(1)
         dev = im_data.device
@@ -356,185 +377,236 @@ class _RFCN(nn.Module):
         if self.training:   # (inference never looks at the ground truth: two small copy kernels less per step)
             gt_boxes = gt_boxes.permute(1, 0, 2, 3).contiguous().detach()
             num_boxes = num_boxes.permute(1, 0, 2).contiguous().detach()
-        c3, c4, c5, top = self._im_to_head(flat)
-        side = None
-        if not self.training and top.is_cuda and not torch.is_grad_enabled():
-            # The proposal layer (select / sort, decode, NMS mask + sweep) is a handful of small kernels that leave most
-            # CUs idle; it runs on a side stream underneath the correlations and the tracking head, which do not depend
-            # on it.  Its first kernel -- select / sort: one 1024-thread, 72 KB-LDS workgroup per image, 84 us -- needs
-            # the scores only and is started as soon as the softmax is done, while the RPN's box-delta convolution
-            # still runs here: when the one-workgroup-per-CU correlation kernels are dispatched it has long been placed.
-            # (Dispatched in the same microseconds, the two race for CUs and the loser's workgroups stay parked on a
-            # full shader engine until one of ITS CUs frees up: +75 us on a correlation or +90 us on the sort;
-            # tools/wg_trace.py, tools/probes/wg_placement.hip.)  The RPN's own convolutions stay on the main stream:
-            # beside the correlation kernels they are starved of CUs (50 -> 220 us).
-            cur = torch.cuda.current_stream(dev)
-            side = getattr(self, "_side_stream", None)
-            if side is None or side.device != dev:
-                side = self._side_stream = torch.cuda.Stream(device=dev)
-            fused = getattr(self, "_fused_trunk", None)
-            conv1 = getattr(fused, "rpn_conv1", None)   # set by the channels-last fused trunk during _im_to_head above
-            if conv1 is not None:
-                fused.rpn_conv1 = None
-            rpn = self.RFCN_rpn
-            pm_early = getattr(self, "_pm_tail", None)
-            corr_done = ()
-            if (pm_early is not None and n_legs == 2 and getattr(fused, "top_rows", None) is not None and
-                    os.environ.get("DTT_CORR5_EARLY", "1") != "0"):
-                self._launch_correlations(pm_early, (c3, c4, c5), (2,), B, dev)   # conv5, on an otherwise empty chip
-                corr_done = (2,)
-            rpn_rows = getattr(fused, "rpn_rows", None)
-            if rpn_rows is not None and pm_early is not None and pm_early.rpn is not None:
-                # both 1x1 heads + the pairwise softmax in ONE hand-written launch over the channels-last rows
-                # (dtt_rpn_head_gemm: no transpose, no library GEMMs, no bias / softmax kernels), straight into the
-                # (B, 2A, H, W) / (B, 4A, H, W) tensors the proposal layer reads
-                from .heads import rpn_head_gemm
-                fused.rpn_rows = None
-                rpn_prob, rpn_bbox = rpn_head_gemm(rpn_rows, pm_early.rpn, n_legs * B, top.size(2), top.size(3))
-                side.wait_stream(cur)
-                with torch.cuda.stream(side):
-                    # scores and box deltas arrive together: one dtt_proposal_forward (the ranking kernel decodes the boxes)
-                    all_rois = rpn.RPN_proposal((rpn_prob, rpn_bbox, im_info.view(n_legs * B, -1), "TEST"))
-            else:
-                conv1, rpn_prob = rpn.head_scores(top, conv1)
-                side.wait_stream(cur)
-                with torch.cuda.stream(side):
-                    selection = rpn.RPN_proposal.select(rpn_prob.detach(), "TEST")
-                rpn_bbox = rpn.RPN_bbox_pred(conv1)
-                side.wait_stream(cur)
-                with torch.cuda.stream(side):
-                    all_rois = rpn.RPN_proposal.finish(selection, rpn_bbox.detach(), im_info.view(n_legs * B, -1), "TEST")
-            rpn_prob.record_stream(side); rpn_bbox.record_stream(side)
-        leg = lambda t, i: t[i * B:(i + 1) * B]
+        c3, c4, c5, top, ex = self._im_to_head_ex(flat)
+        if self.training:
+            train_pm = (getattr(self, "_train_pm", False) and top.is_cuda and torch.is_grad_enabled() and n_legs <= 2
+                        and top.is_contiguous(memory_format=torch.channels_last) and not top.is_contiguous())
+            build = self._forward_train_pm if train_pm else self._forward_train_nchw
+            return build(c3, c4, c5, top, im_info, gt_boxes, num_boxes, n_legs, B, dev)
+        side = all_rois = None
+        corr_done = ()
+        if top.is_cuda and not torch.is_grad_enabled():
+            all_rois, side, corr_done = self._infer_proposals(ex, c3, c4, c5, top, im_info, n_legs, B, dev)
         pm = getattr(self, "_pm_tail", None)
-        if pm is not None and side is not None and n_legs <= 2 and getattr(fused, "top_rows", None) is not None:
+        if pm is not None and side is not None and n_legs <= 2 and ex is not None and ex.top_rows is not None:
             # hand-written heads + position-major pooling (dtt.heads): no NCHW score maps at all
-            return self._inference_tail_pm(pm, fused, c3, c4, c5, all_rois, side, n_legs, B, dev, top=top, corr_done=corr_done)
-        fused_inf = getattr(self, "_fused_trunk", None)
-        if fused_inf is not None and not self.training:
-            fused_inf.top_rows = fused_inf.det_rows = fused_inf.rpn_rows = None   # (not consumed: more than two legs take the NCHW graph below)
-        train_pm = (self.training and getattr(self, "_train_pm", False) and top.is_cuda and torch.is_grad_enabled()
-                    and top.is_contiguous(memory_format=torch.channels_last) and not top.is_contiguous())
-        det = det_heads = None
-        if train_pm:
-            # training on the hand-written heads: one exact-fp32 MFMA GEMM over the channels-last `top` rows
-            # for RFCN_cls_net + RFCN_bbox_net of every image (forward, dX and dW all on dtt_head_gemm: dtt.heads.HeadGemmFn),
-            # position-major score map, lanes = classes PSRoI pooling with a map-stationary backward (PsroiPmFn)
-            from .heads import HeadGemmFn, pack_heads_differentiable, pm_to_nchw
-            rows = top.permute(0, 2, 3, 1).reshape(-1, top.size(1))
-            w_pk, b_pk, det_heads, n_store, stride = pack_heads_differentiable([self.RFCN_cls_net, self.RFCN_bbox_net])
-            det = HeadGemmFn.apply(rows, w_pk, b_pk, n_store, stride)
-            cls_maps = None
-            bbox_maps = pm_to_nchw(det, det_heads[1], n_legs * B, top.size(2), top.size(3))   # the tracking branch's NCHW concat
+            return self._inference_tail_pm(pm, ex, c3, c4, c5, all_rois, side, n_legs, B, dev, top=top, corr_done=corr_done)
+        return self._inference_tail_nchw(c3, c4, c5, top, all_rois, side, im_info, n_legs, B, dev)
+
+    def _infer_proposals(self, ex, c3, c4, c5, top, im_info, n_legs, B, dev):
+        """The RPN heads on the main stream and the proposal layer on a side stream -> (all_rois, side stream, correlations
+        already issued).  The proposal layer (selection, decode, NMS mask + sweep) is a handful of small kernels that leave most
+        CUs idle; it runs underneath the correlations and the tracking head, which do not depend on it.  (Dispatched in the
+        same microseconds as a one-workgroup-per-CU kernel, the two race for CUs and the loser's workgroups stay parked on a
+        full shader engine until one of ITS CUs frees up: tools/wg_trace.py, tools/probes/wg_placement.hip.)  The RPN's own
+        convolutions stay on the main stream: beside the correlation kernels they are starved of CUs."""
+        cur = torch.cuda.current_stream(dev)
+        side = getattr(self, "_side_stream", None)
+        if side is None or side.device != dev:
+            side = self._side_stream = torch.cuda.Stream(device=dev)
+        rpn = self.RFCN_rpn
+        pm = getattr(self, "_pm_tail", None)
+        conv1 = ex.rpn_conv1 if ex is not None else None          # relu(RPN_Conv(top)) when the fused trunk has computed it
+        rpn_rows = ex.rpn_rows if ex is not None else None
+        corr_done = ()
+        if (pm is not None and n_legs == 2 and ex is not None and ex.top_rows is not None and
+                os.environ.get("DTT_CORR5_EARLY", "1") != "0"):
+            self._launch_correlations(pm, (c3, c4, c5), (2,), B, dev)   # conv5, on an otherwise empty chip
+            corr_done = (2,)
+        if rpn_rows is not None and pm is not None and pm.rpn is not None:
+            # both 1x1 heads + the pairwise softmax in ONE hand-written launch over the channels-last rows
+            # (dtt_rpn_head_gemm: no transpose, no library GEMMs, no bias / softmax kernels), straight into the
+            # (B, 2A, H, W) / (B, 4A, H, W) tensors the proposal layer reads
+            from .heads import rpn_head_gemm
+            rpn_prob, rpn_bbox = rpn_head_gemm(rpn_rows, pm.rpn, n_legs * B, top.size(2), top.size(3))
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                # scores and box deltas arrive together: one dtt_proposal_forward (the ranking kernel decodes the boxes)
+                all_rois = rpn.RPN_proposal((rpn_prob, rpn_bbox, im_info.view(n_legs * B, -1), "TEST"))
         else:
-            if top.is_cuda and not top.is_contiguous():
-                top = top.contiguous()
-            cls_maps = self.RFCN_cls_net(top)
-            bbox_maps = self.RFCN_bbox_net(top)
-        conv3 = [leg(c3, i) for i in range(n_legs)]
-        conv4 = [leg(c4, i) for i in range(n_legs)]
-        conv5 = [leg(c5, i) for i in range(n_legs)]
+            # library convolutions: the selection needs the scores only and starts under the box-delta convolution
+            conv1, rpn_prob = rpn.head_scores(top, conv1)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                selection = rpn.RPN_proposal.select(rpn_prob.detach(), "TEST")
+            rpn_bbox = rpn.RPN_bbox_pred(conv1)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                all_rois = rpn.RPN_proposal.finish(selection, rpn_bbox.detach(), im_info.view(n_legs * B, -1), "TEST")
+        rpn_prob.record_stream(side); rpn_bbox.record_stream(side)
+        return all_rois, side, corr_done
+
+    def _inference_tail_nchw(self, c3, c4, c5, top, all_rois, side, im_info, n_legs, B, dev):
+        """Inference on NCHW score maps: library 1x1 heads, `psroi_vote`, the tracking concat written by the correlations'
+        reduce kernels; RPN, proposal layer and PSRoI pooling run once for all n_legs * B images."""
+        leg = lambda t, i: t[i * B:(i + 1) * B]
+        if top.is_cuda and not top.is_contiguous():
+            top = top.contiguous()
+        cls_maps = self.RFCN_cls_net(top)
+        bbox_maps = self.RFCN_bbox_net(top)
+        conv3, conv4, conv5 = ([leg(c, i) for i in range(n_legs)] for c in (c3, c4, c5))
         rfcn_bbox = [leg(bbox_maps, i) for i in range(n_legs)]
-        rois, rois_label = [], []
-        rpn_loss_cls, rpn_loss_bbox, cls_prob, bbox_pred = [], [], [], []
-        loss_cls, loss_bbox = [], []
-        tracking_reg = None
         single_frame = n_legs == 1   # BASELINE configs 1-2: plain R-FCN on one frame, no tracking branch
-        if not self.training:
-            # inference: RPN, proposal layer and PSRoI pooling also run once for all n_legs*B images
-            if side is not None:
-                if not single_frame:
-                    tracking_reg = self.corr_bbox_net(self._tracking_features(rfcn_bbox, conv3, conv4, conv5, whole=(c3, c4, c5)))
-                torch.cuda.current_stream(dev).wait_stream(side)
-                all_rois.record_stream(torch.cuda.current_stream(dev))
-            else:
-                all_rois, _, _ = self.RFCN_rpn(top, im_info.view(n_legs * B, -1), None, None)
-            R = all_rois.size(1)
-            flat_rois = all_rois.view(-1, 5)
-            self._roi_features(top, flat_rois)
-            score = self._pool_vote(self.RFCN_psroi_cls_pool, self.RFCN_cls_score, cls_maps, flat_rois)
-            prob = F.softmax(score, dim=1).view(n_legs, B, R, -1)
-            pred = self._pool_vote(self.RFCN_psroi_loc_pool, self.RFCN_bbox_pred, bbox_maps, flat_rois)
-            pred = pred.view(n_legs, B, R, -1)
-            leg_rois = all_rois.view(n_legs, B, R, 5).clone()
-            for i in range(1, n_legs):
-                leg_rois[i, :, :, 0] -= i * B  # batch index within the leg
-            # everything is already laid out (n_legs, B, R, .): hand the tensors over instead of re-stacking slices
-            zeros = torch.zeros(n_legs, 1, device=dev)
-            zero = zeros[0]
-            tracking_pred = torch.zeros(0, 4, device=dev)
+        tracking_reg = None
+        if side is not None:
             if not single_frame:
-                if tracking_reg is None:
-                    tracking_reg = self.corr_bbox_net(self._tracking_features(rfcn_bbox, conv3, conv4, conv5, whole=(c3, c4, c5)))
-                # tracking RoIs = frame-t RoIs (rfcn.py:192)
-                tracking_pred = self._pool_vote(self.RFCN_psroi_loc_pool, self.RFCN_tracking_pred, tracking_reg,
-                                                leg_rois[0].view(-1, 5))
-            return leg_rois, prob, pred, tracking_pred, zeros, zeros, zeros, zeros, [], zero
-        for i in range(n_legs if self.training else 0):
-            # training keeps the reference's per-leg order: anchor-target and RoI sampling draw from numpy's RNG
-            top_i, cls_map, bbox_map = leg(top, i), (leg(cls_maps, i) if cls_maps is not None else None), rfcn_bbox[i]
-            leg_rois, l_cls, l_box = self.RFCN_rpn(top_i, im_info[i], gt_boxes[i][:, :, :5], num_boxes[i])
-            leg_rois, label, target, w_in, w_out = self.RFCN_proposal_target(leg_rois, gt_boxes[i][:, :, :5],
-                                                                              num_boxes[i])
+                tracking_reg = self.corr_bbox_net(self._tracking_features(rfcn_bbox, conv3, conv4, conv5, whole=(c3, c4, c5)))
+            torch.cuda.current_stream(dev).wait_stream(side)
+            all_rois.record_stream(torch.cuda.current_stream(dev))
+        else:
+            all_rois, _, _ = self.RFCN_rpn(top, im_info.view(n_legs * B, -1), None, None)
+        R = all_rois.size(1)
+        flat_rois = all_rois.view(-1, 5)
+        self._roi_features(top, flat_rois)
+        score = self._pool_vote(self.RFCN_psroi_cls_pool, self.RFCN_cls_score, cls_maps, flat_rois)
+        prob = F.softmax(score, dim=1).view(n_legs, B, R, -1)
+        pred = self._pool_vote(self.RFCN_psroi_loc_pool, self.RFCN_bbox_pred, bbox_maps, flat_rois)
+        pred = pred.view(n_legs, B, R, -1)
+        leg_rois = all_rois.view(n_legs, B, R, 5).clone()
+        for i in range(1, n_legs):
+            leg_rois[i, :, :, 0] -= i * B  # batch index within the leg
+        # everything is already laid out (n_legs, B, R, .): hand the tensors over instead of re-stacking slices
+        zeros = torch.zeros(n_legs, 1, device=dev)
+        tracking_pred = torch.zeros(0, 4, device=dev)
+        if not single_frame:
+            if tracking_reg is None:
+                tracking_reg = self.corr_bbox_net(self._tracking_features(rfcn_bbox, conv3, conv4, conv5, whole=(c3, c4, c5)))
+            # tracking RoIs = frame-t RoIs (rfcn.py:192)
+            tracking_pred = self._pool_vote(self.RFCN_psroi_loc_pool, self.RFCN_tracking_pred, tracking_reg,
+                                            leg_rois[0].view(-1, 5))
+        return leg_rois, prob, pred, tracking_pred, zeros, zeros, zeros, zeros, [], zeros[0]
+
+    def _leg_losses(self, i, B, score, pred, label, target, w_in, w_out, out):
+        """rfcn.py:142-160 for one leg: class gather (class-specific boxes), the two R-FCN losses, the per-leg outputs."""
+        prob = F.softmax(score, dim=1)
+        if not self.class_agnostic:
+            pv = pred.view(pred.size(0), int(pred.size(1) / 4), 4)
+            pred = torch.gather(pv, 1, label.view(-1, 1, 1).expand(label.size(0), 1, 4)).squeeze(1)
+        out["loss_cls"].append(F.cross_entropy(score, label).view(1))
+        out["loss_bbox"].append(_smooth_l1_loss(pred, target, w_in, w_out).view(1))
+        out["cls_prob"].append(prob.view(B, -1, prob.size(1)))
+        out["bbox_pred"].append(pred.view(B, -1, pred.size(1)))
+
+    def _train_outputs(self, out, n_legs, B, tracking_pred, tracking_loss):
+        rois = torch.stack(out["rois"], 0)
+        rois_label = torch.stack(out["rois_label"], 0).view(n_legs, B, -1) if out["rois_label"] else []
+        return (rois, torch.stack(out["cls_prob"], 0), torch.stack(out["bbox_pred"], 0), tracking_pred,
+                torch.stack(out["rpn_loss_cls"], 0), torch.stack(out["rpn_loss_bbox"], 0), torch.stack(out["loss_cls"], 0),
+                torch.stack(out["loss_bbox"], 0), rois_label, tracking_loss)
+
+    @staticmethod
+    def _new_out():
+        return {k: [] for k in ("rois", "rois_label", "rpn_loss_cls", "rpn_loss_bbox", "cls_prob", "bbox_pred", "loss_cls", "loss_bbox")}
+
+    def _forward_train_pm(self, c3, c4, c5, top, im_info, gt_boxes, num_boxes, n_legs, B, dev):
+        """Training on the hand-written heads (rfcn.py:95-250, rpn/rpn.py:58-107).  Every 1x1 head of the
+        graph is the exact-fp32 MFMA GEMM with its own backward (dtt.heads: HeadGemmFn = forward + dX on dtt_head_gemm, dW on
+        dtt_head_gemm_dw): RFCN_cls_net + RFCN_bbox_net of all legs in one launch, the RPN's two heads + pairwise softmax in one
+        launch (RpnHeadFn), corr_bbox_net over tracking rows that the correlations write in place (TrackingRowsFn: no 1051-channel
+        concat, no NCHW copies; the correlation gradient kernels read their columns of the rows' gradient).  The proposal layer
+        runs once for both legs; anchor-target and RoI sampling keep the reference's per-leg order (they draw from numpy's RNG);
+        PSRoI pooling of both legs is one position-major launch pair with a map-stationary backward (PsroiPmFn)."""
+        from .heads import (HeadGemmFn, PsroiPmFn, RpnHeadFn, TrackingRowsFn, pack_heads_differentiable,
+                            pack_rpn_heads_differentiable)
+        rpn = self.RFCN_rpn
+        H, W = top.size(2), top.size(3)
+        scale = self.RFCN_psroi_cls_pool.spatial_scale
+        rows = top.permute(0, 2, 3, 1).reshape(-1, top.size(1))           # (a view of the channels-last map)
+        w_pk, b_pk, det_heads, n_store, stride = pack_heads_differentiable([self.RFCN_cls_net, self.RFCN_bbox_net])
+        det = HeadGemmFn.apply(rows, w_pk, b_pk, n_store, stride)
+        # ---- RPN: 3x3 convolution and both heads once for all legs
+        conv1 = F.relu(rpn.RPN_Conv(top), inplace=True)
+        if not (conv1.is_contiguous(memory_format=torch.channels_last) and not conv1.is_contiguous()):
+            conv1 = conv1.contiguous(memory_format=torch.channels_last)
+        w_rpn, b_rpn, A = pack_rpn_heads_differentiable(rpn.RPN_cls_score, rpn.RPN_bbox_pred)
+        rpn_prob, rpn_bbox = RpnHeadFn.apply(conv1.permute(0, 2, 3, 1).reshape(-1, conv1.size(1)), w_rpn, b_rpn, A, n_legs * B, H, W)
+        all_rois = rpn.proposals(rpn_prob, rpn_bbox, im_info.view(n_legs * B, -1))   # (n_legs * B, post, 5), image index in column 0
+        out = self._new_out()
+        sampled = []
+        for i in range(n_legs):
+            sl = slice(i * B, (i + 1) * B)
+            l_cls, l_box = rpn.losses_from_probabilities(rpn_prob[sl], rpn_bbox[sl], gt_boxes[i][:, :, :5], im_info[i], num_boxes[i])
+            leg_rois = all_rois[sl].clone()
+            leg_rois[:, :, 0] -= i * B                                    # batch index within the leg, as the reference's per-leg RPN
+            leg_rois, label, target, w_in, w_out = self.RFCN_proposal_target(leg_rois, gt_boxes[i][:, :, :5], num_boxes[i])
             label = label.view(-1).long()
-            target = target.view(-1, target.size(2))
-            w_in = w_in.view(-1, w_in.size(2))
-            w_out = w_out.view(-1, w_out.size(2))
-            rois_label.append(label)
-            rois.append(leg_rois)
-            rpn_loss_cls.append(l_cls.view(1)); rpn_loss_bbox.append(l_box.view(1))
+            sampled.append((label, target.view(-1, target.size(2)), w_in.view(-1, w_in.size(2)), w_out.view(-1, w_out.size(2))))
+            out["rois_label"].append(label)
+            out["rois"].append(leg_rois)
+            out["rpn_loss_cls"].append(l_cls.view(1)); out["rpn_loss_bbox"].append(l_box.view(1))
+            if getattr(self._cfg, "RFCN_ROI_FEATURES", ""):
+                feats = (feats if i else []) + [self._roi_features(top[sl].detach(), leg_rois.view(-1, 5))]
+                self.roi_feat = feats
+        # ---- PSRoI pooling + vote of both legs over the one position-major map (one gradient map comes back)
+        rois_all = torch.cat([r.detach().reshape(-1, 5) for r in out["rois"]], 0).clone()
+        n_per = out["rois"][0].size(0) * out["rois"][0].size(1)
+        for i in range(1, n_legs):
+            rois_all[i * n_per:(i + 1) * n_per, 0] += i * B               # batch index inside the (n_legs * B)-image map
+        single_frame = n_legs == 1
+        loc = det_heads[1]
+        n_box = loc["group"] * loc["group"] * loc["cp"]
+        pooled = PsroiPmFn.apply(det, rois_all, n_legs * B, H, W, scale, det_heads, None if single_frame else (loc["offset"], n_box))
+        score_all, pred_all = pooled[0], pooled[1]
+        for i in range(n_legs):
+            label, target, w_in, w_out = sampled[i]
+            self._leg_losses(i, B, score_all[i * n_per:(i + 1) * n_per], pred_all[i * n_per:(i + 1) * n_per], label, target, w_in, w_out, out)
+        if single_frame:
+            return self._train_outputs(out, n_legs, B, torch.zeros(0, 4, device=dev), torch.zeros(1, device=dev))
+        # ---- tracking branch (rfcn.py:166-196) on position-major rows
+        layers = (self.conv3_corr_layer, self.conv4_corr_layer, self.conv5_corr_layer)
+        geoms = tuple((l.pad_size, l.kernel_size, l.max_displacement, l.stride1, l.stride2) for l in layers)
+        K_in = self.corr_bbox_net.weight.shape[1]
+        k_pad = -(-K_in // 32) * 32
+        od, G = loc["od"], loc["group"]
+        perm = torch.arange(K_in)
+        bb, kk = torch.meshgrid(torch.arange(G * G), torch.arange(od), indexing="ij")
+        for l in range(2):   # rows column leg*n_box + bin*od + k  <-  reference channel leg*n_box + k*G*G + bin
+            perm[l * n_box:(l + 1) * n_box] = (l * n_box + kk * G * G + bb).reshape(-1)
+        trk_rows = TrackingRowsFn.apply(pooled[2], c3, c4, c5, B, geoms, k_pad)
+        w_trk, b_trk, trk_heads, n_store_t, stride_t = pack_heads_differentiable([self.corr_bbox_net], k_pad=k_pad, in_perm=perm)
+        trk = HeadGemmFn.apply(trk_rows, w_trk, b_trk, n_store_t, stride_t)
+        trk_rois, trk_label, trk_target, trk_in, trk_out = self.RFCN_tracking_proposal_target(gt_boxes, num_boxes)
+        (tracking_pred,) = PsroiPmFn.apply(trk, trk_rois.contiguous().view(-1, 5), B, H, W, scale, trk_heads, None)
+        tracking_loss = _smooth_l1_loss(tracking_pred, trk_target.view(-1, trk_target.size(2)), trk_in.view(-1, trk_in.size(2)),
+                                        trk_out.view(-1, trk_out.size(2)))
+        return self._train_outputs(out, n_legs, B, tracking_pred, tracking_loss)
+
+    def _forward_train_nchw(self, c3, c4, c5, top, im_info, gt_boxes, num_boxes, n_legs, B, dev):
+        """The reference's training graph (rfcn.py:95-250) on library 1x1 convolutions and the NCHW operators with autograd
+        (PSRoIPoolFunction + AvgPool2d, torch.cat of the tracking features): any trunk, any device the operators run on."""
+        leg = lambda t, i: t[i * B:(i + 1) * B]
+        if top.is_cuda and not top.is_contiguous():
+            top = top.contiguous()
+        cls_maps = self.RFCN_cls_net(top)
+        bbox_maps = self.RFCN_bbox_net(top)
+        conv3, conv4, conv5 = ([leg(c, i) for i in range(n_legs)] for c in (c3, c4, c5))
+        rfcn_bbox = [leg(bbox_maps, i) for i in range(n_legs)]
+        out = self._new_out()
+        for i in range(n_legs):
+            # the reference's per-leg order: anchor-target and RoI sampling draw from numpy's RNG
+            leg_rois, l_cls, l_box = self.RFCN_rpn(leg(top, i), im_info[i], gt_boxes[i][:, :, :5], num_boxes[i])
+            leg_rois, label, target, w_in, w_out = self.RFCN_proposal_target(leg_rois, gt_boxes[i][:, :, :5], num_boxes[i])
+            label = label.view(-1).long()
+            out["rois_label"].append(label)
+            out["rois"].append(leg_rois)
+            out["rpn_loss_cls"].append(l_cls.view(1)); out["rpn_loss_bbox"].append(l_box.view(1))
             flat_rois = leg_rois.view(-1, 5)
             if getattr(self._cfg, "RFCN_ROI_FEATURES", ""):
-                feats = (feats if i else []) + [self._roi_features(top_i.detach(), flat_rois)]
+                feats = (feats if i else []) + [self._roi_features(leg(top, i).detach(), flat_rois)]
                 self.roi_feat = feats
-            if det is not None:
-                from .heads import PsroiPmFn
-                rois_all = flat_rois.detach().clone()
-                rois_all[:, 0] += i * B                     # batch index inside the (n_legs * B)-image score map
-                score, pred = PsroiPmFn.apply(det, rois_all, n_legs * B, top.size(2), top.size(3),
-                                              self.RFCN_psroi_cls_pool.spatial_scale, det_heads)
-            else:
-                score = self._pool_vote(self.RFCN_psroi_cls_pool, self.RFCN_cls_score, cls_map, flat_rois)
-                pred = self._pool_vote(self.RFCN_psroi_loc_pool, self.RFCN_bbox_pred, bbox_map, flat_rois)
-            prob = F.softmax(score, dim=1)
-            if not self.class_agnostic:
-                pv = pred.view(pred.size(0), int(pred.size(1) / 4), 4)
-                pred = torch.gather(pv, 1, label.view(-1, 1, 1).expand(label.size(0), 1, 4)).squeeze(1)
-            loss_cls.append(F.cross_entropy(score, label).view(1))
-            loss_bbox.append(_smooth_l1_loss(pred, target, w_in, w_out).view(1))
-            cls_prob.append(prob.view(B, leg_rois.size(1), -1))
-            bbox_pred.append(pred.view(B, leg_rois.size(1), -1))
-
-        if single_frame:
-            zero = torch.zeros(1, device=dev)
-            rois = torch.stack(rois, 0)
-            if rois_label:
-                rois_label = torch.stack(rois_label, 0).view(n_legs, B, -1)
-            return (rois, torch.stack(cls_prob, 0), torch.stack(bbox_pred, 0), torch.zeros(0, 4, device=dev),
-                    torch.stack(rpn_loss_cls, 0), torch.stack(rpn_loss_bbox, 0), torch.stack(loss_cls, 0),
-                    torch.stack(loss_bbox, 0), rois_label, zero)
-        if tracking_reg is None:
-            tracking_reg = self.corr_bbox_net(self._tracking_features(rfcn_bbox, conv3, conv4, conv5, whole=(c3, c4, c5)))
-        if self.training:
-            trk_rois, trk_label, trk_target, trk_in, trk_out = self.RFCN_tracking_proposal_target(gt_boxes, num_boxes)
-            trk_target = trk_target.view(-1, trk_target.size(2))
-            trk_in = trk_in.view(-1, trk_in.size(2))
-            trk_out = trk_out.view(-1, trk_out.size(2))
-        else:
-            trk_rois = rois[0].clone()  # tracking RoIs = frame-t RoIs (rfcn.py:192)
+            score = self._pool_vote(self.RFCN_psroi_cls_pool, self.RFCN_cls_score, leg(cls_maps, i), flat_rois)
+            pred = self._pool_vote(self.RFCN_psroi_loc_pool, self.RFCN_bbox_pred, rfcn_bbox[i], flat_rois)
+            self._leg_losses(i, B, score, pred, label, target.view(-1, target.size(2)), w_in.view(-1, w_in.size(2)),
+                             w_out.view(-1, w_out.size(2)), out)
+        if n_legs == 1:
+            return self._train_outputs(out, n_legs, B, torch.zeros(0, 4, device=dev), torch.zeros(1, device=dev))
+        tracking_reg = self.corr_bbox_net(self._tracking_features(rfcn_bbox, conv3, conv4, conv5, whole=(c3, c4, c5)))
+        trk_rois, trk_label, trk_target, trk_in, trk_out = self.RFCN_tracking_proposal_target(gt_boxes, num_boxes)
         tracking_pred = self._pool_vote(self.RFCN_psroi_loc_pool, self.RFCN_tracking_pred, tracking_reg,
                                         trk_rois.contiguous().view(-1, 5))
-        if self.training:
-            tracking_loss = _smooth_l1_loss(tracking_pred, trk_target, trk_in, trk_out)
-        else:
-            tracking_loss = torch.zeros(1, device=dev)
-        rois = torch.stack(rois, 0)
-        cls_prob = torch.stack(cls_prob, 0)
-        bbox_pred = torch.stack(bbox_pred, 0)
-        if rois_label:
-            rois_label = torch.stack(rois_label, 0).view(n_legs, B, -1)
-        return (rois, cls_prob, bbox_pred, tracking_pred, torch.stack(rpn_loss_cls, 0), torch.stack(rpn_loss_bbox, 0),
-                torch.stack(loss_cls, 0), torch.stack(loss_bbox, 0), rois_label, tracking_loss)
+        tracking_loss = _smooth_l1_loss(tracking_pred, trk_target.view(-1, trk_target.size(2)), trk_in.view(-1, trk_in.size(2)),
+                                        trk_out.view(-1, trk_out.size(2)))
+        return self._train_outputs(out, n_legs, B, tracking_pred, tracking_loss)
 
     def _init_weights(self):
         if not getattr(self, "pretrained_rfcn", False):
@@ -614,19 +686,26 @@ class resnet(_RFCN):
         return self
 
     def _im_to_head(self, x):
+        """(conv3, conv4, conv5, top) of resnet.py:334-345 -- on the fused trunk when one is attached (dtt.fuse)."""
+        return self._im_to_head_ex(x)[:4]
+
+    def _im_to_head_ex(self, x):
+        """_im_to_head plus what the fused inference trunk computes on the way for the tail (dtt.fuse.TrunkExtras: the
+        channels-last rows of `top` and of relu(RPN_Conv(top)), the early head GEMM's output) -- None on the other trunks."""
         fused = getattr(self, "_fused_trunk", None)
         if fused is not None and not self.training and not torch.is_grad_enabled() and x.is_cuda:
-            return fused(x)  # dtt.fuse: BatchNorm folded, bias + residual + ReLU in one HIP pass
+            res = fused(x)  # dtt.fuse: BatchNorm folded, bias + residual + ReLU in one HIP pass
+            return res if len(res) == 5 else (*res, None)
         fused_train = getattr(self, "_fused_train_trunk", None)
         if fused_train is not None and self.training and torch.is_grad_enabled() and x.is_cuda:
-            return fused_train(x)
+            return (*fused_train(x), None)
         b = self.RFCN_base
         x = b[3](b[2](b[1](b[0](x))))
         conv3 = b[5](b[4](x))
         conv4 = b[6](conv3)
         conv5 = b[7](conv4)
         top = b[9](b[8](conv5))
-        return conv3, conv4, conv5, top
+        return conv3, conv4, conv5, top, None
 
 
 IMAGENET_VID_CLASSES = ["__background__"] + ["class_%d" % i for i in range(1, 31)]

@@ -184,9 +184,16 @@ def _nccl_one_rank_worker(port, q, full_size):
     m_buck, r_buck = replica(True)
     assert r_buck.bucketed and len(r_buck._buckets) >= 2 and not r_plain.bucketed
     step(r_buck)
+    # what autograd hands over for every parameter in THIS step (tensor hooks fire before the bucket hooks): the all-reduce over
+    # one rank is the identity, so after finish_gradients every p.grad -- a view into a flat bucket -- must hold exactly these bits
+    raw = {}
+    handles = [p.register_hook(lambda g, n=n: raw.__setitem__(n, g.detach().clone())) for n, p in m_buck.named_parameters() if p.requires_grad]
     step(r_buck); g_c = grads(m_buck)
+    for h in handles:
+        h.remove()
+    exact = {n: bool(torch.equal(raw[n].reshape(-1), g_c[n].reshape(-1))) if n in raw else None for n in g_c}
     ar_ms = r_buck.time_allreduce_ms(3)
-    res = {"n": len(g_a), "keys_equal": set(g_a) == set(g_c), "bucket_bytes": r_buck.bucket_bytes_total(),
+    res = {"n": len(g_a), "keys_equal": set(g_a) == set(g_c), "bucket_bytes": r_buck.bucket_bytes_total(), "exact": exact,
            "n_buckets": len(r_buck._buckets), "allreduce_ms": ar_ms, "backend": dist.get_backend(),
            "in_bucket": all(any(p.grad.data_ptr() >= f.data_ptr() and p.grad.data_ptr() < f.data_ptr() + f.numel() * 4
                                 for f, _ in r_buck._buckets)
@@ -221,13 +228,14 @@ def test_one_rank_nccl_group_carries_the_gradient_buckets(full_size):
     assert res["backend"] == "nccl" and res["keys_equal"] and res["in_bucket"] and res["n"] > 40
     assert res["n_buckets"] >= 2 and res["bucket_bytes"] > (150 << 20 if full_size else 50 << 20)
     assert res["allreduce_ms"] is not None and res["allreduce_ms"] > 0
+    bad = [n for n, ok in res["exact"].items() if ok is not True]
+    assert not bad, ("gradients changed on their way through the buckets / the 1-rank all-reduce", bad[:5])
     n_det = 0
     for n, det, same, rel, rel_rr in res["rows"]:
         if det:
             assert same, ("deterministic tensor differs between the plain and the bucketed step", n, rel)
             n_det += 1
         else:
-            assert rel <= max(10 * rel_rr, 1e-6), (n, rel, rel_rr)
-    assert n_det >= 10, "no run-to-run deterministic gradient tensors to pin the bucket path on (%d)" % n_det
-    print("1-rank RCCL: %d tensors (%d run-to-run deterministic, all bit-identical through the buckets), %d buckets / %.1f MB, "
-          "all-reduce %.3f ms" % (res["n"], n_det, res["n_buckets"], res["bucket_bytes"] / 1e6, res["allreduce_ms"]))
+            assert rel <= max(10 * rel_rr, 1e-5), (n, rel, rel_rr)
+    print("1-rank RCCL: %d tensors bit-identical through the buckets (%d of them run-to-run deterministic in the plain step), "
+          "%d buckets / %.1f MB, all-reduce %.3f ms" % (res["n"], n_det, res["n_buckets"], res["bucket_bytes"] / 1e6, res["allreduce_ms"]))

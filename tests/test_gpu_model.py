@@ -37,9 +37,13 @@ def test_rfcn_forward_contract_and_parity():
     assert same.float().mean() > 0.9, "only %.3f of RoI rows agree" % same.float().mean()
     d_cls = (cls_prob - ref["cls_prob"]).abs().amax(dim=3)[same]
     d_box = (bbox_pred - ref["bbox_pred"]).abs().amax(dim=3)[same]
-    # (a RoI that agrees to 0.05 px can still straddle a pooling-bin edge the other way: allow a few such rows, bounded)
+    # RoIs that are reproduced exactly (to 1e-4 px) carry the strict bound; a RoI that only agrees to 0.05 px can straddle a
+    # pooling-bin edge the other way: those rows (a few) get the relaxed, still bounded one
     box_tol = 1e-2 * max(1.0, float(ref["bbox_pred"].abs().max()))
-    assert d_cls.max() < 1e-3 and (d_box < box_tol).float().mean() > 0.995 and d_box.max() < 10 * box_tol
+    exact = ((rois - ref["rois"]).abs().amax(dim=3) < 1e-4)[same]
+    assert float(exact.float().mean()) > 0.8, "only %.3f of the matched RoIs are reproduced exactly" % float(exact.float().mean())
+    assert d_cls.max() < 1e-3 and d_box[exact].max() < box_tol
+    assert (d_box < box_tol).float().mean() > 0.995 and d_box.max() < 10 * box_tol
     same0 = same[0].reshape(-1)
     d_trk = (tracking_pred - ref["tracking_pred"]).abs().amax(dim=1)[same0]
     assert d_trk.max() < 1e-2 * max(1.0, float(ref["tracking_pred"].abs().max()))
@@ -432,14 +436,27 @@ def _check_pm_tail(monkeypatch, layers, shapes):
         B = shape[0]
         im, info, gt, nb = make_batch(B, shape[1], shape[2], seed=5, device=dev)
         calibrate_batchnorm_(model, im[:, 0])
-        fuse_for_inference(model)
+        flat = im.permute(1, 0, 2, 3, 4).reshape(2 * B, *im.shape[2:])
+        # O(1) head outputs, so that the comparison below can be ABSOLUTE: the random-init tracking branch (N(0, 0.01) weights
+        # over 1051 inputs, the correlations among them) reaches |x| ~ 1e4 on some maps, where 1e-4 is below one fp32 ulp of the
+        # sums -- the weights of the three heads are rescaled so that their maps stay within +-1 on this input
+        with torch.no_grad():
+            fuse_for_inference(model)
+            c3, c4, c5, top = model._im_to_head(flat)
+            top_nchw = top.contiguous()
+            for conv, x in ((model.RFCN_cls_net, top_nchw), (model.RFCN_bbox_net, top_nchw)):
+                m = float(conv(x).abs().max())
+                conv.weight.mul_(1.0 / max(m, 1.0)); conv.bias.mul_(1.0 / max(m, 1.0))
+            bbox_maps = model.RFCN_bbox_net(top_nchw)
+            feat = model._tracking_features([bbox_maps[:B], bbox_maps[B:]], [c3[:B], c3[B:]], [c4[:B], c4[B:]], [c5[:B], c5[B:]])
+            m = float(model.corr_bbox_net(feat).abs().max())
+            model.corr_bbox_net.weight.mul_(1.0 / max(m, 1.0)); model.corr_bbox_net.bias.mul_(1.0 / max(m, 1.0))
+        fuse_for_inference(model)                              # repack the rescaled heads
         pm, fused = model._pm_tail, model._fused_trunk
         assert pm is not None and fused.pm_heads
         with torch.no_grad():
             out = model(im, info, gt, nb)                      # the production path (position-major tail inside)
-            flat = im.permute(1, 0, 2, 3, 4).reshape(2 * B, *im.shape[2:])
-            c3, c4, c5, top = model._im_to_head(flat)
-            fused.rpn_conv1 = fused.rpn_rows = None
+            c3, c4, c5, top, ex = model._im_to_head_ex(flat)
             conv1_cl = fused.rpn_conv.act(top)                 # relu(RPN_Conv(top)), channels-last: the SAME map feeds both sides
             _, _, rpn_prob, rpn_bbox = model.RFCN_rpn.head(top, conv1_cl.contiguous())
             if pm.rpn is not None:   # the one-launch RPN heads (dtt_rpn_head_gemm) against the library convolutions + softmax
@@ -451,7 +468,7 @@ def _check_pm_tail(monkeypatch, layers, shapes):
             info2 = info.permute(1, 0, 2).reshape(2 * B, -1).contiguous()
             all_rois = model.RFCN_rpn.proposals(rpn_prob, rpn_bbox, info2)
             side = torch.cuda.Stream(device=dev)
-            got = model._inference_tail_pm(pm, fused, c3, c4, c5, all_rois, side, 2, B, dev)
+            got = model._inference_tail_pm(pm, ex, c3, c4, c5, all_rois, side, 2, B, dev)
             # reference graph on the same maps
             top_nchw = top.contiguous()
             cls_maps, bbox_maps = model.RFCN_cls_net(top_nchw), model.RFCN_bbox_net(top_nchw)
@@ -466,15 +483,21 @@ def _check_pm_tail(monkeypatch, layers, shapes):
         for name, a, b in (("cls_prob", got[1], prob), ("bbox_pred", got[2], pred), ("tracking_pred", got[3], trk)):
             assert a.shape == b.shape, name
             err = float((a - b).abs().max())
-            # 1e-4 at O(1) magnitudes; the random-init tracking branch of the 1-image case reaches |x| ~ 1e4, where the
-            # fp32 summation order of two exact-fp32 GEMMs differs by more than that in absolute terms
-            assert err < 1e-4 * max(1.0, float(b.abs().max())), (name, err, float(b.abs().max()))
+            assert float(b.abs().max()) <= 1.0 + 1e-3, (name, float(b.abs().max()))   # O(1) by construction (see above) ...
+            assert err < 1e-4, (name, err)                                            # ... so the north-star tolerance is absolute
         for i in (1, 2, 3):   # and the full forward produced finite outputs of the contract's shapes
             assert out[i].shape == got[i].shape and bool(torch.isfinite(out[i]).all())
-        # single-frame mode (BASELINE configs 1-2) takes the same tail without the tracking branch
+        # single-frame mode (BASELINE configs 1-2) takes the same tail without the tracking branch: leg 0 of the pair, as VALUES --
+        # the same images through the same kernels in a batch of B instead of 2 B (the library GEMMs of the trunk may pick
+        # another tile for the smaller batch: RoIs are matched to 0.05 px, scores on matched RoIs to 1e-3)
         with torch.no_grad():
             one = model(im[:, :1], info[:, :1], gt[:, :1], nb[:, :1])
-        assert one[3].shape[0] == 0 and one[1].shape == (1, B, R, model.n_classes)
+        torch.cuda.synchronize()
+        assert one[3].shape[0] == 0 and one[1].shape == (1, B, R, model.n_classes) and one[0].shape == (1, B, R, 5)
+        same = (one[0][0] - out[0][0]).abs().amax(dim=2) < 0.05
+        assert float(same.float().mean()) > 0.95, "single frame: only %.3f of leg 0's RoIs reproduced" % float(same.float().mean())
+        assert float((one[1][0] - out[1][0]).abs().amax(dim=2)[same].max()) < 1e-3
+        assert float((one[2][0] - out[2][0]).abs().amax(dim=2)[same].max()) < 1e-3
 
 
 def test_bench_step_tail_at_full_size_matches_nchw_tail(monkeypatch):
@@ -511,6 +534,10 @@ def test_config0_single_frame_res50_300px_against_cpu_graph():
     assert same.float().mean() > 0.9, "only %.3f of RoI rows agree" % same.float().mean()
     d_cls = (cls_prob - ref["cls_prob"]).abs().amax(dim=3)[same]
     d_box = (bbox_pred - ref["bbox_pred"]).abs().amax(dim=3)[same]
-    # (a RoI that agrees to 0.05 px can still straddle a pooling-bin edge the other way: allow a few such rows, bounded)
+    # RoIs that are reproduced exactly (to 1e-4 px) carry the strict bound; a RoI that only agrees to 0.05 px can straddle a
+    # pooling-bin edge the other way: those rows (a few) get the relaxed, still bounded one
     box_tol = 1e-2 * max(1.0, float(ref["bbox_pred"].abs().max()))
-    assert d_cls.max() < 1e-3 and (d_box < box_tol).float().mean() > 0.995 and d_box.max() < 10 * box_tol
+    exact = ((rois - ref["rois"]).abs().amax(dim=3) < 1e-4)[same]
+    assert float(exact.float().mean()) > 0.8, "only %.3f of the matched RoIs are reproduced exactly" % float(exact.float().mean())
+    assert d_cls.max() < 1e-3 and d_box[exact].max() < box_tol
+    assert (d_box < box_tol).float().mean() > 0.995 and d_box.max() < 10 * box_tol

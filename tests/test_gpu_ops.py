@@ -268,6 +268,34 @@ def test_correlation_channels_last_autograd(dev, case):
         assert torch.equal(r1.grad, t1.grad) and torch.equal(r2.grad, t2.grad)
 
 
+@pytest.mark.parametrize("chunk", [99, 2])
+@pytest.mark.parametrize("case", [(1, 256, 38, 67, 8, 1, 8, 1, 1), (2, 320, 17, 29, 8, 1, 8, 1, 1), (1, 192, 24, 40, 8, 1, 8, 1, 1),
+                                  (1, 192, 37, 45, 8, 1, 8, 2, 2), (1, 256, 21, 17, 3, 1, 3, 1, 1)])
+def test_correlation_streamed_backward_many_groups_per_work_item(dev, monkeypatch, case, chunk):
+    """The streamed gradient kernels with SEVERAL channel groups per work item (the plan of the full-size training step: 6 of
+    conv5's 32 groups per workgroup; small maps plan one group per item, so the switch DTT_CORR_BWD_CHUNK forces it): the ring
+    runs across group boundaries -- where the rows of a tall tile (the 4 x 1 tiles of an odd block column) all step into fresh
+    positions at once -- accumulators are stored and reset per group.  Both gradients against the oracle."""
+    from dtt.ops import correlation_backward_nhwc, correlation_output_shape
+    monkeypatch.setenv("DTT_CORR_BWD_CHUNK", str(chunk))
+    B, C, H, W, pad, k, d, s1, s2 = case
+    rng = np.random.RandomState(sum(case) + chunk)
+    x1 = rng.normal(size=(B, C, H, W)).astype(np.float32)
+    x2 = rng.normal(size=(B, C, H, W)).astype(np.float32)
+    cl = lambda a: cu(a, dev).contiguous(memory_format=torch.channels_last)
+    t1, t2 = cl(x1), cl(x2)
+    oc, oh, ow = correlation_output_shape(C, H, W, pad, k, d, s1, s2)
+    gout = rng.normal(size=(B, oc, oh, ow)).astype(np.float32)
+    ga, gb = torch.full_like(t1, float("nan")), torch.full_like(t2, float("nan"))
+    correlation_backward_nhwc(cu(gout, dev), t1, t2, ga, gb, pad, k, d, s1, s2)
+    g1, g2 = O.correlation_backward(gout, x1, x2, pad, k, d, s1, s2)
+    np.testing.assert_allclose(ga.cpu().numpy(), g1, rtol=0, atol=1e-4)
+    np.testing.assert_allclose(gb.cpu().numpy(), g2, rtol=0, atol=1e-4)
+    ga2, gb2 = torch.empty_like(t1), torch.empty_like(t2)
+    correlation_backward_nhwc(cu(gout, dev), t1, t2, ga2, gb2, pad, k, d, s1, s2)
+    assert torch.equal(ga, ga2) and torch.equal(gb, gb2)     # run-to-run identical
+
+
 @pytest.mark.parametrize("case", [c for c in CORR_CL_CASES if c[1] % 64 == 0])
 def test_correlation_streamed_backward_rows_layout_and_single_gradients(dev, case):
     """dtt_correlation_backward_nhwc_strided reading gradOut as columns of position-major rows (the gradient of the tracking
