@@ -495,7 +495,8 @@ int dtt_psroi_pm_forward(const float* map, long pixel_stride, int cp, int batch_
  * the AvgPool2d of rfcn.py:62-64): grad_map[pixel][bin*cp + c] = sum over the RoIs of that image whose bin contains the pixel of
  * grad_vote[roi][c] / pooled^2 / bin_area, added in RoI order -- map-stationary, no atomics (the reference scatters with
  * atomicAdd), deterministic.  Every pixel's floats [0, pooled^2 * cp) are WRITTEN (zeros where no RoI reaches): no pre-zeroing.
- * edges: caller-owned scratch, num_rois * (4 * pooled + 1) ints.  cp in {4, 32} as in the forward. */
+ * edges: caller-owned scratch, num_rois * (4 * pooled + 1) + 2 * batch_size ints (the bin edges of every RoI, then the run of RoI
+ * indices of every image: a pixel's workgroup only walks the RoIs of its own image).  cp in {4, 32} as in the forward. */
 int dtt_psroi_pm_backward(const float* grad_vote, const float* rois, int num_rois, int batch_size, int height, int width,
                           int pooled, float spatial_scale, int output_dim, int cp, long pixel_stride, float* grad_map,
                           int* edges, void* stream);

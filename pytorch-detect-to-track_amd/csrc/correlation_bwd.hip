@@ -173,22 +173,26 @@ __global__ __launch_bounds__(kThreads) void corr_bwd_stream_kernel(BGeom g) {
     }
   }
   if (g.ablate & 1) ni = 0;
-  const char* obase = reinterpret_cast<const char*>(g.other + img);
-  int issued = 0;
-  auto issue_position = [&](int P) {
-    const int gi = P / NH, hr = P - gi * NH;
-    const unsigned dst = lds0 + (unsigned)((P % S) * slot_bytes + wave * 1024);
-    const char* gbase = obase + (long)(it.g0 + gi) * (kGC * 4);
+  const char* obase = reinterpret_cast<const char*>(g.other + img) + (long)it.g0 * (kGC * 4);
+  // the next position to issue, tracked incrementally (all scalar: no division on the way): its group's base address, its halo
+  // block row and its ring slot
+  int issued = 0, i_hr = 0, i_slot = 0;
+  const int y_first = g.origin + it.Y0 - g.R;
+  auto issue_next = [&]() {
+    const unsigned dst = lds0 + (unsigned)(i_slot * slot_bytes + wave * 1024);
 #pragma unroll
     for (int i = 0; i < kMaxNI; ++i)
       if (i < ni) {
-        const int y = min(max(g.origin + it.Y0 - g.R + 4 * hr + row_of[i], 0), g.H - 1);
-        dma16b(uptrb(gbase + (unsigned long long)((unsigned)y * g.sy4)), voff[i], dst + (unsigned)(i * kWaves * 1024));
+        const int y = min(max(y_first + 4 * i_hr + row_of[i], 0), g.H - 1);
+        dma16b(uptrb(obase + (unsigned long long)((unsigned)y * g.sy4)), voff[i], dst + (unsigned)(i * kWaves * 1024));
       }
+    ++issued;
+    if (++i_slot == S) i_slot = 0;
+    if (++i_hr == NH) { i_hr = 0; obase += kGC * 4; }
   };
 
   // the ring is filled first (positions 0 .. th - 1 are read in step 0); the band loads queue up behind it
-  for (; issued < min(S, npos); ++issued) issue_position(issued);
+  while (issued < min(S, npos)) issue_next();
 
   // ---------------------------------------------------------------- band: NBR^2 * 4 words per lane, in register order
   float band[NB4];
@@ -246,19 +250,32 @@ __global__ __launch_bounds__(kThreads) void corr_bwd_stream_kernel(BGeom g) {
       // P's slot is free once everybody is done with position P - S < base.
       const int need = min(base + th - 1, npos - 1);
       const int fill = min(base + S - 1, npos - 1);
+      // The scalar work of a refill (a few dozen SALU instructions + the DMA instructions) is taken out of phase on the two waves
+      // that share a SIMD: waves 0 - 3 do it right after the barrier, while their SIMD partners (waves 4 - 7) already feed the
+      // matrix pipe, and those do theirs half a step later underneath the first waves' MFMAs.  Unless the refill is needed by
+      // the very next step (group boundaries): then everybody issues at once.
+      const int need_next = (qi == NBR - 1 ? base + 2 * th : base + th);   // positions <= this are read in the next step
+      bool deferred = false;
       if (issued - 1 >= need) {
         wait_vmcnt_b((issued - 1 - need) * ni);   // mine of the later positions may still fly (loads return in order)
         wg_barrier_b();                           // everybody's share has landed; everybody is done with the positions below `base`
-        for (; issued <= fill; ++issued) issue_position(issued);
+        if (wave >= 4 && fill > need_next) {
+          while (issued <= need_next && issued <= fill) issue_next();
+          deferred = true;
+        } else {
+          while (issued <= fill) issue_next();
+        }
       } else {
         // a tall tile at a group boundary (th rows step into fresh positions at once, the ring holds fewer than 2 th): the slots
         // only come free now -- fill, drain, meet again
         wg_barrier_b();
-        for (; issued <= fill; ++issued) issue_position(issued);
+        while (issued <= fill) issue_next();
         wait_vmcnt_b(0);
         wg_barrier_b();
       }
-      if (do_mfma) {
+      if (!do_mfma) {
+        while (issued <= fill) issue_next();
+      } else {
         const unsigned sp = rd_lane + (unsigned)(((base + wy) % S) * slot_bytes);
         const unsigned row = (unsigned)(HC * kGC * 4);
         auto mm = [&](int t, int buf) {
@@ -279,6 +296,10 @@ __global__ __launch_bounds__(kThreads) void corr_bwd_stream_kernel(BGeom g) {
         rd(sp + 2 * row, 0);
         DTT_LANDED(1, NBR); mm(1, 1);
         __builtin_amdgcn_sched_barrier(0);
+        if (deferred) {
+          while (issued <= fill) issue_next();
+          __builtin_amdgcn_sched_barrier(0);
+        }
         rd(sp + 3 * row, 1);
         DTT_LANDED(0, NBR); mm(2, 0);
         __builtin_amdgcn_sched_barrier(0);
@@ -303,7 +324,9 @@ __global__ __launch_bounds__(kThreads) void corr_bwd_stream_kernel(BGeom g) {
 // band[dir][n][by][bx][(qi * NBR + qj) * 4 + t][lane]: what lane (m = lane % 16: target pixel (m / 4, m % 4) of block (by, bx);
 // k = lane / 16) of the wave that owns the block feeds the MFMA of window block (qi, qj), step t as its A operand = the gradient
 // that couples target m with the other frame's halo pixel (4 qi + t, 4 qj + k) of the block's halo -- zero where the pair lies
-// outside the window, the output range or the image.  One workgroup per (direction, image, block); thread = (lane, t).
+// outside the window, the output range or the image.  One workgroup per (direction, image, block): the block's 16 x D*D pairs are
+// staged through LDS with loads that follow gradOut's contiguous axis (the first version gathered straight from memory: 25 loads
+// per thread each touching 64 cache lines in the planes layout, 16.6 us per conv5 op).
 struct BandGeom {
   const float* gout; long g_sb, g_sc, g_sp;
   float* band;
@@ -316,32 +339,58 @@ struct BandGeom {
 template <int NBR>
 __global__ __launch_bounds__(256) void corr_bwd_band_kernel(BandGeom g) {
   constexpr int NB4 = NBR * NBR * 4;
+  constexpr int MAXD = 4 * (NBR - 1) + 1, MAXD2 = MAXD * MAXD;        // R <= 2 (NBR - 1)
+  constexpr int NIT = (16 * MAXD2 + 255) / 256;
+  __shared__ float G[16 * (MAXD2 + 1)];                               // G[m * (D2 + 1) + d]: gradOut of the pair (target m, displacement d)
   int blk = blockIdx.x;
   const int n0 = g.batch * g.gh[0] * g.gw[0];
   const int dir = blk >= n0 ? 1 : 0;
   blk -= dir ? n0 : 0;
   const int gw = g.gw[dir], gh = g.gh[dir];
   const int bx = blk % gw, by = (blk / gw) % gh, n = blk / (gw * gh);
-  const int lane = threadIdx.x & 63, t = threadIdx.x >> 6;
-  const int m = lane & 15, k = lane >> 4, tyi = m >> 2, txi = m & 3;
-  const int ty = g.lo_y[dir] + 4 * by + tyi, tx = g.lo_x[dir] + 4 * bx + txi;     // target pixel, output coordinates
+  const int tid = threadIdx.x;
+  const int D2 = g.D * g.D, ldg = D2 + 1;
   const float* go = g.gout + (long)n * g.g_sb;
-  float* out = g.band + g.dir_off[dir] + (((long)n * gh + by) * gw + bx) * NB4 * 64 + t * 64 + lane;
+  const int y0 = g.lo_y[dir] + 4 * by, x0 = g.lo_x[dir] + 4 * bx;      // the block's first target pixel, output coordinates
   auto in_img = [&](int y, int x) { return y + g.origin >= 0 && y + g.origin < g.H && x + g.origin >= 0 && x + g.origin < g.W; };
+  // ---- stage: every (target pixel, displacement) pair of the block once, coalesced along the layout's contiguous axis --
+  // planes (g_sp == 1): the four pixels of a block row are 16 contiguous bytes of a plane; rows (g_sc == 1): a pixel's D2
+  // displacements are one contiguous run.  Validity is folded in here.
+  const bool d_fastest = g.g_sc == 1;
+  float v[NIT];
+  int idx[NIT];
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    const int e = tid + i * 256;
+    int m, d;
+    if (d_fastest) { m = e / D2; d = e - m * D2; } else { d = e >> 4; m = e & 15; }
+    const bool live = m < 16 && d < D2;
+    const int ty = y0 + (m >> 2), tx = x0 + (m & 3);
+    const int dyi = d / g.D, dy = dyi - g.R, dx = d - dyi * g.D - g.R;
+    const int py = dir ? ty - dy : ty, px = dir ? tx - dx : tx;       // p: output pixel;  q = p + d: displaced pixel
+    const bool ok = live && py >= 0 && py < g.oh && px >= 0 && px < g.ow && in_img(py, px) && in_img(py + dy, px + dx);
+    const long off = ok ? (long)d * g.g_sc + ((long)py * g.ow + px) * g.g_sp : 0;
+    const float x = go[off];
+    v[i] = ok ? x : 0.f;
+    idx[i] = live ? m * ldg + d : -1;
+  }
+#pragma unroll
+  for (int i = 0; i < NIT; ++i)
+    if (idx[i] >= 0) G[idx[i]] = v[i];
+  __syncthreads();
+  // ---- the band words in register order: thread = (lane, step t); the NBR^2 window blocks unrolled
+  const int lane = tid & 63, t = tid >> 6;
+  const int m = lane & 15, k = lane >> 4, tyi = m >> 2, txi = m & 3;
+  float* out = g.band + g.dir_off[dir] + (((long)n * gh + by) * gw + bx) * NB4 * 64 + t * 64 + lane;
+  const float* Gm = G + m * ldg;
 #pragma unroll
   for (int qi = 0; qi < NBR; ++qi)
 #pragma unroll
     for (int qj = 0; qj < NBR; ++qj) {
       const int hy = 4 * qi + t - tyi, hx = 4 * qj + k - txi;                    // halo pixel - target pixel + R
       const int tj = dir ? 2 * g.R - hy : hy, ti = dir ? 2 * g.R - hx : hx;     // displacement index of the pair
-      const int dy = tj - g.R, dx = ti - g.R;
-      const int py = dir ? ty - dy : ty, px = dir ? tx - dx : tx;               // p: output pixel;  q = p + d: displaced pixel
-      const int qy = py + dy, qx = px + dx;
-      const bool ok = tj >= 0 && tj < g.D && ti >= 0 && ti < g.D && py >= 0 && py < g.oh && px >= 0 && px < g.ow && in_img(py, px) &&
-                      in_img(qy, qx);
-      const long off = ok ? (long)(tj * g.D + ti) * g.g_sc + ((long)py * g.ow + px) * g.g_sp : 0;
-      const float v = go[off];
-      out[(qi * NBR + qj) * 4 * 64] = ok ? v : 0.f;
+      const bool in = tj >= 0 && tj < g.D && ti >= 0 && ti < g.D;
+      out[(qi * NBR + qj) * 4 * 64] = in ? Gm[tj * g.D + ti] : 0.f;
     }
 }
 

@@ -457,14 +457,19 @@ __global__ __launch_bounds__(NW * 64) void psroi_pm_kernel(const float* __restri
 // lanes = classes -- no atomics, no pre-zeroed output (every pixel writes its whole row segment), deterministic.
 // psroi_pm_edges_kernel first turns every RoI into its 4 * P bin edges with the forward's arithmetic (psroi_bin.h).
 __global__ void psroi_pm_edges_kernel(const float* __restrict__ rois, int num_rois, float spatial_scale, int pooled, int height,
-                                      int width, int batch_size, int* __restrict__ edges) {
+                                      int width, int batch_size, int* __restrict__ edges, unsigned* __restrict__ range) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= num_rois) return;
   float roi[5];
 #pragma unroll
   for (int q = 0; q < 5; ++q) roi[q] = rois[(long)r * 5 + q];
   int* e = edges + (long)r * (4 * pooled + 1);
-  e[4 * pooled] = min(max((int)roi[0], 0), batch_size - 1);   // the forward's clamp (psroi_pm_kernel): both directions agree on the image
+  const int b = min(max((int)roi[0], 0), batch_size - 1);     // the forward's clamp (psroi_pm_kernel): both directions agree on the image
+  e[4 * pooled] = b;
+  // the RoIs of image b lie in [first, last] (pre-zeroed words: ~first and last + 1 by atomicMax): a pixel's workgroup only walks
+  // that run -- callers list their RoIs image by image, so the run is the image's own RoIs
+  atomicMax(&range[2 * b], ~(unsigned)r);
+  atomicMax(&range[2 * b + 1], (unsigned)r + 1u);
   for (int k = 0; k < pooled; ++k) {
     const Bin b = psroi_bin(roi, spatial_scale, k, k, pooled, pooled, height, width);   // rows depend on ph only, columns on pw only
     e[k] = b.hstart; e[pooled + k] = b.hend; e[2 * pooled + k] = b.wstart; e[3 * pooled + k] = b.wend;
@@ -474,7 +479,7 @@ __global__ void psroi_pm_edges_kernel(const float* __restrict__ rois, int num_ro
 template <int CP>
 __global__ __launch_bounds__(256) void psroi_pm_bwd_kernel(const float* __restrict__ gvote, const int* __restrict__ edges, int num_rois,
                                                            int output_dim, int pooled, int height, int width, long pixel_stride,
-                                                           float* __restrict__ gmap) {
+                                                           float* __restrict__ gmap, const unsigned* __restrict__ range) {
   constexpr int kMaxHits = 2048;                       // (RoI, bin, weight) triples per chunk of 256 RoIs: at most 4 x 4 bins each in theory,
   __shared__ int hit_r[kMaxHits];                      // 2 x 2 in practice; a chunk that overflows is split (see below)
   __shared__ short hit_bin[kMaxHits];
@@ -488,12 +493,15 @@ __global__ __launch_bounds__(256) void psroi_pm_bwd_kernel(const float* __restri
   const int nbins = pooled * pooled, E = 4 * pooled + 1;
   for (int i = tid; i < nbins * CP; i += 256) accum[i] = 0.f;
   const float inv_bins = 1.f / (float)nbins;
-  for (int r0 = 0; r0 < num_rois; r0 += 256) {
+  // (chunks of 256 RoIs in RoI order, from the first to the last RoI of this pixel's image)
+  const unsigned last1 = range[2 * b + 1];
+  const int r_first = last1 ? (int)~range[2 * b] : 0, r_end = (int)last1;
+  for (int r0 = r_first; r0 < r_end; r0 += 256) {
     // ---- phase 1: RoI r0 + tid -> the bins of that RoI that contain this pixel
     const int r = r0 + tid;
     int nh = 0, ph_lo = 0, ph_hi = -1, pw_lo = 0, pw_hi = -1;
     const int* e = edges + (long)min(r, num_rois - 1) * E;
-    if (r < num_rois && e[4 * pooled] == b) {
+    if (r < r_end && e[4 * pooled] == b) {
       // bins are intervals with non-decreasing edges: the ph whose [hstart, hend) contains h form a contiguous run
       ph_lo = pooled; pw_lo = pooled;
       for (int k = 0; k < pooled; ++k) {
@@ -537,7 +545,7 @@ __global__ __launch_bounds__(256) void psroi_pm_bwd_kernel(const float* __restri
     } else {
       // (pathological chunk: more than 8 bins per RoI on average -- every RoI handled by one thread-serial pass, still in order)
       if (tid < 64) {
-        for (int rr = r0; rr < min(r0 + 256, num_rois); ++rr) {
+        for (int rr = r0; rr < min(r0 + 256, r_end); ++rr) {
           const int* ee = edges + (long)rr * E;
           if (ee[4 * pooled] != b) continue;
           for (int ph = 0; ph < pooled; ++ph) {
@@ -742,7 +750,7 @@ extern "C" int dtt_rpn_head_grad_rows(const float* grad_cls_prob, const float* g
 
 // Backward of dtt_psroi_pm_forward's vote: grad_map (batch*height*width pixels, pixel_stride floats apart; this call writes
 // floats [bin*cp + c] for bin < pooled^2, c < cp of EVERY pixel -- zeros where no RoI reaches, so no pre-zeroing) from
-// grad_vote (num_rois, output_dim).  edges: caller-owned scratch of num_rois * (4 * pooled + 1) ints.
+// grad_vote (num_rois, output_dim).  edges: caller-owned scratch of num_rois * (4 * pooled + 1) + 2 * batch_size ints.
 extern "C" int dtt_psroi_pm_backward(const float* grad_vote, const float* rois, int num_rois, int batch_size, int height, int width,
                                      int pooled, float spatial_scale, int output_dim, int cp, long pixel_stride, float* grad_map,
                                      int* edges, void* stream_) {
@@ -750,22 +758,25 @@ extern "C" int dtt_psroi_pm_backward(const float* grad_vote, const float* rois, 
   DTT_REQUIRE(batch_size > 0 && height > 0 && width > 0 && pooled > 0 && output_dim > 0 && num_rois >= 0, "psroi_pm backward: bad shape");
   DTT_REQUIRE(cp >= output_dim && (long)pooled * pooled * cp <= pixel_stride, "psroi_pm backward: %d bins x %d do not fit the pixel stride %ld",
               pooled * pooled, cp, pixel_stride);
-  DTT_REQUIRE(grad_map && (num_rois == 0 || (grad_vote && rois && edges)), "psroi_pm backward: null pointer");
+  DTT_REQUIRE(grad_map && edges && (num_rois == 0 || (grad_vote && rois)), "psroi_pm backward: null pointer");
   DTT_REQUIRE(cp == 4 || cp == 32, "psroi_pm backward: classes-per-bin padding %d not instantiated (4 or 32)", cp);
   const size_t lds = (size_t)pooled * pooled * cp * sizeof(float);
   DTT_REQUIRE(lds <= 32 * 1024, "psroi_pm backward: pooled size too large");
+  // per-image RoI runs behind the bin edges: 2 words per image, zeroed here, filled by the edges kernel
+  unsigned* range = reinterpret_cast<unsigned*>(edges + (long)(num_rois > 0 ? num_rois : 0) * (4 * pooled + 1));
+  DTT_REQUIRE(hipMemsetAsync(range, 0, sizeof(unsigned) * 2 * batch_size, stream) == hipSuccess, "psroi_pm backward: memset failed");
   if (num_rois > 0) {
     hipLaunchKernelGGL(psroi_pm_edges_kernel, dim3(dtt_cdiv(num_rois, 256)), dim3(256), 0, stream, rois, num_rois, spatial_scale, pooled,
-                       height, width, batch_size, edges);
+                       height, width, batch_size, edges, range);
     DTT_CHECK_LAUNCH("psroi_pm_edges");
   }
   const int npx = batch_size * height * width;
   if (cp == 32)
     hipLaunchKernelGGL((psroi_pm_bwd_kernel<32>), dim3(npx), dim3(256), lds, stream, grad_vote, edges, num_rois, output_dim, pooled, height,
-                       width, pixel_stride, grad_map);
+                       width, pixel_stride, grad_map, range);
   else
     hipLaunchKernelGGL((psroi_pm_bwd_kernel<4>), dim3(npx), dim3(256), lds, stream, grad_vote, edges, num_rois, output_dim, pooled, height,
-                       width, pixel_stride, grad_map);
+                       width, pixel_stride, grad_map, range);
   DTT_CHECK_LAUNCH("psroi_pm_bwd");
   return 1;
 }

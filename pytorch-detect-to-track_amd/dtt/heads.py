@@ -288,7 +288,7 @@ class PsroiPmFn(torch.autograd.Function):
                 assert h["offset"] == covered, "heads must tile the row from column 0"
                 covered += G * G * cp
                 gv = torch.zeros((R, od), dtype=torch.float32, device=dev) if gv is None else gv.contiguous()
-                edges = torch.empty((max(R, 1) * (4 * G + 1),), dtype=torch.int32, device=dev)
+                edges = torch.empty((max(R, 1) * (4 * G + 1) + 2 * batch,), dtype=torch.int32, device=dev)   # bin edges + per-image RoI runs
                 check(_lib.lib().dtt_psroi_pm_backward(ptr(gv), ptr(rois), R, batch, height, width, G, scale, od, cp, stride,
                                                        ctypes.c_void_p(gmap.data_ptr() + 4 * h["offset"]), ptr(edges),
                                                        stream_ptr(dev)), "psroi_pm backward")

@@ -520,7 +520,12 @@ class _RFCN(nn.Module):
             conv1 = conv1.contiguous(memory_format=torch.channels_last)
         w_rpn, b_rpn, A = pack_rpn_heads_differentiable(rpn.RPN_cls_score, rpn.RPN_bbox_pred)
         rpn_prob, rpn_bbox = RpnHeadFn.apply(conv1.permute(0, 2, 3, 1).reshape(-1, conv1.size(1)), w_rpn, b_rpn, A, n_legs * B, H, W)
-        all_rois = rpn.proposals(rpn_prob, rpn_bbox, im_info.view(n_legs * B, -1))   # (n_legs * B, post, 5), image index in column 0
+        if os.environ.get("DTT_TRAIN_PROPOSALS_MERGED", "1") != "0":   # (env: developer A/B switch)
+            all_rois = rpn.proposals(rpn_prob, rpn_bbox, im_info.view(n_legs * B, -1))   # (n_legs * B, post, 5), image index in column 0
+        else:
+            all_rois = torch.cat([rpn.proposals(rpn_prob[i * B:(i + 1) * B], rpn_bbox[i * B:(i + 1) * B], im_info[i]) for i in range(n_legs)], 0)
+            for i in range(1, n_legs):
+                all_rois[i * B:(i + 1) * B, :, 0] += i * B
         out = self._new_out()
         sampled = []
         for i in range(n_legs):

@@ -39,6 +39,7 @@ class _ProposalTargetLayer(nn.Module):
         self._cfg = cfg
         self._num_classes = nclasses
         self.last_status = None   # int32 (B,) on the device: 1 = an image had neither fg nor bg candidates (the reference raises)
+        self._pending_status = []  # the status words of every call since the last status_flag() / check_status(): one per leg
 
     def forward(self, all_rois, gt_boxes, num_boxes):
         T = self._cfg.TRAIN
@@ -96,14 +97,25 @@ class _ProposalTargetLayer(nn.Module):
                                                ptr(targets), ptr(inside), ptr(outside), ptr(status), st),
                   "proposal_target sample")
         self.last_status = status
+        self._pending_status = self._pending_status[-7:] + [status]
         return rois, labels, targets, inside, outside
+
+    def status_flag(self):
+        """A (1,) float tensor on the device: non-zero iff a call since the last status_flag() / check_status() (every leg of the
+        step) met an image with neither foreground nor background candidates.  No host read: the caller folds it into a
+        synchronisation it makes anyway (and, on several ranks, all-reduces it so that every rank aborts together)."""
+        sts, self._pending_status = self._pending_status, []
+        if not sts:
+            return None
+        return torch.stack([(st != 0).any() for st in sts]).any().float().view(1)
 
     def check_status(self):
         """proposal_target_layer_cascade.py:186 raises when an image has neither foreground nor background candidates.  The
         "device" sampler cannot raise inside the step without reading the device (the kernel fills candidate 0 and flags the
-        image instead): call this where the caller synchronises anyway (trainval_net.py does, once per logged loss)."""
-        st = self.last_status
-        if st is not None and bool((st != 0).any().item()):
+        image instead): call this -- or read status_flag() -- right after the forward, BEFORE the loss is used (the reference
+        raises before backward: a flagged step must not update the weights)."""
+        flag = self.status_flag()
+        if flag is not None and bool(flag.item()):
             raise ValueError("bg_num_rois = 0 and fg_num_rois = 0, this should not happen!")
 
 

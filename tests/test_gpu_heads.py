@@ -275,3 +275,97 @@ def test_head_gemm_dw_kernel(M, N, K, g_cols):
     ref = gout[:, :N].double().t() @ x.double()
     err = (outs[0].double() - ref).abs().max().item()
     assert err < 1e-4 * max(1.0, ref.abs().max().item()), err
+
+
+@pytest.mark.parametrize("B,H,W,K,A", [
+    (4, 38, 67, 512, 12),     # the training step: both legs of two frame pairs
+    (2, 13, 17, 64, 2),
+    (1, 9, 11, 96, 6),
+])
+def test_rpn_head_autograd_matches_conv2d_softmax_in_float64(dev, B, H, W, K, A):
+    """RpnHeadFn (rpn.py:63-71 under autograd: one GEMM launch forward; backward = dtt_rpn_head_grad_rows with the pairwise
+    softmax's adjoint, dX on dtt_head_gemm, dW on dtt_head_gemm_dw) over the differentiable packing of the live parameters,
+    against F.conv2d + F.softmax autograd in float64: outputs and all five gradients to 1e-4 of each tensor's largest entry."""
+    from dtt.heads import RpnHeadFn, pack_rpn_heads_differentiable
+    g = torch.Generator().manual_seed(B * 10 + A)
+    cls, box = torch.nn.Conv2d(K, 2 * A, 1), torch.nn.Conv2d(K, 4 * A, 1)
+    for c, sc in ((cls, 0.08), (box, 0.03)):
+        c.weight.data = torch.randn(c.weight.shape, generator=g) * sc
+        c.bias.data = torch.randn(c.bias.shape, generator=g) * 0.1
+    cls, box = cls.to(dev), box.to(dev)
+    x = torch.relu(torch.randn(B, K, H, W, generator=g)).to(dev)
+    rows = x.permute(0, 2, 3, 1).reshape(B * H * W, K).contiguous().requires_grad_(True)
+    w, b, A2 = pack_rpn_heads_differentiable(cls, box)
+    assert A2 == A
+    prob, bbox = RpnHeadFn.apply(rows, w, b, A, B, H, W)
+    gp = torch.randn(prob.shape, generator=g).to(dev)
+    gb = torch.randn(bbox.shape, generator=g).to(dev)
+    ((prob * gp).sum() + (bbox * gb).sum()).backward()
+    x64 = x.double().requires_grad_(True)
+    ref = [t.detach().double().requires_grad_(True) for t in (cls.weight, cls.bias, box.weight, box.bias)]
+    score = F.conv2d(x64, ref[0], ref[1])
+    want_prob = F.softmax(score.view(B, 2, A * H, W), dim=1).view(B, 2 * A, H, W)
+    want_bbox = F.conv2d(x64, ref[2], ref[3])
+    ((want_prob * gp.double()).sum() + (want_bbox * gb.double()).sum()).backward()
+    rel = lambda a, r: float((a.double() - r).abs().max() / r.abs().max().clamp_min(1e-30))
+    assert rel(prob.detach(), want_prob.detach()) < 1e-4 and rel(bbox.detach(), want_bbox.detach()) < 1e-4
+    assert rel(rows.grad.view(B, H, W, K).permute(0, 3, 1, 2), x64.grad) < 1e-4, "dX"
+    for name, p, r in (("cls dW", cls.weight, ref[0]), ("cls dBias", cls.bias, ref[1]), ("box dW", box.weight, ref[2]), ("box dBias", box.bias, ref[3])):
+        assert rel(p.grad, r.grad) < 1e-4, name
+    # only one of the two outputs carries a gradient (the other arrives as None / zeros)
+    rows2 = rows.detach().clone().requires_grad_(True)
+    prob2, bbox2 = RpnHeadFn.apply(rows2, w.detach(), b.detach(), A, B, H, W)
+    (bbox2 * gb).sum().backward()
+    x64b = x.double().requires_grad_(True)
+    (F.conv2d(x64b, ref[2].detach(), ref[3].detach()) * gb.double()).sum().backward()
+    assert rel(rows2.grad.view(B, H, W, K).permute(0, 3, 1, 2), x64b.grad) < 1e-4
+
+
+@pytest.mark.parametrize("B,H,W,C345", [(2, 38, 67, (128, 192, 256)), (1, 20, 31, (64, 64, 128))])
+def test_tracking_rows_autograd_matches_the_reference_concat(dev, B, H, W, C345):
+    """TrackingRowsFn + HeadGemmFn over it = corr_bbox_net(torch.cat([bbox_t, bbox_t+tau, corr3, corr4, corr5], 1)) of
+    rfcn.py:166-174 under autograd: the tracking head's output and the gradients with respect to the box-delta columns, the
+    three trunk maps (both legs) and the head's weight / bias, against the reference graph on NCHW tensors (library 1x1
+    convolution in float64 over the NCHW correlation functions' outputs) to 1e-4 of each tensor's largest entry."""
+    from dtt.heads import HeadGemmFn, TrackingRowsFn, pack_heads_differentiable, pm_to_nchw
+    from dtt.ops import Correlation
+    g = torch.Generator().manual_seed(B + H)
+    od, G = 4, 7
+    n_box = od * G * G
+    cl = lambda t: t.to(dev).contiguous(memory_format=torch.channels_last)
+    c3 = cl(torch.relu(torch.randn(2 * B, C345[0], 2 * H - 1, 2 * W, generator=g))).requires_grad_(True)
+    c4 = cl(torch.relu(torch.randn(2 * B, C345[1], H, W, generator=g))).requires_grad_(True)
+    c5 = cl(torch.relu(torch.randn(2 * B, C345[2], H, W, generator=g))).requires_grad_(True)
+    loc_cols = (0.3 * torch.randn(2 * B * H * W, n_box, generator=g)).to(dev).requires_grad_(True)   # position-major order: bin * od + k
+    layers = (Correlation(8, 1, 8, 2, 2), Correlation(8, 1, 8, 1, 1), Correlation(8, 1, 8, 1, 1))
+    geoms = tuple((l.pad_size, l.kernel_size, l.max_displacement, l.stride1, l.stride2) for l in layers)
+    K_in = 2 * n_box + 81 + 289 + 289
+    conv = torch.nn.Conv2d(K_in, n_box, 1).to(dev)
+    conv.weight.data.normal_(0, 0.02, generator=None)
+    k_pad = -(-K_in // 32) * 32
+    perm = torch.arange(K_in)
+    bb, kk = torch.meshgrid(torch.arange(G * G), torch.arange(od), indexing="ij")
+    for l in range(2):
+        perm[l * n_box:(l + 1) * n_box] = (l * n_box + kk * G * G + bb).reshape(-1)
+    rows = TrackingRowsFn.apply(loc_cols, c3, c4, c5, B, geoms, k_pad)
+    w, b, heads, n_store, stride = pack_heads_differentiable([conv], k_pad=k_pad, in_perm=perm)
+    out = HeadGemmFn.apply(rows, w, b, n_store, stride)
+    got = pm_to_nchw(out, heads[0], B, H, W)
+    gout = torch.randn(got.shape, generator=g).to(dev)
+    (got * gout).sum().backward()
+    # ---- the reference graph: NCHW box-delta maps in the reference's channel order k * G * G + bin, NCHW correlations, torch.cat
+    n3, n4, n5 = (t.detach().contiguous().requires_grad_(True) for t in (c3, c4, c5))
+    loc_ref = loc_cols.detach().clone().requires_grad_(True)
+    bbox = loc_ref.view(2, B, H, W, G * G, od).permute(0, 1, 5, 4, 2, 3).reshape(2, B, n_box, H, W)
+    feats = [bbox[0], bbox[1]] + [l(m[:B], m[B:]) for l, m in zip(layers, (n3, n4, n5))]
+    x = torch.cat(feats, 1)
+    wr, br = conv.weight.detach().double().requires_grad_(True), conv.bias.detach().double().requires_grad_(True)
+    want = F.conv2d(x.double(), wr, br)
+    (want * gout.double()).sum().backward()
+    rel = lambda a, r: float((a.double() - r.double()).abs().max() / r.double().abs().max().clamp_min(1e-30))
+    assert rel(got.detach(), want.detach()) < 1e-4
+    assert rel(loc_cols.grad, loc_ref.grad) < 1e-4, "box-delta columns"
+    for name, a, r in (("conv3", c3, n3), ("conv4", c4, n4), ("conv5", c5, n5)):
+        assert a.grad.is_contiguous(memory_format=torch.channels_last)
+        assert rel(a.grad, r.grad) < 1e-4, name
+    assert rel(conv.weight.grad, wr.grad) < 1e-4 and rel(conv.bias.grad, br.grad) < 1e-4

@@ -37,12 +37,15 @@ def test_rfcn_forward_contract_and_parity():
     assert same.float().mean() > 0.9, "only %.3f of RoI rows agree" % same.float().mean()
     d_cls = (cls_prob - ref["cls_prob"]).abs().amax(dim=3)[same]
     d_box = (bbox_pred - ref["bbox_pred"]).abs().amax(dim=3)[same]
-    # RoIs that are reproduced exactly (to 1e-4 px) carry the strict bound; a RoI that only agrees to 0.05 px can straddle a
-    # pooling-bin edge the other way: those rows (a few) get the relaxed, still bounded one
+    # PSRoI pooling rounds the RoI corners to integers (psroi_pooling_kernel.cu:30-33).  A RoI that agrees to 0.05 px on both
+    # sides (CPU and GPU convolutions differ in the last bits) pools the SAME bins unless one of its corners lies within that
+    # distance of a rounding boundary: rows with all four corners clear of x.5 carry the strict bound, the few others (which
+    # can straddle a bin edge the other way) the relaxed, still bounded one
     box_tol = 1e-2 * max(1.0, float(ref["bbox_pred"].abs().max()))
-    exact = ((rois - ref["rois"]).abs().amax(dim=3) < 1e-4)[same]
-    assert float(exact.float().mean()) > 0.8, "only %.3f of the matched RoIs are reproduced exactly" % float(exact.float().mean())
-    assert d_cls.max() < 1e-3 and d_box[exact].max() < box_tol
+    frac = ref["rois"][..., 1:] - torch.floor(ref["rois"][..., 1:])
+    clear = ((frac - 0.5).abs() > 0.06).all(dim=3)[same]
+    assert float(clear.float().mean()) > 0.5
+    assert d_cls.max() < 1e-3 and d_box[clear].max() < box_tol
     assert (d_box < box_tol).float().mean() > 0.995 and d_box.max() < 10 * box_tol
     same0 = same[0].reshape(-1)
     d_trk = (tracking_pred - ref["tracking_pred"]).abs().amax(dim=1)[same0]
@@ -534,10 +537,77 @@ def test_config0_single_frame_res50_300px_against_cpu_graph():
     assert same.float().mean() > 0.9, "only %.3f of RoI rows agree" % same.float().mean()
     d_cls = (cls_prob - ref["cls_prob"]).abs().amax(dim=3)[same]
     d_box = (bbox_pred - ref["bbox_pred"]).abs().amax(dim=3)[same]
-    # RoIs that are reproduced exactly (to 1e-4 px) carry the strict bound; a RoI that only agrees to 0.05 px can straddle a
-    # pooling-bin edge the other way: those rows (a few) get the relaxed, still bounded one
+    # PSRoI pooling rounds the RoI corners to integers (psroi_pooling_kernel.cu:30-33).  A RoI that agrees to 0.05 px on both
+    # sides (CPU and GPU convolutions differ in the last bits) pools the SAME bins unless one of its corners lies within that
+    # distance of a rounding boundary: rows with all four corners clear of x.5 carry the strict bound, the few others (which
+    # can straddle a bin edge the other way) the relaxed, still bounded one
     box_tol = 1e-2 * max(1.0, float(ref["bbox_pred"].abs().max()))
-    exact = ((rois - ref["rois"]).abs().amax(dim=3) < 1e-4)[same]
-    assert float(exact.float().mean()) > 0.8, "only %.3f of the matched RoIs are reproduced exactly" % float(exact.float().mean())
-    assert d_cls.max() < 1e-3 and d_box[exact].max() < box_tol
+    frac = ref["rois"][..., 1:] - torch.floor(ref["rois"][..., 1:])
+    clear = ((frac - 0.5).abs() > 0.06).all(dim=3)[same]
+    assert float(clear.float().mean()) > 0.5
+    assert d_cls.max() < 1e-3 and d_box[clear].max() < box_tol
     assert (d_box < box_tol).float().mean() > 0.995 and d_box.max() < 10 * box_tol
+
+
+def test_training_graph_on_hand_written_heads_matches_the_library_graph():
+    """`_forward_train_pm` (RPN heads, R-FCN heads and corr_bbox_net on the hand-written GEMM with its own backward, tracking rows
+    written in place by the correlations, one position-major PSRoI pooling for both legs, proposals of both legs in one launch)
+    against `_forward_train_nchw` (library 1x1 convolutions + softmax, torch.cat of the 1051 tracking channels, NCHW PSRoI
+    operators) on the same fused channels-last training trunk, the same weights, batch and random draws: the five losses to 1e-4
+    relative, the gradient of every head / RPN parameter to 1e-3 of its norm, trunk gradients (which collect the correlation and
+    head input gradients through many layers) to 2e-2."""
+    from dtt.config import apply_dataset_defaults, cfg, cfg_from_file
+    from dtt.fuse import fuse_for_training
+    from dtt.synth import build_model, calibrate_batchnorm_, make_batch
+    apply_dataset_defaults("imagenet_vid")
+    cfg_from_file(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cfgs", "res101.yml"))
+    dev = torch.device("cuda:0")
+    B, H, W = 2, 256, 352
+    model = build_model(50, cfg=cfg).to(dev)
+    im, info, gt, nb = make_batch(B, H, W, seed=7, device=dev)
+    calibrate_batchnorm_(model, im[:, 0])
+    model.train()
+    fuse_for_training(model, channels_last=True)
+    assert model._train_pm
+
+    def fixed(cls_prob, bbox_pred, im_info):
+        # proposals that do not depend on the network's outputs, the same box set for every image: both graphs (one call for all
+        # legs / one call per leg) then sample the same RoIs
+        n, R = cls_prob.size(0), 300
+        g = torch.Generator().manual_seed(4242)
+        x1 = torch.rand(R, generator=g) * (W - 40); y1 = torch.rand(R, generator=g) * (H - 40)
+        w = 16 + torch.rand(R, generator=g) * (W * 0.6); h = 16 + torch.rand(R, generator=g) * (H * 0.6)
+        box = torch.stack([x1, y1, (x1 + w).clamp(max=W - 1), (y1 + h).clamp(max=H - 1)], 1)
+        rois = torch.cat([torch.arange(n).float().view(n, 1, 1).expand(n, R, 1), box.view(1, R, 4).expand(n, R, 4)], 2)
+        return rois.contiguous().to(dev)
+    model.RFCN_rpn.proposals = fixed
+
+    def run(pm):
+        model._train_pm = pm
+        model.zero_grad(set_to_none=True)
+        np.random.seed(99)
+        out = model(im, info, gt, nb)
+        losses = [out[i].mean() for i in (4, 5, 6, 7, 9)]
+        sum(losses).backward()
+        torch.cuda.synchronize()
+        return [float(l.detach()) for l in losses], {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}, out
+
+    run(True)                      # warm-up (the libraries pick their kernels on the first step)
+    l_pm, g_pm, o_pm = run(True)
+    l_nc, g_nc, o_nc = run(False)
+    model._train_pm = True
+    for a, b in zip(l_pm, l_nc):
+        assert abs(a - b) <= 1e-4 * max(1.0, abs(b)), (l_pm, l_nc)
+    assert torch.equal(o_pm[0], o_nc[0]) and torch.equal(o_pm[8], o_nc[8])          # same sampled RoIs and labels
+    assert float((o_pm[1] - o_nc[1]).abs().max()) < 1e-4 and float((o_pm[3] - o_nc[3]).abs().max()) < 1e-3 * max(1.0, float(o_nc[3].abs().max()))
+    assert set(g_pm) == set(g_nc)
+    worst = {}
+    for n in g_nc:
+        a, b = g_pm[n].double(), g_nc[n].double()
+        rel = float((a - b).norm() / b.norm().clamp_min(1e-30))
+        worst[n] = rel
+        head = not n.startswith("RFCN_base") or "RFCN_net" in n
+        assert rel < (1e-3 if head else 2e-2), (n, rel, float(b.norm()))
+    for n in ("RFCN_rpn.RPN_cls_score.weight", "RFCN_rpn.RPN_bbox_pred.weight", "RFCN_rpn.RPN_Conv.weight", "corr_bbox_net.weight",
+              "RFCN_cls_net.weight", "RFCN_bbox_net.weight"):
+        assert n in worst and float(g_nc[n].abs().max()) > 0, n

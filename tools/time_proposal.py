@@ -34,6 +34,8 @@ def timeit(name, fn, iters=100, warm=10):
 
 
 cases = ((6000, 300), (12000, 2000)) if not os.environ.get("TEST_ONLY") else ((6000, 300),)
+if os.environ.get("TRAIN_ONLY"):
+    cases = ((12000, 2000),)
 for pre, post in cases:
     fn = lambda: proposal_forward(prob, bbox, info, base, 16, pre, post, 0.7)
     timeit("proposal %d->%d (eager)" % (pre, post), fn)

@@ -196,11 +196,21 @@ def main(argv=None):
             out = runner(im, info, gt, nb)
             rpn_cls, rpn_box, rcnn_cls, rcnn_box, trk = out[4], out[5], out[6], out[7], out[9]
             loss = rpn_cls.mean() + rpn_box.mean() + rcnn_cls.mean() + rcnn_box.mean() + trk.mean()  # :367-368
+            # The reference raises "no fg and no bg RoIs" inside the forward (proposal_target_layer_cascade.py:186), i.e. before
+            # the loss is used.  The device sampler flags the image instead: the flag is read here, with the loss value, in the
+            # step's ONE host read -- before backward and the weight update -- and all-reduced so that every rank aborts together
+            # (a rank raising alone would leave the others waiting in the next gradient all-reduce).
+            flag = model.RFCN_proposal_target.status_flag()
+            flag = torch.zeros(1, device=dev) if flag is None else flag
+            if world > 1:
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            loss_value, bad = torch.cat([loss.detach().view(1), flag]).tolist()
+            if bad:
+                raise ValueError("bg_num_rois = 0 and fg_num_rois = 0, this should not happen!")
             loss.backward()
             runner.finish_gradients()
             optimizer.step()
-            loss_temp += float(loss.detach())   # (the step's one host read)
-            model.RFCN_proposal_target.check_status()   # the reference's "no fg and no bg RoIs" ValueError, deferred to this sync
+            loss_temp += loss_value
             if (step + 1) % args.disp_interval == 0 and rank == 0:
                 n = args.disp_interval
                 fg = int((out[8] != 0).sum())
