@@ -43,9 +43,9 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kGC = 64;                       // channels per group
-constexpr int kWaves = 8, kThreads = kWaves * 64;
+constexpr int kComp = 8, kLoad = 4, kThreads = (kComp + kLoad) * 64;   // 2 compute waves + 1 loader per SIMD (168 registers each)
 constexpr int kLdsMax = 144 * 1024;           // 16 KB of the CU's 160 stay free for small kernels of other streams
-constexpr int kMaxNI = 6;                     // DMA instructions per wave per ring position (halo width <= 48 pixels)
+constexpr int kMaxNI = 12;                    // DMA instructions per loader per ring position (halo width <= 48 pixels)
 constexpr int kMaxSeg = 8;
 constexpr int kTable = 1536;                  // work-item order in the kernel arguments (16-bit item numbers)
 
@@ -59,6 +59,9 @@ struct BGeom {
   long sb;                             // floats between images of other / grad
   unsigned sy4, sx4;                   // bytes between vertically / horizontally adjacent lattice pixels
   int C, H, W;                         // channels, lattice size
+  int stride, ih, iw;                  // lattice stride, image size; cell_fill: a target also zeroes the stride x stride cell of
+  int cell_fill;                       // non-lattice pixels behind it (every pixel is then written by the kernel: no memset)
+  unsigned py4, px4;                   // bytes between vertically / horizontally adjacent IMAGE pixels
   int oh, ow, origin;                  // output size; output (y, x) <-> lattice pixel (origin + y, origin + x)
   int R, D, D2;
   unsigned d2_magic;                   // 2^32 / D2 + 1
@@ -145,8 +148,6 @@ __global__ __launch_bounds__(kThreads) void corr_bwd_stream_kernel(BGeom g) {
   const int item = g.use_table ? (int)g.table[bid] : dtt_xcd_remap(bid, gridDim.x);
   const BItem it = bw_decode(g, item);
   const int th = it.th, tw = it.tw, nwv = th * tw;
-  const bool active = wave < nwv;
-  const int wy = active ? wave / tw : 0, wx = active ? wave - wy * tw : 0;
   const int HC = 4 * (tw + NBR - 1);                  // halo width of the tile, pixels
   const int slot_bytes = 4 * HC * kGC * 4;            // one halo block row of one channel group
   const int NH = th + NBR - 1;                        // halo block rows per group
@@ -154,46 +155,80 @@ __global__ __launch_bounds__(kThreads) void corr_bwd_stream_kernel(BGeom g) {
   const int npos = it.ng * NH;
   const unsigned lds0 = (unsigned)(unsigned long)(const __attribute__((address_space(3))) float*)lds;
   const long img = (long)it.n * g.sb;
+  // A tall tile at a group boundary: th rows step into fresh positions at once and the ring holds fewer than 2 th slots, so the
+  // slots only come free at the barrier -- such a step has two barriers (fill, drain, meet again).  Every wave derives this
+  // from the tile shape alone.
+  const bool tall = th > it.ahead;
 
-  // ---------------------------------------------------------------- LDS-DMA descriptors: instruction j = wave + 8 i of a position
-  // fills slot pixels [4 j, 4 j + 4) (x 64 channels = 1 KB): halo row (4 j) / HC of the block row, columns (4 j) % HC + lane / 16
-  unsigned voff[kMaxNI];
-  int row_of[kMaxNI];
-  int ni = 0;
+  if (wave >= kComp) {
+    // ================================================================ loaders: SALU + LDS-DMA only
+    // Instruction j = lw + 4 i of a position fills slot pixels [4 j, 4 j + 4) (x 64 channels = 1 KB): halo row (4 j) / HC of
+    // the block row, columns (4 j) % HC + lane / 16.  All bookkeeping of the ring (what has landed, what may be refilled) lives
+    // here: the compute waves -- which share their SIMDs with these -- see a barrier per step and nothing else.  (First
+    // version: every wave issued its share of the DMA; the few dozen scalar instructions per step, executed by all eight
+    // waves at once right behind the barrier, added their full length to every step: a wave issues one instruction per
+    // ~4 cycles, and nobody was feeding the matrix pipe meanwhile -- kernel time = MFMA time + 27 us of bookkeeping.)
+    const int lw = wave - kComp;
+    __builtin_amdgcn_s_setprio(3);
+    unsigned voff[kMaxNI];
+    int row_of[kMaxNI];
+    int ni = 0;
 #pragma unroll
-  for (int i = 0; i < kMaxNI; ++i) {
-    const int j = wave + kWaves * i;
-    voff[i] = 0; row_of[i] = 0;
-    if (j < HC) {
-      const int t = (4 * j) / HC, c = 4 * j - t * HC + (lane >> 4);
-      const int x = min(max(g.origin + it.X0 - g.R + c, 0), g.W - 1);    // out-of-image pixels: any in-bounds address (their band words are zero)
-      voff[i] = (unsigned)x * g.sx4 + (unsigned)((lane & 15) << 4);
-      row_of[i] = t;
-      ++ni;
-    }
-  }
-  if (g.ablate & 1) ni = 0;
-  const char* obase = reinterpret_cast<const char*>(g.other + img) + (long)it.g0 * (kGC * 4);
-  // the next position to issue, tracked incrementally (all scalar: no division on the way): its group's base address, its halo
-  // block row and its ring slot
-  int issued = 0, i_hr = 0, i_slot = 0;
-  const int y_first = g.origin + it.Y0 - g.R;
-  auto issue_next = [&]() {
-    const unsigned dst = lds0 + (unsigned)(i_slot * slot_bytes + wave * 1024);
-#pragma unroll
-    for (int i = 0; i < kMaxNI; ++i)
-      if (i < ni) {
-        const int y = min(max(y_first + 4 * i_hr + row_of[i], 0), g.H - 1);
-        dma16b(uptrb(obase + (unsigned long long)((unsigned)y * g.sy4)), voff[i], dst + (unsigned)(i * kWaves * 1024));
+    for (int i = 0; i < kMaxNI; ++i) {
+      const int j = lw + kLoad * i;
+      voff[i] = 0; row_of[i] = 0;
+      if (j < HC) {
+        const int t = (4 * j) / HC, c = 4 * j - t * HC + (lane >> 4);
+        const int x = min(max(g.origin + it.X0 - g.R + c, 0), g.W - 1);    // out-of-image pixels: any in-bounds address (their band words are zero)
+        voff[i] = (unsigned)x * g.sx4 + (unsigned)((lane & 15) << 4);
+        row_of[i] = t;
+        ++ni;
       }
-    ++issued;
-    if (++i_slot == S) i_slot = 0;
-    if (++i_hr == NH) { i_hr = 0; obase += kGC * 4; }
-  };
+    }
+    if (g.ablate & 1) ni = 0;
+    const char* obase = reinterpret_cast<const char*>(g.other + img) + (long)it.g0 * (kGC * 4);
+    // the next position to issue, tracked incrementally (all scalar): its group's base address, halo block row and ring slot
+    int issued = 0, i_hr = 0, i_slot = 0;
+    const int y_first = g.origin + it.Y0 - g.R;
+    auto issue_next = [&]() {
+      const unsigned dst = lds0 + (unsigned)(i_slot * slot_bytes + lw * 1024);
+#pragma unroll
+      for (int i = 0; i < kMaxNI; ++i)
+        if (i < ni) {
+          const int y = min(max(y_first + 4 * i_hr + row_of[i], 0), g.H - 1);
+          dma16b(uptrb(obase + (unsigned long long)((unsigned)y * g.sy4)), voff[i], dst + (unsigned)(i * kLoad * 1024));
+        }
+      ++issued;
+      if (++i_slot == S) i_slot = 0;
+      if (++i_hr == NH) { i_hr = 0; obase += kGC * 4; }
+    };
+    while (issued < min(S, npos)) issue_next();        // the ring is filled first (positions 0 .. th - 1 are read in step 0)
+    int base = 0;
+    for (int gi = 0; gi < it.ng; ++gi) {
+      for (int qi = 0; qi < NBR; ++qi, ++base) {
+        // Positions <= base + th - 1 are read in this step.  After the barrier the ring is refilled as far as it goes: position
+        // P's slot is free once everybody is done with position P - S < base.
+        const int need = min(base + th - 1, npos - 1);
+        const int fill = min(base + S - 1, npos - 1);
+        if (tall && qi == 0 && gi > 0) {
+          wg_barrier_b();
+          while (issued <= fill) issue_next();
+          wait_vmcnt_b(0);
+          wg_barrier_b();
+        } else {
+          wait_vmcnt_b((issued - 1 - need) * ni);   // mine of the later positions may still fly (loads return in order)
+          wg_barrier_b();                           // everybody's share has landed; everybody is done with the positions below `base`
+          while (issued <= fill) issue_next();
+        }
+      }
+      base += th - 1;                               // (the next group's first block row)
+    }
+    return;
+  }
 
-  // the ring is filled first (positions 0 .. th - 1 are read in step 0); the band loads queue up behind it
-  while (issued < min(S, npos)) issue_next();
-
+  // ================================================================ compute
+  const bool active = wave < nwv;
+  const int wy = active ? wave / tw : 0, wx = active ? wave - wy * tw : 0;
   // ---------------------------------------------------------------- band: NBR^2 * 4 words per lane, in register order
   float band[NB4];
   {
@@ -202,34 +237,31 @@ __global__ __launch_bounds__(kThreads) void corr_bwd_stream_kernel(BGeom g) {
 #pragma unroll
     for (int b = 0; b < NB4; ++b) band[b] = (active && !(g.ablate & 8)) ? bp[b * 64] : 0.f;
   }
-  // nothing of the compiler's is outstanding when the loop starts: its own waits then never sit inside the loop, where a
-  // vmcnt(0) would also drain the ring positions in flight
-  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
-
   // ---------------------------------------------------------------- store descriptors: lane -> target row tyi = lane / 16, columns r = 0 .. 3
-  unsigned st_off[4];
-  bool st_ok[4];
+  // (two registers: the byte offset of column 0 and a mask of the columns that are targets; the rest is recomputed per group)
+  unsigned st_base = 0, st_mask = 0;
   {
-    const int ty = it.Y0 + 4 * wy + (lane >> 4);
+    const int ty = it.Y0 + 4 * wy + (lane >> 4), ly = ty + g.origin;
+    const int lx0 = it.X0 + 4 * wx + g.origin;
+    const bool row_ok = active && ty >= g.lo_y && ty <= g.hi_y && ly >= 0 && ly < g.H && !(g.ablate & 4);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int tx = it.X0 + 4 * wx + r;
-      const int ly = ty + g.origin, lx = tx + g.origin;
-      st_ok[r] = active && ty >= g.lo_y && ty <= g.hi_y && tx >= g.lo_x && tx <= g.hi_x && ly >= 0 && ly < g.H && lx >= 0 && lx < g.W &&
-                 !(g.ablate & 4);
-      st_off[r] = st_ok[r] ? (unsigned)ly * g.sy4 + (unsigned)lx * g.sx4 + (unsigned)((lane & 15) << 4) : 0u;
+      const int tx = it.X0 + 4 * wx + r, lx = lx0 + r;
+      if (row_ok && tx >= g.lo_x && tx <= g.hi_x && lx >= 0 && lx < g.W) st_mask |= 1u << r;
     }
+    st_base = (unsigned)max(ly, 0) * g.sy4 + (unsigned)max(lx0, 0) * g.sx4 + (unsigned)((lane & 15) << 4);
+    if (lx0 < 0) st_base -= (unsigned)(-lx0) * g.sx4;       // (columns left of the image are masked out; the offset stays consistent)
   }
-  char* gbase = reinterpret_cast<char*>(g.grad + img);
+  char* gbase = reinterpret_cast<char*>(g.grad + img) + (long)it.g0 * (kGC * 4);
 
   // ---------------------------------------------------------------- main loop: one step = one halo block row of one group
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
   const unsigned rd_lane = lds0 + (unsigned)(wx * 1024 + lane * 16);
+  const unsigned row = (unsigned)(HC * kGC * 4);
   const bool do_mfma = active && !(g.ablate & 2);
   // Operand reads are inline asm the compiler does not track, released by ONE hand-counted s_waitcnt per burst (LDS returns in
   // order): hipcc's own bookkeeping puts a counted wait in front of every group of four MFMAs, and stray issue slots inside
-  // an MFMA stream cost the pipe tens of cycles each (first version of this loop: 20 waits per step, 7.0 k cycles per step
-  // against the 5.1 k of its 160 MFMAs per SIMD).  The wait lists the burst's registers as read-write operands, so the MFMAs
+  // an MFMA stream cost the pipe tens of cycles each.  The wait lists the burst's registers as read-write operands, so the MFMAs
   // that consume them cannot be moved in front of it.
   f32x4 bv[2][NBR];
   auto rd = [&](unsigned addr, int buf) {
@@ -242,42 +274,17 @@ __global__ __launch_bounds__(kThreads) void corr_bwd_stream_kernel(BGeom g) {
     if constexpr (NBR == 5) landed5<LEFT>(bv[buf][0], bv[buf][1], bv[buf][2], bv[buf][NBR - 2], bv[buf][NBR - 1]);      \
     else landed3<LEFT>(bv[buf][0], bv[buf][1], bv[buf][2]);                                                            \
   } while (0)
+  int r_slot = wy % S;                                // ring slot of the position this wave reads: wave row wy runs wy positions ahead
   for (int gi = 0; gi < it.ng; ++gi) {
 #pragma unroll
     for (int qi = 0; qi < NBR; ++qi) {
-      const int base = gi * NH + qi;
-      // Positions <= base + th - 1 are read in this step.  After the barrier the ring is refilled as far as it goes: position
-      // P's slot is free once everybody is done with position P - S < base.
-      const int need = min(base + th - 1, npos - 1);
-      const int fill = min(base + S - 1, npos - 1);
-      // The scalar work of a refill (a few dozen SALU instructions + the DMA instructions) is taken out of phase on the two waves
-      // that share a SIMD: waves 0 - 3 do it right after the barrier, while their SIMD partners (waves 4 - 7) already feed the
-      // matrix pipe, and those do theirs half a step later underneath the first waves' MFMAs.  Unless the refill is needed by
-      // the very next step (group boundaries): then everybody issues at once.
-      const int need_next = (qi == NBR - 1 ? base + 2 * th : base + th);   // positions <= this are read in the next step
-      bool deferred = false;
-      if (issued - 1 >= need) {
-        wait_vmcnt_b((issued - 1 - need) * ni);   // mine of the later positions may still fly (loads return in order)
-        wg_barrier_b();                           // everybody's share has landed; everybody is done with the positions below `base`
-        if (wave >= 4 && fill > need_next) {
-          while (issued <= need_next && issued <= fill) issue_next();
-          deferred = true;
-        } else {
-          while (issued <= fill) issue_next();
-        }
-      } else {
-        // a tall tile at a group boundary (th rows step into fresh positions at once, the ring holds fewer than 2 th): the slots
-        // only come free now -- fill, drain, meet again
-        wg_barrier_b();
-        while (issued <= fill) issue_next();
-        wait_vmcnt_b(0);
-        wg_barrier_b();
-      }
-      if (!do_mfma) {
-        while (issued <= fill) issue_next();
-      } else {
-        const unsigned sp = rd_lane + (unsigned)(((base + wy) % S) * slot_bytes);
-        const unsigned row = (unsigned)(HC * kGC * 4);
+      // nothing of this wave's is outstanding at a barrier: band loads (first step) and stores (later groups) have been issued
+      // long before, LDS reads are consumed -- the builtin tells the compiler so, and its own waits stay out of the loop
+      if (qi == 0 && gi == 0) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the band has arrived
+      if (tall && qi == 0 && gi > 0) wg_barrier_b();
+      wg_barrier_b();
+      if (do_mfma) {
+        const unsigned sp = rd_lane + (unsigned)(r_slot * slot_bytes);
         auto mm = [&](int t, int buf) {
 #pragma unroll
           for (int qj = 0; qj < NBR; ++qj) {
@@ -296,24 +303,31 @@ __global__ __launch_bounds__(kThreads) void corr_bwd_stream_kernel(BGeom g) {
         rd(sp + 2 * row, 0);
         DTT_LANDED(1, NBR); mm(1, 1);
         __builtin_amdgcn_sched_barrier(0);
-        if (deferred) {
-          while (issued <= fill) issue_next();
-          __builtin_amdgcn_sched_barrier(0);
-        }
         rd(sp + 3 * row, 1);
         DTT_LANDED(0, NBR); mm(2, 0);
         __builtin_amdgcn_sched_barrier(0);
         DTT_LANDED(1, 0); mm(3, 1);
         __builtin_amdgcn_sched_barrier(0);
       }
+      if (++r_slot == S) r_slot = 0;
     }
+    r_slot += th - 1;                                 // the next group starts th block rows further on
+    if (r_slot >= S) r_slot -= S;
     // the group is complete: D[m = 4 * (lane / 16) + r][n = lane % 16] of accumulator s is channel 4 n + s of target pixel m
-    char* dst = gbase + (long)(it.g0 + gi) * (kGC * 4);
+    char* dst = gbase + (long)gi * (kGC * 4) + st_base;
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-      if (st_ok[r]) {
+      if (st_mask & (1u << r)) {
         const f32x4 o = {acc0[r] * g.inv, acc1[r] * g.inv, acc2[r] * g.inv, acc3[r] * g.inv};
-        *reinterpret_cast<f32x4*>(dst + st_off[r]) = o;
+        char* px = dst + (unsigned)r * g.sx4;
+        *reinterpret_cast<f32x4*>(px) = o;
+        if (g.cell_fill) {   // strided lattice (conv3): the image pixels between the lattice points have no gradient
+          const int ly = it.Y0 + 4 * wy + (lane >> 4) + g.origin, lx = it.X0 + 4 * wx + r + g.origin;
+          const int ch = min(g.stride, g.ih - ly * g.stride), cw = min(g.stride, g.iw - lx * g.stride);
+          for (int cy = 0; cy < ch; ++cy)
+            for (int cx = 0; cx < cw; ++cx)
+              if (cy | cx) *reinterpret_cast<f32x4*>(px + (unsigned)cy * g.py4 + (unsigned)cx * g.px4) = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
       }
     acc0 = acc1 = acc2 = acc3 = f32x4{0.f, 0.f, 0.f, 0.f};
   }
@@ -331,6 +345,7 @@ struct BandGeom {
   const float* gout; long g_sb, g_sc, g_sp;
   float* band;
   int oh, ow, origin, H, W, R, D;
+  unsigned d_magic, d2_magic;          // 65536 / D + 1 (exact for n < 4096), 2^32 / (D * D) + 1
   int lo_y[2], lo_x[2], gh[2], gw[2];
   long dir_off[2];                     // floats from `band` to a direction's words
   int batch;
@@ -363,10 +378,10 @@ __global__ __launch_bounds__(256) void corr_bwd_band_kernel(BandGeom g) {
   for (int i = 0; i < NIT; ++i) {
     const int e = tid + i * 256;
     int m, d;
-    if (d_fastest) { m = e / D2; d = e - m * D2; } else { d = e >> 4; m = e & 15; }
+    if (d_fastest) { m = mdiv32b(e, g.d2_magic); d = e - m * D2; } else { d = e >> 4; m = e & 15; }
     const bool live = m < 16 && d < D2;
     const int ty = y0 + (m >> 2), tx = x0 + (m & 3);
-    const int dyi = d / g.D, dy = dyi - g.R, dx = d - dyi * g.D - g.R;
+    const int dyi = (int)(((unsigned)min(d, 4095) * g.d_magic) >> 16), dy = dyi - g.R, dx = d - dyi * g.D - g.R;   // (host-made multipliers: no division)
     const int py = dir ? ty - dy : ty, px = dir ? tx - dx : tx;       // p: output pixel;  q = p + d: displaced pixel
     const bool ok = live && py >= 0 && py < g.oh && px >= 0 && px < g.ow && in_img(py, px) && in_img(py + dy, px + dx);
     const long off = ok ? (long)d * g.g_sc + ((long)py * g.ow + px) * g.g_sp : 0;
@@ -621,6 +636,7 @@ int dtt_corr_bwd_stream(const float* gradOutput, long g_sb, long g_sc, long g_sp
   g.H = (ih + s - 1) / s; g.W = (iw + s - 1) / s;
   g.sb = (long)ih * iw * ic;
   g.sx4 = (unsigned)((long)s * ic * 4); g.sy4 = (unsigned)((long)s * iw * ic * 4);
+  g.stride = s; g.ih = ih; g.iw = iw; g.px4 = (unsigned)((long)ic * 4); g.py4 = (unsigned)((long)iw * ic * 4);
   g.oh = goh; g.ow = gow; g.origin = (max_displacement - pad_size) / s;
   g.R = R; g.D = 2 * R + 1;
   g.inv = 1.f / (float)ic;
@@ -635,6 +651,7 @@ int dtt_corr_bwd_stream(const float* gradOutput, long g_sb, long g_sc, long g_sp
   bg.gout = gradOutput; bg.g_sb = g_sb; bg.g_sc = g_sc; bg.g_sp = g_sp;
   bg.band = static_cast<float*>(workspace);
   bg.oh = goh; bg.ow = gow; bg.origin = g.origin; bg.H = g.H; bg.W = g.W; bg.R = R; bg.D = g.D; bg.batch = gob;
+  bg.d_magic = 65536u / (unsigned)g.D + 1u; bg.d2_magic = 0xffffffffu / (unsigned)(g.D * g.D) + 1u;
   int lo[2], hy[2], hx[2];
   bool live[2];
   long off = 0;
@@ -658,11 +675,15 @@ int dtt_corr_bwd_stream(const float* gradOutput, long g_sb, long g_sc, long g_sp
   // pixels that no lattice point maps to (stride > 1, pad != displacement) keep a zero gradient; on the dense lattice of conv4 /
   // conv5 (stride 1, pad == displacement) both kernels write every element themselves
   const bool dense = s == 1 && g.origin == 0 && goh == g.H && gow == g.W;
+  // a strided lattice that the outputs cover completely (conv3: stride 2, pad == displacement): every lattice pixel is a target of
+  // both directions and zeroes the stride x stride cell of image pixels behind it -- again every element is written here
+  const bool lattice_dense = s > 1 && s <= 4 && g.origin == 0 && goh == g.H && gow == g.W;
+  g.cell_fill = lattice_dense ? 1 : 0;
   for (int dir = 0; dir < 2; ++dir) {
     const bool wrt2 = dir == 1;
     if (!(which & (wrt2 ? 2 : 1))) continue;
     float* grad = wrt2 ? gradInput2 : gradInput1;
-    if (!dense) DTT_REQUIRE(hipMemsetAsync(grad, 0, bytes, stream) == hipSuccess, "correlation backward: memset failed");
+    if (!dense && !lattice_dense) DTT_REQUIRE(hipMemsetAsync(grad, 0, bytes, stream) == hipSuccess, "correlation backward: memset failed");
     if (!live[dir]) continue;
     g.lo_y = g.lo_x = lo[dir]; g.hi_y = hy[dir]; g.hi_x = hx[dir];
     g.gh = bg.gh[dir]; g.gw = bg.gw[dir];
@@ -707,8 +728,8 @@ extern "C" int dtt_correlation_backward_plan_check(int batch, int target_h, int 
     if (item < 0 || item >= p.items || seen[item]) return 0;
     seen[item] = 1;
     const BItem it = bw_decode(g, item);
-    if (it.n < 0 || it.n >= batch || it.ng < 1 || it.g0 + it.ng > NG || it.th * it.tw > kWaves) return 0;
-    if (4 * (it.tw + nbr - 1) > kMaxNI * kWaves) return 0;
+    if (it.n < 0 || it.n >= batch || it.ng < 1 || it.g0 + it.ng > NG || it.th * it.tw > kComp) return 0;
+    if (4 * (it.tw + nbr - 1) > kMaxNI * kLoad) return 0;
     if ((size_t)(it.th + it.ahead) * 4 * 4 * (it.tw + nbr - 1) * kGC * 4 > p.lds_bytes || it.ahead < 1) return 0;
     for (int w = 0; w < it.th * it.tw; ++w) {
       const int by = it.Y0 / 4 + w / it.tw, bx = it.X0 / 4 + w % it.tw;

@@ -534,13 +534,24 @@ __global__ __launch_bounds__(256) void psroi_pm_bwd_kernel(const float* __restri
     __syncthreads();
     // ---- phase 2: wave v owns the bins = v (mod 4); it walks the list in order (= RoI order), lanes = classes
     if (total <= kMaxHits) {
-      for (int i = 0; i < total; ++i) {
-        const int bin = hit_bin[i];
-        if ((bin & 3) != wave) continue;
-        if (lane < CP) {
-          const float g = lane < output_dim ? gvote[(long)hit_r[i] * output_dim + lane] : 0.f;
-          accum[bin * CP + lane] += g * hit_w[i];
+      // (eight gradient rows requested before the first add: the walk is a chain of dependent global loads otherwise -- 30 hits
+      //  per pixel at the training shape, one memory round trip each; the adds stay in list order)
+      constexpr int NF = 8;
+      for (int i0 = 0; i0 < total; i0 += NF) {
+        float gv[NF], ww[NF];
+        int bn[NF];
+#pragma unroll
+        for (int u = 0; u < NF; ++u) {
+          const int i = min(i0 + u, total - 1);
+          const int bin = hit_bin[i];
+          const bool mine = i0 + u < total && (bin & 3) == wave;
+          bn[u] = mine ? bin : -1;
+          ww[u] = hit_w[i];
+          gv[u] = (mine && lane < output_dim) ? gvote[(long)hit_r[i] * output_dim + lane] : 0.f;
         }
+#pragma unroll
+        for (int u = 0; u < NF; ++u)
+          if (bn[u] >= 0 && lane < CP) accum[bn[u] * CP + lane] += gv[u] * ww[u];
       }
     } else {
       // (pathological chunk: more than 8 bins per RoI on average -- every RoI handled by one thread-serial pass, still in order)
