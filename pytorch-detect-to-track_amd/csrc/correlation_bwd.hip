@@ -295,7 +295,10 @@ __global__ __launch_bounds__(kThreads) void corr_bwd_stream_kernel(BGeom g) {
             acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[buf][qj][3], acc3, 0, 0, 0);
           }
         };
-        // one burst of NBR ds_read_b128 per halo row t (4 MFMAs per read), issued one row ahead of the MFMAs that consume it
+        // one burst of NBR ds_read_b128 per halo row t (4 MFMAs per read), issued one row ahead of the MFMAs that consume it.
+        // (Measured and dropped: a wave row that is not the tile's last requesting the next step's first bursts BEFORE the barrier
+        //  -- its position has landed already -- so that it starts the step with MFMAs: the operands then live across the barrier
+        //  and the control-flow merge costs registers the kernel does not have at 168: 44 spilled, band words reloaded in the loop.)
         __builtin_amdgcn_sched_barrier(0);
         rd(sp, 0); rd(sp + row, 1);
         DTT_LANDED(0, NBR); mm(0, 0);

@@ -463,16 +463,19 @@ __global__ void psroi_pm_edges_kernel(const float* __restrict__ rois, int num_ro
   float roi[5];
 #pragma unroll
   for (int q = 0; q < 5; ++q) roi[q] = rois[(long)r * 5 + q];
-  int* e = edges + (long)r * (4 * pooled + 1);
+  // word k of RoI r at edges[k * num_rois + r]: the pixel workgroups read word k of 256 consecutive RoIs at a time (the first
+  // version kept a RoI's 4 P + 1 words together: 64 cache lines per wave load in the per-pixel search, 73 M line requests per call)
+  int* e = edges + r;
+  const long ns = num_rois;
   const int b = min(max((int)roi[0], 0), batch_size - 1);     // the forward's clamp (psroi_pm_kernel): both directions agree on the image
-  e[4 * pooled] = b;
+  e[4 * pooled * ns] = b;
   // the RoIs of image b lie in [first, last] (pre-zeroed words: ~first and last + 1 by atomicMax): a pixel's workgroup only walks
   // that run -- callers list their RoIs image by image, so the run is the image's own RoIs
   atomicMax(&range[2 * b], ~(unsigned)r);
   atomicMax(&range[2 * b + 1], (unsigned)r + 1u);
   for (int k = 0; k < pooled; ++k) {
-    const Bin b = psroi_bin(roi, spatial_scale, k, k, pooled, pooled, height, width);   // rows depend on ph only, columns on pw only
-    e[k] = b.hstart; e[pooled + k] = b.hend; e[2 * pooled + k] = b.wstart; e[3 * pooled + k] = b.wend;
+    const Bin bn = psroi_bin(roi, spatial_scale, k, k, pooled, pooled, height, width);   // rows depend on ph only, columns on pw only
+    e[k * ns] = bn.hstart; e[(pooled + k) * ns] = bn.hend; e[(2 * pooled + k) * ns] = bn.wstart; e[(3 * pooled + k) * ns] = bn.wend;
   }
 }
 
@@ -490,7 +493,7 @@ __global__ __launch_bounds__(256) void psroi_pm_bwd_kernel(const float* __restri
   const int px = blockIdx.x;
   const int hw = height * width;
   const int b = px / hw, rem = px - b * hw, h = rem / width, w = rem - h * width;
-  const int nbins = pooled * pooled, E = 4 * pooled + 1;
+  const int nbins = pooled * pooled;
   for (int i = tid; i < nbins * CP; i += 256) accum[i] = 0.f;
   const float inv_bins = 1.f / (float)nbins;
   // (chunks of 256 RoIs in RoI order, from the first to the last RoI of this pixel's image)
@@ -500,13 +503,14 @@ __global__ __launch_bounds__(256) void psroi_pm_bwd_kernel(const float* __restri
     // ---- phase 1: RoI r0 + tid -> the bins of that RoI that contain this pixel
     const int r = r0 + tid;
     int nh = 0, ph_lo = 0, ph_hi = -1, pw_lo = 0, pw_hi = -1;
-    const int* e = edges + (long)min(r, num_rois - 1) * E;
-    if (r < r_end && e[4 * pooled] == b) {
+    const int* e = edges + min(r, num_rois - 1);
+    const long ns = num_rois;
+    if (r < r_end && e[4 * pooled * ns] == b) {
       // bins are intervals with non-decreasing edges: the ph whose [hstart, hend) contains h form a contiguous run
       ph_lo = pooled; pw_lo = pooled;
       for (int k = 0; k < pooled; ++k) {
-        if (e[k] <= h && h < e[pooled + k]) { ph_lo = min(ph_lo, k); ph_hi = k; }
-        if (e[2 * pooled + k] <= w && w < e[3 * pooled + k]) { pw_lo = min(pw_lo, k); pw_hi = k; }
+        if (e[k * ns] <= h && h < e[(pooled + k) * ns]) { ph_lo = min(ph_lo, k); ph_hi = k; }
+        if (e[(2 * pooled + k) * ns] <= w && w < e[(3 * pooled + k) * ns]) { pw_lo = min(pw_lo, k); pw_hi = k; }
       }
       if (ph_hi >= 0 && pw_hi >= 0) nh = (ph_hi - ph_lo + 1) * (pw_hi - pw_lo + 1);
     }
@@ -526,7 +530,7 @@ __global__ __launch_bounds__(256) void psroi_pm_bwd_kernel(const float* __restri
     if (nh > 0 && total <= kMaxHits) {
       for (int ph = ph_lo; ph <= ph_hi; ++ph)
         for (int pw = pw_lo; pw <= pw_hi; ++pw) {
-          const int area = (e[pooled + ph] - e[ph]) * (e[3 * pooled + pw] - e[2 * pooled + pw]);
+          const int area = (e[(pooled + ph) * ns] - e[ph * ns]) * (e[(3 * pooled + pw) * ns] - e[(2 * pooled + pw) * ns]);
           hit_r[pos] = r; hit_bin[pos] = (short)(ph * pooled + pw); hit_w[pos] = inv_bins / (float)area;
           ++pos;
         }
@@ -557,13 +561,14 @@ __global__ __launch_bounds__(256) void psroi_pm_bwd_kernel(const float* __restri
       // (pathological chunk: more than 8 bins per RoI on average -- every RoI handled by one thread-serial pass, still in order)
       if (tid < 64) {
         for (int rr = r0; rr < min(r0 + 256, r_end); ++rr) {
-          const int* ee = edges + (long)rr * E;
-          if (ee[4 * pooled] != b) continue;
+          const int* ee = edges + rr;
+          const long ns = num_rois;
+          if (ee[4 * pooled * ns] != b) continue;
           for (int ph = 0; ph < pooled; ++ph) {
-            if (!(ee[ph] <= h && h < ee[pooled + ph])) continue;
+            if (!(ee[ph * ns] <= h && h < ee[(pooled + ph) * ns])) continue;
             for (int pw = 0; pw < pooled; ++pw) {
-              if (!(ee[2 * pooled + pw] <= w && w < ee[3 * pooled + pw])) continue;
-              const int area = (ee[pooled + ph] - ee[ph]) * (ee[3 * pooled + pw] - ee[2 * pooled + pw]);
+              if (!(ee[(2 * pooled + pw) * ns] <= w && w < ee[(3 * pooled + pw) * ns])) continue;
+              const int area = (ee[(pooled + ph) * ns] - ee[ph * ns]) * (ee[(3 * pooled + pw) * ns] - ee[(2 * pooled + pw) * ns]);
               if (lane < CP) accum[(ph * pooled + pw) * CP + lane] += (lane < output_dim ? gvote[(long)rr * output_dim + lane] : 0.f) * (inv_bins / (float)area);
             }
           }

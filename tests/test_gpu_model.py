@@ -500,8 +500,14 @@ def _check_pm_tail(monkeypatch, layers, shapes):
         same = (one[0][0] - out[0][0]).abs().amax(dim=2) < 0.05
         # (row by row: one swap of two near-tied proposals shifts the rows behind it until the lists meet again)
         assert float(same.float().mean()) > 0.85, "single frame: only %.3f of leg 0's RoIs reproduced" % float(same.float().mean())
-        assert float((one[1][0] - out[1][0]).abs().amax(dim=2)[same].max()) < 1e-3
-        assert float((one[2][0] - out[2][0]).abs().amax(dim=2)[same].max()) < 1e-3
+        # (a RoI matched to 0.05 px pools the same bins unless a corner lies that close to a rounding boundary of
+        #  psroi_pooling_kernel.cu:30-33: rows clear of x.5 carry the strict bound, the others a loose, still bounded one)
+        frac = out[0][0][..., 1:] - torch.floor(out[0][0][..., 1:])
+        clear = same & ((frac - 0.5).abs() > 0.06).all(dim=2)
+        assert float(clear.float().mean()) > 0.5
+        for i in (1, 2):
+            d = (one[i][0] - out[i][0]).abs().amax(dim=2)
+            assert float(d[clear].max()) < 1e-3 and float(d[same].max()) < 5e-2, (i, float(d[clear].max()), float(d[same].max()))
 
 
 def test_bench_step_tail_at_full_size_matches_nchw_tail(monkeypatch):
