@@ -385,7 +385,8 @@ def main():
         main_us = red_us = head_us = psroi_us = rpn_us = None
         assert used == ops_per_step * args.steps, "expected %d correlation ops per step, saw %d in %d steps" % (
             ops_per_step, used, args.steps)
-        if ops_per_step:
+        # (extra() replays steps on rank 0 alone: not in train mode on several ranks, where a step contains collectives)
+        if ops_per_step and (args.mode == "infer" or world == 1):
             if nhwc_corr:
                 main_us = extra("corr_nhwc", ops_per_step, c5)
             elif args.mode == "infer":
@@ -398,7 +399,8 @@ def main():
                 # two heads in one launch carry their own tag
                 head_us = extra("head_gemm", 2 if args.frames == 2 else 1, lambda d: d[0])
                 rpn_us = extra("rpn_head_gemm", 1, lambda d: d[0])
-                psroi_us = extra("psroi_pm", 3 if args.frames == 2 else 2, lambda d: d[0])
+                fused_det = os.environ.get("DTT_PSROI_DET_FUSED", "1") != "0"   # class + box pooling + softmax of a RoI in one launch
+                psroi_us = extra("psroi_pm", (2 if fused_det else 3) - (0 if args.frames == 2 else 1), lambda d: d[0])
         # HBM bytes of the op come from separate rocprofv3 --pmc passes over the same launch (tools/profile_round.sh ->
         # profiles/r03_pmc_conv5.json, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes).  The json records the sha256 of
         # the libdtt_hip.so it was measured on: quoted only for that binary and for the shape the pass was taken on.
@@ -501,10 +503,13 @@ def main():
                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(rb / (rpn_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                                 "launch_us": round(rpn_us, 2), "algorithmic_bytes_per_launch": rb}
         if psroi_us:
-            n_img, od = args.frames * args.batch, 31 * 49
-            ps_bytes = n_img * od * H16 * W16 * 4 + n_img * cfg.TEST.RPN_POST_NMS_TOP_N * 31 * 4   # score maps in, votes out
-            sec["psroi_cls"] = {"kernel": "psroi_pm_kernel (R-FCN class scores: %d x %d x %d x %d position-major map, %d RoIs, "
-                                          "pooling + 7x7 vote)" % (n_img, od, H16, W16, n_img * cfg.TEST.RPN_POST_NMS_TOP_N),
+            fused_det = os.environ.get("DTT_PSROI_DET_FUSED", "1") != "0"
+            n_img, od = args.frames * args.batch, (31 + (4 if fused_det else 0)) * 49
+            ps_bytes = n_img * od * H16 * W16 * 4 + n_img * cfg.TEST.RPN_POST_NMS_TOP_N * (35 if fused_det else 31) * 4   # score maps in, votes out
+            sec["psroi_cls"] = {"kernel": ("psroi_pm_det_kernel (R-FCN class scores + box deltas of a RoI in one launch, softmax in the epilogue: "
+                                           "%d x %d x %d x %d position-major map, %d RoIs, pooling + 7x7 vote)" if fused_det else
+                                           "psroi_pm_kernel (R-FCN class scores: %d x %d x %d x %d position-major map, %d RoIs, "
+                                           "pooling + 7x7 vote)") % (n_img, od, H16, W16, n_img * cfg.TEST.RPN_POST_NMS_TOP_N),
                                 "bound": "hbm", "achieved": round(ps_bytes / (psroi_us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS,
                                 "unit": "GB/s", "frac": round(ps_bytes / (psroi_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                                 "launch_us": round(psroi_us, 2), "algorithmic_bytes_per_launch": ps_bytes}

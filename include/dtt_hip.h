@@ -491,6 +491,13 @@ int dtt_head_gemm_dw(const float* gout, long ldg, int g_cols, const float* x, lo
 int dtt_psroi_pm_forward(const float* map, long pixel_stride, int cp, int batch_size, int num_rois, int height,
                          int width, int pooled, const float* rois, float spatial_scale, int output_dim,
                          float* vote_out, float* pooled_out, void* stream);
+/* Detection pooling of every RoI in ONE launch (rfcn.py:133-140 at inference): class scores and box deltas of the same position-major
+ * map pooled by one workgroup per RoI (same bin edges, same rows) and the softmax over the classes folded into the epilogue.  The class
+ * head starts at float 0 of a pixel (32 slots per bin, n_cls <= 32 used), the box head at float loc_offset (4 per bin).  Votes are the
+ * very sums of dtt_psroi_pm_forward.  cls_prob (num_rois, n_cls), loc_vote (num_rois, n_loc); cls_vote (num_rois, n_cls) or NULL. */
+int dtt_psroi_pm_det_forward(const float* map, long pixel_stride, int loc_offset, int batch_size, int num_rois, int height, int width,
+                             int pooled, const float* rois, float spatial_scale, int n_cls, int n_loc, float* cls_vote, float* cls_prob,
+                             float* loc_vote, void* stream);
 /* Backward of the vote with respect to the position-major map (PSROIPoolBackward, psroi_pooling_kernel.cu:109-170, composed with
  * the AvgPool2d of rfcn.py:62-64): grad_map[pixel][bin*cp + c] = sum over the RoIs of that image whose bin contains the pixel of
  * grad_vote[roi][c] / pooled^2 / bin_area, added in RoI order -- map-stationary, no atomics (the reference scatters with

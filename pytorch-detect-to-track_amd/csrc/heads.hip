@@ -369,26 +369,18 @@ __global__ __launch_bounds__((4 + NLOAD) * 64) void head_gemm_kernel(HeadGeom g)
 // map[((b*H + h)*W + w) * pixel_stride + bin*CP + c].  Bins land in LDS [bin][CP]; the vote (rfcn.py:62-64: AvgPool2d over
 // the P x P bins) is the reference's row-major sum followed by one division; `pooled_out` (optional) receives the bins in
 // the reference layout (R, od, P, P).  All RoIs are resident at once (4 waves per RoI at the 31-class shape).
-template <int CP, int LPB, int NW, int POOLED>
-__global__ __launch_bounds__(NW * 64) void psroi_pm_kernel(const float* __restrict__ map, long pixel_stride, int height,
-                                                           int width, const float* __restrict__ rois,
-                                                           float spatial_scale, int pooled_rt, int output_dim,
-                                                           float* __restrict__ vote, float* __restrict__ pooled_out, int batch_size) {
-  extern __shared__ __attribute__((aligned(16))) float bins[];   // [pooled*pooled][CP]
+// The bins of one RoI for one head: thread `t` of `nthreads` owns VPL = CP / LPB classes of the bins slot, slot + SLOTS, ...
+// (h, w) row-major walk, kFlight positions in flight, adds in order: every (bin, class) sum is one lane's sequential walk in the
+// reference's order.  bins_out: LDS [pooled * pooled][CP].
+template <int CP, int LPB>
+__device__ __forceinline__ void pm_pool_bins(const float* __restrict__ img, long pixel_stride, int height, int width, const float* roi,
+                                             float spatial_scale, int pooled, int t, int nthreads, float* __restrict__ bins_out) {
   constexpr int VPL = CP / LPB, NV = VPL / 4;   // classes / 16-byte pieces per lane
-  constexpr int SLOTS = NW * 64 / LPB;          // bins in flight per workgroup
   constexpr int kFlight = 8;
-  const int pooled = POOLED > 0 ? POOLED : pooled_rt;
-  const int n = blockIdx.x;
-  const int tid = threadIdx.x;
-  const int cq = tid % LPB, slot = tid / LPB;
-  float roi[5];
-#pragma unroll
-  for (int q = 0; q < 5; ++q) roi[q] = rois[(long)n * 5 + q];
-  // a batch index outside the map (a caller's bug: the reference reads out of bounds there) pools image 0 instead of wild memory
-  const int b = min(max((int)roi[0], 0), batch_size - 1);
+  const int SLOTS = nthreads / LPB;             // bins in flight
+  const int cq = t % LPB, slot = t / LPB;
   const int nbins = pooled * pooled;
-  const float* img = map + (long)b * height * width * pixel_stride + cq * VPL;
+  img += cq * VPL;
   for (int bin = slot; bin < nbins; bin += SLOTS) {
     const int ph = bin / pooled, pw = bin - ph * pooled;
     const Bin g = psroi_bin(roi, spatial_scale, ph, pw, pooled, pooled, height, width);
@@ -398,7 +390,6 @@ __global__ __launch_bounds__(NW * 64) void psroi_pm_kernel(const float* __restri
     if (!g.empty) {
       const int nw = g.wend - g.wstart, area = (g.hend - g.hstart) * nw;
       const float* p = img + (long)bin * CP;
-      // (h, w) row-major walk, kFlight positions in flight, adds in order
       int h = g.hstart, w = g.wstart;
       for (int i = 0; i < area; i += kFlight) {
         f32x4 v[kFlight][NV];
@@ -423,28 +414,88 @@ __global__ __launch_bounds__(NW * 64) void psroi_pm_kernel(const float* __restri
       for (int q = 0; q < NV; ++q) sum[q] = f32x4{sum[q][0] / fa, sum[q][1] / fa, sum[q][2] / fa, sum[q][3] / fa};
     }
 #pragma unroll
-    for (int q = 0; q < NV; ++q) *reinterpret_cast<f32x4*>(&bins[bin * CP + cq * VPL + 4 * q]) = sum[q];
+    for (int q = 0; q < NV; ++q) *reinterpret_cast<f32x4*>(&bins_out[bin * CP + cq * VPL + 4 * q]) = sum[q];
   }
+}
+
+// the vote of class `c` (rfcn.py:62-64: AvgPool2d over the P x P bins): the reference's row-major sum, one division
+template <int CP, int POOLED>
+__device__ __forceinline__ float pm_vote(const float* __restrict__ bins, int c, int nbins) {
+  float s = 0.f;
+  if (POOLED > 0) {       // all loads first, then the adds in order
+    float v[POOLED > 0 ? POOLED * POOLED : 1];
+#pragma unroll
+    for (int k = 0; k < POOLED * POOLED; ++k) v[k] = bins[k * CP + c];
+#pragma unroll
+    for (int k = 0; k < POOLED * POOLED; ++k) s += v[k];
+  } else {
+    for (int k = 0; k < nbins; ++k) s += bins[k * CP + c];
+  }
+  return s / (float)nbins;
+}
+
+template <int CP, int LPB, int NW, int POOLED>
+__global__ __launch_bounds__(NW * 64) void psroi_pm_kernel(const float* __restrict__ map, long pixel_stride, int height,
+                                                           int width, const float* __restrict__ rois,
+                                                           float spatial_scale, int pooled_rt, int output_dim,
+                                                           float* __restrict__ vote, float* __restrict__ pooled_out, int batch_size) {
+  extern __shared__ __attribute__((aligned(16))) float bins[];   // [pooled*pooled][CP]
+  const int pooled = POOLED > 0 ? POOLED : pooled_rt;
+  const int n = blockIdx.x;
+  const int tid = threadIdx.x;
+  float roi[5];
+#pragma unroll
+  for (int q = 0; q < 5; ++q) roi[q] = rois[(long)n * 5 + q];
+  // a batch index outside the map (a caller's bug: the reference reads out of bounds there) pools image 0 instead of wild memory
+  const int b = min(max((int)roi[0], 0), batch_size - 1);
+  const int nbins = pooled * pooled;
+  pm_pool_bins<CP, LPB>(map + (long)b * height * width * pixel_stride, pixel_stride, height, width, roi, spatial_scale, pooled, tid, NW * 64, bins);
   __syncthreads();
-  if (tid < output_dim) {   // one thread per class
-    float s = 0.f;
-    if (POOLED > 0) {       // all loads first, then the adds in order
-      float v[POOLED > 0 ? POOLED * POOLED : 1];
-#pragma unroll
-      for (int k = 0; k < POOLED * POOLED; ++k) v[k] = bins[k * CP + tid];
-#pragma unroll
-      for (int k = 0; k < POOLED * POOLED; ++k) s += v[k];
-    } else {
-      for (int k = 0; k < nbins; ++k) s += bins[k * CP + tid];
-    }
-    vote[(long)n * output_dim + tid] = s / (float)nbins;
-  }
+  if (tid < output_dim) vote[(long)n * output_dim + tid] = pm_vote<CP, POOLED>(bins, tid, nbins);   // one thread per class
   if (pooled_out) {
     float* o = pooled_out + (long)n * output_dim * nbins;
     for (int i = tid; i < output_dim * nbins; i += NW * 64) {
       const int ct = i / nbins, k = i - ct * nbins;
       o[i] = bins[k * CP + ct];
     }
+  }
+}
+
+// Detection pooling of a RoI in ONE launch (rfcn.py:133-140): the class scores (CP = 32 slots per bin, waves 0 - 3) and the box
+// deltas (4 per bin, wave 4: lane = bin) of the same position-major map, the same bin edges, the same rows -- and the softmax over
+// the classes folded into the epilogue (the 31 votes of a RoI sit in one wave).  Votes are the very sums of psroi_pm_kernel
+// (shared code); cls_prob = exp(s - max) / sum exp(s - max), with the sum taken in class order.
+template <int POOLED>
+__global__ __launch_bounds__(320) void psroi_pm_det_kernel(const float* __restrict__ map, long pixel_stride, int loc_offset, int height,
+                                                           int width, const float* __restrict__ rois, float spatial_scale, int pooled_rt,
+                                                           int n_cls, int n_loc, float* __restrict__ cls_vote, float* __restrict__ cls_prob,
+                                                           float* __restrict__ loc_vote, int batch_size) {
+  extern __shared__ __attribute__((aligned(16))) float bins[];   // [pooled*pooled][32] class bins, then [pooled*pooled][4] box bins
+  const int pooled = POOLED > 0 ? POOLED : pooled_rt;
+  const int n = blockIdx.x;
+  const int tid = threadIdx.x;
+  float roi[5];
+#pragma unroll
+  for (int q = 0; q < 5; ++q) roi[q] = rois[(long)n * 5 + q];
+  const int b = min(max((int)roi[0], 0), batch_size - 1);
+  const int nbins = pooled * pooled;
+  const float* img = map + (long)b * height * width * pixel_stride;
+  float* lbins = bins + nbins * 32;
+  if (tid < 256) pm_pool_bins<32, 4>(img, pixel_stride, height, width, roi, spatial_scale, pooled, tid, 256, bins);
+  else pm_pool_bins<4, 1>(img + loc_offset, pixel_stride, height, width, roi, spatial_scale, pooled, tid - 256, 64, lbins);
+  __syncthreads();
+  if (tid < 64) {           // wave 0: the class votes and their softmax
+    const float s = tid < n_cls ? pm_vote<32, POOLED>(bins, tid, nbins) : -3.0e38f;
+    if (tid < n_cls && cls_vote) cls_vote[(long)n * n_cls + tid] = s;
+    float m = s;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
+    const float e = tid < n_cls ? expf(s - m) : 0.f;
+    float sum = 0.f;
+    for (int c = 0; c < n_cls; ++c) sum += __shfl(e, c, 64);     // (class order: the same sum on every lane)
+    if (tid < n_cls) cls_prob[(long)n * n_cls + tid] = e / sum;
+  } else if (tid >= 256 && tid - 256 < n_loc) {
+    loc_vote[(long)n * n_loc + (tid - 256)] = pm_vote<4, POOLED>(lbins, tid - 256, nbins);
   }
 }
 
@@ -457,7 +508,8 @@ __global__ __launch_bounds__(NW * 64) void psroi_pm_kernel(const float* __restri
 // lanes = classes -- no atomics, no pre-zeroed output (every pixel writes its whole row segment), deterministic.
 // psroi_pm_edges_kernel first turns every RoI into its 4 * P bin edges with the forward's arithmetic (psroi_bin.h).
 __global__ void psroi_pm_edges_kernel(const float* __restrict__ rois, int num_rois, float spatial_scale, int pooled, int height,
-                                      int width, int batch_size, int* __restrict__ edges, unsigned* __restrict__ range) {
+                                      int width, int batch_size, int* __restrict__ edges, unsigned* __restrict__ range,
+                                      const float* __restrict__ gvote, int output_dim) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= num_rois) return;
   float roi[5];
@@ -467,8 +519,15 @@ __global__ void psroi_pm_edges_kernel(const float* __restrict__ rois, int num_ro
   // version kept a RoI's 4 P + 1 words together: 64 cache lines per wave load in the per-pixel search, 73 M line requests per call)
   int* e = edges + r;
   const long ns = num_rois;
-  const int b = min(max((int)roi[0], 0), batch_size - 1);     // the forward's clamp (psroi_pm_kernel): both directions agree on the image
+  int b = min(max((int)roi[0], 0), batch_size - 1);           // the forward's clamp (psroi_pm_kernel): both directions agree on the image
+  // A RoI whose gradient row is all zeros adds nothing anywhere (background RoIs in the box head: three quarters of the sampled
+  // RoIs; the zero-padded ground-truth rows of the tracking RoIs -- (0,0,0,0) boxes whose 49 bins ALL cover pixel (0, 0): 1400
+  // hits walked by one workgroup, the whole launch waiting for it): it is given to no image
+  bool nonzero = false;
+  for (int c = 0; c < output_dim; ++c) nonzero |= gvote[(long)r * output_dim + c] != 0.f;
+  if (!nonzero) b = -1;
   e[4 * pooled * ns] = b;
+  if (b < 0) return;
   // the RoIs of image b lie in [first, last] (pre-zeroed words: ~first and last + 1 by atomicMax): a pixel's workgroup only walks
   // that run -- callers list their RoIs image by image, so the run is the image's own RoIs
   atomicMax(&range[2 * b], ~(unsigned)r);
@@ -783,7 +842,7 @@ extern "C" int dtt_psroi_pm_backward(const float* grad_vote, const float* rois, 
   DTT_REQUIRE(hipMemsetAsync(range, 0, sizeof(unsigned) * 2 * batch_size, stream) == hipSuccess, "psroi_pm backward: memset failed");
   if (num_rois > 0) {
     hipLaunchKernelGGL(psroi_pm_edges_kernel, dim3(dtt_cdiv(num_rois, 256)), dim3(256), 0, stream, rois, num_rois, spatial_scale, pooled,
-                       height, width, batch_size, edges, range);
+                       height, width, batch_size, edges, range, grad_vote, output_dim);
     DTT_CHECK_LAUNCH("psroi_pm_edges");
   }
   const int npx = batch_size * height * width;
@@ -828,5 +887,33 @@ extern "C" int dtt_psroi_pm_forward(const float* map, long pixel_stride, int cp,
 #undef DTT_PM_LAUNCH
   dtt_prof_end("psroi_pm", stream);
   DTT_CHECK_LAUNCH("psroi_pm");
+  return 1;
+}
+
+// Class scores + box deltas of every RoI in ONE launch, softmax folded in (rfcn.py:133-140 at inference): map as for
+// dtt_psroi_pm_forward; the class head at float 0 of a pixel (32 slots per bin, n_cls <= 32 used), the box head at float loc_offset
+// (4 per bin, n_loc <= 4).  cls_prob (num_rois, n_cls), loc_vote (num_rois, n_loc); cls_vote (num_rois, n_cls) or NULL.
+extern "C" int dtt_psroi_pm_det_forward(const float* map, long pixel_stride, int loc_offset, int batch_size, int num_rois, int height, int width,
+                                        int pooled, const float* rois, float spatial_scale, int n_cls, int n_loc, float* cls_vote,
+                                        float* cls_prob, float* loc_vote, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  DTT_REQUIRE(batch_size > 0 && height > 0 && width > 0 && pooled > 0 && num_rois >= 0, "psroi_pm_det: bad shape");
+  DTT_REQUIRE(n_cls >= 1 && n_cls <= 32 && n_loc >= 1 && n_loc <= 4, "psroi_pm_det: %d classes / %d box outputs not covered (<= 32 / <= 4)", n_cls, n_loc);
+  DTT_REQUIRE(loc_offset >= pooled * pooled * 32 && loc_offset % 4 == 0 && (long)loc_offset + pooled * pooled * 4 <= pixel_stride,
+              "psroi_pm_det: the box head (float %d) must lie behind the %d class bins inside the pixel stride %ld", loc_offset, pooled * pooled, pixel_stride);
+  if (num_rois == 0) return 1;
+  DTT_REQUIRE(map && rois && cls_prob && loc_vote, "psroi_pm_det: null pointer");
+  DTT_REQUIRE(((size_t)map & 15) == 0 && pixel_stride % 4 == 0, "psroi_pm_det: the map must be 16-byte aligned with a pixel stride that is a multiple of 4 floats");
+  const size_t lds = (size_t)pooled * pooled * 36 * sizeof(float);
+  DTT_REQUIRE(lds <= 64 * 1024, "psroi_pm_det: pooled size too large");
+  dtt_prof_begin("psroi_pm", stream);
+  if (pooled == 7)
+    hipLaunchKernelGGL((psroi_pm_det_kernel<7>), dim3(num_rois), dim3(320), lds, stream, map, pixel_stride, loc_offset, height, width, rois,
+                       spatial_scale, pooled, n_cls, n_loc, cls_vote, cls_prob, loc_vote, batch_size);
+  else
+    hipLaunchKernelGGL((psroi_pm_det_kernel<0>), dim3(num_rois), dim3(320), lds, stream, map, pixel_stride, loc_offset, height, width, rois,
+                       spatial_scale, pooled, n_cls, n_loc, cls_vote, cls_prob, loc_vote, batch_size);
+  dtt_prof_end("psroi_pm", stream);
+  DTT_CHECK_LAUNCH("psroi_pm_det");
   return 1;
 }

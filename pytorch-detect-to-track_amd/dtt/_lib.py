@@ -83,6 +83,7 @@ SIGNATURES = {
     "dtt_head_gemm_dw_workspace_bytes": (_Z, [_I, _I, _I]),
     "dtt_head_gemm_dw": (_I, [_P, _L, _I, _P, _L, _I, _I, _I, _P, _P, _Z, _P]),
     "dtt_psroi_pm_forward": (_I, [_P, _L, _I, _I, _I, _I, _I, _I, _P, _F, _I, _P, _P, _P]),
+    "dtt_psroi_pm_det_forward": (_I, [_P, _L, _I, _I, _I, _I, _I, _I, _P, _F, _I, _I, _P, _P, _P, _P]),
     "dtt_tube_link_workspace_bytes": (_Z, [_I, _I]),
     "dtt_tube_link": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "dtt_anchor_target_finish": (_I, [_P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _F, _P, _P, _P, _P, _P]),

@@ -163,6 +163,31 @@ def psroi_pm(pm_map, head, batch, height, width, rois, spatial_scale, want_poole
     return (vote, pooled) if want_pooled else vote
 
 
+def psroi_pm_det(pm_map, cls_head, loc_head, batch, height, width, rois, spatial_scale, want_scores=False):
+    """The detection pooling of rfcn.py:133-140 in ONE launch (`dtt_psroi_pm_det_forward`): class scores and box deltas of every RoI
+    pooled + voted over the same position-major map, the class softmax folded into the kernel's epilogue.
+    Returns (cls_prob (R, n_cls), bbox_pred (R, 4)[, cls_score (R, n_cls)]).  Needs the layout `PackedHeads` produces for the
+    (class, box) pair: 32 class slots per bin from float 0, 4 box deltas per bin behind them."""
+    import ctypes
+    require_gpu(pm_map, rois)
+    require_f32_contig("rois", rois)
+    if rois.dim() != 2 or rois.size(1) != 5:
+        raise ValueError("rois must have shape (R, 5) [batch_idx, x1, y1, x2, y2], got %s" % (tuple(rois.shape),))
+    if cls_head["cp"] != 32 or loc_head["cp"] != 4 or cls_head["offset"] != 0 or cls_head["group"] != loc_head["group"]:
+        raise ValueError("psroi_pm_det: needs a 32-slot class head at float 0 and a 4-slot box head of the same group size")
+    assert pm_map.dtype == torch.float32 and pm_map.stride(1) == 1 and pm_map.shape[0] == batch * height * width
+    R, G = rois.size(0), cls_head["group"]
+    dev = pm_map.device
+    prob = torch.empty((R, cls_head["od"]), dtype=torch.float32, device=dev)
+    pred = torch.empty((R, loc_head["od"]), dtype=torch.float32, device=dev)
+    score = torch.empty((R, cls_head["od"]), dtype=torch.float32, device=dev) if want_scores else None
+    with torch.cuda.device(dev):
+        check(_lib.lib().dtt_psroi_pm_det_forward(ptr(pm_map), pm_map.stride(0), loc_head["offset"], batch, R, height, width, G, ptr(rois),
+                                                  float(spatial_scale), cls_head["od"], loc_head["od"], ptr(score), ptr(prob), ptr(pred),
+                                                  stream_ptr(dev)), "psroi_pm_det")
+    return (prob, pred, score) if want_scores else (prob, pred)
+
+
 # ------------------------------------------------------------------------------------------------ training (autograd)
 def pack_heads_differentiable(convs, group=7, k_pad=None, in_perm=None):
     """PackedHeads' row permutation as differentiable tensor ops on the LIVE parameters (training: the weights change every

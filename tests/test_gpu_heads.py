@@ -369,3 +369,24 @@ def test_tracking_rows_autograd_matches_the_reference_concat(dev, B, H, W, C345)
         assert a.grad.is_contiguous(memory_format=torch.channels_last)
         assert rel(a.grad, r.grad) < 1e-4, name
     assert rel(conv.weight.grad, wr.grad) < 1e-4 and rel(conv.bias.grad, br.grad) < 1e-4
+
+
+@pytest.mark.parametrize("B,H,W,R", [(4, 38, 67, 1200), (2, 20, 30, 77), (1, 6, 9, 300)])
+def test_psroi_pm_det_one_launch_matches_the_two_poolings(dev, B, H, W, R):
+    """dtt_psroi_pm_det_forward (class scores + box deltas of a RoI pooled and voted in one launch, class softmax in the epilogue)
+    against the two dtt_psroi_pm_forward launches + F.softmax it replaces: votes bit-identical (shared pooling code, same vote
+    order), probabilities to 1e-6 (expf + a class-order sum against torch's softmax)."""
+    from dtt.heads import PackedHeads, head_gemm, psroi_pm, psroi_pm_det
+    convs = _convs(dev, 64, (31, 4), seed=R)
+    g = torch.Generator().manual_seed(R)
+    x = torch.relu(torch.randn(B, 64, H, W, generator=g)).to(dev)
+    packed = PackedHeads(convs)
+    pm = head_gemm(x.permute(0, 2, 3, 1).reshape(-1, 64).contiguous(), packed)
+    rois = torch.from_numpy(_rois(np.random.RandomState(R), R, B, H, W)).to(dev)
+    cls_head, loc_head = packed.heads
+    prob, pred, score = psroi_pm_det(pm, cls_head, loc_head, B, H, W, rois, 1.0 / 16, want_scores=True)
+    want_score = psroi_pm(pm, cls_head, B, H, W, rois, 1.0 / 16)
+    want_pred = psroi_pm(pm, loc_head, B, H, W, rois, 1.0 / 16)
+    assert torch.equal(score, want_score) and torch.equal(pred, want_pred)
+    assert float((prob - F.softmax(want_score, dim=1)).abs().max()) < 1e-6
+    assert float((prob.sum(1) - 1).abs().max()) < 1e-5

@@ -497,17 +497,21 @@ def _check_pm_tail(monkeypatch, layers, shapes):
             one = model(im[:, :1], info[:, :1], gt[:, :1], nb[:, :1])
         torch.cuda.synchronize()
         assert one[3].shape[0] == 0 and one[1].shape == (1, B, R, model.n_classes) and one[0].shape == (1, B, R, 5)
-        same = (one[0][0] - out[0][0]).abs().amax(dim=2) < 0.05
-        # (row by row: one swap of two near-tied proposals shifts the rows behind it until the lists meet again)
-        assert float(same.float().mean()) > 0.85, "single frame: only %.3f of leg 0's RoIs reproduced" % float(same.float().mean())
-        # (a RoI matched to 0.05 px pools the same bins unless a corner lies that close to a rounding boundary of
-        #  psroi_pooling_kernel.cu:30-33: rows clear of x.5 carry the strict bound, the others a loose, still bounded one)
-        frac = out[0][0][..., 1:] - torch.floor(out[0][0][..., 1:])
-        clear = same & ((frac - 0.5).abs() > 0.06).all(dim=2)
-        assert float(clear.float().mean()) > 0.5
-        for i in (1, 2):
-            d = (one[i][0] - out[i][0]).abs().amax(dim=2)
-            assert float(d[clear].max()) < 1e-3 and float(d[same].max()) < 5e-2, (i, float(d[clear].max()), float(d[same].max()))
+        # RoIs are matched as SETS per image (one swap of two near-tied proposals shifts every row behind it): every single-frame
+        # RoI to its nearest leg-0 RoI of the pair
+        for b in range(B):
+            ra, rb = one[0][0, b, :, 1:], out[0][0, b, :, 1:]
+            dist, idx = (ra[:, None, :] - rb[None, :, :]).abs().amax(dim=2).min(dim=1)
+            same = dist < 0.05
+            assert float(same.float().mean()) > 0.9, "single frame, image %d: only %.3f of leg 0's RoIs reproduced" % (b, float(same.float().mean()))
+            # (a RoI matched to 0.05 px pools the same bins unless a corner lies that close to a rounding boundary of
+            #  psroi_pooling_kernel.cu:30-33: rows clear of x.5 carry the strict bound, the others a loose, still bounded one)
+            frac = ra - torch.floor(ra)
+            clear = same & ((frac - 0.5).abs() > 0.06).all(dim=1)
+            assert float(clear.float().mean()) > 0.5
+            for i in (1, 2):
+                d = (one[i][0, b] - out[i][0, b][idx]).abs().amax(dim=1)
+                assert float(d[clear].max()) < 1e-3 and float(d[same].max()) < 5e-2, (i, b, float(d[clear].max()), float(d[same].max()))
 
 
 def test_bench_step_tail_at_full_size_matches_nchw_tail(monkeypatch):
