@@ -178,6 +178,24 @@ def spawn_ranks(args):
     return subprocess.call(cmd, env=env)
 
 
+def corr_bwd_secondary(op_us, args, model):
+    """secondary.corr_bwd from the mean durations of a step's three correlation gradient ops (event tag corr_bwd_op), in launch
+    order.  The hand-written training graph runs them inside one autograd node in map order (conv3, conv4, conv5:
+    dtt.heads.TrackingRowsFn.backward); the library graph has three correlation nodes that autograd runs in reverse creation order."""
+    H16, W16 = -(-args.height // 16), -(-args.width // 16)
+    ops = (("corr3_bwd", 512, args.disp // 2), ("corr4_bwd", 1024, args.disp), ("corr5_bwd", 2048, args.disp))
+    if not getattr(model, "_train_pm", False):
+        ops = ops[::-1]
+    bw = {}
+    for us, (name, C, R) in zip(op_us, ops):
+        fl = 2.0 * 2.0 * C * (2 * R + 1) ** 2 * H16 * W16 * args.batch      # both gradients: 2 x the forward's FLOPs
+        bw[name] = {"op_us": round(us, 2), "achieved": round(fl / (us * 1e-6) / 1e12, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(fl / (us * 1e-6) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4), "algorithmic_flops_per_op": fl}
+    return dict(bw, kernel="correlation gradient op = corr_bwd_band_kernel + 2 x corr_bwd_stream_kernel (both gradients of one correlation, "
+                           "channels-last, band-stationary / halo-streamed: dtt_correlation_backward_nhwc_strided; event tag corr_bwd_op), "
+                           "bound: fp32 MFMA")
+
+
 def measure_train_step(args, cfg, dev, world, im, info, gt, nb):
     """BASELINE configs[3]'s per-rank workload beside the inference figure: `--train-steps` timed training steps (forward, five
     losses, backward, bucketed gradient all-reduce, SGD; trainval_net.py:310-368) of a second, identically built model on the same
@@ -244,18 +262,7 @@ def measure_train_step(args, cfg, dev, world, im, info, gt, nb):
         res["gradient_buckets"]["allreduce_ms"] = round(ar, 3)
     durs = kt.durations_us(used)
     if n_ops and used == n_ops * n:
-        # autograd runs the three correlation nodes in reverse creation order: conv5, conv4, conv3
-        H16, W16 = -(-args.height // 16), -(-args.width // 16)
-        bw = {}
-        for pos, (name, C, R) in enumerate((("corr5_bwd", 2048, args.disp), ("corr4_bwd", 1024, args.disp), ("corr3_bwd", 512, args.disp // 2))):
-            v = [durs[i + pos] for i in range(0, len(durs), n_ops)]
-            us = sum(v) / len(v)
-            fl = 2.0 * 2.0 * C * (2 * R + 1) ** 2 * H16 * W16 * args.batch      # both gradients: 2 x the forward's FLOPs
-            bw[name] = {"op_us": round(us, 2), "achieved": round(fl / (us * 1e-6) / 1e12, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(fl / (us * 1e-6) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
-                        "algorithmic_flops_per_op": fl}
-        res["corr_bwd"] = dict(bw, kernel="correlation gradient op = both gradients of one correlation (dtt_correlation_backward_nhwc; "
-                                          "event tag corr_bwd_op), bound: fp32 MFMA")
+        res["corr_bwd"] = corr_bwd_secondary([sum(durs[i + pos] for i in range(0, len(durs), n_ops)) / n for pos in range(n_ops)], args, model)
     if one_rank_group:
         dist.destroy_process_group()
     return res
@@ -402,24 +409,24 @@ def main():
                 fused_det = os.environ.get("DTT_PSROI_DET_FUSED", "1") != "0"   # class + box pooling + softmax of a RoI in one launch
                 psroi_us = extra("psroi_pm", (2 if fused_det else 3) - (0 if args.frames == 2 else 1), lambda d: d[0])
         # HBM bytes of the op come from separate rocprofv3 --pmc passes over the same launch (tools/profile_round.sh ->
-        # profiles/r03_pmc_conv5.json, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes).  The json records the sha256 of
+        # profiles/r04_pmc_conv5.json, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes).  The json records the sha256 of
         # the libdtt_hip.so it was measured on: quoted only for that binary and for the shape the pass was taken on.
         traffic, traffic_src = None, None
         try:
             import hashlib
             from dtt import _lib
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_conv5.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_conv5.json")))
             same_binary = pmc.get("library_sha256") == hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()
             if nhwc_corr and (args.batch, args.height, args.width, args.disp) == (2, 600, 1067, 8):
                 if same_binary:
                     traffic = pmc["traffic_bytes_per_op"]
-                    traffic_src = "static: " + pmc.get("source", "profiles/r03_pmc_conv5.json") + " (same libdtt_hip.so: sha256 checked)"
+                    traffic_src = "static: " + pmc.get("source", "profiles/r04_pmc_conv5.json") + " (same libdtt_hip.so: sha256 checked)"
                 else:
-                    traffic_src = "profiles/r03_pmc_conv5.json was measured on another libdtt_hip.so build: not quoted (rerun tools/profile_round.sh)"
+                    traffic_src = "profiles/r04_pmc_conv5.json was measured on another libdtt_hip.so build: not quoted (rerun tools/profile_round.sh)"
         except (OSError, ValueError, KeyError):
             pass
         corr_us = {}
-        if nhwc_corr and args.disp <= 8 and os.environ.get("DTT_CORR5_EARLY", "1") != "0":
+        if nhwc_corr and args.mode == "infer" and ops_per_step and args.disp <= 8 and os.environ.get("DTT_CORR5_EARLY", "1") != "0":
             order = [int(c) for c in os.environ.get("DTT_CORR_ORDER", "021") if c != "2"]      # after conv5: conv3, conv4 by default
             for pos, which in enumerate(order):
                 v = [durs[i + 1 + pos] for i in range(0, len(durs) - ops_per_step + 1, ops_per_step)]
@@ -513,6 +520,10 @@ def main():
                                 "bound": "hbm", "achieved": round(ps_bytes / (psroi_us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS,
                                 "unit": "GB/s", "frac": round(ps_bytes / (psroi_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                                 "launch_us": round(psroi_us, 2), "algorithmic_bytes_per_launch": ps_bytes}
+        if args.mode == "train" and world == 1 and args.frames == 2:
+            bw_us = [extra("corr_bwd_op", 3, lambda d, pos=pos: d[pos]) for pos in range(3)]
+            if all(v for v in bw_us):
+                sec["corr_bwd"] = corr_bwd_secondary(bw_us, args, model)
         if args.frames == 1:
             # no correlation in the single-frame graph: the dominant hand-written kernel of the step is the class + box head GEMM
             h = sec.get("heads")

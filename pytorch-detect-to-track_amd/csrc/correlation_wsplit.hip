@@ -12,16 +12,18 @@
 //   row-major runs (25 -> 8 + 8 + 9), every wave runs ALL channels for its run, and what it accumulates is final:
 //   no slabs, no tickets, no reducer, no workspace, nothing to race on, bit-identical from run to run by construction.
 //
-//   * Workgroup = 4 compute waves (one per SIMD) + 4 loader waves, one tile of up to four pixel blocks (2 x 2, or 4 x 1 /
-//     1 x 4 / smaller along odd map edges) x one run of window parts.  Work items are laid out by a host-side plan
+//   * Workgroup = 8 compute waves (two per SIMD: a wave PAIR shares a pixel block's window run and takes alternate channel
+//     chunks) + 4 loader waves, one tile of up to four pixel blocks (2 x 2, or 4 x 1 / 1 x 4 / smaller along odd map edges)
+//     x one run of window parts.  Work items are laid out by a host-side plan
 //     (segments of identical tiles) so that tiles x parts fills the chip: 2 x (42 x 3 + 2) = 256 workgroups at 600 px, or
 //     five parts (426 short workgroups, two rounds) when the caller wants CUs left free (`max_workgroups`).
 //   * Loaders stage, per 16-channel chunk, the tile's pixels of frame t and only the halo ROWS its window run touches
 //     (12 - 16 of 24 at three parts) global -> LDS by LDS-DMA in the scalar-base form (SALU + VMEM only), into a ring of
 //     3 - 8 slots; they run up to nslot - 1 chunks ahead with counted s_waitcnt vmcnt.  The 16-byte pieces of a pixel's
 //     64-byte chunk row are XOR-swizzled on the source side so that every ds_read_b128 is bank-conflict free.
-//   * Compute waves: one barrier per chunk; the operands of chunk k+1 (one ds_read_b128 per window block = four MFMA
-//     k-steps) are fetched underneath the MFMAs of chunk k, so the matrix pipe does not drain at chunk boundaries.
+//   * Compute waves: one barrier per chunk; a wave reads the operands of ITS chunk (one ds_read_b128 per window block = four
+//     MFMA k-steps) in two bursts in two consecutive barrier intervals and runs the MFMAs of a burst one interval later, so a
+//     read burst always sits underneath the partner wave's MFMAs; the two waves' sums meet in LDS at the end (fixed order).
 //   * Epilogue: each workgroup assembles ITS window entries in LDS (1/C applied, zero where p or q lies in the padding) and
 //     streams them out in the caller's layout; the three parts of a tile write disjoint entries of the same rows.
 #include <stdlib.h>

@@ -20,7 +20,7 @@ def _run(mode):
     env.pop("RANK", None)
     env.pop("LOCAL_RANK", None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
-           "--mode", mode, "--layers", "50", "--height", "224", "--width", "320"]
+           "--mode", mode, "--layers", "50", "--height", "224", "--width", "320", "--train-steps", "1"]
     p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
@@ -35,3 +35,6 @@ def test_bench_launches_its_own_ranks(mode):
     assert out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "weak"
     assert out["config"]["global_batch"] == 4 and out["value"] > 0
     assert out["roofline"]["ops_timed"] == 2
+    if mode == "infer":   # the training step of configs[3] rides along (secondary.train_step), its buckets reduced over the 2-rank group
+        ts = out["secondary"]["train_step"]
+        assert "error" not in ts and ts["ms_per_step"] > 0 and ts["gradient_buckets"]["count"] >= 1

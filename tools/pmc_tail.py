@@ -9,7 +9,7 @@ import torch
 from dtt.config import cfg
 from dtt.synth import build_model
 from dtt.fuse import fuse_for_inference
-from dtt.heads import head_gemm, psroi_pm
+from dtt.heads import head_gemm, psroi_pm, psroi_pm_det
 from dtt.ops import correlation_forward_nhwc
 dev = torch.device("cuda:0"); B = 2; H, W = 38, 67
 g = torch.Generator().manual_seed(3)
@@ -29,7 +29,6 @@ with torch.no_grad():
             correlation_forward_nhwc(a, b, 8, 1, 8, s, s)
         det = head_gemm(top, pm.det)
         trk = head_gemm(rows, pm.trk)
-        psroi_pm(det, pm.cls_head, 2 * B, H, W, rois, 1 / 16.0)
-        psroi_pm(det, pm.loc_head, 2 * B, H, W, rois, 1 / 16.0)
+        psroi_pm_det(det, pm.cls_head, pm.loc_head, 2 * B, H, W, rois, 1 / 16.0)      # class scores + box deltas + softmax: one launch
         psroi_pm(trk, pm.trk_head, B, H, W, rois[rois[:, 0] < B][:600].contiguous(), 1 / 16.0)
 torch.cuda.synchronize()

@@ -6,7 +6,7 @@ db = sqlite3.connect(sys.argv[1])
 rows = db.execute("select name, start, end from kernels order by start").fetchall()
 short = (("corr_wsplit_kernel<9", "corr5"), ("corr_wsplit_kernel", "corr3/4"), ("proposal_select_sort", "sort"), ("proposal_sort_runs", "runs"), ("proposal_rank_scatter", "rank"),
          ("head_gemm_kernel<3", "rpn"), ("nms_mask", "mask"),
-         ("nms_sweep", "sweep"), ("head_gemm_kernel<10", "head"), ("head_gemm_kernel<6", "trk/rpn"), ("psroi_pm_kernel<32", "psroi"))
+         ("nms_sweep", "sweep"), ("head_gemm_kernel<10", "head"), ("head_gemm_kernel<6", "trk/rpn"), ("psroi_pm_det_kernel", "psroi"), ("psroi_pm_kernel<32", "psroi"))
 steps, cur = [], None
 for n, s, e in rows:
     tag = next((t for k, t in short if k in n), None)
