@@ -1402,23 +1402,23 @@ extern "C" int dtt_correlation_backward_stream_supported(int ic, int kernel_size
 
 static int backward_nhwc_checks(const float* gradOutput, int gob, int goc, int goh, int gow, const float* input1, int ic, int ih, int iw,
                                 const float* input2, const float* gradInput1, const float* gradInput2, int pad_size, int kernel_size,
-                                int max_displacement, int stride1, int stride2, int* nbr) {
+                                int max_displacement, int stride1, int stride2, int* nbr, int max_nbr) {
   DTT_REQUIRE(gradOutput && input1 && input2, "correlation backward: null pointer");
   int eoc, eoh, eow;
   if (!dtt_correlation_output_shape(ic, ih, iw, pad_size, kernel_size, max_displacement, stride1, stride2, &eoc, &eoh, &eow))
     return 0;
   DTT_REQUIRE(gob > 0 && goc == eoc && goh == eoh && gow == eow, "correlation backward: gradOutput shape mismatch");
-  DTT_REQUIRE(fast_path(kernel_size, stride1, stride2, max_displacement, nbr) && *nbr <= 5 && ic % 16 == 0,
-              "correlation backward (channels-last): needs kernel_size 1, stride1 == stride2, max_displacement / stride <= 8 and "
-              "channels %% 16 == 0 (got k=%d s1=%d s2=%d d=%d C=%d)", kernel_size, stride1, stride2, max_displacement, ic);
+  DTT_REQUIRE(fast_path(kernel_size, stride1, stride2, max_displacement, nbr) && *nbr <= max_nbr && ic % 16 == 0,
+              "correlation backward (channels-last): needs kernel_size 1, stride1 == stride2, max_displacement / stride <= %d and "
+              "channels %% 16 == 0 (got k=%d s1=%d s2=%d d=%d C=%d)", max_nbr <= 5 ? 8 : 16, kernel_size, stride1, stride2, max_displacement, ic);
   DTT_REQUIRE(((reinterpret_cast<uintptr_t>(input1) | reinterpret_cast<uintptr_t>(input2) | reinterpret_cast<uintptr_t>(gradInput1) |
                 reinterpret_cast<uintptr_t>(gradInput2)) & 15) == 0, "correlation backward (channels-last): pointers must be 16-byte aligned");
   return 1;
 }
 
 // Both gradients for channels-last inputs (n, ih, iw, ic) and channels-last gradInputs on the band-stationary streamed kernels
-// (correlation_bwd.hip; kernel_size 1, stride1 == stride2, max_displacement / stride <= 8, ic % 64 == 0 -- conv3 / conv4 / conv5 of
-// D&T; dtt_correlation_backward_stream_supported).  gradOut[n, d, p] is read at gradOutput[n * g_batch_stride + d * g_ch_stride +
+// (correlation_bwd.hip; kernel_size 1, stride1 == stride2, max_displacement / stride <= 16, ic % 64 == 0 -- conv3 / conv4 / conv5 of
+// D&T at d = 8 and at BASELINE configs[4]'s d = 16; dtt_correlation_backward_stream_supported).  gradOut[n, d, p] is read at gradOutput[n * g_batch_stride + d * g_ch_stride +
 // p * g_px_stride] (p = oy * ow + ox): the reference's (n, D*D, oh, ow) planes (strides D*D*oh*ow, oh*ow, 1) or columns of
 // position-major rows (g_ch_stride = 1, g_px_stride = the row length).  which: 1 = gradInput1 only, 2 = gradInput2 only, 3 = both.
 // workspace: dtt_correlation_backward_workspace_bytes(...) bytes, caller-owned, overwritten.
@@ -1432,7 +1432,7 @@ extern "C" int dtt_correlation_backward_nhwc_strided(const float* gradOutput, lo
               "correlation backward: null gradient pointer / bad selector");
   int nbr = 0;
   if (!backward_nhwc_checks(gradOutput, gob, goc, goh, gow, input1, ic, ih, iw, input2, gradInput1, gradInput2, pad_size, kernel_size,
-                            max_displacement, stride1, stride2, &nbr))
+                            max_displacement, stride1, stride2, &nbr, 9))
     return 0;
   DTT_REQUIRE(dtt_correlation_backward_stream_supported(ic, kernel_size, max_displacement, stride1, stride2),
               "correlation backward (channels-last, streamed): needs channels %% 64 == 0 (got %d); use dtt_correlation_backward_nhwc", ic);
@@ -1453,7 +1453,7 @@ extern "C" int dtt_correlation_backward_nhwc(const float* gradOutput, int gob, i
   DTT_REQUIRE(gradInput1 && gradInput2, "correlation backward: null pointer");
   int nbr = 0;
   if (!backward_nhwc_checks(gradOutput, gob, goc, goh, gow, input1, ic, ih, iw, input2, gradInput1, gradInput2, pad_size, kernel_size,
-                            max_displacement, stride1, stride2, &nbr))
+                            max_displacement, stride1, stride2, &nbr, 5))
     return 0;
   const FastGeom g = make_geom(gob, ic, ih, iw, goc, goh, gow, pad_size, max_displacement, stride1);
   dtt_prof_begin("corr_bwd_op", stream);

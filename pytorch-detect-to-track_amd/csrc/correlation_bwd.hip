@@ -71,6 +71,8 @@ struct BGeom {
   BSeg seg[kMaxSeg];
   int chunk, ngroups;                  // item -> (chunk index = item / tiles_total, tile = item % tiles_total); groups [ci * chunk, ...)
   int use_table;
+  int hoff_y, hoff_x;                  // window radius > 8: this launch covers the NBR x NBR window blocks from block (hoff / 4), i.e. its
+  int accumulate;                      // halo starts hoff pixels further on; launches after the first ADD to the gradient
   int ablate;                          // developer timing experiments (DTT_CORR_BWD_ABLATE): 1 no DMA, 2 no MFMA, 4 no stores, 8 no band loads
   unsigned short table[kTable];
 };
@@ -179,7 +181,7 @@ __global__ __launch_bounds__(kThreads) void corr_bwd_stream_kernel(BGeom g) {
       voff[i] = 0; row_of[i] = 0;
       if (j < HC) {
         const int t = (4 * j) / HC, c = 4 * j - t * HC + (lane >> 4);
-        const int x = min(max(g.origin + it.X0 - g.R + c, 0), g.W - 1);    // out-of-image pixels: any in-bounds address (their band words are zero)
+        const int x = min(max(g.origin + it.X0 - g.R + g.hoff_x + c, 0), g.W - 1);   // out-of-image pixels: any in-bounds address (their band words are zero)
         voff[i] = (unsigned)x * g.sx4 + (unsigned)((lane & 15) << 4);
         row_of[i] = t;
         ++ni;
@@ -189,7 +191,7 @@ __global__ __launch_bounds__(kThreads) void corr_bwd_stream_kernel(BGeom g) {
     const char* obase = reinterpret_cast<const char*>(g.other + img) + (long)it.g0 * (kGC * 4);
     // the next position to issue, tracked incrementally (all scalar): its group's base address, halo block row and ring slot
     int issued = 0, i_hr = 0, i_slot = 0;
-    const int y_first = g.origin + it.Y0 - g.R;
+    const int y_first = g.origin + it.Y0 - g.R + g.hoff_y;
     auto issue_next = [&]() {
       const unsigned dst = lds0 + (unsigned)(i_slot * slot_bytes + lw * 1024);
 #pragma unroll
@@ -321,8 +323,9 @@ __global__ __launch_bounds__(kThreads) void corr_bwd_stream_kernel(BGeom g) {
 #pragma unroll
     for (int r = 0; r < 4; ++r)
       if (st_mask & (1u << r)) {
-        const f32x4 o = {acc0[r] * g.inv, acc1[r] * g.inv, acc2[r] * g.inv, acc3[r] * g.inv};
+        f32x4 o = {acc0[r] * g.inv, acc1[r] * g.inv, acc2[r] * g.inv, acc3[r] * g.inv};
         char* px = dst + (unsigned)r * g.sx4;
+        if (g.accumulate) o = *reinterpret_cast<const f32x4*>(px) + o;   // (window radius > 8: a later quarter of the window, fixed order)
         *reinterpret_cast<f32x4*>(px) = o;
         if (g.cell_fill) {   // strided lattice (conv3): the image pixels between the lattice points have no gradient
           const int ly = it.Y0 + 4 * wy + (lane >> 4) + g.origin, lx = it.X0 + 4 * wx + r + g.origin;
@@ -349,17 +352,20 @@ struct BandGeom {
   float* band;
   int oh, ow, origin, H, W, R, D;
   unsigned d_magic, d2_magic;          // 65536 / D + 1 (exact for n < 4096), 2^32 / (D * D) + 1
+  int qoff_y, qoff_x;                  // window radius > 8: the launch's NBR x NBR window blocks start at block (qoff_y, qoff_x)
   int lo_y[2], lo_x[2], gh[2], gw[2];
   long dir_off[2];                     // floats from `band` to a direction's words
   int batch;
 };
 
-template <int NBR>
+template <int NBR, bool SUB>
 __global__ __launch_bounds__(256) void corr_bwd_band_kernel(BandGeom g) {
   constexpr int NB4 = NBR * NBR * 4;
-  constexpr int MAXD = 4 * (NBR - 1) + 1, MAXD2 = MAXD * MAXD;        // R <= 2 (NBR - 1)
-  constexpr int NIT = (16 * MAXD2 + 255) / 256;
-  __shared__ float G[16 * (MAXD2 + 1)];                               // G[m * (D2 + 1) + d]: gradOut of the pair (target m, displacement d)
+  // the displacements one launch can touch per axis: the whole window (2 R + 1 <= 4 (NBR - 1) + 1), or -- SUB: window radius > 8,
+  // the window covered in quarters of NBR x NBR blocks -- the 4 NBR + 3 rows a quarter's halo spans around a 4 x 4 block
+  constexpr int WIN = SUB ? 4 * NBR + 3 : 4 * (NBR - 1) + 1, WIN2 = WIN * WIN;
+  constexpr int NIT = (16 * WIN2 + 255) / 256;
+  __shared__ float G[16 * (WIN2 + 1)];                                // G[m * ldg + w]: gradOut of the pair (target m, displacement w)
   int blk = blockIdx.x;
   const int n0 = g.batch * g.gh[0] * g.gw[0];
   const int dir = blk >= n0 ? 1 : 0;
@@ -367,12 +373,16 @@ __global__ __launch_bounds__(256) void corr_bwd_band_kernel(BandGeom g) {
   const int gw = g.gw[dir], gh = g.gh[dir];
   const int bx = blk % gw, by = (blk / gw) % gh, n = blk / (gw * gh);
   const int tid = threadIdx.x;
-  const int D2 = g.D * g.D, ldg = D2 + 1;
+  // staged displacement indices: tj in [tj0, tj0 + W), ti in [ti0, ti0 + W)
+  const int W = SUB ? WIN : g.D, W2 = W * W, ldg = W2 + 1;
+  const int tj0 = !SUB ? 0 : (dir ? 2 * g.R - 4 * g.qoff_y - 4 * NBR + 1 : 4 * g.qoff_y - 3);
+  const int ti0 = !SUB ? 0 : (dir ? 2 * g.R - 4 * g.qoff_x - 4 * NBR + 1 : 4 * g.qoff_x - 3);
+  const unsigned w_magic = SUB ? 65536u / (unsigned)WIN + 1u : g.d_magic, w2_magic = SUB ? 0xffffffffu / (unsigned)WIN2 + 1u : g.d2_magic;
   const float* go = g.gout + (long)n * g.g_sb;
   const int y0 = g.lo_y[dir] + 4 * by, x0 = g.lo_x[dir] + 4 * bx;      // the block's first target pixel, output coordinates
   auto in_img = [&](int y, int x) { return y + g.origin >= 0 && y + g.origin < g.H && x + g.origin >= 0 && x + g.origin < g.W; };
   // ---- stage: every (target pixel, displacement) pair of the block once, coalesced along the layout's contiguous axis --
-  // planes (g_sp == 1): the four pixels of a block row are 16 contiguous bytes of a plane; rows (g_sc == 1): a pixel's D2
+  // planes (g_sp == 1): the four pixels of a block row are 16 contiguous bytes of a plane; rows (g_sc == 1): a pixel's
   // displacements are one contiguous run.  Validity is folded in here.
   const bool d_fastest = g.g_sc == 1;
   float v[NIT];
@@ -380,17 +390,20 @@ __global__ __launch_bounds__(256) void corr_bwd_band_kernel(BandGeom g) {
 #pragma unroll
   for (int i = 0; i < NIT; ++i) {
     const int e = tid + i * 256;
-    int m, d;
-    if (d_fastest) { m = mdiv32b(e, g.d2_magic); d = e - m * D2; } else { d = e >> 4; m = e & 15; }
-    const bool live = m < 16 && d < D2;
+    int m, w;
+    if (d_fastest) { m = mdiv32b(e, w2_magic); w = e - m * W2; } else { w = e >> 4; m = e & 15; }
+    const bool live = m < 16 && w < W2;
     const int ty = y0 + (m >> 2), tx = x0 + (m & 3);
-    const int dyi = (int)(((unsigned)min(d, 4095) * g.d_magic) >> 16), dy = dyi - g.R, dx = d - dyi * g.D - g.R;   // (host-made multipliers: no division)
+    const int wy = (int)(((unsigned)min(w, 4095) * w_magic) >> 16);                // (host-made multipliers: no division)
+    const int tj = tj0 + wy, ti = ti0 + w - wy * W;
+    const int dy = tj - g.R, dx = ti - g.R;
     const int py = dir ? ty - dy : ty, px = dir ? tx - dx : tx;       // p: output pixel;  q = p + d: displaced pixel
-    const bool ok = live && py >= 0 && py < g.oh && px >= 0 && px < g.ow && in_img(py, px) && in_img(py + dy, px + dx);
-    const long off = ok ? (long)d * g.g_sc + ((long)py * g.ow + px) * g.g_sp : 0;
+    const bool ok = live && tj >= 0 && tj < g.D && ti >= 0 && ti < g.D && py >= 0 && py < g.oh && px >= 0 && px < g.ow &&
+                    in_img(py, px) && in_img(py + dy, px + dx);
+    const long off = ok ? (long)(tj * g.D + ti) * g.g_sc + ((long)py * g.ow + px) * g.g_sp : 0;
     const float x = go[off];
     v[i] = ok ? x : 0.f;
-    idx[i] = live ? m * ldg + d : -1;
+    idx[i] = live ? m * ldg + w : -1;
   }
 #pragma unroll
   for (int i = 0; i < NIT; ++i)
@@ -405,10 +418,10 @@ __global__ __launch_bounds__(256) void corr_bwd_band_kernel(BandGeom g) {
   for (int qi = 0; qi < NBR; ++qi)
 #pragma unroll
     for (int qj = 0; qj < NBR; ++qj) {
-      const int hy = 4 * qi + t - tyi, hx = 4 * qj + k - txi;                    // halo pixel - target pixel + R
-      const int tj = dir ? 2 * g.R - hy : hy, ti = dir ? 2 * g.R - hx : hx;     // displacement index of the pair
+      const int hy = 4 * (qi + g.qoff_y) + t - tyi, hx = 4 * (qj + g.qoff_x) + k - txi;   // halo pixel - target pixel + R
+      const int tj = dir ? 2 * g.R - hy : hy, ti = dir ? 2 * g.R - hx : hx;               // displacement index of the pair
       const bool in = tj >= 0 && tj < g.D && ti >= 0 && ti < g.D;
-      out[(qi * NBR + qj) * 4 * 64] = in ? Gm[tj * g.D + ti] : 0.f;
+      out[(qi * NBR + qj) * 4 * 64] = in ? Gm[(tj - tj0) * W + (ti - ti0)] : 0.f;
     }
 }
 
@@ -599,7 +612,7 @@ bool target_range(bool wrt2, int oh, int ow, int H, int W, int origin, int R, in
 extern "C" int dtt_correlation_backward_stream_supported(int ic, int kernel_size, int max_displacement, int stride1, int stride2) {
   if (kernel_size != 1 || stride1 != stride2 || stride1 < 1 || max_displacement % stride1 != 0) return 0;
   const int R = max_displacement / stride1;
-  return R >= 1 && R <= 8 && ic % kGC == 0;
+  return R >= 1 && R <= 16 && ic % kGC == 0;   // (radius 9 .. 16: the window in four quarters of 5 x 5 blocks)
 }
 
 // bytes of workspace dtt_correlation_backward_nhwc_strided needs for this geometry (the band words of both directions); 0 where the
@@ -668,12 +681,6 @@ int dtt_corr_bwd_stream(const float* gradOutput, long g_sb, long g_sc, long g_sp
     off += (long)gob * bg.gh[dir] * bg.gw[dir] * nbr * nbr * 4 * 64;
     band_blocks += gob * bg.gh[dir] * bg.gw[dir];
   }
-  if (band_blocks > 0) {
-    if (nbr == 3) hipLaunchKernelGGL((corr_bwd_band_kernel<3>), dim3(band_blocks), dim3(256), 0, stream, bg);
-    else hipLaunchKernelGGL((corr_bwd_band_kernel<5>), dim3(band_blocks), dim3(256), 0, stream, bg);
-    DTT_CHECK_LAUNCH("corr_bwd_band_kernel");
-  }
-
   const size_t bytes = (size_t)gob * ic * ih * iw * sizeof(float);
   // pixels that no lattice point maps to (stride > 1, pad != displacement) keep a zero gradient; on the dense lattice of conv4 /
   // conv5 (stride 1, pad == displacement) both kernels write every element themselves
@@ -681,30 +688,47 @@ int dtt_corr_bwd_stream(const float* gradOutput, long g_sb, long g_sc, long g_sp
   // a strided lattice that the outputs cover completely (conv3: stride 2, pad == displacement): every lattice pixel is a target of
   // both directions and zeroes the stride x stride cell of image pixels behind it -- again every element is written here
   const bool lattice_dense = s > 1 && s <= 4 && g.origin == 0 && goh == g.H && gow == g.W;
-  g.cell_fill = lattice_dense ? 1 : 0;
-  for (int dir = 0; dir < 2; ++dir) {
-    const bool wrt2 = dir == 1;
-    if (!(which & (wrt2 ? 2 : 1))) continue;
-    float* grad = wrt2 ? gradInput2 : gradInput1;
-    if (!dense && !lattice_dense) DTT_REQUIRE(hipMemsetAsync(grad, 0, bytes, stream) == hipSuccess, "correlation backward: memset failed");
-    if (!live[dir]) continue;
-    g.lo_y = g.lo_x = lo[dir]; g.hi_y = hy[dir]; g.hi_x = hx[dir];
-    g.gh = bg.gh[dir]; g.gw = bg.gw[dir];
-    g.band = bg.band + bg.dir_off[dir];
-    const PlanKey key{gob, g.hi_y - g.lo_y + 1, g.hi_x - g.lo_x + 1, nbr, ic / kGC, ncu, getenv("DTT_CORR_BWD_CHUNK") ? atoi(getenv("DTT_CORR_BWD_CHUNK")) : 0};
-    const BPlan* p = cached_plan(key);
-    DTT_REQUIRE(p != nullptr, "correlation backward (streamed): no plan for %d x %d targets, radius %d", key.eh, key.ew, R);
-    g.other = wrt2 ? input1 : input2;
-    g.grad = grad;
-    g.nseg = p->nseg; g.tiles_per_image = p->tiles_per_image; g.tiles_total = p->tiles_total;
-    for (int i = 0; i < kMaxSeg; ++i) g.seg[i] = i < p->nseg ? p->seg[i] : BSeg{0x7fffffff, 0, 0, 1, 1, 1, 1, 1};
-    g.chunk = p->chunk; g.ngroups = p->ngroups; g.use_table = p->use_table;
-    if (p->use_table) memcpy(g.table, p->table.data(), sizeof(unsigned short) * p->items);
-    int ok;
-    // (one kernel for both directions: which gradient a launch computes is a matter of its band words and of `other`)
-    ok = nbr == 3 ? launch_stream<3>(g, p->items, p->lds_bytes, stream) : launch_stream<5>(g, p->items, p->lds_bytes, stream);
-    if (!ok) return 0;
-  }
+  for (int dir = 0; dir < 2; ++dir)
+    if ((which & (dir ? 2 : 1)) && !dense && !lattice_dense)
+      DTT_REQUIRE(hipMemsetAsync(dir ? gradInput2 : gradInput1, 0, bytes, stream) == hipSuccess, "correlation backward: memset failed");
+  // Window radius > 8 (BASELINE configs[4]: d = 16, 33 x 33 displacements = 9 x 9 window blocks, 324 band words per lane): the window
+  // is covered in quarters of NBR x NBR = 5 x 5 blocks -- per quarter one band launch and one launch per direction whose halo starts
+  // 20 pixels further on; the quarters after the first ADD to the gradient (read-modify-write of the same workgroup's own
+  // elements, in a fixed order: deterministic, still no atomics).
+  const int nbr_full = 1 + (R + 1) / 2, nq = (nbr_full + nbr - 1) / nbr;
+  for (int qa = 0; qa < nq; ++qa)
+    for (int qb = 0; qb < nq; ++qb) {
+      const bool first = qa == 0 && qb == 0;
+      bg.qoff_y = qa * nbr; bg.qoff_x = qb * nbr;
+      if (band_blocks > 0) {
+        if (nbr == 3) hipLaunchKernelGGL((corr_bwd_band_kernel<3, false>), dim3(band_blocks), dim3(256), 0, stream, bg);
+        else if (nq == 1) hipLaunchKernelGGL((corr_bwd_band_kernel<5, false>), dim3(band_blocks), dim3(256), 0, stream, bg);
+        else hipLaunchKernelGGL((corr_bwd_band_kernel<5, true>), dim3(band_blocks), dim3(256), 0, stream, bg);
+        DTT_CHECK_LAUNCH("corr_bwd_band_kernel");
+      }
+      g.hoff_y = 4 * bg.qoff_y; g.hoff_x = 4 * bg.qoff_x;
+      g.accumulate = first ? 0 : 1;
+      g.cell_fill = (lattice_dense && first) ? 1 : 0;
+      for (int dir = 0; dir < 2; ++dir) {
+        const bool wrt2 = dir == 1;
+        if (!(which & (wrt2 ? 2 : 1)) || !live[dir]) continue;
+        g.lo_y = g.lo_x = lo[dir]; g.hi_y = hy[dir]; g.hi_x = hx[dir];
+        g.gh = bg.gh[dir]; g.gw = bg.gw[dir];
+        g.band = bg.band + bg.dir_off[dir];
+        const PlanKey key{gob, g.hi_y - g.lo_y + 1, g.hi_x - g.lo_x + 1, nbr, ic / kGC, ncu, getenv("DTT_CORR_BWD_CHUNK") ? atoi(getenv("DTT_CORR_BWD_CHUNK")) : 0};
+        const BPlan* p = cached_plan(key);
+        DTT_REQUIRE(p != nullptr, "correlation backward (streamed): no plan for %d x %d targets, radius %d", key.eh, key.ew, R);
+        g.other = wrt2 ? input1 : input2;
+        g.grad = wrt2 ? gradInput2 : gradInput1;
+        g.nseg = p->nseg; g.tiles_per_image = p->tiles_per_image; g.tiles_total = p->tiles_total;
+        for (int i = 0; i < kMaxSeg; ++i) g.seg[i] = i < p->nseg ? p->seg[i] : BSeg{0x7fffffff, 0, 0, 1, 1, 1, 1, 1};
+        g.chunk = p->chunk; g.ngroups = p->ngroups; g.use_table = p->use_table;
+        if (p->use_table) memcpy(g.table, p->table.data(), sizeof(unsigned short) * p->items);
+        // (one kernel for both directions: which gradient a launch computes is a matter of its band words and of `other`)
+        const int ok = nbr == 3 ? launch_stream<3>(g, p->items, p->lds_bytes, stream) : launch_stream<5>(g, p->items, p->lds_bytes, stream);
+        if (!ok) return 0;
+      }
+    }
   return 1;
 }
 
@@ -713,7 +737,7 @@ int dtt_corr_bwd_stream(const float* gradOutput, long g_sb, long g_sc, long g_sp
 // table is a permutation of the items, and every tile shape fits its ring.
 extern "C" int dtt_correlation_backward_plan_check(int batch, int target_h, int target_w, int window_radius, int channels,
                                                    int compute_units) {
-  if (window_radius < 1 || window_radius > 8 || channels % kGC != 0 || batch < 1 || target_h < 1 || target_w < 1) return 0;
+  if (window_radius < 1 || window_radius > 16 || channels % kGC != 0 || batch < 1 || target_h < 1 || target_w < 1) return 0;
   const int R = window_radius, nbr = R <= 4 ? 3 : 5;
   BPlan p;
   if (!plan_bwd(batch, target_h, target_w, nbr, channels / kGC, compute_units > 0 ? compute_units : 256, &p)) return 0;
@@ -752,7 +776,7 @@ extern "C" int dtt_correlation_backward_plan_check(int batch, int target_h, int 
 // developer / test hook: the plan's shape (work items, channel groups per item, LDS bytes, whether the order rides in the arguments)
 extern "C" int dtt_correlation_backward_plan(int batch, int target_h, int target_w, int window_radius, int channels, int compute_units,
                                              int* items, int* chunk, int* lds_bytes, int* table) {
-  if (window_radius < 1 || window_radius > 8 || channels % kGC != 0) return 0;
+  if (window_radius < 1 || window_radius > 16 || channels % kGC != 0) return 0;
   const int R = window_radius, nbr = R <= 4 ? 3 : 5;
   BPlan p;
   if (!plan_bwd(batch, target_h, target_w, nbr, channels / kGC, compute_units > 0 ? compute_units : 256, &p)) return 0;

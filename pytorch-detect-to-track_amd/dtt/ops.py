@@ -210,7 +210,8 @@ class CorrelationNHWCFunction(Function):
     gradients in either direction.  Geometry: kernel_size 1, stride1 == stride2, max_displacement / stride <= 8,
     channels % 16 == 0 (`Correlation.forward` routes everything else through the NCHW functions)."""
 
-    MAX_RADIUS = 8   # window radius max_displacement / stride the channels-last gradient kernels take
+    MAX_RADIUS = 16  # window radius max_displacement / stride the channels-last kernels take (gradients: channels % 64 == 0; round 1's
+                     # gradient kernels, which take the other channel counts, stop at 8)
 
     @staticmethod
     def supports(input1, input2, kernel_size, max_displacement, stride1, stride2, pad_size=None):
@@ -218,8 +219,10 @@ class CorrelationNHWCFunction(Function):
         through `.contiguous()` + CorrelationFunction.  pad_size None: the caller's padding is not checked (legacy callers)."""
         if not (input1.is_cuda and input1.dtype == torch.float32 and input1.shape == input2.shape and
                 _is_channels_last(input1) and _is_channels_last(input2) and kernel_size == 1 and stride1 == stride2 and
-                stride2 > 0 and 1 <= max_displacement // stride2 <= CorrelationNHWCFunction.MAX_RADIUS and
-                input1.size(1) % 16 == 0):
+                stride2 > 0 and input1.size(1) % 16 == 0):
+            return False
+        radius = max_displacement // stride2
+        if not 1 <= radius <= (CorrelationNHWCFunction.MAX_RADIUS if input1.size(1) % 64 == 0 else 8):
             return False
         # the kernels address the stride lattice: displacement and (displacement - padding) must be multiples of the stride
         if max_displacement % stride2 != 0 or (pad_size is not None and (max_displacement - pad_size) % stride2 != 0):

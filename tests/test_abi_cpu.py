@@ -143,11 +143,13 @@ def test_correlation_streamed_backward_plans_without_gpu():
                       64 * int(rs.randint(1, 33)), int(rs.choice([1, 8, 64, 104, 240, 256, 304]))))
     for c in cases:
         assert L.dtt_correlation_backward_plan_check(*c) == 1, c
-    assert L.dtt_correlation_backward_plan_check(1, 8, 8, 9, 64, 256) == 0      # radius > 8: not these kernels
+    assert L.dtt_correlation_backward_plan_check(1, 8, 8, 12, 64, 256) == 1     # radius 9 .. 16: the same launches, once per window quarter
+    assert L.dtt_correlation_backward_plan_check(1, 8, 8, 17, 64, 256) == 0     # radius > 16: not these kernels
     assert L.dtt_correlation_backward_plan_check(1, 8, 8, 4, 48, 256) == 0      # channels % 64 != 0: round 1's kernels
     assert L.dtt_correlation_backward_stream_supported(2048, 1, 8, 1, 1) == 1 and L.dtt_correlation_backward_stream_supported(512, 1, 8, 2, 2) == 1
     assert L.dtt_correlation_backward_stream_supported(80, 1, 8, 1, 1) == 0 and L.dtt_correlation_backward_stream_supported(64, 3, 8, 1, 1) == 0
-    assert L.dtt_correlation_backward_stream_supported(64, 1, 16, 1, 1) == 0
+    assert L.dtt_correlation_backward_stream_supported(64, 1, 16, 1, 1) == 1 and L.dtt_correlation_backward_stream_supported(64, 1, 17, 1, 1) == 0
+    assert L.dtt_correlation_backward_workspace_bytes(1, 1024, 36, 63, 16, 1, 16, 1, 1) == 2 * 9 * 16 * 100 * 64 * 4   # d = 16: one quarter at a time
     # workspace: the band words of both directions, NBR^2 * 4 * 64 floats per 4 x 4 target block
     assert L.dtt_correlation_backward_workspace_bytes(2, 2048, 38, 67, 8, 1, 8, 1, 1) == 2 * 2 * 10 * 17 * 100 * 64 * 4
     assert L.dtt_correlation_backward_workspace_bytes(2, 80, 38, 67, 8, 1, 8, 1, 1) == 0

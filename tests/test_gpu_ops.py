@@ -296,6 +296,40 @@ def test_correlation_streamed_backward_many_groups_per_work_item(dev, monkeypatc
     assert torch.equal(ga, ga2) and torch.equal(gb, gb2)     # run-to-run identical
 
 
+@pytest.mark.parametrize("case", [(1, 64, 20, 27, 16, 1, 16, 1, 1),     # BASELINE configs[4]'s d = 16: 33 x 33 window, four quarters
+                                  (2, 128, 13, 30, 12, 1, 12, 1, 1),    # R = 12: the last quarter holds two of its five block rows
+                                  (1, 64, 36, 63, 16, 1, 16, 1, 1),     # the configs[4] map size
+                                  (1, 64, 41, 37, 20, 1, 20, 2, 2),     # stride-2 lattice, R = 10
+                                  (1, 64, 17, 19, 9, 1, 9, 1, 1),       # R = 9: the second quarter is almost empty
+                                  (1, 64, 24, 24, 10, 1, 16, 1, 1)])    # pad < displacement at R = 16
+def test_correlation_streamed_backward_window_radius_above_8(dev, case):
+    """Window radius 9 .. 16 on channels-last maps (the training step of BASELINE configs[4] stays channels-last): the
+    window is covered in four quarters of 5 x 5 blocks, the quarters after the first add to the gradient in a fixed order.
+    dtt.ops.Correlation under autograd: forward and both gradients against the oracle, gradients channels-last, run-to-run
+    identical."""
+    from dtt.ops import Correlation, CorrelationNHWCFunction
+    B, C, H, W, pad, k, d, s1, s2 = case
+    rng = np.random.RandomState(sum(case) + 3)
+    x1 = rng.normal(size=(B, C, H, W)).astype(np.float32)
+    x2 = rng.normal(size=(B, C, H, W)).astype(np.float32)
+    layer = Correlation(pad, k, d, s1, s2)
+    t1 = cu(x1, dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    t2 = cu(x2, dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    assert CorrelationNHWCFunction.supports(t1, t2, k, d, s1, s2, pad)
+    out = layer(t1, t2)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), O.correlation_forward(x1, x2, pad, k, d, s1, s2), rtol=0, atol=1e-4)
+    gout = rng.normal(size=tuple(out.shape)).astype(np.float32)
+    out.backward(cu(gout, dev))
+    for t in (t1, t2):
+        assert t.grad.is_contiguous(memory_format=torch.channels_last) and t.grad.shape == t.shape
+    g1, g2 = O.correlation_backward(gout, x1, x2, pad, k, d, s1, s2)
+    np.testing.assert_allclose(t1.grad.cpu().numpy(), g1, rtol=0, atol=1e-4)
+    np.testing.assert_allclose(t2.grad.cpu().numpy(), g2, rtol=0, atol=1e-4)
+    r1, r2 = t1.detach().clone().requires_grad_(True), t2.detach().clone().requires_grad_(True)
+    layer(r1, r2).backward(cu(gout, dev))
+    assert torch.equal(r1.grad, t1.grad) and torch.equal(r2.grad, t2.grad)
+
+
 @pytest.mark.parametrize("case", [c for c in CORR_CL_CASES if c[1] % 64 == 0])
 def test_correlation_streamed_backward_rows_layout_and_single_gradients(dev, case):
     """dtt_correlation_backward_nhwc_strided reading gradOut as columns of position-major rows (the gradient of the tracking
