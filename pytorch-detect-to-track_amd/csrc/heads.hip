@@ -95,7 +95,7 @@ __device__ __forceinline__ int pass_begin(const HeadGeom& g, int ntg, int p) {
 // chunk s: the first operands of chunk s+1 are fetched underneath that segment, so the matrix pipe does not drain at
 // chunk boundaries.  Three LDS stages make that legal (after barrier s+1 the loaders fill stage s+2 while stages s and
 // s+1 are both still being read).
-template <int TPX, int NTW, int CNT, bool PIN, int NSTAGE>
+template <int TPX, int NTW, int CNT, bool PIN, int NSTAGE, bool RPN>
 __device__ __forceinline__ void head_pass(const HeadGeom& g, const float* lds, int s_begin, int tile0, int t0, int cnt,
                                           int p0, int lane, int wave) {
   constexpr int XROWS = TPX * 16;
@@ -183,7 +183,7 @@ __device__ __forceinline__ void head_pass(const HeadGeom& g, const float* lds, i
   for (int kc = 0; kc + 1 < KC; ++kc) { do_step(std::false_type{}, kc); pin(); }
   do_step(std::true_type{}, KC - 1);
   HEAD_STAMP(wave, 400 + 4 * (s_begin / KC));
-  if (g.epilogue == 1) {
+  if constexpr (RPN) {
     // RPN heads: pairwise softmax in registers (a lane holds two whole (bg, fg) pairs), NCHW planes out -- the layout
     // proposal_select_sort / proposal_decode read; 16 consecutive pixels per lane group = 64-byte runs
 #pragma unroll
@@ -218,14 +218,20 @@ __device__ __forceinline__ void head_pass(const HeadGeom& g, const float* lds, i
       }
     }
   } else {
+    // (one wave-uniform base + 32-bit per-lane byte offsets, M * ldc * 4 < 2^32 is checked by the host: forty 64-bit row pointers
+    //  per lane were what the 256-register wide configuration spilled)
+    char* ob = reinterpret_cast<char*>(g.out);
+    const unsigned ldc4 = (unsigned)(g.ldc * 4);
+    const unsigned row0 = (unsigned)(p0 + l15);
 #pragma unroll
     for (int t = 0; t < CNT; ++t) {
       if (t < cnt && !(g.ablate & 4)) {
         const int col = (tile0 + t) * 16 + 4 * lg;
+        const unsigned off0 = row0 * ldc4 + (unsigned)col * 4u;
 #pragma unroll
         for (int pt = 0; pt < TPX; ++pt) {
           const int row = p0 + pt * 16 + l15;
-          if (row < g.M && col < g.n_store) *reinterpret_cast<f32x4*>(g.out + (long)row * g.ldc + col) = acc[t][pt];
+          if (row < g.M && col < g.n_store) *reinterpret_cast<f32x4*>(ob + (off0 + (unsigned)(pt * 16) * ldc4)) = acc[t][pt];
         }
       }
     }
@@ -235,7 +241,7 @@ __device__ __forceinline__ void head_pass(const HeadGeom& g, const float* lds, i
 
 // 4 compute waves (one per SIMD) + NLOAD loader waves.  Loaders move chunk s+1 global -> LDS by LDS-DMA while the compute
 // waves run the MFMAs of chunk s; one barrier per chunk, three LDS stages (see head_pass).
-template <int TPX, int NTW, int NLOAD, bool PIN, int NSTAGE>
+template <int TPX, int NTW, int NLOAD, bool PIN, int NSTAGE, bool RPN>
 __global__ __launch_bounds__((4 + NLOAD) * 64) void head_gemm_kernel(HeadGeom g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int XROWS = TPX * 16;
@@ -349,7 +355,7 @@ __global__ __launch_bounds__((4 + NLOAD) * 64) void head_gemm_kernel(HeadGeom g)
     const int cmax = (L + 3) >> 2;   // workgroup-uniform tiles per wave in this pass
     const int t0 = part_begin(L, 4, wave), cnt = part_begin(L, 4, wave + 1) - t0;
     const int tile0 = nt_lo + pb + t0;
-#define DTT_HEAD_PASS(C) head_pass<TPX, NTW, C, PIN, NSTAGE>(g, lds, s_begin, tile0, t0, cnt, p0, lane, wave)
+#define DTT_HEAD_PASS(C) head_pass<TPX, NTW, C, PIN, NSTAGE, RPN>(g, lds, s_begin, tile0, t0, cnt, p0, lane, wave)
     if constexpr (NTW >= 7) { if (cmax == 7) { DTT_HEAD_PASS(7); continue; } }
     if constexpr (NTW >= 6) { if (cmax == 6) { DTT_HEAD_PASS(6); continue; } }
     if constexpr (NTW >= 5) { if (cmax == 5) { DTT_HEAD_PASS(5); continue; } }
@@ -538,10 +544,11 @@ __global__ void psroi_pm_edges_kernel(const float* __restrict__ rois, int num_ro
   }
 }
 
-template <int CP>
+template <int CP, int POOLED>
 __global__ __launch_bounds__(256) void psroi_pm_bwd_kernel(const float* __restrict__ gvote, const int* __restrict__ edges, int num_rois,
-                                                           int output_dim, int pooled, int height, int width, long pixel_stride,
+                                                           int output_dim, int pooled_rt, int height, int width, long pixel_stride,
                                                            float* __restrict__ gmap, const unsigned* __restrict__ range) {
+  const int pooled = POOLED > 0 ? POOLED : pooled_rt;   // (compile-time 7: the edge words of a RoI are requested in one batch)
   constexpr int kMaxHits = 2048;                       // (RoI, bin, weight) triples per chunk of 256 RoIs: at most 4 x 4 bins each in theory,
   __shared__ int hit_r[kMaxHits];                      // 2 x 2 in practice; a chunk that overflows is split (see below)
   __shared__ short hit_bin[kMaxHits];
@@ -567,9 +574,20 @@ __global__ __launch_bounds__(256) void psroi_pm_bwd_kernel(const float* __restri
     if (r < r_end && e[4 * pooled * ns] == b) {
       // bins are intervals with non-decreasing edges: the ph whose [hstart, hend) contains h form a contiguous run
       ph_lo = pooled; pw_lo = pooled;
-      for (int k = 0; k < pooled; ++k) {
-        if (e[k * ns] <= h && h < e[(pooled + k) * ns]) { ph_lo = min(ph_lo, k); ph_hi = k; }
-        if (e[(2 * pooled + k) * ns] <= w && w < e[(3 * pooled + k) * ns]) { pw_lo = min(pw_lo, k); pw_hi = k; }
+      if constexpr (POOLED > 0) {
+        int ev[4 * POOLED];
+#pragma unroll
+        for (int k = 0; k < 4 * POOLED; ++k) ev[k] = e[k * ns];
+#pragma unroll
+        for (int k = 0; k < POOLED; ++k) {
+          if (ev[k] <= h && h < ev[POOLED + k]) { ph_lo = min(ph_lo, k); ph_hi = k; }
+          if (ev[2 * POOLED + k] <= w && w < ev[3 * POOLED + k]) { pw_lo = min(pw_lo, k); pw_hi = k; }
+        }
+      } else {
+        for (int k = 0; k < pooled; ++k) {
+          if (e[k * ns] <= h && h < e[(pooled + k) * ns]) { ph_lo = min(ph_lo, k); ph_hi = k; }
+          if (e[(2 * pooled + k) * ns] <= w && w < e[(3 * pooled + k) * ns]) { pw_lo = min(pw_lo, k); pw_hi = k; }
+        }
       }
       if (ph_hi >= 0 && pw_hi >= 0) nh = (ph_hi - ph_lo + 1) * (pw_hi - pw_lo + 1);
     }
@@ -640,21 +658,21 @@ __global__ __launch_bounds__(256) void psroi_pm_bwd_kernel(const float* __restri
   for (int i = tid; i < nbins * CP; i += 256) dst[i] = accum[i];
 }
 
-template <int TPX, int NTW, int NLOAD, bool PIN, int NSTAGE = 3>
+template <int TPX, int NTW, int NLOAD, bool PIN, int NSTAGE = 3, bool RPN = false>
 int launch_head(const HeadGeom& g, hipStream_t stream) {
   constexpr size_t lds = (size_t)NSTAGE * (TPX * 16 + 4 * NTW * 16) * kBK * sizeof(float);
   static_assert(lds <= 160 * 1024, "three stages must fit the CU's LDS");
   static DttDeviceOnce once;
   bool& raised_here = once.here();
   if (lds > 64 * 1024 && !raised_here) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(head_gemm_kernel<TPX, NTW, NLOAD, PIN, NSTAGE>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(head_gemm_kernel<TPX, NTW, NLOAD, PIN, NSTAGE, RPN>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     DTT_REQUIRE(e == hipSuccess, "head_gemm: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
     raised_here = true;
   }
-  const char* tag = g.epilogue == 1 ? "rpn_head_gemm" : "head_gemm";   // (the RPN launch carries its own timing tag)
+  const char* tag = RPN ? "rpn_head_gemm" : "head_gemm";   // (the RPN launch carries its own timing tag)
   dtt_prof_begin(tag, stream);
-  hipLaunchKernelGGL((head_gemm_kernel<TPX, NTW, NLOAD, PIN, NSTAGE>), dim3(g.n_groups * g.strips), dim3((4 + NLOAD) * 64), lds, stream, g);
+  hipLaunchKernelGGL((head_gemm_kernel<TPX, NTW, NLOAD, PIN, NSTAGE, RPN>), dim3(g.n_groups * g.strips), dim3((4 + NLOAD) * 64), lds, stream, g);
   dtt_prof_end(tag, stream);
   DTT_CHECK_LAUNCH("head_gemm");
   return 1;
@@ -714,6 +732,8 @@ static int head_gemm_launch(HeadGeom g, const float* x, long ldx, int M, int K, 
     while (dtt_cdiv(g.nt_total, g.n_groups) > kMaxPasses * 4 * ntw) ++g.n_groups;
     plan_passes(g, dtt_cdiv(g.nt_total, g.n_groups), ntw, passes);
     (void)ntw_env; (void)pin_env;
+    DTT_REQUIRE(g.epilogue == 0, "rpn_head_gemm: %d packed output rows exceed the narrow configurations (<= 256) the RPN epilogue is built for", g.nt_total * 16);
+    DTT_REQUIRE((unsigned long long)M * (unsigned long long)ldc * 4ull < (1ull << 32), "head_gemm: output of %d x %ld floats exceeds the 32-bit store offsets", M, ldc);
     return nload == 2 ? launch_head<10, 4, 2, false>(g, stream) : launch_head<10, 4, 4, false>(g, stream);
   }
   static const int narrow_cfg = getenv("DTT_HEAD_NARROW") ? atoi(getenv("DTT_HEAD_NARROW")) : 61;   // developer A/B switch (24 = the small-M form)
@@ -728,6 +748,12 @@ static int head_gemm_launch(HeadGeom g, const float* x, long ldx, int M, int K, 
     g.strips = dtt_cdiv(M, tpx * 16);
     g.n_groups = dtt_cdiv(g.nt_total, 4);
     plan_passes(g, dtt_cdiv(g.nt_total, g.n_groups), 1, 1);
+    DTT_REQUIRE((unsigned long long)M * (unsigned long long)ldc * 4ull < (1ull << 32), "head_gemm: output of %d x %ld floats exceeds the 32-bit store offsets", M, ldc);
+    if (g.epilogue == 1) {   // the RPN's heads: the epilogue with the pairwise softmax is compiled into these instantiations only
+      if (tpx == 3) return launch_head<3, 1, 2, false, 4, true>(g, stream);
+      if (tpx == 6) return launch_head<6, 1, 2, false, 4, true>(g, stream);
+      return launch_head<5, 1, 2, false, 4, true>(g, stream);
+    }
     if (tpx == 3) return launch_head<3, 1, 2, false, 4>(g, stream);
     if (tpx == 6) return launch_head<6, 1, 2, false, 4>(g, stream);
     return launch_head<5, 1, 2, false, 4>(g, stream);
@@ -738,6 +764,8 @@ static int head_gemm_launch(HeadGeom g, const float* x, long ldx, int M, int K, 
   g.strips = dtt_cdiv(M, TPX * 16);
   g.n_groups = 1;
   plan_passes(g, g.nt_total, NTW, 1);
+  DTT_REQUIRE((unsigned long long)M * (unsigned long long)ldc * 4ull < (1ull << 32), "head_gemm: output of %d x %ld floats exceeds the 32-bit store offsets", M, ldc);
+  if (g.epilogue == 1) return launch_head<TPX, NTW, 1, false, 3, true>(g, stream);
   return launch_head<TPX, NTW, 1, false>(g, stream);
 }
 
@@ -846,12 +874,12 @@ extern "C" int dtt_psroi_pm_backward(const float* grad_vote, const float* rois, 
     DTT_CHECK_LAUNCH("psroi_pm_edges");
   }
   const int npx = batch_size * height * width;
-  if (cp == 32)
-    hipLaunchKernelGGL((psroi_pm_bwd_kernel<32>), dim3(npx), dim3(256), lds, stream, grad_vote, edges, num_rois, output_dim, pooled, height,
-                       width, pixel_stride, grad_map, range);
-  else
-    hipLaunchKernelGGL((psroi_pm_bwd_kernel<4>), dim3(npx), dim3(256), lds, stream, grad_vote, edges, num_rois, output_dim, pooled, height,
-                       width, pixel_stride, grad_map, range);
+#define DTT_PMB_LAUNCH(CPV, PV)                                                                                                  \
+  hipLaunchKernelGGL((psroi_pm_bwd_kernel<CPV, PV>), dim3(npx), dim3(256), lds, stream, grad_vote, edges, num_rois, output_dim, pooled, \
+                     height, width, pixel_stride, grad_map, range)
+  if (cp == 32) { if (pooled == 7) DTT_PMB_LAUNCH(32, 7); else DTT_PMB_LAUNCH(32, 0); }
+  else { if (pooled == 7) DTT_PMB_LAUNCH(4, 7); else DTT_PMB_LAUNCH(4, 0); }
+#undef DTT_PMB_LAUNCH
   DTT_CHECK_LAUNCH("psroi_pm_bwd");
   return 1;
 }
