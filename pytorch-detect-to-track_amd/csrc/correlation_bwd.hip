@@ -277,65 +277,69 @@ __global__ __launch_bounds__(kThreads) void corr_bwd_stream_kernel(BGeom g) {
     else landed3<LEFT>(bv[buf][0], bv[buf][1], bv[buf][2]);                                                            \
   } while (0)
   int r_slot = wy % S;                                // ring slot of the position this wave reads: wave row wy runs wy positions ahead
-  for (int gi = 0; gi < it.ng; ++gi) {
+  // Measured and dropped (A/B builds on one box, conv5 / conv4 per gradient): a wave row that is not the tile's last requesting
+  // the next step's first burst BEFORE the barrier -- its position has landed already -- so that it starts the step with MFMAs.
+  // As a run-time flag inside the loop: 44 registers spilled (two register states merge at every step).  As a second copy of the
+  // loop chosen once per wave: no spills in the steps, 93.4 / 52.2 us against 91.9 / 50.8 without -- the 24 bytes of scratch it
+  // does need are reloaded in the first step of every group.
+  {
+    for (int gi = 0; gi < it.ng; ++gi) {
 #pragma unroll
-    for (int qi = 0; qi < NBR; ++qi) {
-      // nothing of this wave's is outstanding at a barrier: band loads (first step) and stores (later groups) have been issued
-      // long before, LDS reads are consumed -- the builtin tells the compiler so, and its own waits stay out of the loop
-      if (qi == 0 && gi == 0) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the band has arrived
-      if (tall && qi == 0 && gi > 0) wg_barrier_b();
-      wg_barrier_b();
-      if (do_mfma) {
-        const unsigned sp = rd_lane + (unsigned)(r_slot * slot_bytes);
-        auto mm = [&](int t, int buf) {
+      for (int qi = 0; qi < NBR; ++qi) {
+        // nothing of this wave's is outstanding at a barrier that the compiler knows of: band loads (first step) and stores
+        // (later groups) were issued long before -- the builtin tells it so, and its own waits stay out of the loop
+        if (qi == 0 && gi == 0) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the band has arrived
+        if (tall && qi == 0 && gi > 0) wg_barrier_b();
+        wg_barrier_b();
+        if (do_mfma) {
+          const unsigned sp = rd_lane + (unsigned)(r_slot * slot_bytes);
+          auto mm = [&](int t, int buf) {
 #pragma unroll
-          for (int qj = 0; qj < NBR; ++qj) {
-            const float a = band[(qi * NBR + qj) * 4 + t];
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[buf][qj][0], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[buf][qj][1], acc1, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[buf][qj][2], acc2, 0, 0, 0);
-            acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[buf][qj][3], acc3, 0, 0, 0);
-          }
-        };
-        // one burst of NBR ds_read_b128 per halo row t (4 MFMAs per read), issued one row ahead of the MFMAs that consume it.
-        // (Measured and dropped: a wave row that is not the tile's last requesting the next step's first bursts BEFORE the barrier
-        //  -- its position has landed already -- so that it starts the step with MFMAs: the operands then live across the barrier
-        //  and the control-flow merge costs registers the kernel does not have at 168: 44 spilled, band words reloaded in the loop.)
-        __builtin_amdgcn_sched_barrier(0);
-        rd(sp, 0); rd(sp + row, 1);
-        DTT_LANDED(0, NBR); mm(0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        rd(sp + 2 * row, 0);
-        DTT_LANDED(1, NBR); mm(1, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        rd(sp + 3 * row, 1);
-        DTT_LANDED(0, NBR); mm(2, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        DTT_LANDED(1, 0); mm(3, 1);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if (++r_slot == S) r_slot = 0;
-    }
-    r_slot += th - 1;                                 // the next group starts th block rows further on
-    if (r_slot >= S) r_slot -= S;
-    // the group is complete: D[m = 4 * (lane / 16) + r][n = lane % 16] of accumulator s is channel 4 n + s of target pixel m
-    char* dst = gbase + (long)gi * (kGC * 4) + st_base;
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-      if (st_mask & (1u << r)) {
-        f32x4 o = {acc0[r] * g.inv, acc1[r] * g.inv, acc2[r] * g.inv, acc3[r] * g.inv};
-        char* px = dst + (unsigned)r * g.sx4;
-        if (g.accumulate) o = *reinterpret_cast<const f32x4*>(px) + o;   // (window radius > 8: a later quarter of the window, fixed order)
-        *reinterpret_cast<f32x4*>(px) = o;
-        if (g.cell_fill) {   // strided lattice (conv3): the image pixels between the lattice points have no gradient
-          const int ly = it.Y0 + 4 * wy + (lane >> 4) + g.origin, lx = it.X0 + 4 * wx + r + g.origin;
-          const int ch = min(g.stride, g.ih - ly * g.stride), cw = min(g.stride, g.iw - lx * g.stride);
-          for (int cy = 0; cy < ch; ++cy)
-            for (int cx = 0; cx < cw; ++cx)
-              if (cy | cx) *reinterpret_cast<f32x4*>(px + (unsigned)cy * g.py4 + (unsigned)cx * g.px4) = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int qj = 0; qj < NBR; ++qj) {
+              const float a = band[(qi * NBR + qj) * 4 + t];
+              acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[buf][qj][0], acc0, 0, 0, 0);
+              acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[buf][qj][1], acc1, 0, 0, 0);
+              acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[buf][qj][2], acc2, 0, 0, 0);
+              acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[buf][qj][3], acc3, 0, 0, 0);
+            }
+          };
+          // one burst of NBR ds_read_b128 per halo row t (4 MFMAs per read), issued one row ahead of the MFMAs that consume it
+          __builtin_amdgcn_sched_barrier(0);
+          rd(sp, 0); rd(sp + row, 1);
+          DTT_LANDED(0, NBR); mm(0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          rd(sp + 2 * row, 0);
+          DTT_LANDED(1, NBR); mm(1, 1);
+          __builtin_amdgcn_sched_barrier(0);
+          rd(sp + 3 * row, 1);
+          DTT_LANDED(0, NBR); mm(2, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          DTT_LANDED(1, 0); mm(3, 1);
+          __builtin_amdgcn_sched_barrier(0);
         }
+        if (++r_slot == S) r_slot = 0;
       }
-    acc0 = acc1 = acc2 = acc3 = f32x4{0.f, 0.f, 0.f, 0.f};
+      r_slot += th - 1;                                 // the next group starts th block rows further on
+      if (r_slot >= S) r_slot -= S;
+      // the group is complete: D[m = 4 * (lane / 16) + r][n = lane % 16] of accumulator s is channel 4 n + s of target pixel m
+      char* dst = gbase + (long)gi * (kGC * 4) + st_base;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (st_mask & (1u << r)) {
+          f32x4 o = {acc0[r] * g.inv, acc1[r] * g.inv, acc2[r] * g.inv, acc3[r] * g.inv};
+          char* px = dst + (unsigned)r * g.sx4;
+          if (g.accumulate) o = *reinterpret_cast<const f32x4*>(px) + o;   // (window radius > 8: a later quarter of the window, fixed order)
+          *reinterpret_cast<f32x4*>(px) = o;
+          if (g.cell_fill) {   // strided lattice (conv3): the image pixels between the lattice points have no gradient
+            const int ly = it.Y0 + 4 * wy + (lane >> 4) + g.origin, lx = it.X0 + 4 * wx + r + g.origin;
+            const int ch = min(g.stride, g.ih - ly * g.stride), cw = min(g.stride, g.iw - lx * g.stride);
+            for (int cy = 0; cy < ch; ++cy)
+              for (int cx = 0; cx < cw; ++cx)
+                if (cy | cx) *reinterpret_cast<f32x4*>(px + (unsigned)cy * g.py4 + (unsigned)cx * g.px4) = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+        }
+      acc0 = acc1 = acc2 = acc3 = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
   }
 }
 #undef DTT_LANDED
@@ -353,6 +357,7 @@ struct BandGeom {
   int oh, ow, origin, H, W, R, D;
   unsigned d_magic, d2_magic;          // 65536 / D + 1 (exact for n < 4096), 2^32 / (D * D) + 1
   int qoff_y, qoff_x;                  // window radius > 8: the launch's NBR x NBR window blocks start at block (qoff_y, qoff_x)
+  int ablate;                          // developer timing experiments (DTT_CORR_BWD_ABLATE): 32 no gradOut loads, 64 no band stores
   int lo_y[2], lo_x[2], gh[2], gw[2];
   long dir_off[2];                     // floats from `band` to a direction's words
   int batch;
@@ -379,6 +384,7 @@ __global__ __launch_bounds__(256) void corr_bwd_band_kernel(BandGeom g) {
   const int ti0 = !SUB ? 0 : (dir ? 2 * g.R - 4 * g.qoff_x - 4 * NBR + 1 : 4 * g.qoff_x - 3);
   const unsigned w_magic = SUB ? 65536u / (unsigned)WIN + 1u : g.d_magic, w2_magic = SUB ? 0xffffffffu / (unsigned)WIN2 + 1u : g.d2_magic;
   const float* go = g.gout + (long)n * g.g_sb;
+  const unsigned sc32 = (unsigned)g.g_sc, sp32 = (unsigned)g.g_sp;
   const int y0 = g.lo_y[dir] + 4 * by, x0 = g.lo_x[dir] + 4 * bx;      // the block's first target pixel, output coordinates
   auto in_img = [&](int y, int x) { return y + g.origin >= 0 && y + g.origin < g.H && x + g.origin >= 0 && x + g.origin < g.W; };
   // ---- stage: every (target pixel, displacement) pair of the block once, coalesced along the layout's contiguous axis --
@@ -400,8 +406,9 @@ __global__ __launch_bounds__(256) void corr_bwd_band_kernel(BandGeom g) {
     const int py = dir ? ty - dy : ty, px = dir ? tx - dx : tx;       // p: output pixel;  q = p + d: displaced pixel
     const bool ok = live && tj >= 0 && tj < g.D && ti >= 0 && ti < g.D && py >= 0 && py < g.oh && px >= 0 && px < g.ow &&
                     in_img(py, px) && in_img(py + dy, px + dx);
-    const long off = ok ? (long)(tj * g.D + ti) * g.g_sc + ((long)py * g.ow + px) * g.g_sp : 0;
-    const float x = go[off];
+    // (32-bit offsets: one image's gradOut stays below 2^31 floats -- host-checked)
+    const unsigned off = ok ? (unsigned)(tj * g.D + ti) * sc32 + (unsigned)(py * g.ow + px) * sp32 : 0u;
+    const float x = (g.ablate & 32) ? 1.f : go[off];
     v[i] = ok ? x : 0.f;
     idx[i] = live ? m * ldg + w : -1;
   }
@@ -421,7 +428,8 @@ __global__ __launch_bounds__(256) void corr_bwd_band_kernel(BandGeom g) {
       const int hy = 4 * (qi + g.qoff_y) + t - tyi, hx = 4 * (qj + g.qoff_x) + k - txi;   // halo pixel - target pixel + R
       const int tj = dir ? 2 * g.R - hy : hy, ti = dir ? 2 * g.R - hx : hx;               // displacement index of the pair
       const bool in = tj >= 0 && tj < g.D && ti >= 0 && ti < g.D;
-      out[(qi * NBR + qj) * 4 * 64] = in ? Gm[(tj - tj0) * W + (ti - ti0)] : 0.f;
+      const float bw = in ? Gm[(tj - tj0) * W + (ti - ti0)] : 0.f;
+      if (!(g.ablate & 64) || bw == 12345.f) out[(qi * NBR + qj) * 4 * 64] = bw;
     }
 }
 
@@ -642,6 +650,11 @@ int dtt_corr_bwd_stream(const float* gradOutput, long g_sb, long g_sc, long g_sp
   const int s = stride, R = max_displacement / s;
   DTT_REQUIRE((max_displacement - pad_size) % s == 0, "correlation backward (channels-last): displacement - padding must be a multiple of the stride");
   DTT_REQUIRE((long)ih * iw * ic * 4 < 0xffffffffl, "correlation backward (channels-last): one image exceeds the 32-bit offset range");
+  {
+    const long D2l = (long)(2 * R + 1) * (2 * R + 1), npx = (long)goh * gow;
+    DTT_REQUIRE(g_sc >= 0 && g_sp >= 0 && (D2l - 1) * g_sc + (npx - 1) * g_sp < (1l << 31),
+                "correlation backward (channels-last): gradOutput strides exceed the 32-bit offset range of one image");
+  }
   const size_t ws_need = dtt_correlation_backward_workspace_bytes(gob, ic, ih, iw, pad_size, 1, max_displacement, s, s);
   DTT_REQUIRE(workspace && workspace_bytes >= ws_need && (reinterpret_cast<uintptr_t>(workspace) & 3) == 0,
               "correlation backward (channels-last): workspace of %zu bytes needed (dtt_correlation_backward_workspace_bytes), got %zu",
@@ -668,6 +681,7 @@ int dtt_corr_bwd_stream(const float* gradOutput, long g_sb, long g_sc, long g_sp
   bg.band = static_cast<float*>(workspace);
   bg.oh = goh; bg.ow = gow; bg.origin = g.origin; bg.H = g.H; bg.W = g.W; bg.R = R; bg.D = g.D; bg.batch = gob;
   bg.d_magic = 65536u / (unsigned)g.D + 1u; bg.d2_magic = 0xffffffffu / (unsigned)(g.D * g.D) + 1u;
+  bg.ablate = ablate;
   int lo[2], hy[2], hx[2];
   bool live[2];
   long off = 0;
