@@ -142,3 +142,36 @@ def test_replicas_fold_identical_constants():
         assert p.exitcode == 0
     sigs = [g[0] for g in got]
     assert sigs[0] == sigs[1] and len(sigs[0]) > 100
+
+
+def test_force_buckets_at_world_one_matches_the_plain_step():
+    """DataParallelSnippets(force_buckets=True) at world size 1 (what bench.py's secondary.train_step and the 1-rank RCCL test on the
+    GPU box run): the hooks and flat buckets of the N-rank path without a process group -- gradients bit-identical to the plain
+    step over two steps (buckets are reused), views laid out in the buckets, unused parameters zero-filled, no averaging."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "pytorch-detect-to-track_amd")]
+    from dtt.dist import DataParallelSnippets
+    assert not dist.is_initialized()
+    g = torch.Generator().manual_seed(0)
+    data = torch.randn(6, 3, 8, 8, generator=g)
+    torch.manual_seed(5)
+    plain, bucketed = Toy(), Toy()
+    bucketed.load_state_dict(plain.state_dict())
+    dp0 = DataParallelSnippets(plain, 1)
+    dp1 = DataParallelSnippets(bucketed, 1, bucket_bytes=1024, force_buckets=True)
+    assert not dp0.bucketed and dp1.bucketed and len(dp1._buckets) >= 2 and dp1.bucket_bytes_total() > 0
+    assert dp1.time_allreduce_ms() is None                     # no process group: nothing to time
+    for step in range(2):
+        for dp in (dp0, dp1):
+            dp.zero_grad(set_to_none=True)
+            dp(data).sum().backward()
+            dp.finish_gradients()
+        for (n, p), (_, q) in zip(plain.named_parameters(), bucketed.named_parameters()):
+            if not p.requires_grad:
+                continue
+            if p.grad is None:                                 # never used: the bucketed path hands the optimizer zeros
+                assert q.grad is not None and float(q.grad.abs().max()) == 0.0, n
+            else:
+                assert torch.equal(p.grad, q.grad), (n, step)
+                assert any(q.grad.data_ptr() >= f.data_ptr() and q.grad.data_ptr() < f.data_ptr() + f.numel() * 4 for f, _ in dp1._buckets), n
