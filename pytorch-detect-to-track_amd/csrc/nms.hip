@@ -15,16 +15,25 @@ constexpr int kSuperWords = kSuper / kTile;  // 16
 constexpr int kRowStride = kSuperWords + 1;  // 17 words: conflict-free ds_read_b64 down a column
 constexpr int kSweepThreads = 1024;
 
-// devIoU (.cu:31-39): same operations, same order, no contraction (file built with -ffp-contract=off).
-__device__ __forceinline__ float dev_iou(const float a0, const float a1, const float a2, const float a3,
-                                         const float b0, const float b1, const float b2, const float b3) {
+// devIoU(a, b) > thresh (.cu:31-39, 101: same operations, same order, no contraction -- the file is built with
+// -ffp-contract=off) with the division skipped when no lane of the wave needs it.  fl(inter / uni) > thresh is decided by
+// inter against thresh * uni whenever the two are further apart than the roundings involved (1e-6 relative against 2^-23 for the
+// product and the quotient together): the common case -- disjoint boxes have inter == 0 -- costs two multiplies and two compares
+// instead of a correctly rounded division; a wave in which any lane is within that margin (or has a non-positive / non-finite
+// union) takes the reference's division for all its lanes.  The same answer as devIoU(a, b) > thresh in every case.
+__device__ __forceinline__ bool iou_over(const float a0, const float a1, const float a2, const float a3, const float Sa,
+                                         const float b0, const float b1, const float b2, const float b3, const float thresh) {
   float left = fmaxf(a0, b0), right = fminf(a2, b2);
   float top = fmaxf(a1, b1), bottom = fminf(a3, b3);
   float width = fmaxf(right - left + 1, 0.f), height = fmaxf(bottom - top + 1, 0.f);
   float interS = width * height;
-  float Sa = (a2 - a0 + 1) * (a3 - a1 + 1);
   float Sb = (b2 - b0 + 1) * (b3 - b1 + 1);
-  return interS / (Sa + Sb - interS);
+  const float uni = Sa + Sb - interS;
+  const float p = thresh * uni;
+  const bool sure_hit = interS > p * 1.000001f, sure_miss = interS < p * 0.999999f;
+  const bool decided = thresh > 0.f && uni > 1e-30f && uni < 1e30f && (sure_hit || sure_miss);
+  if (__all(decided)) return sure_hit;
+  return interS / uni > thresh;
 }
 
 constexpr int kMaskWaves = 4;      // waves per 64 x 64 tile: each takes 16 of the tile's 64 columns
@@ -81,9 +90,10 @@ __global__ __launch_bounds__(kMaskThreads) void nms_mask_kernel(const float* __r
       const int cur = kTile * row_start + t;
       const float* p = b + (long)cur * boxes_dim;
       const float a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3];
+      const float Sa = (a2 - a0 + 1) * (a3 - a1 + 1);
       unsigned bits = 0;
       for (int i = i0; i < i1; ++i) {
-        if (dev_iou(a0, a1, a2, a3, bb[i * 4 + 0], bb[i * 4 + 1], bb[i * 4 + 2], bb[i * 4 + 3]) > thresh)
+        if (iou_over(a0, a1, a2, a3, Sa, bb[i * 4 + 0], bb[i * 4 + 1], bb[i * 4 + 2], bb[i * 4 + 3], thresh))
           bits |= 1u << (i - i0);
       }
       unsigned short* word = reinterpret_cast<unsigned short*>(m + (long)cur * col_blocks + col_start);

@@ -116,6 +116,42 @@ def test_nms_threshold_boundary(dev):
     np.testing.assert_array_equal(nms(cu(dets, dev), 0.7).cpu().numpy().ravel(), O.nms(dets, 0.7))
 
 
+@pytest.mark.parametrize("case", ["exact_ratio", "one_ulp_below", "degenerate"])
+def test_nms_division_shortcut_edges(dev, case):
+    """nms_mask_kernel decides IoU > thresh from inter against thresh * union and only divides when a lane of the wave is within
+    1e-6 of the threshold (nms.hip: iou_over).  Pairs whose IoU is EXACTLY the threshold (integer areas 100 / 200 -> 0.5, 150 / 200
+    -> 0.75, ...: strict '>' keeps both), the same pairs with the threshold one ulp lower (now suppressed), and boxes the shortcut
+    must not touch -- negative and zero areas, areas that overflow to inf -- all inside ordinary clusters so that a wave holds
+    decided and undecided lanes at once.  Keep list identical to the oracle's (nms_cuda_kernel.cu:31-39, 101)."""
+    from dtt.ops import nms
+    rng = np.random.RandomState(31)
+    dets = clustered_dets(rng, 700)
+    if case == "degenerate":
+        dets[5, :4] = [50, 50, 20, 90]            # x2 < x1 - 1: negative width, negative area
+        dets[17, :4] = [60, 60, 59, 200]          # x2 == x1 - 1: zero area
+        dets[33, :4] = [-3e19, -3e19, 3e19, 3e19] # area overflows to inf
+        dets[34, :4] = [-2e19, -2e19, 3e19, 3e19]
+        dets[70, :4] = [100, 100, 100, 100]       # a single pixel
+        dets[71, :4] = [100, 100, 100, 100]
+        threshes = [0.7, 0.3]
+    else:
+        # nested integer boxes: IoU = area(inner) / area(outer) exactly
+        pairs = [((0, 0, 9, 9), (0, 0, 9, 19)), ((300, 300, 314, 309), (300, 300, 319, 309)), ((40, 500, 46, 506), (40, 500, 53, 513))]
+        for k, (a, b) in enumerate(pairs):
+            dets[100 + 64 * k, :4] = np.float32(a) + 1000 * (k + 1)      # far from the clusters, in different 64-box tiles
+            dets[131 + 64 * k, :4] = np.float32(b) + 1000 * (k + 1)
+        threshes = [np.float32(0.5), np.float32(0.75), np.float32(0.25)]
+        if case == "one_ulp_below":
+            threshes = [np.nextafter(t, np.float32(0)) for t in threshes]
+    for t in threshes:
+        ref = O.nms(dets, float(t))
+        got = nms(cu(dets, dev), float(t)).cpu().numpy().ravel()
+        np.testing.assert_array_equal(got, ref)
+    if case != "degenerate":
+        kept = set(O.nms(dets, float(threshes[0])).tolist())
+        assert (131 in kept) == (case == "exact_ratio")                  # IoU == 0.5: kept under '>', dropped one ulp below
+
+
 # --------------------------------------------------------------------------------------------- PSRoI
 @pytest.mark.parametrize("B,od,H,W,R", [(2, 4, 38, 67, 300), (1, 31, 19, 32, 64), (3, 5, 24, 40, 37)])
 def test_psroi_forward_bit_exact_and_backward(dev, B, od, H, W, R):
