@@ -324,26 +324,44 @@ class _RFCN(nn.Module):
         det = ex.det_rows                                               # (n_legs*B*H*W, stride): issued by the fused trunk ...
         if det is None:
             det = head_gemm(top_rows, pm.det)                           # ... or here
+        R = all_rois.size(1)
+        scale = self.RFCN_psroi_cls_pool.spatial_scale
+        fused_det = (pm.cls_head["cp"] == 32 and pm.loc_head["cp"] == 4 and os.environ.get("DTT_PSROI_DET_FUSED", "1") != "0")
+        det_on_side = fused_det and not single_frame and os.environ.get("DTT_PSROI_DET_SIDE", "0") == "1"   # developer A/B (measured: no gain, below)
+        prob = pred = None
+        if det_on_side:
+            # The detection pooling needs the score map and the RoIs, not the tracking head: on the SIDE stream it could run beside
+            # the tracking head's GEMM (32 us, 40 CUs idle) instead of behind it.  Measured (round 4, rocprofv3 of the captured step):
+            # the pooling still starts 8 us after the tracking head ends and 22 us after the second sweep, and the nodes behind it
+            # pay 7 - 14 us each -- 238.9 - 239.2 frame-pairs/s against 238.3 - 239.8 on the same box.  Off by default: the tail
+            # below stays on one stream after the proposal layer has joined.
+            from .heads import psroi_pm_det
+            det_ready = torch.cuda.Event()
+            det_ready.record(cur)
+            side.wait_event(det_ready)
+            with torch.cuda.stream(side):
+                prob, pred = psroi_pm_det(det, pm.cls_head, pm.loc_head, n_legs * B, H, W, all_rois.view(-1, 5), scale)
+            det.record_stream(side); prob.record_stream(cur); pred.record_stream(cur)
+            prob, pred = prob.view(n_legs, B, R, -1), pred.view(n_legs, B, R, -1)
         if not single_frame:
             gather_column_blocks(rows, 0, det, pm.loc_head["offset"], B * hw, n_legs, pm.n_box)   # box deltas of both legs
             trk = head_gemm(rows, pm.trk)                           # (B*H*W, stride)
-        R = all_rois.size(1)
         # The poolings need the RoIs as the NMS epilogue wrote them (image index inside the n_legs * B batch): they start as soon
-        # as the proposal layer is done.  The per-leg copy the caller gets back (batch index within the leg) is made on the side
-        # stream BESIDE them -- it used to sit, with its two small launches and a stream hop, between the NMS and the first pooling.
+        # as the proposal layer is done.  The per-leg copy the caller gets back (batch index within the leg) is ONE elementwise
+        # launch behind the poolings (it was a clone -- a copy node of the captured graph -- and an in-place subtract on the side
+        # stream in front of them).  What remains between the last of {second sweep, tracking head} and the detection pooling is
+        # the join of the two queues itself: 20 - 28 us in every trace of the round (profiles/r04_bench_step_sequence.txt), with
+        # the copy in front, behind, or on the other stream.
         rois_ready = torch.cuda.Event()
         rois_ready.record(side)
-        with torch.cuda.stream(side):
-            leg_rois = all_rois.view(n_legs, B, R, 5).clone()
-            for i in range(1, n_legs):
-                leg_rois[i, :, :, 0] -= i * B  # batch index within the leg
         cur.wait_event(rois_ready)
-        all_rois.record_stream(cur); leg_rois.record_stream(cur)
+        all_rois.record_stream(cur)
         flat_rois = all_rois.view(-1, 5)
-        scale = self.RFCN_psroi_cls_pool.spatial_scale
         if top is not None:
             self._roi_features(top, flat_rois)
-        if pm.cls_head["cp"] == 32 and pm.loc_head["cp"] == 4 and os.environ.get("DTT_PSROI_DET_FUSED", "1") != "0":
+        if prob is not None:
+            pass                                                        # (issued on the side stream above)
+        elif fused_det:
             # class scores + box deltas of a RoI in ONE launch, the class softmax in its epilogue (was: pooling 17 + softmax 3.6 +
             # pooling 10.3 us in a row, the second pooling re-reading the rows and RoIs the first had just read)
             from .heads import psroi_pm_det
@@ -353,13 +371,26 @@ class _RFCN(nn.Module):
             score = psroi_pm(det, pm.cls_head, n_legs * B, H, W, flat_rois, scale)
             prob = F.softmax(score, dim=1).view(n_legs, B, R, -1)
             pred = psroi_pm(det, pm.loc_head, n_legs * B, H, W, flat_rois, scale).view(n_legs, B, R, -1)
-        zeros = torch.zeros(n_legs, 1, device=dev)
+        # (the zero "losses" of an inference step, rfcn.py:125-126: one cached read-only tensor instead of a fill launch per step)
+        zeros = self._leg_offsets(n_legs, 0, dev)[:, 0, 0, :1]             # (B = 0: all zeros) -> (n_legs, 1)
         tracking_pred = torch.zeros(0, 4, device=dev)
         if trk is not None:
             # frame-t RoIs (rfcn.py:192): leg 0 of all_rois -- its batch indices are already leg-local
             tracking_pred = psroi_pm(trk, pm.trk_head, B, H, W, all_rois[:B].reshape(-1, 5), scale)
-        cur.wait_stream(side)   # leg_rois
+        leg_rois = all_rois.view(n_legs, B, R, 5) - self._leg_offsets(n_legs, B, dev)   # batch index within the leg
+        cur.wait_stream(side)   # (the side-stream pooling of the A/B switch)
         return leg_rois, prob, pred, tracking_pred, zeros, zeros, zeros, zeros, [], zeros[0]
+
+    def _leg_offsets(self, n_legs, B, dev):
+        """(n_legs, 1, 1, 5) with i * B in column 0 of leg i: all_rois' image index -> the index within the leg (cached: no fill
+        kernels inside a captured step)."""
+        key = (n_legs, B, str(dev))
+        cache = self.__dict__.setdefault("_leg_offsets_cache", {})
+        if key not in cache:
+            offs = torch.zeros(n_legs, 1, 1, 5)
+            offs[:, 0, 0, 0] = torch.arange(n_legs, dtype=torch.float32) * B
+            cache[key] = offs.to(dev)
+        return cache[key]
 
     # ------------------------------------------------------------------------------------------------ forward: four graphs
     # `forward` flattens the legs, runs the trunk and picks one of four graph builders (rfcn.py:66-250 is the contract of all):
