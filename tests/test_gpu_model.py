@@ -503,8 +503,11 @@ def _check_pm_tail(monkeypatch, layers, shapes):
         assert torch.equal(got1[1][0], got[1][0]) and torch.equal(got1[2][0], got[2][0])
         # (b) End to end (`model` on one frame per snippet): a batch of B images instead of 2 B -- the fused trunk times MIOpen, F(2,3)
         # and F(4,3) Winograd per layer and SHAPE and keeps the fastest (dtt/fuse.py), so the two batch sizes may run different
-        # algorithms (1e-3 relative apart): proposals near the NMS threshold flip.  RoIs are matched as SETS per image; most must
-        # be reproduced, and the scores of matched RoIs that pool the same bins must agree to that accuracy.
+        # algorithms (1e-3 relative apart): proposals near the NMS threshold flip -- with random-init weights about half of them,
+        # and which half depends on the algorithms the box's timing picked (0.47 - 0.60 of leg 0's RoIs reproduced over the round's
+        # boxes).  RoIs are matched as SETS per image; a tenth must be reproduced (the wiring check: a wrong leg, image or scale
+        # reproduces none), and the scores of matched RoIs that pool the same bins must agree to the trunk's accuracy.  The VALUE
+        # check of the single-frame path is (a) above.
         with torch.no_grad():
             one = model(im[:, :1], info[:, :1], gt[:, :1], nb[:, :1])
         torch.cuda.synchronize()
@@ -513,14 +516,14 @@ def _check_pm_tail(monkeypatch, layers, shapes):
             ra, rb = one[0][0, b, :, 1:], out[0][0, b, :, 1:]
             dist, idx = (ra[:, None, :] - rb[None, :, :]).abs().amax(dim=2).min(dim=1)
             same = dist < 0.05
-            assert float(same.float().mean()) > 0.5, "single frame, image %d: only %.3f of leg 0's RoIs reproduced" % (b, float(same.float().mean()))
+            assert float(same.float().mean()) > 0.1, "single frame, image %d: only %.3f of leg 0's RoIs reproduced" % (b, float(same.float().mean()))
             # (a RoI matched to 0.05 px pools the same bins unless a corner lies that close to a rounding boundary of
             #  psroi_pooling_kernel.cu:30-33)
             frac = ra - torch.floor(ra)
             clear = same & ((frac - 0.5).abs() > 0.06).all(dim=1)
             for i in (1, 2):
                 d = (one[i][0, b] - out[i][0, b][idx]).abs().amax(dim=1)
-                assert float(d[clear].max()) < 2e-2, (i, b, float(d[clear].max()))
+                assert bool(clear.any()) and float(d[clear].max()) < 2e-2, (i, b, float(d[clear].max()))
 
 
 def test_bench_step_tail_at_full_size_matches_nchw_tail(monkeypatch):
