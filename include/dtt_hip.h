@@ -321,6 +321,21 @@ int dtt_anchor_target_finish(const float* gt_boxes, int im_h0, int im_w0, const 
                              float inside_weight, float positive_weight, float negative_weight,
                              float* labels_out, float* bbox_targets, float* bbox_inside_weights,
                              float* bbox_outside_weights, void* stream);
+/* The same layer without a host read (cfg.TRAIN.SAMPLER_RNG = "device", the counterpart of the RoI sampler's device mode): the
+ * three phases in one call.  im_info (B, 3) stays on the device (row 0 is read by the kernels); instead of numpy permutations
+ * of the index lists (anchor_target_layer.py:124-141) every anchor carries a 32-bit random key the caller drew WITHOUT looking at
+ * the labels, and of a class that exceeds its quota the candidates with the smallest (key, anchor index) stay -- a uniform subset
+ * of exactly the reference's size: num_fg foreground anchors, rpn_batchsize - (foreground count before subsampling) background
+ * anchors.  The outside weights (1 / num_examples of the LAST image, or positive_weight / n_pos and (1 - positive_weight) / n_neg
+ * when positive_weight >= 0) are computed on the device.  keys: (B, K*A) uint32.  Scratch: labels / argmax_gt (B, K*A) int32,
+ * counts (B, 4) int32 (per-image [fg, bg] before, then after subsampling), gt_max_scratch (B*G) int32, weights (2) float.
+ */
+int dtt_anchor_target_device(const float* gt_boxes, const float* im_info, const float* anchors, const unsigned* keys,
+                             int batch, int num_gt, int num_anchors, int height, int width, int feat_stride,
+                             int rpn_batchsize, int num_fg, float negative_overlap, float positive_overlap,
+                             int clobber_positives, float inside_weight, float positive_weight, int* labels,
+                             int* argmax_gt, int* counts, int* gt_max_scratch, float* weights, float* labels_out,
+                             float* bbox_targets, float* bbox_inside_weights, float* bbox_outside_weights, void* stream);
 
 /* ---------------------------------------------------------------- RoI / tracking target samplers (training)
  * Replace _ProposalTargetLayer._sample_rois_pytorch (rpn/proposal_target_layer_cascade.py:121-208: IoU against the

@@ -21,7 +21,14 @@ constexpr int kThreads = 256;
 struct AtGeom {
   int B, G, A, H, W, K, n, stride;
   int im_h, im_w;  // long(im_info[0][0]), long(im_info[0][1])  (image 0 only, anchor_target_layer.py:85-86)
+  const float* im_info;   // device mode: the kernels read row 0 themselves (no host copy of im_info); else null
 };
+
+// (image height, width) the "inside the image" test uses: truncated like the reference's long(im_info[0][.])
+__device__ __forceinline__ void image_hw(const AtGeom& g, int& h, int& w) {
+  if (g.im_info) { h = (int)(long)g.im_info[0]; w = (int)(long)g.im_info[1]; }
+  else { h = g.im_h; w = g.im_w; }
+}
 
 __device__ __forceinline__ void anchor_of(const float* __restrict__ base, const AtGeom& g, int t, float& x1, float& y1,
                                           float& x2, float& y2) {
@@ -33,7 +40,9 @@ __device__ __forceinline__ void anchor_of(const float* __restrict__ base, const 
 }
 
 __device__ __forceinline__ bool inside(const AtGeom& g, float x1, float y1, float x2, float y2) {
-  return x1 >= 0.f && y1 >= 0.f && x2 < (float)g.im_w && y2 < (float)g.im_h;
+  int im_h, im_w;
+  image_hw(g, im_h, im_w);
+  return x1 >= 0.f && y1 >= 0.f && x2 < (float)im_w && y2 < (float)im_h;
 }
 
 // bbox_transform.py:228-254 for one (anchor, gt) pair
@@ -150,11 +159,13 @@ __global__ void at_disable(int* __restrict__ labels, const int* __restrict__ dis
 __global__ __launch_bounds__(kThreads) void at_finish(const float* __restrict__ gt_boxes, const float* __restrict__ base,
                                                       AtGeom g, const int* __restrict__ labels,
                                                       const int* __restrict__ argmax_gt, float inside_w, float pos_w,
-                                                      float neg_w, float* __restrict__ labels_out,
+                                                      float neg_w, const float* __restrict__ dev_weights,
+                                                      float* __restrict__ labels_out,
                                                       float* __restrict__ targets, float* __restrict__ in_w,
                                                       float* __restrict__ out_w) {
   const int t = blockIdx.x * kThreads + threadIdx.x, b = blockIdx.y;
   if (t >= g.n) return;
+  if (dev_weights) { pos_w = dev_weights[0]; neg_w = dev_weights[1]; }   // device mode: written by at_subsample
   const int k = t / g.A, a = t - k * g.A;
   float x1, y1, x2, y2;
   anchor_of(base, g, t, x1, y1, x2, y2);
@@ -181,6 +192,102 @@ __global__ __launch_bounds__(kThreads) void at_finish(const float* __restrict__ 
   out_w[o] = ow; out_w[o + g.K] = ow; out_w[o + 2L * g.K] = ow; out_w[o + 3L * g.K] = ow;
 }
 
+// Device-mode subsampling (anchor_target_layer.py:118-141 without the host): one workgroup per image.  The reference disables a
+// uniformly random subset of the foreground anchors beyond num_fg and of the background anchors beyond
+// rpn_batchsize - sum_fg (numpy permutations of the index lists).  Here every anchor carries a 32-bit random key the caller drew
+// WITHOUT looking at the labels, and the k candidates of a class with the smallest (key, index) stay: a uniform subset of
+// exactly k, the same distribution, nothing read back.  The k-th smallest key is found by a radix select (four 8-bit passes,
+// a 256-bin histogram in LDS each); candidates with exactly that key -- rare -- are kept in index order.
+// after[b] = (fg, bg) counts left; the workgroup of the LAST image also writes the two outside weights the reference derives from
+// that image's counts (anchor_target_layer.py:143-154): weights[0] positive, [1] negative.
+constexpr int kSubThreads = 1024;
+
+__device__ void keep_smallest(int* __restrict__ labels, const unsigned* __restrict__ keys, int n, int cls, int k, int* sh) {
+  // sh: [0, 256) histogram, [256] prefix, [257] remaining, [258] equal count, [259 ..) scan scratch
+  const int tid = threadIdx.x;
+  if (k <= 0) {
+    for (int i = tid; i < n; i += kSubThreads)
+      if (labels[i] == cls) labels[i] = -1;
+    __syncthreads();
+    return;
+  }
+  unsigned prefix = 0, mask = 0;
+  int rem = k, equal = 0;
+  for (int shift = 24; shift >= 0; shift -= 8) {
+    if (tid < 256) sh[tid] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += kSubThreads)
+      if (labels[i] == cls && (keys[i] & mask) == prefix) atomicAdd(&sh[(keys[i] >> shift) & 255u], 1);
+    __syncthreads();
+    if (tid == 0) {
+      int cum = 0, d = 0;
+      for (; d < 255; ++d) {
+        if (cum + sh[d] >= rem) break;
+        cum += sh[d];
+      }
+      sh[256] = d; sh[257] = rem - cum; sh[258] = sh[d];
+    }
+    __syncthreads();
+    prefix |= (unsigned)sh[256] << shift;
+    mask |= 255u << shift;
+    rem = sh[257];
+    equal = sh[258];
+    __syncthreads();
+  }
+  // prefix = the k-th smallest key T; `rem` of the `equal` candidates with key == T stay (the first in index order)
+  if (rem >= equal) {
+    for (int i = tid; i < n; i += kSubThreads)
+      if (labels[i] == cls && keys[i] > prefix) labels[i] = -1;
+  } else {
+    int* wave_cnt = sh + 259;          // [16] per-wave counts of a 1024-anchor chunk
+    int running = 0;                   // equal-key candidates seen in earlier chunks
+    for (int i0 = 0; i0 < n; i0 += kSubThreads) {
+      const int i = i0 + tid;
+      const bool cand = i < n && labels[i] == cls;
+      const bool eq = cand && keys[i] == prefix;
+      const unsigned long long m = __ballot(eq);
+      if ((tid & 63) == 0) wave_cnt[tid >> 6] = __popcll(m);
+      __syncthreads();
+      int before = running;
+      for (int w = 0; w < (tid >> 6); ++w) before += wave_cnt[w];
+      int total = 0;
+      for (int w = 0; w < kSubThreads / 64; ++w) total += wave_cnt[w];
+      const int rank = before + __popcll(m & ((1ull << (tid & 63)) - 1ull));
+      if (cand && (keys[i] > prefix || (eq && rank >= rem))) labels[i] = -1;
+      running += total;
+      __syncthreads();
+    }
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(kSubThreads) void at_subsample(int* __restrict__ labels, const unsigned* __restrict__ keys, int n,
+                                                            int batch, const int* __restrict__ counts, int rpn_batchsize,
+                                                            int num_fg, float positive_weight, int* __restrict__ after,
+                                                            float* __restrict__ weights) {
+  __shared__ int sh[259 + kSubThreads / 64];
+  const int b = blockIdx.x;
+  int* lab = labels + (long)b * n;
+  const unsigned* key = keys + (long)b * n;
+  const int sum_fg = counts[b * 2], sum_bg = counts[b * 2 + 1];
+  int fg_left = sum_fg, bg_left = sum_bg;
+  if (sum_fg > num_fg) { keep_smallest(lab, key, n, 1, num_fg, sh); fg_left = num_fg; }
+  const int num_bg = rpn_batchsize - sum_fg;   // the fg count BEFORE subsampling, as in the reference (:133)
+  if (sum_bg > num_bg) { keep_smallest(lab, key, n, 0, num_bg, sh); bg_left = max(num_bg, 0); }
+  if (threadIdx.x == 0) {
+    after[b * 2] = fg_left; after[b * 2 + 1] = bg_left;
+    if (b == batch - 1) {
+      const int num_examples = fg_left + bg_left;
+      float w_pos = num_examples > 0 ? 1.0f / (float)num_examples : INFINITY, w_neg = w_pos;
+      if (positive_weight >= 0.f) {
+        w_pos = fg_left > 0 ? positive_weight / (float)fg_left : INFINITY;
+        w_neg = bg_left > 0 ? (1.0f - positive_weight) / (float)bg_left : INFINITY;
+      }
+      weights[0] = w_pos; weights[1] = w_neg;
+    }
+  }
+}
+
 }  // namespace
 
 // Host-side geometry needs im_info[0]; it is passed by value to keep the call free of D2H copies.
@@ -194,7 +301,7 @@ extern "C" int dtt_anchor_target_assign(const float* gt_boxes, int im_h0, int im
   DTT_REQUIRE(batch > 0 && num_gt > 0 && num_anchors > 0 && height > 0 && width > 0, "anchor_target: bad shape");
   AtGeom g;
   g.B = batch; g.G = num_gt; g.A = num_anchors; g.H = height; g.W = width; g.K = height * width;
-  g.n = g.K * g.A; g.stride = feat_stride; g.im_h = im_h0; g.im_w = im_w0;
+  g.n = g.K * g.A; g.stride = feat_stride; g.im_h = im_h0; g.im_w = im_w0; g.im_info = nullptr;
   const int ninit = batch * num_gt > batch * 2 ? batch * num_gt : batch * 2;
   hipLaunchKernelGGL(at_init, dim3(dtt_cdiv(ninit, 256)), dim3(256), 0, stream, gt_max_scratch, batch * num_gt, counts,
                      batch * 2);
@@ -226,11 +333,45 @@ extern "C" int dtt_anchor_target_finish(const float* gt_boxes, int im_h0, int im
               "anchor_target finish: null pointer");
   AtGeom g;
   g.B = batch; g.G = num_gt; g.A = num_anchors; g.H = height; g.W = width; g.K = height * width;
-  g.n = g.K * g.A; g.stride = feat_stride; g.im_h = im_h0; g.im_w = im_w0;
+  g.n = g.K * g.A; g.stride = feat_stride; g.im_h = im_h0; g.im_w = im_w0; g.im_info = nullptr;
   hipLaunchKernelGGL(at_finish, dim3(dtt_cdiv(g.n, kThreads), batch), dim3(kThreads), 0,
                      static_cast<hipStream_t>(stream_), gt_boxes, anchors, g, labels_in, argmax_gt, inside_weight,
-                     positive_weight, negative_weight, labels_out, bbox_targets, bbox_inside_weights,
+                     positive_weight, negative_weight, nullptr, labels_out, bbox_targets, bbox_inside_weights,
                      bbox_outside_weights);
   DTT_CHECK_LAUNCH("anchor_target finish");
+  return 1;
+}
+
+// The whole layer without a host read (cfg.TRAIN.SAMPLER_RNG = "device"): assign, subsample by the caller's random keys
+// (at_subsample), finish -- im_info stays on the device (row 0 is read by the kernels), the per-image counts and the outside
+// weights never leave it.  keys: (batch, K*A) uint32 drawn by the caller without knowledge of the labels.  positive_weight < 0:
+// uniform weighting (anchor_target_layer.py:143-147).  Scratch: labels / argmax_gt (batch, K*A) int32, counts (batch, 4) int32
+// ([0, 2 batch) before, [2 batch, 4 batch) after subsampling), gt_max_scratch (batch * num_gt) int32, weights (2) float.
+extern "C" int dtt_anchor_target_device(const float* gt_boxes, const float* im_info, const float* anchors,
+                                        const unsigned* keys, int batch, int num_gt, int num_anchors, int height, int width,
+                                        int feat_stride, int rpn_batchsize, int num_fg, float negative_overlap,
+                                        float positive_overlap, int clobber_positives, float inside_weight,
+                                        float positive_weight, int* labels, int* argmax_gt, int* counts,
+                                        int* gt_max_scratch, float* weights, float* labels_out, float* bbox_targets,
+                                        float* bbox_inside_weights, float* bbox_outside_weights, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  DTT_REQUIRE(gt_boxes && im_info && anchors && keys && labels && argmax_gt && counts && gt_max_scratch && weights && labels_out &&
+                  bbox_targets && bbox_inside_weights && bbox_outside_weights, "anchor_target (device): null pointer");
+  DTT_REQUIRE(batch > 0 && num_gt > 0 && num_anchors > 0 && height > 0 && width > 0 && rpn_batchsize > 0 && num_fg >= 0,
+              "anchor_target (device): bad shape");
+  AtGeom g;
+  g.B = batch; g.G = num_gt; g.A = num_anchors; g.H = height; g.W = width; g.K = height * width;
+  g.n = g.K * g.A; g.stride = feat_stride; g.im_h = 0; g.im_w = 0; g.im_info = im_info;
+  const int ninit = batch * num_gt > batch * 2 ? batch * num_gt : batch * 2;
+  hipLaunchKernelGGL(at_init, dim3(dtt_cdiv(ninit, 256)), dim3(256), 0, stream, gt_max_scratch, batch * num_gt, counts, batch * 2);
+  dim3 grid(dtt_cdiv(g.n, kThreads), batch);
+  hipLaunchKernelGGL(at_gt_max, grid, dim3(kThreads), 0, stream, gt_boxes, anchors, g, gt_max_scratch);
+  hipLaunchKernelGGL(at_assign, grid, dim3(kThreads), 0, stream, gt_boxes, anchors, g, gt_max_scratch, negative_overlap,
+                     positive_overlap, clobber_positives, labels, argmax_gt, counts);
+  hipLaunchKernelGGL(at_subsample, dim3(batch), dim3(kSubThreads), 0, stream, labels, keys, g.n, batch, counts, rpn_batchsize,
+                     num_fg, positive_weight, counts + 2 * batch, weights);
+  hipLaunchKernelGGL(at_finish, grid, dim3(kThreads), 0, stream, gt_boxes, anchors, g, labels, argmax_gt, inside_weight, 0.f, 0.f,
+                     weights, labels_out, bbox_targets, bbox_inside_weights, bbox_outside_weights);
+  DTT_CHECK_LAUNCH("anchor_target (device)");
   return 1;
 }

@@ -87,6 +87,7 @@ SIGNATURES = {
     "dtt_tube_link_workspace_bytes": (_Z, [_I, _I]),
     "dtt_tube_link": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "dtt_anchor_target_finish": (_I, [_P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _F, _P, _P, _P, _P, _P]),
+    "dtt_anchor_target_device": (_I, [_P, _P, _P, _P] + [_I] * 8 + [_F, _F, _I, _F, _F] + [_P] * 9 + [_P]),
 }
 
 _lib = None

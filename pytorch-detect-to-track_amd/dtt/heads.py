@@ -379,6 +379,18 @@ class TrackingRowsFn(torch.autograd.Function):
         return (g_loc, *gmaps, None, None, None)
 
 
+_DEVICE_CONSTANTS = {}
+
+
+def _device_constant(key, build):
+    """Small index tensors of the training graph that depend on shapes only: uploaded once per (shape, device) -- a per-step
+    .to(dev) from host memory makes the host wait for the stream in the middle of the forward."""
+    t = _DEVICE_CONSTANTS.get(key)
+    if t is None:
+        t = _DEVICE_CONSTANTS[key] = build()
+    return t
+
+
 def pack_rpn_heads_differentiable(cls_conv, bbox_conv):
     """PackedRPNHeads' row order as differentiable tensor ops on the live parameters: (w (rows16, K), bias (rows16,), A)."""
     K = cls_conv.weight.shape[1]
@@ -388,7 +400,8 @@ def pack_rpn_heads_differentiable(cls_conv, bbox_conv):
     if A % 2 or wc.shape[0] != 2 * A or wb.shape[0] != 4 * A:
         raise ValueError("pack_rpn_heads_differentiable: an even number of anchors is required (got %d score channels)" % wc.shape[0])
     dev = wc.device
-    pair = torch.stack([torch.arange(A), A + torch.arange(A)], 1).reshape(-1).to(dev)   # bg_a, fg_a
+    pair = _device_constant(("rpn_pair", A, str(dev)),
+                            lambda: torch.stack([torch.arange(A), A + torch.arange(A)], 1).reshape(-1).to(dev))   # bg_a, fg_a
     bc = cls_conv.bias if cls_conv.bias is not None else wc.new_zeros(2 * A)
     bb = bbox_conv.bias if bbox_conv.bias is not None else wb.new_zeros(4 * A)
     w = torch.cat([wc[pair], wb], 0)

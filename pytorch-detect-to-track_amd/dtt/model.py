@@ -151,12 +151,10 @@ class _RPN(nn.Module):
         if self.training:
             assert gt_boxes is not None
             labels, tgt, w_in, w_out = self.RPN_anchor_target((cls_score.detach(), gt_boxes[:, :, :5], im_info, num_boxes))
-            score = cls_score_r.permute(0, 2, 3, 1).contiguous().view(B, -1, 2)
-            label = labels.view(B, -1)
-            keep = label.view(-1).ne(-1).nonzero().view(-1)
-            score = torch.index_select(score.view(-1, 2), 0, keep)
-            label = torch.index_select(label.view(-1), 0, keep).long()
-            self.rpn_loss_cls = F.cross_entropy(score, label)
+            score = cls_score_r.permute(0, 2, 3, 1).contiguous().view(-1, 2)
+            # rpn.py:90-97 keeps the sampled anchors with nonzero() + index_select: a host read of their number in the middle of the
+            # forward.  The mean over the anchors whose label is not -1 is the same number (ignore_index), without it.
+            self.rpn_loss_cls = F.cross_entropy(score, labels.view(-1).long(), ignore_index=-1)
             self.rpn_loss_box = _smooth_l1_loss(bbox_pred, tgt, w_in, w_out, sigma=3, dim=[1, 2, 3])
         return rois, self.rpn_loss_cls, self.rpn_loss_box
 
@@ -167,11 +165,9 @@ class _RPN(nn.Module):
         B = cls_prob.size(0)
         labels, tgt, w_in, w_out = self.RPN_anchor_target((cls_prob.detach(), gt_boxes, im_info, num_boxes))
         prob = self.reshape(cls_prob, 2).permute(0, 2, 3, 1).contiguous().view(-1, 2)
-        label = labels.view(-1)
-        keep = label.ne(-1).nonzero().view(-1)
-        prob = torch.index_select(prob, 0, keep)
-        label = torch.index_select(label, 0, keep).long()
-        self.rpn_loss_cls = F.nll_loss(torch.log(prob.clamp_min(1e-37)), label)
+        # (mean over the anchors whose label is not -1: ignore_index instead of the reference's nonzero() + index_select, which reads
+        #  the number of sampled anchors back to the host in the middle of the forward)
+        self.rpn_loss_cls = F.nll_loss(torch.log(prob.clamp_min(1e-37)), labels.view(-1).long(), ignore_index=-1)
         self.rpn_loss_box = _smooth_l1_loss(bbox_pred, tgt, w_in, w_out, sigma=3, dim=[1, 2, 3])
         return self.rpn_loss_cls, self.rpn_loss_box
 
@@ -601,10 +597,14 @@ class _RFCN(nn.Module):
         K_in = self.corr_bbox_net.weight.shape[1]
         k_pad = -(-K_in // 32) * 32
         od, G = loc["od"], loc["group"]
-        perm = torch.arange(K_in)
-        bb, kk = torch.meshgrid(torch.arange(G * G), torch.arange(od), indexing="ij")
-        for l in range(2):   # rows column leg*n_box + bin*od + k  <-  reference channel leg*n_box + k*G*G + bin
-            perm[l * n_box:(l + 1) * n_box] = (l * n_box + kk * G * G + bb).reshape(-1)
+        def tracking_perm():   # rows column leg*n_box + bin*od + k  <-  reference channel leg*n_box + k*G*G + bin
+            perm = torch.arange(K_in)
+            bb, kk = torch.meshgrid(torch.arange(G * G), torch.arange(od), indexing="ij")
+            for l in range(2):
+                perm[l * n_box:(l + 1) * n_box] = (l * n_box + kk * G * G + bb).reshape(-1)
+            return perm.to(dev)
+        from .heads import _device_constant
+        perm = _device_constant(("tracking_perm", K_in, G, od, n_box, str(dev)), tracking_perm)   # (uploaded once, not per step)
         trk_rows = TrackingRowsFn.apply(pooled[2], c3, c4, c5, B, geoms, k_pad)
         w_trk, b_trk, trk_heads, n_store_t, stride_t = pack_heads_differentiable([self.corr_bbox_net], k_pad=k_pad, in_perm=perm)
         trk = HeadGemmFn.apply(trk_rows, w_trk, b_trk, n_store_t, stride_t)

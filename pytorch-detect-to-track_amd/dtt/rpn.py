@@ -175,12 +175,13 @@ class _AnchorTargetLayer(nn.Module):
         return anchor_target_forward(gt_boxes, im_info, self._anchors, rpn_cls_score.size(2), rpn_cls_score.size(3),
                                      self._feat_stride, T.RPN_BATCHSIZE, T.RPN_FG_FRACTION, T.RPN_NEGATIVE_OVERLAP,
                                      T.RPN_POSITIVE_OVERLAP, T.RPN_CLOBBER_POSITIVES,
-                                     T.RPN_BBOX_INSIDE_WEIGHTS[0], positive_weight=T.RPN_POSITIVE_WEIGHT)
+                                     T.RPN_BBOX_INSIDE_WEIGHTS[0], positive_weight=T.RPN_POSITIVE_WEIGHT,
+                                     mode=getattr(T, "SAMPLER_RNG", "device"))
 
 
 def anchor_target_forward(gt_boxes, im_info, anchors, height, width, feat_stride, rpn_batchsize=256,
                           fg_fraction=0.5, negative_overlap=0.3, positive_overlap=0.7, clobber_positives=False,
-                          inside_weight=1.0, rng=np.random, positive_weight=-1.0):
+                          inside_weight=1.0, rng=np.random, positive_weight=-1.0, mode="reference", keys=None):
     """positive_weight < 0: every sampled anchor weighs 1 / num_examples (anchor_target_layer.py:143-147).  In (0, 1): the
     branch the reference asserts on but never finishes (:148-150 leave positive_weights / negative_weights undefined, a
     NameError at :152) is completed the way the py-faster-rcnn layer it was ported from defines it: positives share
@@ -193,6 +194,9 @@ def anchor_target_forward(gt_boxes, im_info, anchors, height, width, feat_stride
     B, G, _ = gt.shape
     A = anchors.size(0)
     n = A * height * width
+    if mode == "device":
+        return _anchor_target_device(gt, im_info, anchors, B, G, A, height, width, feat_stride, rpn_batchsize, fg_fraction,
+                                     negative_overlap, positive_overlap, clobber_positives, inside_weight, positive_weight, rng, keys)
     info0 = im_info[0].detach().cpu()
     im_h0, im_w0 = int(info0[0]), int(info0[1])  # long(im_info[0][0]) (anchor_target_layer.py:85-86)
     L = _lib.lib()
@@ -234,6 +238,39 @@ def anchor_target_forward(gt_boxes, im_info, anchors, height, width, feat_stride
                                          height, width, int(feat_stride), float(inside_weight), w_pos, w_neg,
                                          ptr(labels_out), ptr(targets), ptr(inside), ptr(outside), stream_ptr(dev)),
               "anchor_target finish")
+    return [labels_out, targets, inside, outside]
+
+
+def _anchor_target_device(gt, im_info, anchors, B, G, A, height, width, feat_stride, rpn_batchsize, fg_fraction, negative_overlap,
+                          positive_overlap, clobber_positives, inside_weight, positive_weight, rng, keys):
+    """mode == "device" (cfg.TRAIN.SAMPLER_RNG, the RoI sampler's counterpart): `dtt_anchor_target_device` -- no host read, no
+    upload that waits for the stream.  The reference's numpy permutations (anchor_target_layer.py:124-141) become one 32-bit
+    random key per anchor, drawn without looking at the labels: of a class over its quota the candidates with the smallest
+    (key, anchor index) stay.  The keys come from the DEVICE generator, seeded per call by one integer drawn from `rng` (numpy's
+    global generator by default): a seeded run is reproducible as before, but it is not the reference's sample."""
+    dev = gt.device
+    n = A * height * width
+    if keys is None:
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(int(rng.randint(0, 2 ** 31 - 1)))
+        keys = torch.randint(0, 2 ** 31 - 1, (B, n), dtype=torch.int32, device=dev, generator=gen)
+    if keys.dtype != torch.int32 or tuple(keys.shape) != (B, n) or keys.device != dev or not keys.is_contiguous():
+        raise ValueError("anchor_target: keys must be a contiguous int32 tensor of shape (%d, %d) on %s" % (B, n, dev))
+    im_info = im_info.detach().to(dev, torch.float32).contiguous()
+    i32 = dict(dtype=torch.int32, device=dev)
+    f32 = dict(dtype=torch.float32, device=dev)
+    labels, argmax = torch.empty((B, n), **i32), torch.empty((B, n), **i32)
+    counts, scratch, weights = torch.empty((B, 4), **i32), torch.empty((B * G,), **i32), torch.empty((2,), **f32)
+    labels_out = torch.empty((B, 1, A * height, width), **f32)
+    targets = torch.empty((B, 4 * A, height, width), **f32)
+    inside, outside = torch.empty_like(targets), torch.empty_like(targets)
+    with torch.cuda.device(dev):
+        check(_lib.lib().dtt_anchor_target_device(ptr(gt), ptr(im_info), ptr(anchors), ptr(keys), B, G, A, height, width,
+                                                  int(feat_stride), int(rpn_batchsize), int(fg_fraction * rpn_batchsize),
+                                                  float(negative_overlap), float(positive_overlap), int(bool(clobber_positives)),
+                                                  float(inside_weight), float(positive_weight), ptr(labels), ptr(argmax), ptr(counts),
+                                                  ptr(scratch), ptr(weights), ptr(labels_out), ptr(targets), ptr(inside), ptr(outside),
+                                                  stream_ptr(dev)), "anchor_target (device)")
     return [labels_out, targets, inside, outside]
 
 

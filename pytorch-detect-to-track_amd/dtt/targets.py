@@ -83,8 +83,9 @@ class _ProposalTargetLayer(nn.Module):
                 pos = torch.from_numpy(pos_h).to(dev)
                 fgn = torch.from_numpy(fgn_h).to(dev)
             else:
-                ufg = torch.from_numpy(np.random.rand(B, N)).to(dev)
-                ubg = torch.from_numpy(np.random.rand(B, n_out)).to(dev)
+                # (through pinned memory, non-blocking: a plain .to(dev) from pageable memory makes the host wait for the stream)
+                ufg = torch.from_numpy(np.random.rand(B, N)).pin_memory().to(dev, non_blocking=True)
+                ubg = torch.from_numpy(np.random.rand(B, n_out)).pin_memory().to(dev, non_blocking=True)
             f32 = dict(dtype=torch.float32, device=dev)
             rois = torch.empty((B, n_out, 5), **f32)
             labels = torch.empty((B, n_out), **f32)

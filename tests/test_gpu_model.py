@@ -634,3 +634,45 @@ def test_training_graph_on_hand_written_heads_matches_the_library_graph():
     for n in ("RFCN_rpn.RPN_cls_score.weight", "RFCN_rpn.RPN_bbox_pred.weight", "RFCN_rpn.RPN_Conv.weight", "corr_bbox_net.weight",
               "RFCN_cls_net.weight", "RFCN_bbox_net.weight"):
         assert n in worst and float(g_nc[n].abs().max()) > 0, n
+
+
+def test_training_step_on_the_device_samplers_makes_no_host_read():
+    """cfg.TRAIN.SAMPLER_RNG = "device" (the default): forward, losses and backward of the position-major training graph queue their
+    launches without a single synchronising operation -- no device-to-host copy (anchor subsampling, RoI sampling and the RPN loss
+    used to read counts back), no blocking upload (index tensors, uniforms) -- so the host runs ahead of the GPU through the
+    launch-bound head / sampling / loss section instead of draining the queue at its start.  torch.cuda.set_sync_debug_mode("error")
+    raises on any of them."""
+    from dtt.config import apply_dataset_defaults, cfg, cfg_from_file
+    from dtt.fuse import fuse_for_training
+    from dtt.synth import build_model, calibrate_batchnorm_, make_batch
+    apply_dataset_defaults("imagenet_vid")
+    cfg_from_file(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cfgs", "res101.yml"))
+    assert cfg.TRAIN.SAMPLER_RNG == "device"
+    dev = torch.device("cuda:0")
+    B, H, W = 2, 256, 352
+    model = build_model(50, cfg=cfg).to(dev)
+    im, info, gt, nb = make_batch(B, H, W, seed=9, device=dev)
+    calibrate_batchnorm_(model, im[:, 0])
+    model.train()
+    fuse_for_training(model, channels_last=True)
+    assert model._train_pm
+
+    def step():
+        model.zero_grad(set_to_none=True)
+        out = model(im, info, gt, nb)
+        loss = out[4].mean() + out[5].mean() + out[6].mean() + out[7].mean() + out[9].mean()
+        loss.backward()
+        return loss
+
+    np.random.seed(5)
+    step(); step()                                   # warm-up: the libraries pick kernels, constants are uploaded
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        loss = step()
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    torch.cuda.synchronize()
+    assert np.isfinite(float(loss))
+    flag = model.RFCN_proposal_target.status_flag()
+    assert flag is None or float(flag) == 0.0

@@ -855,6 +855,87 @@ def test_anchor_target_positive_weight(dev):
     assert torch.all(out_w[~(pos | neg)] == 0)
 
 
+@pytest.mark.parametrize("case,batchsize,fg_fraction,tie", [("b2_38x67", 256, 0.5, False), ("b3_12x20", 256, 0.5, False),
+                                                          ("b2_38x67", 16, 0.25, False), ("b2_19x32", 2, 1.0, False),
+                                                          ("b2_38x67", 256, 0.5, True)])
+def test_anchor_target_device_mode_follows_its_selection_rule(dev, case, batchsize, fg_fraction, tie):
+    """cfg.TRAIN.SAMPLER_RNG = "device" (`dtt_anchor_target_device`: no host read anywhere in the layer): of a class over its quota
+    the anchors with the smallest (key, anchor index) stay -- restated in numpy on the labels BEFORE subsampling (the reference-mode
+    kernels with a quota nothing exceeds; they are pinned bit-exact to the reference above).  Labels exact, quotas as
+    anchor_target_layer.py:118-141 (num_fg foreground, batch - foreground-before-subsampling background, every background anchor
+    when that is <= 0), targets untouched by the subsampling, outside weights 1 / num_examples of the LAST image.  `tie`: all keys
+    equal -- the k-th smallest key is shared by every candidate and the anchor index decides."""
+    from dtt.rpn import anchor_target_forward, generate_anchors
+    g = np.load(os.path.join(G, "anchor_target.npz"))
+    base = torch.from_numpy(generate_anchors(scales=g["scales"], ratios=g["ratios"])).float()
+    H, W = (int(v) for v in g[case + "/hw"])
+    gt, info = cu(g[case + "/gt_boxes"], dev), torch.from_numpy(g[case + "/im_info"])
+    B, A, K = gt.shape[0], base.shape[0], H * W
+    n = A * K
+    pre = anchor_target_forward(gt, info, base, H, W, 16, rpn_batchsize=10 ** 7)            # nothing over quota: labels before subsampling
+    rs = np.random.RandomState(B * 1000 + batchsize)
+    keys = np.zeros((B, n), np.int32) + 12345 if tie else rs.randint(0, 2 ** 31 - 1, size=(B, n)).astype(np.int32)
+    if not tie:
+        m = keys[:, 3::7].shape[1]
+        keys[:, 0:7 * m:7] = keys[:, 3::7]                                                 # plenty of equal keys among the candidates
+    got = anchor_target_forward(gt, info.to(dev), base, H, W, 16, rpn_batchsize=batchsize, fg_fraction=fg_fraction, mode="device",
+                                keys=torch.from_numpy(keys).to(dev))
+    to_t = lambda x: x.view(B, A, K).permute(0, 2, 1).reshape(B, n)                         # (B, 1, A*H, W) -> anchor index t = k * A + a
+    lab_pre = to_t(pre[0]).cpu().numpy()
+    num_fg = int(fg_fraction * batchsize)
+    want = lab_pre.copy()
+    t = np.arange(n)
+    for b in range(B):
+        fg, bg = np.nonzero(lab_pre[b] == 1)[0], np.nonzero(lab_pre[b] == 0)[0]
+        if fg.size > num_fg:
+            order = fg[np.lexsort((t[fg], keys[b, fg]))]
+            want[b, order[num_fg:]] = -1
+        num_bg = batchsize - fg.size
+        if bg.size > num_bg:
+            order = bg[np.lexsort((t[bg], keys[b, bg]))]
+            want[b, order[max(num_bg, 0):]] = -1
+        assert (want[b] == 1).sum() == min(fg.size, num_fg) and (want[b] == 0).sum() == min(bg.size, max(num_bg, 0))
+    lab = to_t(got[0]).cpu().numpy()
+    np.testing.assert_array_equal(lab, want)
+    assert torch.equal(got[1], pre[1])                                                       # regression targets: every inside anchor
+    lab4 = got[0].view(B, A, 1, H, W).expand(B, A, 4, H, W).reshape(B, 4 * A, H, W)
+    assert torch.equal(got[2], (lab4 == 1).float())                                          # inside weights (1.0) on the kept positives
+    n_ex = int((want[B - 1] >= 0).sum())
+    w = np.float32(1.0) / np.float32(n_ex) if n_ex else np.float32(np.inf)
+    assert torch.equal(got[3], (lab4 >= 0).float() * float(w)) if n_ex else True
+    if batchsize == 256 and not tie:
+        assert (lab_pre != want).any()                                                       # the case does subsample
+
+
+def test_anchor_target_device_mode_is_seeded_by_numpy_and_reads_nothing_back(dev):
+    """The layer in device mode: the keys come from the device generator, seeded by ONE integer drawn from numpy's global generator
+    per call -- the same numpy seed gives the same sample, another seed another one -- and the call makes no synchronising
+    operation (torch.cuda.set_sync_debug_mode("error") would raise on a device-to-host copy or a blocking upload)."""
+    from dtt.config import cfg
+    from dtt.rpn import _AnchorTargetLayer
+    g = np.load(os.path.join(G, "anchor_target.npz"))
+    case = "b2_38x67"
+    H, W = (int(v) for v in g[case + "/hw"])
+    gt, info = cu(g[case + "/gt_boxes"], dev), cu(g[case + "/im_info"], dev)
+    import copy
+    c = copy.deepcopy(cfg)
+    c.TRAIN.SAMPLER_RNG = "device"
+    layer = _AnchorTargetLayer(16, [int(v) for v in g["scales"]], [float(v) for v in g["ratios"]], cfg=c).to(dev)
+    score = torch.zeros(gt.shape[0], 2 * layer._num_anchors, H, W, device=dev)
+    nb = torch.zeros(gt.shape[0], 1, device=dev)
+    np.random.seed(21); a = layer((score, gt, info, nb))
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        np.random.seed(21); b = layer((score, gt, info, nb))
+        np.random.seed(22); d = layer((score, gt, info, nb))
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+    assert not torch.equal(a[0], d[0]) and torch.equal(a[1], d[1])
+    assert int((a[0] == 1).sum()) + int((a[0] == 0).sum()) <= gt.shape[0] * c.TRAIN.RPN_BATCHSIZE
+
+
 # ------------------------------------------------------------------------ test-time per-class NMS
 @pytest.mark.parametrize("R,ncls,agnostic,mpi", [(300, 31, True, 100), (300, 31, False, 100), (1000, 31, True, 100),
                                                   (77, 5, True, 0), (300, 31, True, 5)])
