@@ -243,6 +243,7 @@ def measure_train_step(args, cfg, dev, world, im, info, gt, nb):
     t0 = time.perf_counter()
     for _ in range(n):
         step()
+    host = time.perf_counter() - t0      # the host has QUEUED n steps (nothing in a step reads the device: dtt/rpn.py, SAMPLER_RNG "device")
     sync()
     elapsed = time.perf_counter() - t0
     used = kt.detach()
@@ -250,7 +251,7 @@ def measure_train_step(args, cfg, dev, world, im, info, gt, nb):
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    res = {"ms_per_step": round(elapsed / n * 1e3, 3), "steps": n, "warmup": n_warm,
+    res = {"ms_per_step": round(elapsed / n * 1e3, 3), "steps": n, "warmup": n_warm, "host_queue_ms_per_step": round(host / n * 1e3, 3),
            "frame_pairs_per_s": round(args.batch * world * n / elapsed, 2),
            "workload": "BASELINE.json configs[3] per-rank step: Res-%d D&T training, %dx%d, bs=%d per GPU (forward + 5 losses + backward "
                        "+ bucketed all-reduce + SGD)" % (args.layers, args.height, args.width, args.batch),

@@ -196,85 +196,115 @@ __global__ __launch_bounds__(kThreads) void at_finish(const float* __restrict__ 
 // uniformly random subset of the foreground anchors beyond num_fg and of the background anchors beyond
 // rpn_batchsize - sum_fg (numpy permutations of the index lists).  Here every anchor carries a 32-bit random key the caller drew
 // WITHOUT looking at the labels, and the k candidates of a class with the smallest (key, index) stay: a uniform subset of
-// exactly k, the same distribution, nothing read back.  The k-th smallest key is found by a radix select (four 8-bit passes,
-// a 256-bin histogram in LDS each); candidates with exactly that key -- rare -- are kept in index order.
+// exactly k, the same distribution, nothing read back.  The k-th smallest key is found by a radix select (four 8-bit passes over
+// the image's labels and keys, a 256-bin histogram in LDS per class: foreground and background are selected in the same passes);
+// candidates with exactly that key -- rare -- are kept in index order.
 // after[b] = (fg, bg) counts left; the workgroup of the LAST image also writes the two outside weights the reference derives from
 // that image's counts (anchor_target_layer.py:143-154): weights[0] positive, [1] negative.
 constexpr int kSubThreads = 1024;
-
-__device__ void keep_smallest(int* __restrict__ labels, const unsigned* __restrict__ keys, int n, int cls, int k, int* sh) {
-  // sh: [0, 256) histogram, [256] prefix, [257] remaining, [258] equal count, [259 ..) scan scratch
-  const int tid = threadIdx.x;
-  if (k <= 0) {
-    for (int i = tid; i < n; i += kSubThreads)
-      if (labels[i] == cls) labels[i] = -1;
-    __syncthreads();
-    return;
-  }
-  unsigned prefix = 0, mask = 0;
-  int rem = k, equal = 0;
-  for (int shift = 24; shift >= 0; shift -= 8) {
-    if (tid < 256) sh[tid] = 0;
-    __syncthreads();
-    for (int i = tid; i < n; i += kSubThreads)
-      if (labels[i] == cls && (keys[i] & mask) == prefix) atomicAdd(&sh[(keys[i] >> shift) & 255u], 1);
-    __syncthreads();
-    if (tid == 0) {
-      int cum = 0, d = 0;
-      for (; d < 255; ++d) {
-        if (cum + sh[d] >= rem) break;
-        cum += sh[d];
-      }
-      sh[256] = d; sh[257] = rem - cum; sh[258] = sh[d];
-    }
-    __syncthreads();
-    prefix |= (unsigned)sh[256] << shift;
-    mask |= 255u << shift;
-    rem = sh[257];
-    equal = sh[258];
-    __syncthreads();
-  }
-  // prefix = the k-th smallest key T; `rem` of the `equal` candidates with key == T stay (the first in index order)
-  if (rem >= equal) {
-    for (int i = tid; i < n; i += kSubThreads)
-      if (labels[i] == cls && keys[i] > prefix) labels[i] = -1;
-  } else {
-    int* wave_cnt = sh + 259;          // [16] per-wave counts of a 1024-anchor chunk
-    int running = 0;                   // equal-key candidates seen in earlier chunks
-    for (int i0 = 0; i0 < n; i0 += kSubThreads) {
-      const int i = i0 + tid;
-      const bool cand = i < n && labels[i] == cls;
-      const bool eq = cand && keys[i] == prefix;
-      const unsigned long long m = __ballot(eq);
-      if ((tid & 63) == 0) wave_cnt[tid >> 6] = __popcll(m);
-      __syncthreads();
-      int before = running;
-      for (int w = 0; w < (tid >> 6); ++w) before += wave_cnt[w];
-      int total = 0;
-      for (int w = 0; w < kSubThreads / 64; ++w) total += wave_cnt[w];
-      const int rank = before + __popcll(m & ((1ull << (tid & 63)) - 1ull));
-      if (cand && (keys[i] > prefix || (eq && rank >= rem))) labels[i] = -1;
-      running += total;
-      __syncthreads();
-    }
-  }
-  __syncthreads();
-}
+constexpr int kBatch = 16;   // label / key pairs in flight per thread
 
 __global__ __launch_bounds__(kSubThreads) void at_subsample(int* __restrict__ labels, const unsigned* __restrict__ keys, int n,
                                                             int batch, const int* __restrict__ counts, int rpn_batchsize,
                                                             int num_fg, float positive_weight, int* __restrict__ after,
                                                             float* __restrict__ weights) {
-  __shared__ int sh[259 + kSubThreads / 64];
-  const int b = blockIdx.x;
+  // per class c (0 background, 1 foreground): hist[c][256]; ctl[c] = {digit, remaining, equal}
+  __shared__ int hist[2][256];
+  __shared__ int ctl[2][3];
+  __shared__ int wave_cnt[kSubThreads / 64];
+  const int b = blockIdx.x, tid = threadIdx.x;
   int* lab = labels + (long)b * n;
   const unsigned* key = keys + (long)b * n;
   const int sum_fg = counts[b * 2], sum_bg = counts[b * 2 + 1];
-  int fg_left = sum_fg, bg_left = sum_bg;
-  if (sum_fg > num_fg) { keep_smallest(lab, key, n, 1, num_fg, sh); fg_left = num_fg; }
   const int num_bg = rpn_batchsize - sum_fg;   // the fg count BEFORE subsampling, as in the reference (:133)
-  if (sum_bg > num_bg) { keep_smallest(lab, key, n, 0, num_bg, sh); bg_left = max(num_bg, 0); }
-  if (threadIdx.x == 0) {
+  // class c is cut down to quota[c] when it has more candidates than that (quota <= 0: every candidate goes)
+  const int quota[2] = {num_bg, num_fg};
+  const bool cut[2] = {sum_bg > num_bg, sum_fg > num_fg};
+  const bool sel[2] = {cut[0] && quota[0] > 0, cut[1] && quota[1] > 0};   // a k-th smallest key has to be found
+  unsigned prefix[2] = {0u, 0u};
+  int rem[2] = {quota[0], quota[1]}, equal[2] = {0, 0};
+  unsigned mask = 0;
+  if (sel[0] || sel[1]) {
+    // radix select, both classes in the same four passes over the image's labels / keys
+    for (int shift = 24; shift >= 0; shift -= 8) {
+      if (tid < 512) hist[tid >> 8][tid & 255] = 0;
+      __syncthreads();
+      // (one CU walks the image: kBatch label / key pairs per thread are requested before any is used -- the pass is a chain of
+      //  memory round trips otherwise, 30 of them at 30 552 anchors)
+      for (int i0 = tid; i0 < n; i0 += kBatch * kSubThreads) {
+        int cs[kBatch];
+        unsigned ks[kBatch];
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+          const int i = min(i0 + u * kSubThreads, n - 1);
+          cs[u] = lab[i]; ks[u] = key[i];
+        }
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+          const int c = cs[u];
+          if (i0 + u * kSubThreads < n && c >= 0 && (c ? sel[1] : sel[0]) && (ks[u] & mask) == (c ? prefix[1] : prefix[0]))
+            atomicAdd(&hist[c][(ks[u] >> shift) & 255u], 1);
+        }
+      }
+      __syncthreads();
+      if ((tid == 0 || tid == 64) && sel[tid >> 6]) {   // one lane per class walks its 256 bins
+        const int c = tid >> 6;
+        int cum = 0, d = 0;
+        for (; d < 255; ++d) {
+          if (cum + hist[c][d] >= rem[c]) break;
+          cum += hist[c][d];
+        }
+        ctl[c][0] = d; ctl[c][1] = rem[c] - cum; ctl[c][2] = hist[c][d];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+        if (sel[c]) { prefix[c] |= (unsigned)ctl[c][0] << shift; rem[c] = ctl[c][1]; equal[c] = ctl[c][2]; }
+      mask |= 255u << shift;
+      __syncthreads();
+    }
+  }
+  // prefix[c] = the k-th smallest key T of class c; rem[c] of the equal[c] candidates with key == T stay (the first in index order)
+  const bool ordered[2] = {sel[0] && rem[0] < equal[0], sel[1] && rem[1] < equal[1]};
+  if (cut[0] || cut[1]) {
+    for (int i0 = tid; i0 < n; i0 += kBatch * kSubThreads) {
+      int cs[kBatch];
+      unsigned ks[kBatch];
+#pragma unroll
+      for (int u = 0; u < kBatch; ++u) {
+        const int i = min(i0 + u * kSubThreads, n - 1);
+        cs[u] = lab[i]; ks[u] = key[i];
+      }
+#pragma unroll
+      for (int u = 0; u < kBatch; ++u) {
+        const int i = i0 + u * kSubThreads, c = cs[u];
+        if (i >= n || c < 0 || !(c ? cut[1] : cut[0])) continue;
+        if (!(c ? sel[1] : sel[0]) || ks[u] > (c ? prefix[1] : prefix[0])) lab[i] = -1;
+      }
+    }
+  }
+  for (int c = 0; c < 2; ++c) {
+    if (!ordered[c]) continue;   // (uniform)
+    int running = 0;             // equal-key candidates seen in earlier chunks
+    for (int i0 = 0; i0 < n; i0 += kSubThreads) {
+      const int i = i0 + tid;
+      const bool eq = i < n && lab[i] == c && key[i] == prefix[c];
+      const unsigned long long m = __ballot(eq);
+      __syncthreads();
+      if ((tid & 63) == 0) wave_cnt[tid >> 6] = __popcll(m);
+      __syncthreads();
+      int before = running, total = 0;
+      for (int w = 0; w < kSubThreads / 64; ++w) {
+        if (w < (tid >> 6)) before += wave_cnt[w];
+        total += wave_cnt[w];
+      }
+      const int rank = before + __popcll(m & ((1ull << (tid & 63)) - 1ull));
+      if (eq && rank >= rem[c]) lab[i] = -1;
+      running += total;
+    }
+  }
+  if (tid == 0) {
+    const int fg_left = cut[1] ? max(num_fg, 0) : sum_fg, bg_left = cut[0] ? max(num_bg, 0) : sum_bg;
     after[b * 2] = fg_left; after[b * 2 + 1] = bg_left;
     if (b == batch - 1) {
       const int num_examples = fg_left + bg_left;
