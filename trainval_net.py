@@ -178,6 +178,9 @@ def main(argv=None):
         sizes = [len(l.dataset) for l in loaders]
         per_epoch = int(min(sizes) / (args.batch_size * world))
         n_steps_data = 2 * per_epoch if len(loaders) > 1 else per_epoch
+    if dev.type == "cuda":
+        read_stream = torch.cuda.Stream(device=dev)           # the step's one host read (loss value + sampler status)
+        host_pair = torch.empty(2, dtype=torch.float32).pin_memory()
     for epoch in range(args.start_epoch, args.max_epochs):   # trainval_net.py:317
         if epoch % (args.lr_decay_step + 1) == 0:
             for g in optimizer.param_groups:  # adjust_learning_rate (net_utils.py:63-66)
@@ -198,17 +201,35 @@ def main(argv=None):
             loss = rpn_cls.mean() + rpn_box.mean() + rcnn_cls.mean() + rcnn_box.mean() + trk.mean()  # :367-368
             # The reference raises "no fg and no bg RoIs" inside the forward (proposal_target_layer_cascade.py:186), i.e. before
             # the loss is used.  The device sampler flags the image instead: the flag is read here, with the loss value, in the
-            # step's ONE host read -- before backward and the weight update -- and all-reduced so that every rank aborts together
+            # step's ONE host read -- before the weight update -- and all-reduced so that every rank aborts together
             # (a rank raising alone would leave the others waiting in the next gradient all-reduce).
             flag = model.RFCN_proposal_target.status_flag()
             flag = torch.zeros(1, device=dev) if flag is None else flag
             if world > 1:
                 dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-            loss_value, bad = torch.cat([loss.detach().view(1), flag]).tolist()
-            if bad:
-                raise ValueError("bg_num_rois = 0 and fg_num_rois = 0, this should not happen!")
-            loss.backward()
-            runner.finish_gradients()
+            if dev.type == "cuda":
+                # The read rides on a side stream that waits for the FORWARD only: backward is queued first, so the GPU keeps
+                # working while the host waits for the two numbers (a plain .tolist() here drains the launch queue right in front
+                # of the launch-bound start of backward).  A flagged step still raises before the weight update.
+                packed = torch.cat([loss.detach().view(1), flag])
+                fwd_done = torch.cuda.Event()
+                fwd_done.record()
+                loss.backward()
+                runner.finish_gradients()
+                with torch.cuda.stream(read_stream):
+                    read_stream.wait_event(fwd_done)
+                    host_pair.copy_(packed, non_blocking=True)
+                packed.record_stream(read_stream)
+                read_stream.synchronize()
+                loss_value, bad = host_pair.tolist()
+                if bad:
+                    raise ValueError("bg_num_rois = 0 and fg_num_rois = 0, this should not happen!")
+            else:
+                loss_value, bad = torch.cat([loss.detach().view(1), flag]).tolist()
+                if bad:
+                    raise ValueError("bg_num_rois = 0 and fg_num_rois = 0, this should not happen!")
+                loss.backward()
+                runner.finish_gradients()
             optimizer.step()
             loss_temp += loss_value
             if (step + 1) % args.disp_interval == 0 and rank == 0:
