@@ -907,6 +907,37 @@ def test_anchor_target_device_mode_follows_its_selection_rule(dev, case, batchsi
         assert (lab_pre != want).any()                                                       # the case does subsample
 
 
+def test_anchor_target_device_mode_draws_uniform_subsets(dev):
+    """The device-mode subset is uniform: over 300 seeded calls with a quota of 56 of ~250 background anchors per image, every
+    candidate is kept about 300 * 56 / m times (binomial, +- 5 sigma) and every call keeps exactly the quota.  (The draws are the
+    device generator's, seeded from numpy: the counts are the same on every box.)"""
+    from dtt.rpn import anchor_target_forward, generate_anchors
+    g = np.load(os.path.join(G, "anchor_target.npz"))
+    base = torch.from_numpy(generate_anchors(scales=g["scales"], ratios=g["ratios"])).float()
+    case = "b3_12x20"
+    H, W = (int(v) for v in g[case + "/hw"])
+    gt, info = cu(g[case + "/gt_boxes"], dev), cu(g[case + "/im_info"], dev)
+    pre = anchor_target_forward(gt, info.cpu(), base, H, W, 16, rpn_batchsize=10 ** 7)[0]
+    cand = (pre == 0)
+    trials, batchsize = 300, 64
+    kept = torch.zeros_like(pre)
+    np.random.seed(77)
+    for _ in range(trials):
+        lab = anchor_target_forward(gt, info, base, H, W, 16, rpn_batchsize=batchsize, mode="device")[0]
+        assert bool(((lab == 0) <= cand).all())                                      # only candidates are kept
+        kept += (lab == 0).float()
+    for b in range(gt.shape[0]):
+        m = int(cand[b].sum())
+        k = batchsize - int((pre[b] == 1).sum())                                       # the reference's background quota
+        assert 0 < k < m
+        cnt = kept[b][cand[b]].cpu().numpy()
+        assert cnt.sum() == trials * k                                                 # exactly the quota, every call
+        p = k / m
+        sigma = np.sqrt(trials * p * (1 - p))
+        assert np.abs(cnt - trials * p).max() < 5 * sigma, (b, cnt.min(), cnt.max(), trials * p, sigma)
+        assert abs(cnt.std() - sigma) < 0.25 * sigma                                   # spread of a binomial, not of a biased rule
+
+
 def test_anchor_target_device_mode_is_seeded_by_numpy_and_reads_nothing_back(dev):
     """The layer in device mode: the keys come from the device generator, seeded by ONE integer drawn from numpy's global generator
     per call -- the same numpy seed gives the same sample, another seed another one -- and the call makes no synchronising
