@@ -58,7 +58,9 @@ __global__ __launch_bounds__(kMaskThreads) void nms_mask_kernel(const float* __r
                                                                 long box_batch_stride, const int* __restrict__ n_per_image,
                                                                 int n_max, float thresh, unsigned long long* __restrict__ mask,
                                                                 long mask_batch_stride, int col_blocks, int row_block0,
-                                                                int row_block_end, int col_block0, int check_done) {
+                                                                int row_block_end, int col_block0, int check_done,
+                                                                const int* __restrict__ keep, long keep_batch_stride,
+                                                                int kept_row_limit) {
   const int col_start = blockIdx.x + col_block0, img = blockIdx.z;
   // second phase of a two-phase NMS: nothing to do for an image whose sweep already has max_keep survivors
   if (check_done && mask[img * mask_batch_stride + mask_state_offset(n_max, col_blocks)] != 0ULL) return;
@@ -72,19 +74,44 @@ __global__ __launch_bounds__(kMaskThreads) void nms_mask_kernel(const float* __r
   const int t = threadIdx.x & (kTile - 1), q = threadIdx.x >> 6;
   const int i0 = q * (kTile / kMaskWaves), i1 = min(i0 + kTile / kMaskWaves, col_size);
   bool staged = false;
+  auto stage_columns = [&]() {   // (uniform: the callers' loop bounds do not depend on the thread)
+    if (staged) return;
+    if (threadIdx.x < col_size) {
+      const float* p = b + (long)(kTile * col_start + threadIdx.x) * boxes_dim;
+      bb[threadIdx.x * 4 + 0] = p[0];
+      bb[threadIdx.x * 4 + 1] = p[1];
+      bb[threadIdx.x * 4 + 2] = p[2];
+      bb[threadIdx.x * 4 + 3] = p[3];
+    }
+    __syncthreads();
+    staged = true;
+  };
+  if (keep) {
+    // Second phase, rows of the FIRST phase's boxes (below kept_row_limit): the sweep only ever reads the rows of boxes it kept
+    // (the replay over the new columns), so only those are computed -- in groups of 64 entries of the image's keep list -- and the
+    // rows of suppressed boxes stay unwritten.  The row blocks from kept_row_limit / 64 on follow below as usual.
+    const int kept = (int)m[mask_state_offset(n_max, col_blocks) + 1];
+    const int* kl = keep + img * keep_batch_stride;
+    for (int g0 = blockIdx.y * kTile; g0 < kept; g0 += gridDim.y * kTile) {
+      stage_columns();
+      if (g0 + t < kept) {
+        const int cur = kl[g0 + t];
+        const float* p = b + (long)cur * boxes_dim;
+        const float a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3];
+        const float Sa = (a2 - a0 + 1) * (a3 - a1 + 1);
+        unsigned bits = 0;
+        for (int i = i0; i < i1; ++i) {
+          if (iou_over(a0, a1, a2, a3, Sa, bb[i * 4 + 0], bb[i * 4 + 1], bb[i * 4 + 2], bb[i * 4 + 3], thresh))
+            bits |= 1u << (i - i0);
+        }
+        reinterpret_cast<unsigned short*>(m + (long)cur * col_blocks + col_start)[q] = (unsigned short)bits;
+      }
+    }
+    row_block0 = max(row_block0, kept_row_limit / kTile);
+  }
   for (int row_start = row_block0 + blockIdx.y; row_start < row_block_end && row_start <= col_start; row_start += gridDim.y) {
     if (row_start * kTile >= n_boxes) break;
-    if (!staged) {   // (uniform: the loop bounds do not depend on the thread)
-      if (threadIdx.x < col_size) {
-        const float* p = b + (long)(kTile * col_start + threadIdx.x) * boxes_dim;
-        bb[threadIdx.x * 4 + 0] = p[0];
-        bb[threadIdx.x * 4 + 1] = p[1];
-        bb[threadIdx.x * 4 + 2] = p[2];
-        bb[threadIdx.x * 4 + 3] = p[3];
-      }
-      __syncthreads();
-      staged = true;
-    }
+    stage_columns();
     const int row_size = min(n_boxes - row_start * kTile, kTile);
     if (t < row_size) {
       const int cur = kTile * row_start + t;
@@ -403,7 +430,7 @@ int dtt_nms_phase1(const float* boxes, int boxes_dim, long box_batch_stride, con
   const int rb1 = split ? min(cb, split * kSuperWords) : cb;   // row AND column blocks of the first mask launch
   dtt_prof_begin("nms_mask", stream);
   hipLaunchKernelGGL(nms_mask_kernel, dim3(rb1, rb1, batch), dim3(kMaskThreads), 0, stream, boxes, boxes_dim, box_batch_stride,
-                     n_per_image, n_max, thresh, mask, mask_batch_stride, cb, 0, rb1, 0, 0);
+                     n_per_image, n_max, thresh, mask, mask_batch_stride, cb, 0, rb1, 0, 0, nullptr, 0L, 0);
   dtt_prof_end("nms_mask", stream);
   DTT_CHECK_LAUNCH("nms_mask_kernel");
   dtt_prof_begin("nms_sweep", stream);
@@ -427,7 +454,8 @@ int dtt_nms_phase2(const float* boxes, int boxes_dim, long box_batch_stride, con
   const int rb1 = min(cb, split * kSuperWords);
   if (cb > rb1) {   // column blocks rb1 .. cb-1, all their rows (a short grid that loops over the row blocks)
     hipLaunchKernelGGL(nms_mask_kernel, dim3(cb - rb1, 8, batch), dim3(kMaskThreads), 0, stream, boxes, boxes_dim, box_batch_stride,
-                       n_per_image, n_max, thresh, mask, mask_batch_stride, cb, 0, cb, rb1, 1);
+                       n_per_image, n_max, thresh, mask, mask_batch_stride, cb, 0, cb, rb1, 1, keep_out, keep_batch_stride,
+                       rb1 * kTile);
     DTT_CHECK_LAUNCH("nms_mask_kernel (phase 2)");
   }
   hipLaunchKernelGGL(nms_sweep_kernel, dim3(batch), dim3(kSweepThreads), lds, stream, mask, mask_batch_stride,
