@@ -348,6 +348,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    host_queue = time.perf_counter() - t0   # the host has queued the timed steps (it reads nothing back inside a step)
     sync()
     elapsed = time.perf_counter() - t0
     used = kt.detach()
@@ -442,6 +443,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "host_queue_ms_per_step": round(host_queue / args.steps * 1e3, 3),   # (rank 0's host: how long it takes to QUEUE a step)
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

@@ -327,7 +327,7 @@ class _RFCN(nn.Module):
         prob = pred = None
         if det_on_side:
             # The detection pooling needs the score map and the RoIs, not the tracking head: on the SIDE stream it could run beside
-            # the tracking head's GEMM (32 us, 40 CUs idle) instead of behind it.  Measured (round 4, rocprofv3 of the captured step):
+            # the tracking head's GEMM (32 us, 40 CUs idle) instead of behind it.  Measured (round 4, rocprofv3 of the bench step):
             # the pooling still starts 8 us after the tracking head ends and 22 us after the second sweep, and the nodes behind it
             # pay 7 - 14 us each -- 238.9 - 239.2 frame-pairs/s against 238.3 - 239.8 on the same box.  Off by default: the tail
             # below stays on one stream after the proposal layer has joined.
@@ -344,7 +344,7 @@ class _RFCN(nn.Module):
             trk = head_gemm(rows, pm.trk)                           # (B*H*W, stride)
         # The poolings need the RoIs as the NMS epilogue wrote them (image index inside the n_legs * B batch): they start as soon
         # as the proposal layer is done.  The per-leg copy the caller gets back (batch index within the leg) is ONE elementwise
-        # launch behind the poolings (it was a clone -- a copy node of the captured graph -- and an in-place subtract on the side
+        # launch behind the poolings (it was a clone -- a runtime copy launch -- and an in-place subtract on the side
         # stream in front of them).  What remains between the last of {second sweep, tracking head} and the detection pooling is
         # the join of the two queues itself: 20 - 28 us in every trace of the round (profiles/r04_bench_step_sequence.txt), with
         # the copy in front, behind, or on the other stream.
@@ -379,7 +379,7 @@ class _RFCN(nn.Module):
 
     def _leg_offsets(self, n_legs, B, dev):
         """(n_legs, 1, 1, 5) with i * B in column 0 of leg i: all_rois' image index -> the index within the leg (cached: no fill
-        kernels inside a captured step)."""
+        launches per step)."""
         key = (n_legs, B, str(dev))
         cache = self.__dict__.setdefault("_leg_offsets_cache", {})
         if key not in cache:
