@@ -269,10 +269,19 @@ def measure_train_step(args, cfg, dev, world, im, info, gt, nb):
     return res
 
 
+_JSON_OUT = sys.stdout
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))
+    # stdout carries ONE line, the JSON.  Whatever the libraries write to file descriptor 1 -- RCCL prints its version banner there when
+    # the 1-rank communicator of the training-step measurement is torn down, i.e. AFTER the JSON line -- goes to stderr instead.
+    global _JSON_OUT
+    sys.stdout.flush()
+    _JSON_OUT = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, "--gpus %d but the launcher started %d ranks" % (args.gpus, world)
     rank = int(os.environ.get("RANK", "0"))
@@ -549,7 +558,7 @@ def main():
         def give_up():
             if rank == 0:
                 out.setdefault("secondary", {})["train_step"] = {"error": "no result within 600 s"}
-                print(json.dumps(out), flush=True)
+                print(json.dumps(out), file=_JSON_OUT, flush=True)
             os._exit(0)
         dog = threading.Timer(600.0, give_up)
         dog.daemon = True
@@ -564,7 +573,7 @@ def main():
         if rank == 0:
             out.setdefault("secondary", {})["train_step"] = ts
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=_JSON_OUT, flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

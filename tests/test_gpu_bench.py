@@ -25,6 +25,8 @@ def _run(mode):
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]          # rank 0 prints ONE line
+    # ... and nothing follows it on stdout (RCCL's version banner, written at communicator teardown, used to)
+    assert [l for l in p.stdout.splitlines() if l.strip()][-1] == lines[0], p.stdout[-2000:]
     return json.loads(lines[0])
 
 
@@ -38,3 +40,21 @@ def test_bench_launches_its_own_ranks(mode):
     if mode == "infer":   # the training step of configs[3] rides along (secondary.train_step), its buckets reduced over the 2-rank group
         ts = out["secondary"]["train_step"]
         assert "error" not in ts and ts["ms_per_step"] > 0 and ts["gradient_buckets"]["count"] >= 1
+
+
+def test_single_gpu_line_is_the_only_thing_on_stdout():
+    """N = 1, default mode: the training-step measurement behind the timed region initialises a 1-rank `nccl` (= RCCL) group, and RCCL
+    writes its version banner to file descriptor 1 when that communicator goes away -- after the JSON line.  bench.py keeps stdout
+    for the ONE line the driver parses (everything else on fd 1 is routed to stderr)."""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "DTT_BENCH_BACKEND"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--layers", "50",
+           "--height", "224", "--width", "320", "--train-steps", "1"]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), p.stdout[-3000:]
+    out = json.loads(lines[0])
+    ts = out["secondary"]["train_step"]
+    assert "error" not in ts and ts["ms_per_step"] > 0 and ts["gradient_buckets"]["collective"].startswith("rccl")
