@@ -272,6 +272,20 @@ def measure_train_step(args, cfg, dev, world, im, info, gt, nb):
 _JSON_OUT = sys.stdout
 
 
+def emit_line(out):
+    """The one JSON line, as the LAST thing the process writes anywhere: the C runtime's buffered streams are flushed first (RCCL
+    printf()s its version banner when the communicator is created; with stdout a pipe it would otherwise sit in the stdio buffer
+    until exit and come out behind the line, also for a caller that reads stdout and stderr through one pipe)."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:   # noqa: BLE001
+        pass
+    sys.stdout.flush()
+    sys.stderr.flush()
+    print(json.dumps(out), file=_JSON_OUT, flush=True)
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -558,7 +572,7 @@ def main():
         def give_up():
             if rank == 0:
                 out.setdefault("secondary", {})["train_step"] = {"error": "no result within 600 s"}
-                print(json.dumps(out), file=_JSON_OUT, flush=True)
+                emit_line(out)
             os._exit(0)
         dog = threading.Timer(600.0, give_up)
         dog.daemon = True
@@ -573,7 +587,7 @@ def main():
         if rank == 0:
             out.setdefault("secondary", {})["train_step"] = ts
     if rank == 0:
-        print(json.dumps(out), file=_JSON_OUT, flush=True)
+        emit_line(out)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
