@@ -276,6 +276,11 @@ def emit_line(out):
     """The one JSON line, as the LAST thing the process writes anywhere: the C runtime's buffered streams are flushed first (RCCL
     printf()s its version banner when the communicator is created; with stdout a pipe it would otherwise sit in the stdio buffer
     until exit and come out behind the line, also for a caller that reads stdout and stderr through one pipe)."""
+    flush_c_streams()
+    print(json.dumps(out), file=_JSON_OUT, flush=True)
+
+
+def flush_c_streams():
     try:
         import ctypes
         ctypes.CDLL(None).fflush(None)
@@ -283,7 +288,6 @@ def emit_line(out):
         pass
     sys.stdout.flush()
     sys.stderr.flush()
-    print(json.dumps(out), file=_JSON_OUT, flush=True)
 
 
 def main():
@@ -586,6 +590,9 @@ def main():
         dog.cancel()
         if rank == 0:
             out.setdefault("secondary", {})["train_step"] = ts
+    flush_c_streams()          # every rank: nothing buffered may come out behind rank 0's line
+    if world > 1:
+        dist.barrier()
     if rank == 0:
         emit_line(out)
     if world > 1:
