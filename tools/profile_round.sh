@@ -31,6 +31,15 @@ timeout 600 rocprofv3 --kernel-trace -d $O/trace -o tr -- python bench.py --mode
 python tools/rocpd_steady.py $(ls $O/trace/*.db | head -1) 3 "corr_wsplit_kernel<3" 400 > $O/train_steady_state.txt 2>&1
 python tools/rocpd_stats.py $(ls $O/trace/*.db | head -1) > $O/train_kernel_stats.txt 2>&1
 rm -rf $O/trace
+# counters of the streamed gradient kernels, one map per pass (per-kernel averages then belong to it)
+for m in conv5 conv4; do
+for c in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE SQ_WAVE_CYCLES; do
+  (cd /tmp && ONLY=$m ITERS=5 timeout 400 rocprofv3 --kernel-trace --pmc $c -d $O/trace -o p -- python $OLDPWD/tools/time_corr_bwd.py > $O/tp.log 2>&1)
+  echo "== $m  $c" >> $O/pmc_corr_bwd.txt
+  python tools/rocpd_pmc.py $(ls $O/trace/*.db $O/trace/*/*.db 2>/dev/null | head -1) 2>&1 | grep "corr_bwd_stream\|corr_bwd_band" >> $O/pmc_corr_bwd.txt
+  rm -rf $O/trace $O/tp.log
+done
+done
 # the correlation gradient kernels alone (conv5 / conv4 / conv3 at B = 2: streamed kernels next to round 1's), per kernel by rocprofv3,
 # and with the DMA / the MFMAs / both ablated (DTT_CORR_BWD_ABLATE 1 / 2 / 3)
 for a in 0 1 2 3; do

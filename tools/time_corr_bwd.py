@@ -31,7 +31,10 @@ def timeit(name, fn, flops):
 
 
 g = torch.Generator().manual_seed(3)
+ONLY = os.environ.get("ONLY", "")      # e.g. ONLY=conv5: one map (per-kernel counter averages of a --pmc pass then belong to it)
 for name, C, H, W, s in (("conv5", 2048, 38, 67, 1), ("conv4", 1024, 38, 67, 1), ("conv3", 512, 75, 134, 2)):
+    if ONLY and name != ONLY:
+        continue
     f1 = torch.relu(torch.randn(B, C, H, W, generator=g)).to(dev).contiguous(memory_format=torch.channels_last)
     f2 = torch.relu(f1.roll((1, 2), (2, 3)) + 0.1 * torch.randn(B, C, H, W, device=dev)).contiguous(memory_format=torch.channels_last)
     oc, oh, ow = correlation_output_shape(C, H, W, D, 1, D, s, s)
