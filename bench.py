@@ -178,22 +178,76 @@ def spawn_ranks(args):
     return subprocess.call(cmd, env=env)
 
 
+def max_over_ranks(elapsed, world, dev, backend):
+    """(max over ranks, [every rank's value]) of a rank-local wall time: the line reports the slowest rank (the contract) and shows
+    the spread, so a straggler -- one rank still timing library candidates, a GPU with a neighbour's job on it -- is visible."""
+    if world <= 1:
+        return elapsed, [elapsed]
+    t = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+    every = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(every, t)
+    vals = [float(v.item()) for v in every]
+    return max(vals), vals
+
+
+def measured_traffic(stem):
+    """The newest profiles/r*_<stem>.json (written by tools/profile_round.sh from separate rocprofv3 --pmc passes) whose
+    `library_sha256` is the sha256 of the libdtt_hip.so loaded here -> (json, file name); (None, reason) when there is none.
+    Counter-derived HBM bytes are quoted only for the binary they were measured on."""
+    import glob
+    import hashlib
+    from dtt import _lib
+    try:
+        sha = hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()
+    except OSError:
+        return None, "libdtt_hip.so not readable"
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*_%s.json" % stem)), reverse=True)
+    for f in files:
+        try:
+            pmc = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        if pmc.get("library_sha256") == sha:
+            return pmc, "profiles/" + os.path.basename(f)
+    return None, ("%s was measured on another libdtt_hip.so build: not quoted (rerun tools/profile_round.sh)" % ("profiles/" + os.path.basename(files[0]))
+                  if files else "no profiles/r*_%s.json" % stem)
+
+
 def corr_bwd_secondary(op_us, args, model):
     """secondary.corr_bwd from the mean durations of a step's three correlation gradient ops (event tag corr_bwd_op), in launch
     order.  The hand-written training graph runs them inside one autograd node in map order (conv3, conv4, conv5:
     dtt.heads.TrackingRowsFn.backward); the library graph has three correlation nodes that autograd runs in reverse creation order."""
     H16, W16 = -(-args.height // 16), -(-args.width // 16)
-    ops = (("corr3_bwd", 512, args.disp // 2), ("corr4_bwd", 1024, args.disp), ("corr5_bwd", 2048, args.disp))
+    H8, W8 = -(-args.height // 8), -(-args.width // 8)
+    ops = (("corr3_bwd", 512, args.disp // 2, H8 * W8), ("corr4_bwd", 1024, args.disp, H16 * W16), ("corr5_bwd", 2048, args.disp, H16 * W16))
     if not getattr(model, "_train_pm", False):
         ops = ops[::-1]
+    pmc, pmc_src = measured_traffic("pmc_corr_bwd")
+    same_shape = (args.batch, args.height, args.width, args.disp) == (2, 600, 1067, 8)
     bw = {}
-    for us, (name, C, R) in zip(op_us, ops):
-        fl = 2.0 * 2.0 * C * (2 * R + 1) ** 2 * H16 * W16 * args.batch      # both gradients: 2 x the forward's FLOPs
-        bw[name] = {"op_us": round(us, 2), "achieved": round(fl / (us * 1e-6) / 1e12, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(fl / (us * 1e-6) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4), "algorithmic_flops_per_op": fl}
+    for us, (name, C, R, HWc) in zip(op_us, ops):
+        D2 = (2 * R + 1) ** 2
+        fl = 2.0 * 2.0 * C * D2 * H16 * W16 * args.batch      # both gradients: 2 x the forward's FLOPs
+        # both maps read once, both gradient maps written once, gradOut read once (SURVEY 8d's per-op bytes for the backward)
+        by = (4 * C * HWc * 4 + D2 * H16 * W16 * 4) * args.batch
+        mf, hb = fl / (us * 1e-6) / 1e12, by / (us * 1e-6) / 1e9
+        # conv3 moves 166 MB for 1.1 GFLOP per gradient pair: its bound is HBM; conv4 / conv5 are bound by the fp32 MFMA rate
+        bound = "hbm" if hb / HBM_PEAK_GBS > mf / FP32_MFMA_PEAK_TFLOPS else "mfma"
+        e = {"op_us": round(us, 2), "bound": bound,
+             "achieved": round(mf if bound == "mfma" else hb, 2), "peak": FP32_MFMA_PEAK_TFLOPS if bound == "mfma" else HBM_PEAK_GBS,
+             "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
+             "frac": round(mf / FP32_MFMA_PEAK_TFLOPS if bound == "mfma" else hb / HBM_PEAK_GBS, 4),
+             "mfma": {"achieved": round(mf, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(mf / FP32_MFMA_PEAK_TFLOPS, 4)},
+             "hbm": {"achieved": round(hb, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hb / HBM_PEAK_GBS, 4)},
+             "algorithmic_flops_per_op": fl, "algorithmic_bytes_per_op": by, "traffic": None}
+        m = (pmc or {}).get(name[:5].replace("corr", "conv"))
+        if m and same_shape:
+            e["traffic"] = m["traffic_bytes_per_op"]
+        bw[name] = e
+    bw["traffic_source"] = (pmc_src + " (same libdtt_hip.so: sha256 checked; FETCH_SIZE x 2 + WRITE_SIZE over the op's three launches)"
+                            if pmc and same_shape else (pmc_src if not pmc else "counters were taken at B=2, 600x1067, d=8: not quoted for this shape"))
     return dict(bw, kernel="correlation gradient op = corr_bwd_band_kernel + 2 x corr_bwd_stream_kernel (both gradients of one correlation, "
-                           "channels-last, band-stationary / halo-streamed: dtt_correlation_backward_nhwc_strided; event tag corr_bwd_op), "
-                           "bound: fp32 MFMA")
+                           "channels-last, band-stationary / halo-streamed: dtt_correlation_backward_nhwc_strided; event tag corr_bwd_op)")
 
 
 def measure_train_step(args, cfg, dev, world, im, info, gt, nb):
@@ -247,14 +301,13 @@ def measure_train_step(args, cfg, dev, world, im, info, gt, nb):
     sync()
     elapsed = time.perf_counter() - t0
     used = kt.detach()
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    res = {"ms_per_step": round(elapsed / n * 1e3, 3), "steps": n, "warmup": n_warm, "host_queue_ms_per_step": round(host / n * 1e3, 3),
+    elapsed, per_rank = max_over_ranks(elapsed, world, dev, os.environ.get("DTT_BENCH_BACKEND", "nccl"))
+    res = {"ms_per_step": round(elapsed / n * 1e3, 3), "ms_per_step_ranks": [round(v / n * 1e3, 3) for v in per_rank],
+           "steps": n, "warmup": n_warm, "host_queue_ms_per_step": round(host / n * 1e3, 3),
            "frame_pairs_per_s": round(args.batch * world * n / elapsed, 2),
-           "workload": "BASELINE.json configs[3] per-rank step: Res-%d D&T training, %dx%d, bs=%d per GPU (forward + 5 losses + backward "
-                       "+ bucketed all-reduce + SGD)" % (args.layers, args.height, args.width, args.batch),
+           "workload": "BASELINE.json configs[%d] per-rank step: Res-%d D&T training, %dx%d, correlation d=%d%s, bs=%d per GPU (forward + 5 "
+                       "losses + backward + bucketed all-reduce + SGD)" % (4 if args.disp == 16 else 3, args.layers, args.height, args.width, args.disp,
+                                                                          "" if args.pooling == "psroi" else " + RoI-%s of the top map" % args.pooling, args.batch),
            "gradient_buckets": {"count": len(runner._buckets), "bytes": runner.bucket_bytes_total(),
                                 "collective": ("rccl all_reduce over %d rank(s)" % dist.get_world_size()) if dist.is_initialized() else "none",
                                 "allreduce_ms": None}}
@@ -309,6 +362,8 @@ def main():
     # (ranks then share devices; inference mode only -- the training path all-reduces device buffers over RCCL)
     backend = os.environ.get("DTT_BENCH_BACKEND", "nccl")
     local = local if backend == "nccl" else local % torch.cuda.device_count()
+    from dtt.dist import isolate_library_caches
+    isolate_library_caches(local, world)   # every rank its own MIOpen find-db / kernel cache: N processes search on the first step
     torch.cuda.set_device(local)  # before the process group exists: RCCL binds its communicator to the current device
     dev = torch.device("cuda", local)
     if world > 1:
@@ -379,10 +434,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     used = kt.detach()
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed, per_rank = max_over_ranks(elapsed, world, dev, backend)
 
     def extra(tag, per_step, pick, n=8):
         """A few more (untimed) steps with another kernel's launches bracketed -- the library records one tag at a time.
@@ -438,22 +490,16 @@ def main():
                 fused_det = os.environ.get("DTT_PSROI_DET_FUSED", "1") != "0"   # class + box pooling + softmax of a RoI in one launch
                 psroi_us = extra("psroi_pm", (2 if fused_det else 3) - (0 if args.frames == 2 else 1), lambda d: d[0])
         # HBM bytes of the op come from separate rocprofv3 --pmc passes over the same launch (tools/profile_round.sh ->
-        # profiles/r04_pmc_conv5.json, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes).  The json records the sha256 of
+        # profiles/rNN_pmc_conv5.json, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes).  The json records the sha256 of
         # the libdtt_hip.so it was measured on: quoted only for that binary and for the shape the pass was taken on.
         traffic, traffic_src = None, None
-        try:
-            import hashlib
-            from dtt import _lib
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_conv5.json")))
-            same_binary = pmc.get("library_sha256") == hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()
-            if nhwc_corr and (args.batch, args.height, args.width, args.disp) == (2, 600, 1067, 8):
-                if same_binary:
-                    traffic = pmc["traffic_bytes_per_op"]
-                    traffic_src = "static: " + pmc.get("source", "profiles/r04_pmc_conv5.json") + " (same libdtt_hip.so: sha256 checked)"
-                else:
-                    traffic_src = "profiles/r04_pmc_conv5.json was measured on another libdtt_hip.so build: not quoted (rerun tools/profile_round.sh)"
-        except (OSError, ValueError, KeyError):
-            pass
+        pmc, pmc_file = measured_traffic("pmc_conv5")
+        if nhwc_corr and (args.batch, args.height, args.width, args.disp) == (2, 600, 1067, 8):
+            if pmc is not None:
+                traffic = pmc["traffic_bytes_per_op"]
+                traffic_src = "static: " + pmc.get("source", pmc_file) + " [" + pmc_file + "] (same libdtt_hip.so: sha256 checked)"
+            else:
+                traffic_src = pmc_file
         corr_us = {}
         if nhwc_corr and args.mode == "infer" and ops_per_step and args.disp <= 8 and os.environ.get("DTT_CORR5_EARLY", "1") != "0":
             order = [int(c) for c in os.environ.get("DTT_CORR_ORDER", "021") if c != "2"]      # after conv5: conv3, conv4 by default
@@ -470,6 +516,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "ms_per_step_ranks": [round(v / args.steps * 1e3, 3) for v in per_rank],     # every rank's own clock; the line's value uses the max
             "host_queue_ms_per_step": round(host_queue / args.steps * 1e3, 3),   # (rank 0's host: how long it takes to QUEUE a step)
             "higher_is_better": True,
             "scaling": "weak",

@@ -188,6 +188,27 @@ class DataParallelSnippets(nn.Module):
         return self.module.state_dict(*a, **k)
 
 
+def isolate_library_caches(local_rank, world, env=None):
+    """One process per GPU means N processes that each let MIOpen search its convolution algorithms on the first step.  MIOpen keeps
+    what it finds in a per-user sqlite find-db and a kernel cache under $HOME: N ranks writing the same files lock each other out for
+    the whole warm-up (or read a half-written entry).  Give every rank its own MIOPEN_USER_DB_PATH / MIOPEN_CUSTOM_CACHE_DIR --
+    must run before the first convolution of the process (the library reads the variables when its handle is created).  A user's
+    own setting wins.  (hipBLASLt candidate timing, dtt_gemm_tune, keeps its picks in process memory: nothing is shared.)
+    Returns the directory used, or None when nothing was changed (one rank, or both variables already set)."""
+    import os
+    import tempfile
+    env = os.environ if env is None else env
+    if world <= 1 or ("MIOPEN_USER_DB_PATH" in env and "MIOPEN_CUSTOM_CACHE_DIR" in env):
+        return None
+    base = os.path.join(env.get("DTT_CACHE_ROOT", tempfile.gettempdir()), "dtt_miopen_uid%d_rank%d" % (os.getuid(), local_rank))
+    for key, sub in (("MIOPEN_USER_DB_PATH", "db"), ("MIOPEN_CUSTOM_CACHE_DIR", "cache")):
+        if key not in env:
+            d = os.path.join(base, sub)
+            os.makedirs(d, exist_ok=True)
+            env[key] = d
+    return base
+
+
 def broadcast_module_state(module, process_group=None, src=0):
     """Rank `src`'s parameters and buffers (BatchNorm statistics included) to every rank.  Must run BEFORE anything
     that snapshots them into constants (dtt.fuse.fuse_for_training folds the frozen-BatchNorm statistics and the frozen

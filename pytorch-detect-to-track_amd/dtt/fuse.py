@@ -282,8 +282,9 @@ def fuse_for_training(model, channels_last=False):
     # RFCN_cls_net + RFCN_bbox_net as ONE hand-written MFMA GEMM with a hand-written backward, position-major PSRoI pooling
     # forward / backward (dtt.heads.HeadGemmFn / PsroiPmFn): needs the channels-last `top`, class-agnostic boxes and at most
     # 32 classes (the pooling kernel's lane layout).  DTT_TRAIN_PM=0: the library convolutions + NCHW pooling kernels.
+    # An odd anchor count (the 9-anchor default of the non-imagenet datasets) keeps the library graph: the packed RPN heads pair anchors.
     model._train_pm = bool(channels_last and os.environ.get("DTT_TRAIN_PM", "1") != "0" and getattr(model, "class_agnostic", False)
-                           and getattr(model, "n_classes", 99) <= 32)
+                           and getattr(model, "n_classes", 99) <= 32 and model.RFCN_rpn.RPN_cls_score.weight.shape[0] % 4 == 0)
     return model
 
 

@@ -413,8 +413,11 @@ class _RFCN(nn.Module):
             num_boxes = num_boxes.permute(1, 0, 2).contiguous().detach()
         c3, c4, c5, top, ex = self._im_to_head_ex(flat)
         if self.training:
+            # (the hand-written RPN heads pack (bg, fg) pairs two to a 4-row group: an even anchor count.  The default 9-anchor
+            #  configurations of the non-imagenet datasets train on the library graph, as their inference falls back in PositionMajorTail.)
             train_pm = (getattr(self, "_train_pm", False) and top.is_cuda and torch.is_grad_enabled() and n_legs <= 2
-                        and top.is_contiguous(memory_format=torch.channels_last) and not top.is_contiguous())
+                        and top.is_contiguous(memory_format=torch.channels_last) and not top.is_contiguous()
+                        and self.RFCN_rpn.RPN_cls_score.weight.shape[0] % 4 == 0)
             build = self._forward_train_pm if train_pm else self._forward_train_nchw
             return build(c3, c4, c5, top, im_info, gt_boxes, num_boxes, n_legs, B, dev)
         side = all_rois = None

@@ -175,3 +175,18 @@ def test_force_buckets_at_world_one_matches_the_plain_step():
             else:
                 assert torch.equal(p.grad, q.grad), (n, step)
                 assert any(q.grad.data_ptr() >= f.data_ptr() and q.grad.data_ptr() < f.data_ptr() + f.numel() * 4 for f, _ in dp1._buckets), n
+
+
+def test_isolate_library_caches_gives_every_rank_its_own_miopen_paths(tmp_path):
+    """N processes on N GPUs must not share MIOpen's per-user find-db / kernel cache during the first step's algorithm search."""
+    from dtt.dist import isolate_library_caches
+    envs = []
+    for r in range(3):
+        e = {"DTT_CACHE_ROOT": str(tmp_path)}
+        base = isolate_library_caches(r, 3, env=e)
+        assert base and os.path.isdir(e["MIOPEN_USER_DB_PATH"]) and os.path.isdir(e["MIOPEN_CUSTOM_CACHE_DIR"])
+        envs.append(e)
+    assert len({e["MIOPEN_USER_DB_PATH"] for e in envs}) == 3 and len({e["MIOPEN_CUSTOM_CACHE_DIR"] for e in envs}) == 3
+    assert isolate_library_caches(0, 1, env={}) is None                                     # one rank: nothing to isolate
+    mine = {"MIOPEN_USER_DB_PATH": "/x", "MIOPEN_CUSTOM_CACHE_DIR": "/y"}
+    assert isolate_library_caches(1, 8, env=mine) is None and mine["MIOPEN_USER_DB_PATH"] == "/x"   # the user's setting wins

@@ -13,15 +13,15 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(mode):
+def _run(mode, gpus=2, extra=()):
     env = dict(os.environ)
     env["DTT_BENCH_BACKEND"] = "gloo"
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
     env.pop("LOCAL_RANK", None)
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
-           "--mode", mode, "--layers", "50", "--height", "224", "--width", "320", "--train-steps", "1"]
-    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+           "--mode", mode, "--layers", "50", "--height", "224", "--width", "320", "--train-steps", "1"] + list(extra)
+    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=1500)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]          # rank 0 prints ONE line
@@ -37,9 +37,22 @@ def test_bench_launches_its_own_ranks(mode):
     assert out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "weak"
     assert out["config"]["global_batch"] == 4 and out["value"] > 0
     assert out["roofline"]["ops_timed"] == 2
+    assert len(out["ms_per_step_ranks"]) == 2 and max(out["ms_per_step_ranks"]) == out["ms_per_step"]   # every rank's clock, the max is reported
     if mode == "infer":   # the training step of configs[3] rides along (secondary.train_step), its buckets reduced over the 2-rank group
         ts = out["secondary"]["train_step"]
         assert "error" not in ts and ts["ms_per_step"] > 0 and ts["gradient_buckets"]["count"] >= 1
+
+
+def test_bench_eight_ranks_training_control_flow():
+    """The command line the driver runs on the 8-GPU node (`bench.py --gpus 8 --mode train`: BASELINE configs[3], global batch 16),
+    here with the eight ranks sharing this box's one GPU over gloo: start-up of eight processes (each its own MIOpen find-db,
+    dtt.dist.isolate_library_caches), the broadcast of rank 0's state, eight bucketed all-reduces per step, ONE JSON line with
+    n_gpus == 8 and every rank's own step time in it."""
+    out = _run("train", gpus=8)
+    assert out["n_gpus"] == 8 and out["backend"] == "gloo" and out["config"]["global_batch"] == 16
+    assert out["steps"] == 2 and out["value"] > 0 and out["scaling"] == "weak"
+    assert len(out["ms_per_step_ranks"]) == 8 and max(out["ms_per_step_ranks"]) == out["ms_per_step"]
+    assert "dp8" in out["config"]["parallelism"]
 
 
 def test_single_gpu_line_is_the_only_thing_on_stdout():

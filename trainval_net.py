@@ -121,6 +121,8 @@ def main(argv=None):
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
+        from dtt.dist import isolate_library_caches
+        isolate_library_caches(local, world)   # every rank its own MIOpen find-db / kernel cache
         torch.cuda.set_device(local)  # before the process group exists: RCCL binds its communicator to this device
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world)
