@@ -32,10 +32,12 @@ extern "C" {
 /* ---------------------------------------------------------------- misc */
 int dtt_abi_version(void);
 const char* dtt_last_error(void);
-/* Measurement hook (no reference counterpart): bracket every launch of the kernel named `tag`
- * (e.g. "corr_fwd_mfma", "corr_fwd_reduce", "psroi_fwd_plane", "nms_mask", "nms_sweep",
- * "proposal_select_sort") with hipEventRecord(begin_events[i]) / hipEventRecord(end_events[i]) on the
- * launch stream, for the first n launches.  tag = NULL detaches.  Events are hipEvent_t handles owned
+/* Measurement hook (no reference counterpart): bracket every launch (or whole op) named `tag` with
+ * hipEventRecord(begin_events[i]) / hipEventRecord(end_events[i]) on the launch stream, for the first n launches.
+ * Tags -- ops: "corr_fwd_op" (one forward correlation, whatever kernels it takes), "corr_bwd_op" (both gradients of one
+ * correlation: band kernel + two streamed launches); kernels: "corr_nhwc" (corr_wsplit_kernel), "corr_fwd_mfma" /
+ * "corr_fwd_reduce" (the NCHW pair), "head_gemm", "rpn_head_gemm", "psroi_pm" (position-major poolings), "psroi_fwd_plane",
+ * "nms_mask", "nms_sweep", "proposal_select_sort".  tag = NULL detaches.  Events are hipEvent_t handles owned
  * by the caller.  dtt_profile_count() = launches recorded so far. */
 int dtt_profile_attach(const char* tag, void** begin_events, void** end_events, int n);
 int dtt_profile_count(void);

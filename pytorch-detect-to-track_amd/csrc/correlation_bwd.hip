@@ -12,9 +12,9 @@
 //   columns -- and the lane then holds, per target pixel, four consecutive channels: the result leaves as float4 stores
 //   straight from the accumulators.  No LDS epilogue, no exchange, no partial sums, every gradient element written once.
 //
-//   * Workgroup = 8 waves = a tile of th x tw target blocks (2 x 4; 4 x 1 / 2 x 1 ... along odd map edges), every wave
-//     also issues its share of the LDS-DMA (global_load_lds_dwordx4, scalar base): no loader waves, so two waves per SIMD
-//     may use 256 registers each (band 100 + accumulators 16 + operands).
+//   * Workgroup = 8 compute waves = a tile of th x tw target blocks (2 x 4; 4 x 1 / 2 x 1 ... along odd map edges) + 4 loader
+//     waves (kComp / kLoad below) that issue the LDS-DMA (global_load_lds_dwordx4, scalar base) and keep the ring's bookkeeping
+//     off the compute waves: three waves per SIMD at 168 registers each (band 100 + accumulators 16 + operands).
 //   * The halo of a 64-channel group is streamed as BLOCK ROWS (4 halo rows x the tile's halo width x 64 channels = one ring
 //     slot, 32 KB for a 2 x 4 tile): wave row wy consumes block rows wy .. wy + NBR - 1 of a group, i.e. it runs `wy` ring
 //     positions ahead of wave row 0 -- every wave has NBR steps of work per group although the tile's halo has th + NBR - 1

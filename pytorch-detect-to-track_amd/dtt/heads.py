@@ -457,7 +457,8 @@ class RpnHeadFn(torch.autograd.Function):
                 wt = torch.zeros((K, LG), dtype=torch.float32, device=dev)    # dX (M, K) = grows (M, LG) @ wt.T
                 wt[:, :N16] = w.t()
                 gx = torch.empty((M, K), dtype=torch.float32, device=dev)
-                check(L.dtt_head_gemm(ptr(grows), LG, M, LG, ptr(wt), ptr(torch.zeros(K, dtype=torch.float32, device=dev)), K, ptr(gx),
+                zero_bias = _device_constant(("zero_bias", K, str(dev)), lambda: torch.zeros(K, dtype=torch.float32, device=dev))   # (read only; lives on)
+                check(L.dtt_head_gemm(ptr(grows), LG, M, LG, ptr(wt), ptr(zero_bias), K, ptr(gx),
                                       K, K, 0, stream_ptr(dev)), "rpn head dX")
             if ctx.needs_input_grad[1]:
                 gw = torch.empty((N16, K), dtype=torch.float32, device=dev)

@@ -161,7 +161,10 @@ class _RPN(nn.Module):
     def losses_from_probabilities(self, cls_prob, bbox_pred, gt_boxes, im_info, num_boxes):
         """rpn.py:74-107 for one leg when the heads come out of the one-launch GEMM, whose epilogue has already applied the
         pairwise softmax (dtt.heads.RpnHeadFn): the cross-entropy of rpn.py:97 over the sampled anchors is -log of the label's
-        probability (the same number to rounding; the softmax's adjoint is applied in RpnHeadFn.backward)."""
+        probability (the same number to rounding; the softmax's adjoint is applied in RpnHeadFn.backward).
+        Known difference, diverging runs only: when the label's probability underflows to 0 in fp32 (a logit gap above ~87) the loss
+        reads 85.2 (= -log 1e-37) and that anchor's gradient is 0, where the reference's cross_entropy on the logits keeps growing
+        with a gradient of p - y = -1.  Nothing below that gap differs."""
         B = cls_prob.size(0)
         labels, tgt, w_in, w_out = self.RPN_anchor_target((cls_prob.detach(), gt_boxes, im_info, num_boxes))
         prob = self.reshape(cls_prob, 2).permute(0, 2, 3, 1).contiguous().view(-1, 2)
@@ -299,7 +302,10 @@ class _RFCN(nn.Module):
         """rfcn.py:133-140, 166-196 at inference on the position-major layout: one MFMA GEMM for the class + box heads of
         every image (`dtt_head_gemm`), lanes = classes PSRoI pooling + vote (`dtt_psroi_pm_forward`), the tracking
         head's input rows assembled in place (box-delta columns copied, correlations written by their kernels).
-        ex: the fused trunk's TrunkExtras (channels-last `top` rows, the early head GEMM's output)."""
+        ex: the fused trunk's TrunkExtras (channels-last `top` rows, the early head GEMM's output).
+        The four loss outputs and the tracking loss of the returned 10-tuple are views of ONE cached zero tensor (inference has no
+        losses; allocating and filling them cost two launches per step): read-only -- a caller that wants to accumulate into them
+        must clone first."""
         from .heads import gather_column_blocks, head_gemm, psroi_pm
         top_rows, (H, W) = ex.top_rows, ex.top_hw
         cur = torch.cuda.current_stream(dev)

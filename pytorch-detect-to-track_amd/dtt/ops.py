@@ -161,6 +161,11 @@ def _is_channels_last(t):
     return t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last) and not t.is_contiguous()
 
 
+def corr_bwd_stream_enabled():
+    """DTT_CORR_BWD_STREAM=0 (developer A/B switch): the band-stationary streamed gradient kernels off, round 1's kernels instead."""
+    return os.environ.get("DTT_CORR_BWD_STREAM", "1") != "0"
+
+
 def correlation_backward_nhwc(grad_output, input1, input2, g1, g2, pad_size, kernel_size, max_displacement, stride1, stride2,
                               rows=None, col=0):
     """Both correlation gradients on channels-last maps, written into the channels-last tensors g1 / g2 (either may be None).
@@ -172,15 +177,22 @@ def correlation_backward_nhwc(grad_output, input1, input2, g1, g2, pad_size, ker
     B, C, H, W = input1.shape
     oc, oh, ow = correlation_output_shape(C, H, W, pad_size, kernel_size, max_displacement, stride1, stride2)
     dev = input1.device
-    streamed = bool(L.dtt_correlation_backward_stream_supported(C, kernel_size, max_displacement, stride1, stride2)) and \
-        os.environ.get("DTT_CORR_BWD_STREAM", "1") != "0"
+    streamed = bool(L.dtt_correlation_backward_stream_supported(C, kernel_size, max_displacement, stride1, stride2)) and corr_bwd_stream_enabled()
     with torch.cuda.device(dev):
         if not streamed:
-            if rows is not None or g1 is None or g2 is None:
-                raise ValueError("correlation backward (channels-last): %d channels take the round-1 kernels, which need a contiguous "
-                                 "gradOutput tensor and both gradient outputs" % C)
+            # round 1's kernels: a contiguous (B, D*D, oh, ow) gradOutput and both gradient outputs.  A rows-form gradient is
+            # gathered into that tensor first, a gradient the caller does not want goes to a scratch map, a sliced destination is
+            # filled through a contiguous-in-channels-last temporary (this path is the developer switch's and the fallback of
+            # channel counts that are not a multiple of 64: correctness first)
+            if max_displacement // max(stride2, 1) > 8:
+                raise ValueError("correlation backward (channels-last): window radius %d needs the streamed kernels (channels %% 64 == 0, "
+                                 "DTT_CORR_BWD_STREAM not 0)" % (max_displacement // max(stride2, 1)))
+            if rows is not None:
+                grad_output = rows[:, col:col + oc].reshape(B, oh, ow, oc).permute(0, 3, 1, 2)
             grad_output = grad_output.contiguous()
-            check(L.dtt_correlation_backward_nhwc(ptr(grad_output), B, oc, oh, ow, ptr(input1), C, H, W, ptr(input2), ptr(g1), ptr(g2),
+            t1 = g1 if g1 is not None else torch.empty_like(input1)
+            t2 = g2 if g2 is not None else torch.empty_like(input2)
+            check(L.dtt_correlation_backward_nhwc(ptr(grad_output), B, oc, oh, ow, ptr(input1), C, H, W, ptr(input2), ptr(t1), ptr(t2),
                                                   pad_size, kernel_size, max_displacement, stride1, stride2, stream_ptr(dev)),
                   "correlation backward (channels-last)")
             return
@@ -222,7 +234,8 @@ class CorrelationNHWCFunction(Function):
                 stride2 > 0 and input1.size(1) % 16 == 0):
             return False
         radius = max_displacement // stride2
-        if not 1 <= radius <= (CorrelationNHWCFunction.MAX_RADIUS if input1.size(1) % 64 == 0 else 8):
+        wide = input1.size(1) % 64 == 0 and corr_bwd_stream_enabled()    # radius 9 .. 16: only the streamed gradient kernels take it
+        if not 1 <= radius <= (CorrelationNHWCFunction.MAX_RADIUS if wide else 8):
             return False
         # the kernels address the stride lattice: displacement and (displacement - padding) must be multiples of the stride
         if max_displacement % stride2 != 0 or (pad_size is not None and (max_displacement - pad_size) % stride2 != 0):
