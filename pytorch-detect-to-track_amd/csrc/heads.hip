@@ -34,15 +34,11 @@ typedef const __attribute__((address_space(1))) void glb_void_t;
 
 constexpr int kBK = 32;   // k per stage = one 128-byte line per row
 
-// Store form of the wide / narrow (non-RPN) epilogue -- developer A/B (tools/build_variant.sh):
-//   0  A = weights, B = pixels: a lane holds 4 consecutive channels of one pixel, one 16-byte store per accumulator (a quarter-wave
-//      touches 16 rows x 16 B)
-//   1  A = pixels, B = weights (the transposed product: the same k order per element): a lane holds ONE channel of 4 consecutive
-//      pixels, four 4-byte stores per accumulator -- a quarter-wave writes 64 contiguous bytes of one row
-//   2  as 0 with non-temporal stores
-#ifndef DTT_HEAD_STORE
-#define DTT_HEAD_STORE 0
-#endif
+// The wide / narrow (non-RPN) epilogue stores with the non-temporal hint.  Round 5, rocprofv3 --pmc WRITE_SIZE on the class + box launch
+// (10184 x 1764 floats = 71.9 MB stored): plain 16-byte stores 92.2 MB (1.28x: the 64-byte half lines of an accumulator tile are written
+// back by the L2 more than once), non-temporal 72.2 MB (1.005x), the same duration (the launch is MFMA-bound).  A transposed product
+// (A = pixels: 64 contiguous bytes per quarter-wave, four 4-byte stores per accumulator) left the counter at 93.7 MB -- the lane pattern
+// was not the cause (profiles/r05_head_store_ab.txt).  -DDTT_HEAD_PLAIN_STORES restores the plain stores for an A/B.
 
 constexpr int kMaxPasses = 8;
 
@@ -118,13 +114,7 @@ __device__ __forceinline__ void head_pass(const HeadGeom& g, const float* lds, i
   f32x4 acc[CNT][TPX];
 #pragma unroll
   for (int t = 0; t < CNT; ++t) {
-    f32x4 b4;
-    if constexpr (DTT_HEAD_STORE == 1 && !RPN) {
-      const float b1 = g.bias[(long)min(tile0 + t, g.nt_total - 1) * 16 + l15];
-      b4 = f32x4{b1, b1, b1, b1};
-    } else {
-      b4 = *reinterpret_cast<const f32x4*>(g.bias + (long)min(tile0 + t, g.nt_total - 1) * 16 + 4 * lg);
-    }
+    const f32x4 b4 = *reinterpret_cast<const f32x4*>(g.bias + (long)min(tile0 + t, g.nt_total - 1) * 16 + 4 * lg);
 #pragma unroll
     for (int pt = 0; pt < TPX; ++pt) acc[t][pt] = b4;
   }
@@ -184,10 +174,7 @@ __device__ __forceinline__ void head_pass(const HeadGeom& g, const float* lds, i
         for (int j = 0; j < 4; ++j)
 #pragma unroll
           for (int q = 0; q < TPG; ++q)
-            if constexpr (DTT_HEAD_STORE == 1 && !RPN)
-              acc[t][pxg * TPG + q] = __builtin_amdgcn_mfma_f32_16x16x4f32(bx[seg & 1][q][j], aw[hh][t][j], acc[t][pxg * TPG + q], 0, 0, 0);
-            else
-              acc[t][pxg * TPG + q] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[hh][t][j], bx[seg & 1][q][j], acc[t][pxg * TPG + q], 0, 0, 0);
+            acc[t][pxg * TPG + q] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[hh][t][j], bx[seg & 1][q][j], acc[t][pxg * TPG + q], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
   };
@@ -241,26 +228,6 @@ __device__ __forceinline__ void head_pass(const HeadGeom& g, const float* lds, i
     //  per lane were what the 256-register wide configuration spilled)
     char* ob = reinterpret_cast<char*>(g.out);
     const unsigned ldc4 = (unsigned)(g.ldc * 4);
-    if constexpr (DTT_HEAD_STORE == 1) {
-      // lane = (channel l15 of the tile, pixels 4 * lg .. 4 * lg + 3): register r goes to row 4 * lg + r, 64 contiguous bytes per quarter-wave
-      unsigned lgo = (unsigned)lg;
-      asm volatile("" : "+v"(lgo));       // (opaque here: the row offsets below are computed at the stores, not hoisted above the K loop and spilled)
-      const unsigned row0 = (unsigned)p0 + 4u * lgo;
-#pragma unroll
-      for (int t = 0; t < CNT; ++t) {
-        if (t < cnt && !(g.ablate & 4)) {
-          const int col = (tile0 + t) * 16 + l15;
-          const unsigned off0 = row0 * ldc4 + (unsigned)col * 4u;
-#pragma unroll
-          for (int pt = 0; pt < TPX; ++pt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int row = p0 + pt * 16 + 4 * lg + r;
-              if (row < g.M && col < g.n_store) *reinterpret_cast<float*>(ob + (off0 + (unsigned)(pt * 16 + r) * ldc4)) = acc[t][pt][r];
-            }
-        }
-      }
-    } else {
     const unsigned row0 = (unsigned)(p0 + l15);
 #pragma unroll
     for (int t = 0; t < CNT; ++t) {
@@ -271,12 +238,14 @@ __device__ __forceinline__ void head_pass(const HeadGeom& g, const float* lds, i
         for (int pt = 0; pt < TPX; ++pt) {
           const int row = p0 + pt * 16 + l15;
           if (row < g.M && col < g.n_store) {
-            if constexpr (DTT_HEAD_STORE == 2) __builtin_nontemporal_store(acc[t][pt], reinterpret_cast<f32x4*>(ob + (off0 + (unsigned)(pt * 16) * ldc4)));
-            else *reinterpret_cast<f32x4*>(ob + (off0 + (unsigned)(pt * 16) * ldc4)) = acc[t][pt];
+#ifdef DTT_HEAD_PLAIN_STORES
+            *reinterpret_cast<f32x4*>(ob + (off0 + (unsigned)(pt * 16) * ldc4)) = acc[t][pt];
+#else
+            __builtin_nontemporal_store(acc[t][pt], reinterpret_cast<f32x4*>(ob + (off0 + (unsigned)(pt * 16) * ldc4)));
+#endif
           }
         }
       }
-    }
     }
   }
   HEAD_STAMP(wave, 401 + 4 * (s_begin / KC));

@@ -6,7 +6,11 @@
     proposals and random draws, at Res-101 600 x 1067 / d = 8 (configs[3] per rank) and 563 x 1000 / d = 16 + RoI-Align (configs[4]
     per rank).  The comparison is made where the two graphs meet the trunk: the gradients of the conv3 / conv4 / conv5 maps (what the
     correlation gradient kernels write, correlation_cuda_kernel.cu:108-290, 371-473) and of the 512-channel top map (head dX + RPN)
-    to 1e-3 of their norm, the five losses to 1e-4, every head / RPN parameter gradient to 1e-3.  A per-tensor table is printed.
+    to 1e-4 of their norm, the five losses to 1e-4, every head / RPN parameter gradient to 1e-4, trunk parameters to 1e-3.  A
+    per-tensor table is printed.  The comparison runs with torch.backends.cudnn.deterministic = True: at the configs[4] shape (two
+    images per trunk batch) MIOpen's default fp32 kernels are NOT reproducible from run to run -- two runs of the SAME graph differ
+    in the forward maps' last bits and, through flipped ReLU gates, by 1e-2 in the map gradients (tools/debug_d16c.py, round 5) --
+    which says nothing about either graph; with the deterministic kernels each graph repeats bit for bit and the two agree to 4e-6.
   * one full configs[4] per-rank training step (d = 16: 33 x 33 displacements, corr_bbox_net 2859 -> 196): contract shapes, finite
     gradients for every trainable parameter, a directional derivative through corr_bbox_net and the R-FCN heads.
 """
@@ -97,10 +101,19 @@ def test_training_graphs_agree_at_full_size(H, W, B, disp, roi):
         return [float(l.detach()) for l in losses], g, out
 
     c.TRAIN.SAMPLER_RNG = "reference"      # both graphs draw the same anchor / RoI subsets (numpy stream, seeded above)
-    run(True)                              # warm-up: the libraries pick their kernels on the first step
-    l_pm, g_pm, o_pm = run(True)
-    l_nc, g_nc, o_nc = run(False)
+    was = torch.backends.cudnn.deterministic
+    torch.backends.cudnn.deterministic = True   # the library trunk repeats bit for bit (see the module docstring)
+    try:
+        run(True)                              # warm-up: the libraries pick their kernels on the first step
+        l_pm, g_pm, o_pm = run(True)
+        l_pm2, g_pm2, _ = run(True)
+        l_nc, g_nc, o_nc = run(False)
+    finally:
+        torch.backends.cudnn.deterministic = was
     model._train_pm = True
+    # the hand-written graph is reproducible: fixed summation orders everywhere, no atomics (north star: bit-exact indices, run-to-run
+    # identical correlation gradients)
+    assert l_pm == l_pm2 and all(torch.equal(g_pm[n], g_pm2[n]) for n in g_pm)
     assert torch.equal(o_pm[0], o_nc[0]) and torch.equal(o_pm[8], o_nc[8])            # same sampled RoIs and labels
     for a, b in zip(l_pm, l_nc):
         assert abs(a - b) <= 1e-4 * max(1.0, abs(b)), (l_pm, l_nc)
@@ -126,7 +139,7 @@ def test_training_graphs_agree_at_full_size(H, W, B, disp, roi):
         assert nrm > 0 or kind == "trunk", n
         # maps and heads: one or two hand-written kernels away from the losses; trunk parameters collect the map gradients through
         # up to 23 library layers whose algorithms are picked per run
-        assert rel < (1e-3 if kind in ("map", "head") else 2e-2), (n, rel, nrm)
+        assert rel < (1e-4 if kind in ("map", "head") else 1e-3), (n, rel, nrm)
 
 
 def test_configs4_training_step_d16_roi_align_full_size():

@@ -27,6 +27,9 @@ sel = steps[-n:]
 seqs = {tuple(sorted(t for t, _, _ in st)) for st in sel}
 if len(sel) < n or len(seqs) != 1:
     print("REFUSED: the last %d tails do not hold the same launches (%d distinct sets) -- not %d identical inference steps" % (n, len(seqs), n))
+    import collections
+    for q in seqs:
+        print("   ", dict(collections.Counter(q)), " x %d steps" % sum(1 for st in sel if tuple(sorted(t for t, _, _ in st)) == q))
     sys.exit(3)
 for st in sel:
     t0 = st[0][1]
