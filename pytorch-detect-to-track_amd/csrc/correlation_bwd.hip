@@ -73,6 +73,8 @@ struct BGeom {
   int use_table;
   int hoff_y, hoff_x;                  // window radius > 8: this launch covers the NBR x NBR window blocks from block (hoff / 4), i.e. its
   int accumulate;                      // halo starts hoff pixels further on; launches after the first ADD to the gradient
+  int ny, nx;                          // ... of which only the first ny block rows / nx block columns lie inside the window (the others'
+                                       // band words are all zero: the PARTIAL instantiation skips their MFMAs)
   int ablate;                          // developer timing experiments (DTT_CORR_BWD_ABLATE): 1 no DMA, 2 no MFMA, 4 no stores, 8 no band loads
   unsigned short table[kTable];
 };
@@ -140,7 +142,7 @@ __host__ __device__ __forceinline__ BItem bw_decode(const BGeom& g, int item) {
   return it;
 }
 
-template <int NBR>
+template <int NBR, bool PARTIAL = false>
 __global__ __launch_bounds__(kThreads) void corr_bwd_stream_kernel(BGeom g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int NB4 = NBR * NBR * 4;
@@ -291,11 +293,14 @@ __global__ __launch_bounds__(kThreads) void corr_bwd_stream_kernel(BGeom g) {
         if (qi == 0 && gi == 0) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the band has arrived
         if (tall && qi == 0 && gi > 0) wg_barrier_b();
         wg_barrier_b();
-        if (do_mfma) {
+        // (PARTIAL: a quarter of a 9 x 9-block window holds 5 x 5, 5 x 4, 4 x 5 or 4 x 4 blocks that can be non-zero -- 81 of the 100
+        //  the four launches walk; the block rows / columns beyond are skipped, wave-uniformly, the ring and the barriers stay)
+        if (do_mfma && (!PARTIAL || qi < g.ny)) {
           const unsigned sp = rd_lane + (unsigned)(r_slot * slot_bytes);
           auto mm = [&](int t, int buf) {
 #pragma unroll
             for (int qj = 0; qj < NBR; ++qj) {
+              if (PARTIAL && qj >= g.nx) continue;
               const float a = band[(qi * NBR + qj) * 4 + t];
               acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[buf][qj][0], acc0, 0, 0, 0);
               acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[buf][qj][1], acc1, 0, 0, 0);
@@ -587,17 +592,17 @@ const BPlan* cached_plan(const PlanKey& k) {
   return p;
 }
 
-template <int NBR>
+template <int NBR, bool PARTIAL = false>
 int launch_stream(const BGeom& g, int items, size_t lds_bytes, hipStream_t stream) {
   static DttDeviceOnce once;
   bool& done = once.here();
   if (!done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(corr_bwd_stream_kernel<NBR>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(corr_bwd_stream_kernel<NBR, PARTIAL>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMax);
     DTT_REQUIRE(e == hipSuccess, "correlation backward (streamed): cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
     done = true;
   }
-  hipLaunchKernelGGL((corr_bwd_stream_kernel<NBR>), dim3(items), dim3(kThreads), lds_bytes, stream, g);
+  hipLaunchKernelGGL((corr_bwd_stream_kernel<NBR, PARTIAL>), dim3(items), dim3(kThreads), lds_bytes, stream, g);
   DTT_CHECK_LAUNCH("corr_bwd_stream_kernel");
   return 1;
 }
@@ -721,6 +726,9 @@ int dtt_corr_bwd_stream(const float* gradOutput, long g_sb, long g_sc, long g_sp
         DTT_CHECK_LAUNCH("corr_bwd_band_kernel");
       }
       g.hoff_y = 4 * bg.qoff_y; g.hoff_x = 4 * bg.qoff_x;
+      g.ny = std::min(nbr, nbr_full - bg.qoff_y); g.nx = std::min(nbr, nbr_full - bg.qoff_x);
+      static const bool skip_off = getenv("DTT_CORR_BWD_NO_SKIP") != nullptr;     // developer A/B switch
+      const bool partial = nq > 1 && (g.ny < nbr || g.nx < nbr) && !skip_off;
       g.accumulate = first ? 0 : 1;
       g.cell_fill = (lattice_dense && first) ? 1 : 0;
       for (int dir = 0; dir < 2; ++dir) {
@@ -739,7 +747,8 @@ int dtt_corr_bwd_stream(const float* gradOutput, long g_sb, long g_sc, long g_sp
         g.chunk = p->chunk; g.ngroups = p->ngroups; g.use_table = p->use_table;
         if (p->use_table) memcpy(g.table, p->table.data(), sizeof(unsigned short) * p->items);
         // (one kernel for both directions: which gradient a launch computes is a matter of its band words and of `other`)
-        const int ok = nbr == 3 ? launch_stream<3>(g, p->items, p->lds_bytes, stream) : launch_stream<5>(g, p->items, p->lds_bytes, stream);
+        const int ok = nbr == 3 ? launch_stream<3>(g, p->items, p->lds_bytes, stream)
+                                : partial ? launch_stream<5, true>(g, p->items, p->lds_bytes, stream) : launch_stream<5>(g, p->items, p->lds_bytes, stream);
         if (!ok) return 0;
       }
     }

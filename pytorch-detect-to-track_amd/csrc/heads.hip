@@ -390,11 +390,10 @@ __global__ __launch_bounds__((4 + NLOAD) * 64) void head_gemm_kernel(HeadGeom g)
 // The bins of one RoI for one head: thread `t` of `nthreads` owns VPL = CP / LPB classes of the bins slot, slot + SLOTS, ...
 // (h, w) row-major walk, kFlight positions in flight, adds in order: every (bin, class) sum is one lane's sequential walk in the
 // reference's order.  bins_out: LDS [pooled * pooled][CP].
-template <int CP, int LPB>
+template <int CP, int LPB, int kFlight = 8>
 __device__ __forceinline__ void pm_pool_bins(const float* __restrict__ img, long pixel_stride, int height, int width, const float* roi,
                                              float spatial_scale, int pooled, int t, int nthreads, float* __restrict__ bins_out) {
-  constexpr int VPL = CP / LPB, NV = VPL / 4;   // classes / 16-byte pieces per lane
-  constexpr int kFlight = 8;
+  constexpr int VPL = CP / LPB, NV = VPL / 4;   // classes / 16-byte pieces per lane; kFlight positions of a bin in flight per lane
   const int SLOTS = nthreads / LPB;             // bins in flight
   const int cq = t % LPB, slot = t / LPB;
   const int nbins = pooled * pooled;
@@ -479,12 +478,22 @@ __global__ __launch_bounds__(NW * 64) void psroi_pm_kernel(const float* __restri
   }
 }
 
+// Waves per SIMD the detection pooling is compiled for (the second __launch_bounds__ argument).  A workgroup is 5 waves; at 86
+// registers 5 waves fit a SIMD, i.e. 4 workgroups a CU: 1024 of the 1200 RoIs of an inference step are resident and the other 176
+// run as a second, nearly empty round.  7 waves per SIMD (<= 72 registers) make it 5 workgroups a CU = 1280: one round.
+#ifndef DTT_PSROI_DET_WAVES
+#define DTT_PSROI_DET_WAVES 7
+#endif
+#ifndef DTT_PSROI_DET_FLIGHT
+#define DTT_PSROI_DET_FLIGHT 5
+#endif
+
 // Detection pooling of a RoI in ONE launch (rfcn.py:133-140): the class scores (CP = 32 slots per bin, waves 0 - 3) and the box
 // deltas (4 per bin, wave 4: lane = bin) of the same position-major map, the same bin edges, the same rows -- and the softmax over
 // the classes folded into the epilogue (the 31 votes of a RoI sit in one wave).  Votes are the very sums of psroi_pm_kernel
 // (shared code); cls_prob = exp(s - max) / sum exp(s - max), with the sum taken in class order.
 template <int POOLED>
-__global__ __launch_bounds__(320) void psroi_pm_det_kernel(const float* __restrict__ map, long pixel_stride, int loc_offset, int height,
+__global__ __launch_bounds__(320, DTT_PSROI_DET_WAVES) void psroi_pm_det_kernel(const float* __restrict__ map, long pixel_stride, int loc_offset, int height,
                                                            int width, const float* __restrict__ rois, float spatial_scale, int pooled_rt,
                                                            int n_cls, int n_loc, float* __restrict__ cls_vote, float* __restrict__ cls_prob,
                                                            float* __restrict__ loc_vote, int batch_size) {
@@ -499,7 +508,8 @@ __global__ __launch_bounds__(320) void psroi_pm_det_kernel(const float* __restri
   const int nbins = pooled * pooled;
   const float* img = map + (long)b * height * width * pixel_stride;
   float* lbins = bins + nbins * 32;
-  if (tid < 256) pm_pool_bins<32, 4>(img, pixel_stride, height, width, roi, spatial_scale, pooled, tid, 256, bins);
+  // (class part: DTT_PSROI_DET_FLIGHT positions x two 16-byte pieces in flight per lane -- what fits the register budget above)
+  if (tid < 256) pm_pool_bins<32, 4, DTT_PSROI_DET_FLIGHT>(img, pixel_stride, height, width, roi, spatial_scale, pooled, tid, 256, bins);
   else pm_pool_bins<4, 1>(img + loc_offset, pixel_stride, height, width, roi, spatial_scale, pooled, tid - 256, 64, lbins);
   __syncthreads();
   if (tid < 64) {           // wave 0: the class votes and their softmax

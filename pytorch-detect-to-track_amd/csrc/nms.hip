@@ -139,6 +139,16 @@ __global__ __launch_bounds__(kMaskThreads) void nms_mask_kernel(const float* __r
   }
 }
 
+#ifdef DTT_NMS_TRACE   // developer build (tools/nms_phases.py): shader cycles of the sweep's phases, summed per image and launch
+__device__ unsigned long long dtt_nms_cycles[64 * 8];
+#define NMS_T0() unsigned long long t_prev = __builtin_readcyclecounter()
+#define NMS_ACC(slot) do { const unsigned long long t_now = __builtin_readcyclecounter(); \
+    if (threadIdx.x == 0 && blockIdx.x < 32) dtt_nms_cycles[((sc_begin > 0 ? 32 : 0) + blockIdx.x) * 8 + (slot)] += t_now - t_prev; t_prev = t_now; } while (0)
+#else
+#define NMS_T0() do {} while (0)
+#define NMS_ACC(slot) do {} while (0)
+#endif
+
 __device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
   unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
   unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
@@ -186,6 +196,7 @@ __global__ __launch_bounds__(kSweepThreads) void nms_sweep_kernel(
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int cb = (n + kTile - 1) / kTile;
   const int limit = (max_keep > 0 && max_keep < n) ? max_keep : n;
+  NMS_T0();
 
   if (sc_begin > 0) {
     if (state[0] != 0ULL) return;   // the first phase finished this image (and wrote its outputs)
@@ -213,6 +224,7 @@ __global__ __launch_bounds__(kSweepThreads) void nms_sweep_kernel(
     if (tid == 0) { ctl[0] = 0; ctl[1] = 0; ctl[2] = 0; }
   }
   __syncthreads();
+  NMS_ACC(0);   // set-up / replay of the first phase's kept rows
 
   const int n_super = (n + kSuper - 1) / kSuper;
   const int sc_last = min(sc_end, n_super);
@@ -245,6 +257,7 @@ __global__ __launch_bounds__(kSweepThreads) void nms_sweep_kernel(
       }
     }
     __syncthreads();
+    NMS_ACC(1);   // A: staging
     // ---- B: serial part, wave 0 only.  Lanes 0..15 hold the removal words of this super-chunk in a register (R).  A chunk
     //         of 64 boxes is settled from the boxes' "lower" words L (bit i of L[j]: box i < j of the chunk overlaps box j):
     //         kept = alive & ~{ j : L[j] & kept != 0 } iterated from kept = alive.  The dependence only runs from lower to
@@ -309,6 +322,7 @@ __global__ __launch_bounds__(kSweepThreads) void nms_sweep_kernel(
       if (lane == 0) { ctl[0] = nk; ctl[1] = total; ctl[2] = done ? 1 : 0; }
     }
     __syncthreads();
+    NMS_ACC(2);   // B: serial walk
     const int nk = ctl[0];
     const bool done = ctl[2] != 0;
     // ---- C: kept rows suppress boxes of the later super-chunks.  Thread (j, slice) ORs the words of
@@ -338,6 +352,7 @@ __global__ __launch_bounds__(kSweepThreads) void nms_sweep_kernel(
       }
     }
     __syncthreads();
+    NMS_ACC(3);   // C: kept rows over the later super-chunks
     if (done) break;
   }
   const int total = ctl[1];
@@ -372,6 +387,17 @@ __global__ __launch_bounds__(kSweepThreads) void nms_sweep_kernel(
     }
   }
 }
+
+}  // namespace
+#ifdef DTT_NMS_TRACE
+extern "C" int dtt_nms_cycles_read(unsigned long long* host, int reset) {
+  (void)hipDeviceSynchronize();
+  int ok = hipMemcpyFromSymbol(host, HIP_SYMBOL(dtt_nms_cycles), sizeof(unsigned long long) * 64 * 8) == hipSuccess;
+  if (reset) { static unsigned long long zero[64 * 8]; ok &= hipMemcpyToSymbol(HIP_SYMBOL(dtt_nms_cycles), zero, sizeof(zero)) == hipSuccess; }
+  return ok;
+}
+#endif
+namespace {
 
 size_t sweep_lds_bytes(int col_blocks) {
   return (size_t)kSuper * kRowStride * 8 + (size_t)col_blocks * 8 + (size_t)kSuper * 4 + 16;

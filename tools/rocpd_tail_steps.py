@@ -22,6 +22,11 @@ for n, s, e in rows:
         cur = []; steps.append(cur)
     if cur is not None:
         cur.append((tag, s, e))
+# what is launched behind a step's last pooling (the next step's trunk issues its class + box head GEMM ahead of the next conv5
+# correlation) belongs to the next step, not to this tail
+for st in steps:
+    last = max((i for i, (t, _, _) in enumerate(st) if t == "psroi"), default=len(st) - 1)
+    del st[last + 1:]
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 sel = steps[-n:]
 seqs = {tuple(sorted(t for t, _, _ in st)) for st in sel}
