@@ -228,8 +228,9 @@ def corr_bwd_secondary(op_us, args, model):
     for us, (name, C, R, HWc) in zip(op_us, ops):
         D2 = (2 * R + 1) ** 2
         fl = 2.0 * 2.0 * C * D2 * H16 * W16 * args.batch      # both gradients: 2 x the forward's FLOPs
-        # both maps read once, both gradient maps written once, gradOut read once (SURVEY 8d's per-op bytes for the backward)
-        by = (4 * C * HWc * 4 + D2 * H16 * W16 * 4) * args.batch
+        # both gradient maps written once (whole maps: conv3's non-lattice pixels get their zeros from the same kernels), the LATTICE
+        # pixels of both maps read once (conv3: every second pixel in both directions), gradOut read once
+        by = (2 * C * HWc * 4 + 2 * C * H16 * W16 * 4 + D2 * H16 * W16 * 4) * args.batch
         mf, hb = fl / (us * 1e-6) / 1e12, by / (us * 1e-6) / 1e9
         # conv3 moves 166 MB for 1.1 GFLOP per gradient pair: its bound is HBM; conv4 / conv5 are bound by the fp32 MFMA rate
         bound = "hbm" if hb / HBM_PEAK_GBS > mf / FP32_MFMA_PEAK_TFLOPS else "mfma"

@@ -478,14 +478,16 @@ __global__ __launch_bounds__(NW * 64) void psroi_pm_kernel(const float* __restri
   }
 }
 
-// Waves per SIMD the detection pooling is compiled for (the second __launch_bounds__ argument).  A workgroup is 5 waves; at 86
-// registers 5 waves fit a SIMD, i.e. 4 workgroups a CU: 1024 of the 1200 RoIs of an inference step are resident and the other 176
-// run as a second, nearly empty round.  7 waves per SIMD (<= 72 registers) make it 5 workgroups a CU = 1280: one round.
+// Waves per SIMD the detection pooling is compiled for (the second __launch_bounds__ argument) and positions in flight per lane of
+// the class part.  A workgroup is 5 waves; at 86 registers 5 waves fit a SIMD, i.e. 4 workgroups a CU: 1024 of the 1200 RoIs of an
+// inference step are resident at once.  Round 5 A/B inside bench.py (profiles/r05_psroi_det_ab.txt): 7 waves x 6 in flight (68
+// registers, 1280 RoIs resident) 28.1 us, 8 x 5 29.0, 8 x 4 31.9 against 28.9 for 5 x 8 on the same box -- residency is not what bounds
+// the launch, the per-lane chain of dependent round trips over a large RoI's bins is (fewer positions in flight = more trips).
 #ifndef DTT_PSROI_DET_WAVES
-#define DTT_PSROI_DET_WAVES 7
+#define DTT_PSROI_DET_WAVES 5
 #endif
 #ifndef DTT_PSROI_DET_FLIGHT
-#define DTT_PSROI_DET_FLIGHT 5
+#define DTT_PSROI_DET_FLIGHT 8
 #endif
 
 // Detection pooling of a RoI in ONE launch (rfcn.py:133-140): the class scores (CP = 32 slots per bin, waves 0 - 3) and the box

@@ -184,8 +184,9 @@ __global__ __launch_bounds__(kSweepThreads) void nms_sweep_kernel(
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned long long* sb = reinterpret_cast<unsigned long long*>(smem);            // [kSuper][kRowStride]
   unsigned long long* remv = sb + (size_t)kSuper * kRowStride;                      // [col_blocks]
-  int* kept_list = reinterpret_cast<int*>(remv + col_blocks);                       // [kSuper]
-  int* ctl = kept_list + kSuper;                                                    // [0]=nk, [1]=total, [2]=done
+  unsigned long long* lowbuf = remv + col_blocks;                                   // [kSuper]: the "lower" words of the staged super-chunk
+  int* kept_list = reinterpret_cast<int*>(lowbuf + kSuper);                         // [2][kSuper]: this super-chunk's and the previous one's
+  int* ctl = kept_list + 2 * kSuper;                                                // [0]=nk, [1]=total, [2]=done
 
   const int img = blockIdx.x;
   const int n = n_per_image ? n_per_image[img] : n_max;
@@ -228,36 +229,96 @@ __global__ __launch_bounds__(kSweepThreads) void nms_sweep_kernel(
 
   const int n_super = (n + kSuper - 1) / kSuper;
   const int sc_last = min(sc_end, n_super);
+  const int col_end = (two_phase && sc_begin == 0) ? min(cb, sc_end * kSuperWords) : cb;   // columns that exist in this phase
+  // Software pipeline over the super-chunks (round 5; the serial walk B of wave 0 is what cannot be shortened):
+  //   * the diagonal super-block of super-chunk sc + 1 is LOADED into registers (16 words per thread, one round trip) while wave 0
+  //     walks super-chunk sc, and only written to LDS once sc is done with the staging area -- the staging latency (a quarter of the
+  //     sweep: profiles/r05_nms_sweep_phases_before.txt) disappears under B;
+  //   * the rows kept in super-chunk sc suppress boxes of ALL later super-chunks, but only the 16 words of super-chunk sc + 1 are
+  //     needed before its walk starts: those (C_near) are OR-ed by the whole workgroup right after B, the other columns (C_far) by
+  //     waves 1 .. 15 WHILE wave 0 walks super-chunk sc + 1 (its kept list lives in the other half of a double buffer; the words
+  //     C_far touches lie beyond the ones that walk reads).
+  // The recursion is unchanged -- the same rows are OR-ed into the same words before anybody reads them -- so the keep list is too.
+  constexpr int NL = 16;   // words per thread: a full 1024 x 16-word super-block is ONE round of loads
+  unsigned long long pre[NL], pre_low;
+  auto prefetch = [&](int sc) {       // diagonal super-block of super-chunk sc -> registers (unconditional, clamped loads)
+    const int base = sc * kSuper, rows = min(kSuper, n - base), w0 = sc * kSuperWords, nw = min(kSuperWords, cb - w0);
+    const int total = rows * nw;
+    pre_low = lower[base + min(tid, rows - 1)];
+#pragma unroll
+    for (int u = 0; u < NL; ++u) {
+      const int idx = min(tid + u * kSweepThreads, total - 1);
+      const int r = nw == kSuperWords ? idx >> 4 : idx / nw, j = idx - r * nw;
+      pre[u] = m[(long)(base + r) * col_blocks + w0 + j];
+    }
+  };
+  auto stage = [&](int sc) {          // registers -> LDS (words left of a row's own block were never written by the mask kernel: 0)
+    const int base = sc * kSuper, rows = min(kSuper, n - base), w0 = sc * kSuperWords, nw = min(kSuperWords, cb - w0);
+    const int total = rows * nw;
+    lowbuf[tid] = tid < rows ? pre_low : 0ULL;
+#pragma unroll
+    for (int u = 0; u < NL; ++u) {
+      const int idx = tid + u * kSweepThreads;
+      if (idx < total) {
+        const int r = nw == kSuperWords ? idx >> 4 : idx / nw, j = idx - r * nw;
+        sb[r * kRowStride + j] = ((r >> 6) <= j) ? pre[u] : 0ULL;
+      }
+    }
+  };
+  // kept rows (local numbers in kl, nk of them) of the super-chunk at row `base` OR-ed into remv[c_lo .. c_hi) by `nthr` threads,
+  // this thread being number t of them: thread (column, slice) walks its share of the rows with 8 loads in flight, the slices of a
+  // column meet with an LDS atomic (order-free)
+  auto or_rows = [&](const int* kl, int nk, int base, int c_lo, int c_hi, int t, int nthr) {
+    const int ncol = c_hi - c_lo;
+    if (ncol <= 0 || nk <= 0 || t < 0) return;
+    const int jt = ncol <= 16 ? 16 : ((ncol + 63) & ~63);
+    const int nslice = nthr / jt;
+    if (nslice < 1) {   // (more columns than threads: a strided walk, one slice)
+      for (int jj = t; jj < ncol; jj += nthr) {
+        unsigned long long accw = 0;
+        const unsigned long long* col = m + (long)base * col_blocks + c_lo + jj;
+        for (int k = 0; k < nk; ++k) accw |= col[(long)kl[k] * col_blocks];
+        if (accw) atomicOr(&remv[c_lo + jj], accw);
+      }
+      return;
+    }
+    const int jj = t % jt, sl = t / jt;
+    if (sl >= nslice || jj >= ncol) return;
+    unsigned long long accw = 0;
+    const unsigned long long* col = m + (long)base * col_blocks + c_lo + jj;
+    int k = sl;
+    for (; k + 7 * nslice < nk; k += 8 * nslice) {
+      unsigned long long v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = col[(long)kl[k + u * nslice] * col_blocks];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) accw |= v[u];
+    }
+    {   // the remainder: up to seven more, all in flight together
+      unsigned long long v[7];
+#pragma unroll
+      for (int u = 0; u < 7; ++u) v[u] = (k + u * nslice < nk) ? col[(long)kl[k + u * nslice] * col_blocks] : 0ULL;
+#pragma unroll
+      for (int u = 0; u < 7; ++u) accw |= v[u];
+    }
+    if (accw) atomicOr(&remv[c_lo + jj], accw);
+  };
+  int* kept_buf[2] = {kept_list, kept_list + kSuper};
+  int far_nk = 0, far_base = 0, far_lo = 0, cur = 0;     // pending C_far: rows of kept_buf[cur ^ 1]
+  if (sc_begin < sc_last) prefetch(sc_begin);
   for (int sc = sc_begin; sc < sc_last; ++sc) {
     const int base = sc * kSuper;
     const int rows = min(kSuper, n - base);
     const int w0 = sc * kSuperWords;
     const int nw = min(kSuperWords, cb - w0);
-    // ---- A: stage the diagonal super-block (unconditional loads, 16 in flight per thread; words left
-    //         of a row's own block were never written by the mask kernel and are replaced by 0)
-    {
-      const int total = rows * nw;
-      constexpr int NL = 16;   // loads in flight per thread: a full 1024 x 16-word super-block is ONE round trip
-      for (int i0 = tid; i0 < total; i0 += NL * kSweepThreads) {
-        unsigned long long v[NL];
-#pragma unroll
-        for (int u = 0; u < NL; ++u) {
-          const int idx = min(i0 + u * kSweepThreads, total - 1);
-          const int r = idx / nw, j = idx - r * nw;
-          v[u] = m[(long)(base + r) * col_blocks + w0 + j];
-        }
-#pragma unroll
-        for (int u = 0; u < NL; ++u) {
-          const int idx = i0 + u * kSweepThreads;
-          if (idx < total) {
-            const int r = idx / nw, j = idx - r * nw;
-            sb[r * kRowStride + j] = ((r >> 6) <= j) ? v[u] : 0ULL;
-          }
-        }
-      }
-    }
+    int* kept_list = kept_buf[cur];
+    // ---- A: the diagonal super-block, loaded during the previous walk, goes to LDS
+    stage(sc);
     __syncthreads();
     NMS_ACC(1);   // A: staging
+    if (sc + 1 < sc_last) prefetch(sc + 1);               // in flight under B / C_far
+    // ---- C_far of the previous super-chunk (waves 1 .. 15), beside B
+    if (wave != 0) or_rows(kept_buf[cur ^ 1], far_nk, far_base, far_lo, col_end, tid - 64, kSweepThreads - 64);
     // ---- B: serial part, wave 0 only.  Lanes 0..15 hold the removal words of this super-chunk in a register (R).  A chunk
     //         of 64 boxes is settled from the boxes' "lower" words L (bit i of L[j]: box i < j of the chunk overlaps box j):
     //         kept = alive & ~{ j : L[j] & kept != 0 } iterated from kept = alive.  The dependence only runs from lower to
@@ -270,13 +331,15 @@ __global__ __launch_bounds__(kSweepThreads) void nms_sweep_kernel(
       int nk = 0;
       bool done = false;
       unsigned long long R = (lane < nw) ? remv[w0 + lane] : 0ULL;
-      unsigned long long Lnext = lane < rows ? lower[base + lane] : 0ULL;
+      // (nothing in the walk touches global memory: the boxes' "lower" words were staged with the block, the keep list leaves after the
+      //  walk -- a store per chunk sat in front of the next chunk's load in the in-order memory counter, a full round trip per chunk)
+      unsigned long long Lnext = lowbuf[lane];
       for (int c = 0; c < nw && !done; ++c) {
         const unsigned long long r = readlane64(R, c);
         const int rows_c = min(kTile, rows - c * kTile);
         const unsigned long long valid = rows_c == kTile ? ~0ULL : ((1ULL << rows_c) - 1ULL);
         const unsigned long long L = Lnext;
-        if (c + 1 < nw) Lnext = ((c + 1) * kTile + lane < rows) ? lower[base + (c + 1) * kTile + lane] : 0ULL;   // in flight during this chunk
+        if (c + 1 < nw) Lnext = lowbuf[(c + 1) * kTile + lane];   // in flight during this chunk
         const unsigned long long alive = ~r & valid;
         unsigned long long kept = alive;
         for (;;) {
@@ -291,7 +354,6 @@ __global__ __launch_bounds__(kSweepThreads) void nms_sweep_kernel(
         if ((kept >> lane) & 1ULL) {
           const int rank = __builtin_popcountll(kept & ((1ULL << lane) - 1ULL));
           kept_list[nk + rank] = c * kTile + lane;
-          if (keep) keep[total + rank] = base + c * kTile + lane;
         }
         nk += nkept;
         total += nkept;
@@ -314,46 +376,43 @@ __global__ __launch_bounds__(kSweepThreads) void nms_sweep_kernel(
             }
             accw |= (v[0] | v[1]) | (v[2] | v[3]);
           }
-          accw |= __shfl_xor(accw, 16);
-          accw |= __shfl_xor(accw, 32);
+          // the four quarters (rows of 16 lanes) meet in every lane: two register swaps (v_permlane16_swap / v_permlane32_swap, VALU)
+          // where __shfl_xor went through the LDS crossbar twice, back to back
+          {
+            unsigned lo = (unsigned)accw, hi = (unsigned)(accw >> 32);
+            auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false); lo = a[0] | a[1];
+            auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false); hi = b[0] | b[1];
+            auto c2 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false); lo = c2[0] | c2[1];
+            auto d2 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false); hi = d2[0] | d2[1];
+            accw = ((unsigned long long)hi << 32) | lo;
+          }
           if (owner && quarter == 0) R |= accw;
         }
       }
       if (lane == 0) { ctl[0] = nk; ctl[1] = total; ctl[2] = done ? 1 : 0; }
     }
     __syncthreads();
-    NMS_ACC(2);   // B: serial walk
+    NMS_ACC(2);   // B: serial walk (C_far of the previous super-chunk beside it)
     const int nk = ctl[0];
     const bool done = ctl[2] != 0;
-    // ---- C: kept rows suppress boxes of the later super-chunks.  Thread (j, slice) ORs the words of
-    //         column j over its share of the kept rows in registers (8 independent loads in flight),
-    //         then merges with one LDS atomic.
-    const int wnext = w0 + nw;
-    const int col_end = (two_phase && sc_begin == 0) ? min(cb, sc_end * kSuperWords) : cb;   // columns that exist in this phase
-    const int nrem = col_end - wnext;
-    if (!done && nrem > 0 && nk > 0) {
-      int jt = 64;
-      while (jt < nrem && jt < kSweepThreads) jt <<= 1;
-      const int nslice = kSweepThreads / jt;
-      const int j = tid % jt, sl = tid / jt;
-      for (int jj = j; jj < nrem; jj += jt) {
-        unsigned long long accw = 0;
-        const unsigned long long* col = m + (long)base * col_blocks + wnext + jj;
-        int k = sl;
-        for (; k + 7 * nslice < nk; k += 8 * nslice) {
-          unsigned long long v[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) v[u] = col[(long)kept_list[k + u * nslice] * col_blocks];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) accw |= v[u];
-        }
-        for (; k < nk; k += nslice) accw |= col[(long)kept_list[k] * col_blocks];
-        if (accw) atomicOr(&remv[wnext + jj], accw);
-      }
+    if (keep) {   // the super-chunk's survivors into the keep list, by everybody
+      const int first = ctl[1] - nk;
+      for (int i = tid; i < nk; i += kSweepThreads) keep[first + i] = base + kept_list[i];
     }
+    // ---- C_near: the kept rows over the 16 words of the next super-chunk, everybody
+    const int wnext = w0 + nw;
+    const int near_hi = min(col_end, wnext + kSuperWords);
+    if (!done) or_rows(kept_list, nk, base, wnext, near_hi, tid, kSweepThreads);
+    far_nk = done ? 0 : nk; far_base = base; far_lo = near_hi;
+    cur ^= 1;
     __syncthreads();
-    NMS_ACC(3);   // C: kept rows over the later super-chunks
+    NMS_ACC(3);   // C_near
     if (done) break;
+  }
+  // the last super-chunk's far columns (none when the loop ran to the end of the phase's columns; kept general)
+  if (ctl[2] == 0 && far_nk > 0 && far_lo < col_end) {
+    or_rows(kept_buf[cur ^ 1], far_nk, far_base, far_lo, col_end, tid, kSweepThreads);
+    __syncthreads();
   }
   const int total = ctl[1];
   if (two_phase) {
@@ -400,7 +459,7 @@ extern "C" int dtt_nms_cycles_read(unsigned long long* host, int reset) {
 namespace {
 
 size_t sweep_lds_bytes(int col_blocks) {
-  return (size_t)kSuper * kRowStride * 8 + (size_t)col_blocks * 8 + (size_t)kSuper * 4 + 16;
+  return (size_t)kSuper * kRowStride * 8 + (size_t)col_blocks * 8 + (size_t)kSuper * 8 + (size_t)2 * kSuper * 4 + 16;
 }
 
 }  // namespace

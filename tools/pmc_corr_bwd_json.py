@@ -34,7 +34,7 @@ for spec in sys.argv[2:]:
     name, fdb, wdb = spec.split(":")
     f, w = per_kernel(fdb, "FETCH_SIZE"), per_kernel(wdb, "WRITE_SIZE")
     C, px, win = SHAPES[name]
-    algo = (4 * C * px * 4 + win * 38 * 67 * 4) * 2
+    algo = (2 * C * px * 4 + 2 * C * 38 * 67 * 4 + win * 38 * 67 * 4) * 2      # gradients written whole, lattice pixels read, gradOut read (B = 2)
     assert "stream" in f and "band" in f and f["stream"][0] == 2 * f["band"][0], (name, f)
     fetch_kb = f["band"][1] + 2 * f["stream"][1]
     write_kb = w["band"][1] + 2 * w["stream"][1]
