@@ -195,6 +195,8 @@ int dtt_psroi_vote_forward(const float* bottom_data, float spatial_scale, int ba
  * IoU bit matrix is computed in two stream-ordered phases -- the rows the sweep needs first, the rest only if the keep list
  * is still short -- with the same keep list (the workspace holds the matrix, the parked sweep state, and one word per box:
  * the overlaps with the earlier boxes of its own 64-box chunk, from which the sweep settles a chunk in a few wave-wide steps).
+ * boxes_num <= 65408: the sweep keeps one removal word per 64 boxes next to its 156 KB of staging area in one CU's LDS (the
+ * call fails with a message beyond that; the reference has no such bound but needs boxes_num^2 / 8 bytes of mask either way).
  */
 size_t dtt_nms_workspace_bytes(int boxes_num);
 int dtt_nms(int* keep_out, int* num_out, const float* boxes, int boxes_num, int boxes_dim,

@@ -21,13 +21,13 @@ constexpr int kSweepThreads = 1024;
 // product and the quotient together): the common case -- disjoint boxes have inter == 0 -- costs two multiplies and two compares
 // instead of a correctly rounded division; a wave in which any lane is within that margin (or has a non-positive / non-finite
 // union) takes the reference's division for all its lanes.  The same answer as devIoU(a, b) > thresh in every case.
+// Sb = (b2 - b0 + 1) * (b3 - b1 + 1), the column box's area, is made once per staged column (the same expression, the same bits).
 __device__ __forceinline__ bool iou_over(const float a0, const float a1, const float a2, const float a3, const float Sa,
-                                         const float b0, const float b1, const float b2, const float b3, const float thresh) {
+                                         const float b0, const float b1, const float b2, const float b3, const float Sb, const float thresh) {
   float left = fmaxf(a0, b0), right = fminf(a2, b2);
   float top = fmaxf(a1, b1), bottom = fminf(a3, b3);
   float width = fmaxf(right - left + 1, 0.f), height = fmaxf(bottom - top + 1, 0.f);
   float interS = width * height;
-  float Sb = (b2 - b0 + 1) * (b3 - b1 + 1);
   const float uni = Sa + Sb - interS;
   const float p = thresh * uni;
   const bool sure_hit = interS > p * 1.000001f, sure_miss = interS < p * 0.999999f;
@@ -71,6 +71,7 @@ __global__ __launch_bounds__(kMaskThreads) void nms_mask_kernel(const float* __r
   unsigned long long* lower = m + mask_lower_offset(n_max, col_blocks);
   const int col_size = min(n_boxes - col_start * kTile, kTile);
   __shared__ float bb[kTile * 4];
+  __shared__ float bs[kTile];      // areas of the staged column boxes
   const int t = threadIdx.x & (kTile - 1), q = threadIdx.x >> 6;
   const int i0 = q * (kTile / kMaskWaves), i1 = min(i0 + kTile / kMaskWaves, col_size);
   bool staged = false;
@@ -82,6 +83,7 @@ __global__ __launch_bounds__(kMaskThreads) void nms_mask_kernel(const float* __r
       bb[threadIdx.x * 4 + 1] = p[1];
       bb[threadIdx.x * 4 + 2] = p[2];
       bb[threadIdx.x * 4 + 3] = p[3];
+      bs[threadIdx.x] = (p[2] - p[0] + 1) * (p[3] - p[1] + 1);
     }
     __syncthreads();
     staged = true;
@@ -101,7 +103,7 @@ __global__ __launch_bounds__(kMaskThreads) void nms_mask_kernel(const float* __r
         const float Sa = (a2 - a0 + 1) * (a3 - a1 + 1);
         unsigned bits = 0;
         for (int i = i0; i < i1; ++i) {
-          if (iou_over(a0, a1, a2, a3, Sa, bb[i * 4 + 0], bb[i * 4 + 1], bb[i * 4 + 2], bb[i * 4 + 3], thresh))
+          if (iou_over(a0, a1, a2, a3, Sa, bb[i * 4 + 0], bb[i * 4 + 1], bb[i * 4 + 2], bb[i * 4 + 3], bs[i], thresh))
             bits |= 1u << (i - i0);
         }
         reinterpret_cast<unsigned short*>(m + (long)cur * col_blocks + col_start)[q] = (unsigned short)bits;
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(kMaskThreads) void nms_mask_kernel(const float* __r
       const float Sa = (a2 - a0 + 1) * (a3 - a1 + 1);
       unsigned bits = 0;
       for (int i = i0; i < i1; ++i) {
-        if (iou_over(a0, a1, a2, a3, Sa, bb[i * 4 + 0], bb[i * 4 + 1], bb[i * 4 + 2], bb[i * 4 + 3], thresh))
+        if (iou_over(a0, a1, a2, a3, Sa, bb[i * 4 + 0], bb[i * 4 + 1], bb[i * 4 + 2], bb[i * 4 + 3], bs[i], thresh))
           bits |= 1u << (i - i0);
       }
       unsigned short* word = reinterpret_cast<unsigned short*>(m + (long)cur * col_blocks + col_start);

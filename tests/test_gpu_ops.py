@@ -67,6 +67,29 @@ def test_nms_bit_exact(dev, n, thresh):
     np.testing.assert_array_equal(got.cpu().numpy().ravel(), ref)
 
 
+@pytest.mark.parametrize("n,clusters,mk", [(12000, 2600, 2000),    # the training proposal layer: 12000 -> 2000, reached in the second phase
+                                          (12000, 1500, 2000),    # heavy overlap: fewer clusters than max_keep, every super-chunk is walked
+                                          (12000, 5000, 2000),    # spread out: max_keep inside the first phase
+                                          (20000, 3000, 2000), (20000, 900, 0), (12345, 700, 0)])   # 20 super-chunks; keep all; a ragged last block
+def test_nms_training_size_sweep_pipeline(dev, n, clusters, mk):
+    """The sweep as a software pipeline (round 5: the next diagonal super-block is loaded under the serial walk, the far columns of a
+    super-chunk's kept rows are OR-ed beside the NEXT walk by the other waves, the keep list leaves after the walk): keep lists at
+    the training proposal layer's sizes and beyond, single- and two-phase, against the oracle (nms_cuda_kernel.cu:131-144)."""
+    from dtt.ops import nms
+    rng = np.random.RandomState(n + clusters + mk)
+    ctr = rng.uniform(0, 1000, size=(clusters, 2))
+    wh = rng.uniform(30, 200, size=(clusters, 2))
+    which = rng.randint(0, clusters, size=n)
+    jitter = rng.normal(0, 2.5, size=(n, 4))
+    boxes = np.concatenate([ctr[which] - wh[which] / 2, ctr[which] + wh[which] / 2], 1) + jitter
+    dets = np.concatenate([boxes, np.sort(rng.uniform(0, 1, n))[::-1][:, None]], 1).astype(np.float32)
+    ref = O.nms(dets, 0.7)
+    got = nms(cu(dets, dev), 0.7, max_keep=mk).cpu().numpy().ravel()
+    np.testing.assert_array_equal(got, ref[:mk] if mk else ref)
+    again = nms(cu(dets, dev), 0.7, max_keep=mk).cpu().numpy().ravel()
+    np.testing.assert_array_equal(got, again)
+
+
 def test_nms_empty_and_max_keep(dev):
     from dtt.ops import nms
     assert nms(torch.zeros((0, 5), device=dev), 0.7) == []
