@@ -326,15 +326,16 @@ def test_fused_training_trunk_matches_reference_graph():
                 (y * probe).sum().backward()
                 outs.append((y.detach().clone(), xi.grad.clone(), [c.weight.grad.clone() for c in ft.convs[k:k + n]]))
             (y0, gx0, gw0), (y1, gx1, gw1), (y2, gx2, gw2) = outs
-            assert float((y0 - y2).norm()) <= 2e-5 * float(y0.norm()) and float((gx0 - gx2).norm()) <= 5e-3 * float(gx0.norm())
+            assert float((y0 - y2).norm()) <= 2e-5 * float(y0.norm()) and float((gx0 - gx2).norm()) <= 1e-2 * float(gx0.norm())
             for a, b in zip(gw0, gw2):
-                assert float((a - b).norm()) <= 5e-3 * max(1e-12, float(a.norm())), k
+                assert float((a - b).norm()) <= 1e-2 * max(1e-12, float(a.norm())), k
             # forward to fp32 rounding; gradients to the accuracy of MIOpen's Winograd backward kernels (the two graphs
-            # hand them differently scaled weights), far below what a wrong mask / missing residual term would give
+            # hand them differently scaled weights; which kernels a box picks varies: 5.3e-3 seen on one of three boxes in round 5),
+            # far below what a wrong mask / missing residual term would give (O(1))
             close = lambda a, b, tol: float((a - b).norm()) <= tol * max(1e-12, float(a.norm()))
-            assert close(y0, y1, 2e-5) and close(gx0, gx1, 5e-3), (k, float((y0 - y1).norm() / y0.norm()), float((gx0 - gx1).norm() / gx0.norm()))
+            assert close(y0, y1, 2e-5) and close(gx0, gx1, 1e-2), (k, float((y0 - y1).norm() / y0.norm()), float((gx0 - gx1).norm() / gx0.norm()))
             for a, b in zip(gw0, gw1):
-                assert close(a, b, 5e-3), (k, float((a - b).norm() / a.norm()))
+                assert close(a, b, 1e-2), (k, float((a - b).norm() / a.norm()))
             k += n
             checked += 1
     assert checked == 13  # layer2..layer4 of ResNet-50
