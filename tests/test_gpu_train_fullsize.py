@@ -143,7 +143,7 @@ def test_training_graphs_agree_at_full_size(H, W, B, disp, roi):
         assert rel < (1e-4 if kind in ("map", "head") else 1e-3), (n, rel, nrm)
 
 
-def test_configs4_training_step_d16_roi_align_full_size():
+def test_configs4_training_step_d16_roi_align_full_size(monkeypatch):
     """BASELINE configs[4]'s per-rank workload as ONE training step: Res-101 D&T, a 563 x 1000 frame pair, correlation d = 16
     (conv4 / conv5 windows 33 x 33 = 1089 channels each, conv3 17 x 17 = 289; corr_bbox_net 2859 -> 196, resnet.py:311-312),
     RoI-Align of the top map for the sampled RoIs (faster_rcnn.py:72-83) beside the PSRoI heads, through prepare_replica (frozen
@@ -162,6 +162,9 @@ def test_configs4_training_step_d16_roi_align_full_size():
     runner = prepare_replica(model, 1, channels_last=True)
     assert model._train_pm
     c.TRAIN.SAMPLER_RNG = "reference"
+    # the evaluations below must see the same forward: at this shape MIOpen's default kernels differ from run to run in the last bits
+    # (module docstring), enough to swap two near-tied proposals between the two sides of a finite difference
+    monkeypatch.setattr(torch.backends.cudnn, "deterministic", True)
 
     def loss_of():
         np.random.seed(c.RNG_SEED)   # same anchor / RoI samples on every evaluation
