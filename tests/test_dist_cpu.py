@@ -33,7 +33,7 @@ class Toy(nn.Module):
         return self.frozen(self.alias(torch.relu(self.b(torch.relu(self.a(x)))))).mean(dim=(1, 2, 3))
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, n_snip=6):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -45,12 +45,12 @@ def _worker(rank, world, port, q):
     model = Toy()
     dp = DataParallelSnippets(model, world, bucket_bytes=1024)  # tiny buckets -> several all-reduces
     g = torch.Generator().manual_seed(0)
-    data = torch.randn(6, 3, 8, 8, generator=g)
-    mine = list(shard_snippets(6, rank, world))
+    data = torch.randn(n_snip, 3, 8, 8, generator=g)
+    mine = list(shard_snippets(n_snip, rank, world))
     grads = []
     for step in range(2):  # two steps: buckets must be reusable
         dp.zero_grad(set_to_none=True)
-        loss = dp(data[mine]).sum() / 6.0 * world   # per-rank mean convention: sum/N_global * world -> avg over ranks
+        loss = dp(data[mine]).sum() / float(n_snip) * world   # per-rank mean convention: sum/N_global * world -> avg over ranks
         loss.backward()
         dp.finish_gradients()
         grads.append({n: p.grad.clone().numpy() for n, p in model.named_parameters()
@@ -62,26 +62,32 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_gradients_match_single_process():
-    world = 2
+import pytest
+
+
+@pytest.mark.parametrize("world,n_snip", [(2, 6), (8, 16)], ids=["two_ranks", "eight_ranks_global_batch_16"])
+def test_rank_gradients_match_single_process(world, n_snip):
+    """world 8 / 16 snippets = BASELINE configs[3]'s layout (8 GPUs, global batch 16, two snippets per rank): what the 8-GPU node runs
+    over RCCL, here over gloo on CPU."""
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
-    procs = [ctx.Process(target=_worker, args=(r, world, _free_port() if r < 0 else PORT, q)) for r in range(world)]
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, n_snip)) for r in range(world)]
     for p in procs:
         p.start()
     w0, grads = q.get()
     w0 = {n: torch.from_numpy(v) for n, v in w0.items()}
     grads = [{n: torch.from_numpy(v) for n, v in g.items()} for g in grads]
     for p in procs:
-        p.join(60)
+        p.join(120)
         assert p.exitcode == 0
     torch.manual_seed(100)  # rank 0's initial weights
     ref = Toy()
     for n, p in ref.named_parameters():
         assert torch.equal(p.detach(), w0[n]), n
     g = torch.Generator().manual_seed(0)
-    data = torch.randn(6, 3, 8, 8, generator=g)
-    (ref(data).sum() / 6.0).backward()
+    data = torch.randn(n_snip, 3, 8, 8, generator=g)
+    (ref(data).sum() / float(n_snip)).backward()
     for step in range(2):
         for n, p in ref.named_parameters():
             if p.requires_grad and p.grad is not None and n in grads[step]:
