@@ -378,16 +378,43 @@ def main():
     cfg.RFCN_ROI_FEATURES = "" if args.pooling == "psroi" else args.pooling
     torch.backends.cudnn.benchmark = True
 
-    model = build_model(args.layers, cfg=cfg).to(dev)
-    im, info, gt, nb = make_batch(args.batch, args.height, args.width, seed=3 + rank, device=dev)
-    calibrate_batchnorm_(model, im[:, 0])
+    # Developer mode DTT_BENCH_BACKEND=gloo with more ranks than GPUs: the ranks take turns through the start-up that needs no collective
+    # (first touch of the device, code-object loads of the first launches).  Eight processes loading code objects on ONE device at the
+    # same moment have aborted with HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION inside a stock ATen kernel (round 5,
+    # tests/test_gpu_z_bench.py); on the node every rank owns its GPU and nothing is serialised.
+    shared_device = world > 1 and backend != "nccl" and world > torch.cuda.device_count()
+
+    def in_turns(fn):
+        if not shared_device:
+            return fn()
+        res = None
+        for r in range(world):
+            if r == rank:
+                res = fn()
+                torch.cuda.synchronize(dev)
+            dist.barrier()
+        return res
+
+    def build():
+        m = build_model(args.layers, cfg=cfg).to(dev)
+        batch = make_batch(args.batch, args.height, args.width, seed=3 + rank, device=dev)
+        calibrate_batchnorm_(m, batch[0][:, 0])
+        return m, batch
+    model, (im, info, gt, nb) = in_turns(build)
     if args.frames == 1:   # BASELINE configs[1]: plain R-FCN on one frame (dtt/model.py: n_legs == 1, no tracking branch)
         im, info, gt, nb = (t[:, :1].contiguous() for t in (im, info, gt, nb))
     if args.mode == "train":
         from dtt.dist import make_optimizer, prepare_replica
         model.train()
         # rank 0's state to every rank, THEN the frozen BatchNorm folded out of the activation path, THEN the buckets
-        runner = prepare_replica(model, world, channels_last=not args.nchw_trunk)
+        if shared_device:   # (the same three steps, the collective-free middle one rank at a time)
+            from dtt.dist import DataParallelSnippets, broadcast_module_state
+            from dtt.fuse import fuse_for_training
+            broadcast_module_state(model)
+            in_turns(lambda: fuse_for_training(model, channels_last=not args.nchw_trunk))
+            runner = DataParallelSnippets(model, world)
+        else:
+            runner = prepare_replica(model, world, channels_last=not args.nchw_trunk)
         opt = make_optimizer(model, cfg, lr=1e-4)
 
         def step():

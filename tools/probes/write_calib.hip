@@ -3,7 +3,7 @@
 //   half64  : every wave stores 16 rows x 64 B (lane = (row, 16-byte piece)), rows 7168 B apart, the other half of each
 //             128-B line never written -- one accumulator tile of head_gemm_kernel's epilogue
 //   pair128 : the same wave stores both 64-B halves of the line back to back (two instructions)
-//   linear  : a fully coalesced 16 B/lane streaming store of the same number of bytes as half64
+//   linear  : a fully coalesced 16 B/lane streaming store (16 x 16 B per row: four times the bytes of half64)
 //   runs17  : every wave stores 64 consecutive floats starting at an arbitrary 4-byte offset of a 1184-float row -- the
 //             window-split correlation's write-out (partial lines at both ends of a run)
 // Build: hipcc --offload-arch=gfx950 -O3 -o write_calib tools/probes/write_calib.hip ; run under
@@ -51,6 +51,6 @@ int main() {
     hipLaunchKernelGGL(runs17, dim3(nrows / wpb), dim3(wg), 0, 0, buf, nrows, 1184L);
   }
   hipDeviceSynchronize();
-  printf("stored bytes: half64 %ld  pair128 %ld  linear %ld  runs17 %ld\n", nrows * 64, nrows * 128, nrows * 64, nrows * 256);
+  printf("stored bytes: half64 %ld  pair128 %ld  linear %ld  runs17 %ld\n", nrows * 64, nrows * 128, nrows * 256, nrows * 256);
   return 0;
 }
