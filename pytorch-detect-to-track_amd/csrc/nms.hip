@@ -150,6 +150,16 @@ __device__ unsigned long long dtt_nms_cycles[64 * 8];
 #define NMS_T0() do {} while (0)
 #define NMS_ACC(slot) do {} while (0)
 #endif
+#ifdef DTT_NMS_TRACE   // inside wave 0's walk: slots 4 (settling a chunk), 5 (keep-list entries), 6 (row OR + quarter reduction), 7 (fixpoint iterations)
+#define NMS_B0() unsigned long long tb_prev = __builtin_readcyclecounter()
+#define NMS_BACC(slot) do { const unsigned long long tb_now = __builtin_readcyclecounter(); \
+    if (lane == 0 && blockIdx.x < 32) dtt_nms_cycles[((sc_begin > 0 ? 32 : 0) + blockIdx.x) * 8 + (slot)] += tb_now - tb_prev; tb_prev = tb_now; } while (0)
+#define NMS_BCOUNT(slot, v) do { if (lane == 0 && blockIdx.x < 32) dtt_nms_cycles[((sc_begin > 0 ? 32 : 0) + blockIdx.x) * 8 + (slot)] += (v); } while (0)
+#else
+#define NMS_B0() do {} while (0)
+#define NMS_BACC(slot) do {} while (0)
+#define NMS_BCOUNT(slot, v) do {} while (0)
+#endif
 
 __device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
   unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
@@ -344,8 +354,10 @@ __global__ __launch_bounds__(kSweepThreads) void nms_sweep_kernel(
         if (c + 1 < nw) Lnext = lowbuf[(c + 1) * kTile + lane];   // in flight during this chunk
         const unsigned long long alive = ~r & valid;
         unsigned long long kept = alive;
+        NMS_B0();
         for (;;) {
           const unsigned long long next = alive & ~__ballot((L & kept) != 0ULL);
+          NMS_BCOUNT(7, 1);
           if (next == kept) break;
           kept = next;
         }
@@ -360,6 +372,7 @@ __global__ __launch_bounds__(kSweepThreads) void nms_sweep_kernel(
         nk += nkept;
         total += nkept;
         if (total >= limit) done = true;
+        NMS_BACC(4);
         if (!done && c + 1 < nw) {
           const int j = lane & 15, quarter = lane >> 4;
           const bool owner = j > c && j < nw;
@@ -389,6 +402,7 @@ __global__ __launch_bounds__(kSweepThreads) void nms_sweep_kernel(
             accw = ((unsigned long long)hi << 32) | lo;
           }
           if (owner && quarter == 0) R |= accw;
+          NMS_BACC(6);
         }
       }
       if (lane == 0) { ctl[0] = nk; ctl[1] = total; ctl[2] = done ? 1 : 0; }

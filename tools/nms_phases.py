@@ -34,4 +34,6 @@ print("BBOX_STD=%g  kept %s  proposal layer %.1f us per call" % (std, out[1].tol
 for ph in (0, 1):
     for b in range(B):
         v = [buf[((32 if ph else 0) + b) * 8 + k] / N for k in range(4)]
-        print("phase %d image %d: set-up %7.0f  A %7.0f  B %7.0f  C %7.0f  total %7.0f cycles" % (ph + 1, b, v[0], v[1], v[2], v[3], sum(v)))
+        w = [buf[((32 if ph else 0) + b) * 8 + k] / N for k in range(4, 8)]
+        print("phase %d image %d: set-up %7.0f  A %7.0f  B %7.0f  C %7.0f  total %7.0f cycles   inside B: settle %7.0f  row-OR %7.0f  fixpoint iterations %5.0f" % (
+            ph + 1, b, v[0], v[1], v[2], v[3], sum(v), w[0], w[2], w[3]))
