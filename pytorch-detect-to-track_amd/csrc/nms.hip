@@ -377,20 +377,24 @@ __global__ __launch_bounds__(kSweepThreads) void nms_sweep_kernel(
           const int j = lane & 15, quarter = lane >> 4;
           const bool owner = j > c && j < nw;
           const unsigned long long* col = sb + (size_t)(c * kTile + quarter * 16) * kRowStride + (owner ? j : 0);
-          unsigned kk = (unsigned)(kept >> (quarter * 16)) & 0xFFFFu;
-          unsigned long long accw = 0;
-          while (__any(kk != 0)) {
-            unsigned long long v[4] = {0, 0, 0, 0};
+          // all 16 rows of the quarter are read unconditionally (immediate offsets, two bursts of eight in flight) and masked by their
+          // kept bits: no serial ctz / loop over the kept rows, one LDS latency per burst (round 5: the row-OR was two thirds of the
+          // walk, profiles/r05_nms_walk_breakdown.txt)
+          const unsigned kk = (unsigned)(kept >> (quarter * 16)) & 0xFFFFu;
+          unsigned alo = 0, ahi = 0;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              if (kk != 0) {
-                const int i = __builtin_ctz(kk);
-                kk &= kk - 1;
-                v[u] = col[i * kRowStride];
-              }
+          for (int h = 0; h < 2; ++h) {
+            unsigned long long v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = col[(h * 8 + u) * kRowStride];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const unsigned msk = 0u - ((kk >> (h * 8 + u)) & 1u);      // all ones for a kept row (v_bfe_i32), then one v_and_or per half
+              alo |= (unsigned)v[u] & msk;
+              ahi |= (unsigned)(v[u] >> 32) & msk;
             }
-            accw |= (v[0] | v[1]) | (v[2] | v[3]);
           }
+          unsigned long long accw = ((unsigned long long)ahi << 32) | alo;
           // the four quarters (rows of 16 lanes) meet in every lane: two register swaps (v_permlane16_swap / v_permlane32_swap, VALU)
           // where __shfl_xor went through the LDS crossbar twice, back to back
           {
