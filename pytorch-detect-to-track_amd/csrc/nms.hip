@@ -24,8 +24,14 @@ constexpr int kSweepThreads = 1024;
 // Sb = (b2 - b0 + 1) * (b3 - b1 + 1), the column box's area, is made once per staged column (the same expression, the same bits).
 __device__ __forceinline__ bool iou_over(const float a0, const float a1, const float a2, const float a3, const float Sa,
                                          const float b0, const float b1, const float b2, const float b3, const float Sb, const float thresh) {
-  float left = fmaxf(a0, b0), right = fminf(a2, b2);
-  float top = fmaxf(a1, b1), bottom = fminf(a3, b3);
+  // max / min of two coordinates as the bare instructions: fmaxf / fminf make the compiler put a canonicalising v_max_f32 x, x in front
+  // for every value that comes out of LDS (4 of the 33 vector instructions per IoU test; the mask kernel is VALU-bound, and it even
+  // folds v_med3_f32 with an infinity back into that form).  For non-NaN inputs v_max_f32 / v_min_f32 return one of their operands.
+  float left, right, top, bottom;
+  asm("v_max_f32 %0, %1, %2" : "=v"(left) : "v"(a0), "v"(b0));
+  asm("v_min_f32 %0, %1, %2" : "=v"(right) : "v"(a2), "v"(b2));
+  asm("v_max_f32 %0, %1, %2" : "=v"(top) : "v"(a1), "v"(b1));
+  asm("v_min_f32 %0, %1, %2" : "=v"(bottom) : "v"(a3), "v"(b3));
   float width = fmaxf(right - left + 1, 0.f), height = fmaxf(bottom - top + 1, 0.f);
   float interS = width * height;
   const float uni = Sa + Sb - interS;
