@@ -584,7 +584,9 @@ def main():
                          "algorithmic_flops_per_op": flops, "algorithmic_bytes_per_op": bytes_},
         }
         sec = {}
-        for which, name, C, HWc in ((1, "corr4", 1024, H16 * W16), (0, "corr3", 512, -(-args.height // 8) * -(-args.width // 8))):
+        # (conv3 correlates the stride-2 lattice of the /8 maps: the op reads H16 x W16 lattice pixels of each map, not the whole maps --
+        #  counting the whole maps, as rounds 1 - 4 did, tripled its HBM fraction)
+        for which, name, C, HWc in ((1, "corr4", 1024, H16 * W16), (0, "corr3", 512, H16 * W16)):
             if which in corr_us and corr_us[which] > 0:
                 R = args.disp if which == 1 else args.disp // 2
                 Dw = (2 * R + 1) ** 2
@@ -593,7 +595,7 @@ def main():
                 us = corr_us[which]
                 sec[name] = {"kernel": "conv%d correlation op = corr_wsplit_kernel (%d ch, planned for 240 CUs: it runs beside the proposal "
                                        "layer; event tag corr_fwd_op)" % (4 if which == 1 else 3, C),
-                             "bound": "mfma" if which == 1 else "hbm", "op_us": round(us, 2),
+                             "bound": "mfma" if fl / FP32_MFMA_PEAK_TFLOPS / 1e12 >= by / HBM_PEAK_GBS / 1e9 else "hbm", "op_us": round(us, 2),
                              "mfma": {"achieved": round(fl / (us * 1e-6) / 1e12, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                       "frac": round(fl / (us * 1e-6) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)},
                              "hbm": {"achieved": round(by / (us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -29,7 +29,7 @@ out = {"library_sha256": hashlib.sha256(open(LIB, "rb").read()).hexdigest(),
        "fetch_correction": "x2 (MI355X_MICROARCH.md, HBM section: FETCH_SIZE tallies 128-B requests at 64 B; confirmed on this 64-B-per-pixel DMA pattern by tools/probes/fetch_calib.hip, profiles/r02_fetch_calib.txt)",
        "write_correction": "x1 (tools/probes/write_calib.hip, profiles/r03_write_calib.txt (round 3; the probe is unchanged))"}
 algo = {"conv5": (2 * 2048 * 38 * 67 * 4 + 289 * 38 * 67 * 4) * 2, "conv4": (2 * 1024 * 38 * 67 * 4 + 289 * 38 * 67 * 4) * 2,
-        "conv3": (2 * 512 * 75 * 134 * 4 + 81 * 38 * 67 * 4) * 2}
+        "conv3": (2 * 512 * 38 * 67 * 4 + 81 * 38 * 67 * 4) * 2}      # (the stride-2 lattice of the 75 x 134 maps: 38 x 67 pixels per map are read)
 for i, name in enumerate(("conv5", "conv4", "conv3")):
     f = [v for k, (_, v) in enumerate(fetch) if k % 3 == i][1:]     # drop the first (cold) launch
     w = [v for k, (_, v) in enumerate(write) if k % 3 == i][1:]
