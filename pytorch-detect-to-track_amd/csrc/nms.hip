@@ -180,12 +180,14 @@ __device__ __forceinline__ unsigned long long readlane64(unsigned long long v, i
 
 // Greedy sweep (nms_cuda_kernel.cu:131-144) for one image per workgroup.
 //   for i ascending: if bit i of remv is clear -> keep i, remv |= mask[i][i/64 ...]
-// restructured so that global-memory latency is paid twice per 1024 boxes instead of once per box:
-//   A. the 1024 x 16-word diagonal super-block of the mask is staged in LDS with one bulk load;
-//   B. wave 0 walks its 16 chunks: per chunk one LDS column read gives every lane its box's
-//      diagonal word, the serial keep decision runs on scalars (ctz / readlane), kept lanes OR
-//      their row into the later local words with LDS atomics;
-//   C. all waves OR the kept rows' remaining words (later super-chunks) into remv, again in bulk.
+// restructured so that global-memory latency is off the serial path (per 1024-box super-chunk; a software pipeline, see the loop):
+//   A. the 1024 x 16-word diagonal super-block of the mask and the boxes' "lower" words, loaded into registers while the
+//      PREVIOUS super-chunk was walked, go to LDS;
+//   B. wave 0 walks the 16 chunks of 64 boxes: a chunk is settled from its lower words by a wave-wide fixpoint (a handful of
+//      ballots), then lane (word, quarter) ORs that word of the chunk's kept rows -- all 16 rows of the quarter read from LDS
+//      unconditionally and masked -- and the quarters meet through v_permlane swaps; nothing in the walk touches global memory.
+//      Beside it waves 1 .. 15 OR the previous super-chunk's kept rows over the columns beyond the next super-chunk (C_far);
+//   C. everybody ORs the kept rows over the 16 words of the next super-chunk (C_near) and writes the keep-list entries.
 // Optionally writes the surviving boxes straight into the RoI tensor (proposal layer epilogue).
 //
 // Two-phase use (sc_begin / sc_end = range of 1024-box super-chunks; dtt_nms_batched_launch): when only max_keep << n
