@@ -52,9 +52,10 @@ constexpr int kTable = 1536;                  // work-item order in the kernel a
 struct BSeg { int tile0, by0, bx0, nty, ntx, th, tw, ahead; };   // ahead: ring slots beyond the th being read
 
 struct BGeom {
-  const float* other;                  // the frame the window runs over (frame t+tau for gradInput1, frame t for gradInput2), channels-last
-  float* grad;                         // gradient of the target frame, channels-last
-  const float* band;                   // this direction's band words [image][block row][block column][NBR^2 * 4][64 lanes]
+  const float* other[2];               // the frame the window runs over (frame t+tau for gradInput1, frame t for gradInput2), channels-last;
+  float* grad[2];                      // gradient of the target frame, channels-last.  [1]: the second direction of a MERGED launch
+  const float* band;                   // band words [quarter][direction][image][block row][block column][NBR^2][64 lanes][4 steps]
+  int nimg;                            // images per direction: a merged launch plans 2 * nimg "images", image n >= nimg = direction 1's n - nimg
   int gh, gw;                          // its grid of 4 x 4 target blocks
   long sb;                             // floats between images of other / grad
   unsigned sy4, sx4;                   // bytes between vertically / horizontally adjacent lattice pixels
@@ -69,12 +70,12 @@ struct BGeom {
   float inv;                           // 1 / C
   int nseg, tiles_per_image, tiles_total;
   BSeg seg[kMaxSeg];
-  int chunk, ngroups;                  // item -> (chunk index = item / tiles_total, tile = item % tiles_total); groups [ci * chunk, ...)
-  int use_table;
-  int hoff_y, hoff_x;                  // window radius > 8: this launch covers the NBR x NBR window blocks from block (hoff / 4), i.e. its
-  int accumulate;                      // halo starts hoff pixels further on; launches after the first ADD to the gradient
-  int ny, nx;                          // ... of which only the first ny block rows / nx block columns lie inside the window (the others'
-                                       // band words are all zero: the PARTIAL instantiation skips their MFMAs)
+  int chunk, rem, ngroups;             // item -> (chunk index ci = item / tiles_total, tile = item % tiles_total); the channel groups are
+  int use_table;                       // dealt evenly: the first `rem` chunks hold chunk + 1 groups, the others `chunk`
+  // window radius > 8 (MULTI): the (up to) 9 x 9 window blocks are walked as 2 x 2 QUARTERS of NBR x NBR blocks inside one launch --
+  // per channel group the halo of quarter (qa, qb) starts 4 NBR (qa, qb) pixels further on, the accumulators run through all four,
+  int nyl, nxl;                        // the second quarter row / column holds only nyl / nxl blocks that lie inside the window,
+  long band_q;                         // and a quarter's band words lie band_q floats behind the previous quarter's
   int ablate;                          // developer timing experiments (DTT_CORR_BWD_ABLATE): 1 no DMA, 2 no MFMA, 4 no stores, 8 no band loads
   unsigned short table[kTable];
 };
@@ -137,31 +138,37 @@ __host__ __device__ __forceinline__ BItem bw_decode(const BGeom& g, int item) {
   it.th = sg.th; it.tw = sg.tw; it.ahead = sg.ahead;
   it.Y0 = g.lo_y + 4 * (sg.by0 + tyi * sg.th);
   it.X0 = g.lo_x + 4 * (sg.bx0 + txi * sg.tw);
-  it.g0 = ci * g.chunk;
-  it.ng = min(g.chunk, g.ngroups - it.g0);
+  it.g0 = ci * g.chunk + min(ci, g.rem);
+  it.ng = g.chunk + (ci < g.rem ? 1 : 0);
   return it;
 }
 
-template <int NBR, bool PARTIAL = false>
+template <int NBR, bool MULTI = false>
 __global__ __launch_bounds__(kThreads) void corr_bwd_stream_kernel(BGeom g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  constexpr int NB4 = NBR * NBR * 4;
+  constexpr int NB2 = NBR * NBR;
+  constexpr int NSEG = MULTI ? 4 : 1;                 // window quarters walked per channel group
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int bid = blockIdx.x;
   const int item = g.use_table ? (int)g.table[bid] : dtt_xcd_remap(bid, gridDim.x);
-  const BItem it = bw_decode(g, item);
+  BItem it = bw_decode(g, item);
+  const int dir = it.n >= g.nimg ? 1 : 0;             // (merged launch: the second half of the planned images is direction 1)
+  const int n_eff = it.n;
+  it.n -= dir ? g.nimg : 0;
   const int th = it.th, tw = it.tw, nwv = th * tw;
   const int HC = 4 * (tw + NBR - 1);                  // halo width of the tile, pixels
   const int slot_bytes = 4 * HC * kGC * 4;            // one halo block row of one channel group
-  const int NH = th + NBR - 1;                        // halo block rows per group
   const int S = th + it.ahead;                        // ring slots
-  const int npos = it.ng * NH;
+  const int nyl = MULTI ? g.nyl : NBR, nxl = MULTI ? g.nxl : NBR;
+  // halo block rows per channel group: th + ny - 1 per quarter
+  const int rows_group = MULTI ? 2 * (th + NBR - 1) + 2 * (th + nyl - 1) : th + NBR - 1;
+  const int npos = it.ng * rows_group;
   const unsigned lds0 = (unsigned)(unsigned long)(const __attribute__((address_space(3))) float*)lds;
   const long img = (long)it.n * g.sb;
-  // A tall tile at a group boundary: th rows step into fresh positions at once and the ring holds fewer than 2 th slots, so the
-  // slots only come free at the barrier -- such a step has two barriers (fill, drain, meet again).  Every wave derives this
-  // from the tile shape alone.
+  // A tall tile at a segment boundary (next channel group / next quarter): th rows step into fresh positions at once and the ring
+  // holds fewer than 2 th slots, so the slots only come free at the barrier -- such a step has two barriers (fill, drain, meet
+  // again).  Every wave derives this from the tile shape alone.
   const bool tall = th > it.ahead;
 
   if (wave >= kComp) {
@@ -174,58 +181,76 @@ __global__ __launch_bounds__(kThreads) void corr_bwd_stream_kernel(BGeom g) {
     // ~4 cycles, and nobody was feeding the matrix pipe meanwhile -- kernel time = MFMA time + 27 us of bookkeeping.)
     const int lw = wave - kComp;
     __builtin_amdgcn_s_setprio(3);
-    unsigned voff[kMaxNI];
+    unsigned voff[kMaxNI], voff_b[MULTI ? kMaxNI : 1];   // voff_b: the quarters of the second column (halo 4 NBR pixels further right)
     int row_of[kMaxNI];
     int ni = 0;
 #pragma unroll
     for (int i = 0; i < kMaxNI; ++i) {
       const int j = lw + kLoad * i;
       voff[i] = 0; row_of[i] = 0;
+      if (MULTI) voff_b[i] = 0;
       if (j < HC) {
         const int t = (4 * j) / HC, c = 4 * j - t * HC + (lane >> 4);
-        const int x = min(max(g.origin + it.X0 - g.R + g.hoff_x + c, 0), g.W - 1);   // out-of-image pixels: any in-bounds address (their band words are zero)
+        const int x = min(max(g.origin + it.X0 - g.R + c, 0), g.W - 1);   // out-of-image pixels: any in-bounds address (their band words are zero)
         voff[i] = (unsigned)x * g.sx4 + (unsigned)((lane & 15) << 4);
+        if (MULTI) {
+          const int xb = min(max(g.origin + it.X0 - g.R + 4 * NBR + c, 0), g.W - 1);
+          voff_b[i] = (unsigned)xb * g.sx4 + (unsigned)((lane & 15) << 4);
+        }
         row_of[i] = t;
         ++ni;
       }
     }
     if (g.ablate & 1) ni = 0;
-    const char* obase = reinterpret_cast<const char*>(g.other + img) + (long)it.g0 * (kGC * 4);
-    // the next position to issue, tracked incrementally (all scalar): its group's base address, halo block row and ring slot
-    int issued = 0, i_hr = 0, i_slot = 0;
-    const int y_first = g.origin + it.Y0 - g.R + g.hoff_y;
+    const char* obase = reinterpret_cast<const char*>(g.other[dir] + img) + (long)it.g0 * (kGC * 4);
+    // the next position to issue, tracked incrementally (all scalar): its group's base address, quarter, halo block row, ring slot
+    int issued = 0, i_hr = 0, i_slot = 0, i_q = 0, i_nh = th + NBR - 1;
+    const int y_first = g.origin + it.Y0 - g.R;
     auto issue_next = [&]() {
       const unsigned dst = lds0 + (unsigned)(i_slot * slot_bytes + lw * 1024);
+      const int y_q = y_first + (MULTI && (i_q & 2) ? 4 * NBR : 0) + 4 * i_hr;
+      const bool right = MULTI && (i_q & 1);
 #pragma unroll
       for (int i = 0; i < kMaxNI; ++i)
         if (i < ni) {
-          const int y = min(max(y_first + 4 * i_hr + row_of[i], 0), g.H - 1);
-          dma16b(uptrb(obase + (unsigned long long)((unsigned)y * g.sy4)), voff[i], dst + (unsigned)(i * kLoad * 1024));
+          const int y = min(max(y_q + row_of[i], 0), g.H - 1);
+          dma16b(uptrb(obase + (unsigned long long)((unsigned)y * g.sy4)), right ? voff_b[MULTI ? i : 0] : voff[i], dst + (unsigned)(i * kLoad * 1024));
         }
       ++issued;
       if (++i_slot == S) i_slot = 0;
-      if (++i_hr == NH) { i_hr = 0; obase += kGC * 4; }
+      if (++i_hr == i_nh) {
+        i_hr = 0;
+        if (MULTI) {
+          if (++i_q == NSEG) { i_q = 0; obase += kGC * 4; }
+          i_nh = th + ((i_q & 2) ? nyl : NBR) - 1;
+        } else {
+          obase += kGC * 4;
+        }
+      }
     };
     while (issued < min(S, npos)) issue_next();        // the ring is filled first (positions 0 .. th - 1 are read in step 0)
     int base = 0;
     for (int gi = 0; gi < it.ng; ++gi) {
-      for (int qi = 0; qi < NBR; ++qi, ++base) {
-        // Positions <= base + th - 1 are read in this step.  After the barrier the ring is refilled as far as it goes: position
-        // P's slot is free once everybody is done with position P - S < base.
-        const int need = min(base + th - 1, npos - 1);
-        const int fill = min(base + S - 1, npos - 1);
-        if (tall && qi == 0 && gi > 0) {
-          wg_barrier_b();
-          while (issued <= fill) issue_next();
-          wait_vmcnt_b(0);
-          wg_barrier_b();
-        } else {
-          wait_vmcnt_b((issued - 1 - need) * ni);   // mine of the later positions may still fly (loads return in order)
-          wg_barrier_b();                           // everybody's share has landed; everybody is done with the positions below `base`
-          while (issued <= fill) issue_next();
+      for (int q = 0; q < NSEG; ++q) {
+        const int ny = (q & 2) ? nyl : NBR;
+        for (int qi = 0; qi < ny; ++qi, ++base) {
+          // Positions <= base + th - 1 are read in this step.  After the barrier the ring is refilled as far as it goes: position
+          // P's slot is free once everybody is done with position P - S < base.
+          const int need = min(base + th - 1, npos - 1);
+          const int fill = min(base + S - 1, npos - 1);
+          if (tall && qi == 0 && (gi | q) != 0) {
+            wg_barrier_b();
+            while (issued <= fill) issue_next();
+            wait_vmcnt_b(0);
+            wg_barrier_b();
+          } else {
+            wait_vmcnt_b((issued - 1 - need) * ni);   // mine of the later positions may still fly (loads return in order)
+            wg_barrier_b();                           // everybody's share has landed; everybody is done with the positions below `base`
+            while (issued <= fill) issue_next();
+          }
         }
+        base += th - 1;                               // (the next segment's first block row)
       }
-      base += th - 1;                               // (the next group's first block row)
     }
     return;
   }
@@ -233,14 +258,33 @@ __global__ __launch_bounds__(kThreads) void corr_bwd_stream_kernel(BGeom g) {
   // ================================================================ compute
   const bool active = wave < nwv;
   const int wy = active ? wave / tw : 0, wx = active ? wave - wy * tw : 0;
-  // ---------------------------------------------------------------- band: NBR^2 * 4 words per lane, in register order
-  float band[NB4];
-  {
-    const int by = (it.Y0 - g.lo_y) / 4 + wy, bx = (it.X0 - g.lo_x) / 4 + wx;
-    const float* bp = g.band + ((((long)it.n * g.gh + by) * g.gw + bx) * NB4) * 64 + lane;
+  // ---------------------------------------------------------------- band: NBR^2 x 4 words per lane, in register order (one 16-byte
+  // load per window block: the four steps of a block are consecutive)
+  f32x4 band[NB2];
+  // (waves without a block -- a short tile -- read block (0, 0)'s words and never use them; ablation 8 reads ONE block's words
+  //  everywhere: the loads stay, their traffic goes)
+  const int bby = (g.ablate & 8) ? 0 : (it.Y0 - g.lo_y) / 4 + wy, bbx = (g.ablate & 8) ? 0 : (it.X0 - g.lo_x) / 4 + wx;
+  const char* bpu = uptrb(reinterpret_cast<const char*>(g.band + ((((long)((g.ablate & 8) ? 0 : n_eff) * g.gh + bby) * g.gw + bbx) * NB2) * 256));
+  const unsigned lane16 = (unsigned)lane * 16u;
+  // MULTI: the band loads are inline asm the compiler does not track (a tracked load that is re-issued inside the loop drags counted
+  // waits into every MFMA group, and a conditional one a branch and a full drain per load): row qi of a quarter's words is requested
+  // right behind step qi of the quarter before, 5 x 16 bytes per lane, and released by ONE counted wait in front of step qi
+  auto band_row = [&](const char* base, int qi) {
 #pragma unroll
-    for (int b = 0; b < NB4; ++b) band[b] = (active && !(g.ablate & 8)) ? bp[b * 64] : 0.f;
+    for (int qj = 0; qj < NBR; ++qj) {
+      const int e = qi * NBR + qj;
+      asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(band[e]) : "v"(lane16), "s"(base + (e / 4) * 4096), "n"((e % 4) * 1024));
+    }
+  };
+  if constexpr (MULTI) {
+#pragma unroll
+    for (int qi = 0; qi < NBR; ++qi) band_row(bpu, qi);
+  } else {
+    const f32x4* bp = reinterpret_cast<const f32x4*>(bpu) + lane;
+#pragma unroll
+    for (int b = 0; b < NB2; ++b) band[b] = bp[b * 64];
   }
+  const long band_qb = MULTI ? g.band_q * 4 : 0;      // bytes between the quarters' band words
   // ---------------------------------------------------------------- store descriptors: lane -> target row tyi = lane / 16, columns r = 0 .. 3
   // (two registers: the byte offset of column 0 and a mask of the columns that are targets; the rest is recomputed per group)
   unsigned st_base = 0, st_mask = 0;
@@ -256,9 +300,9 @@ __global__ __launch_bounds__(kThreads) void corr_bwd_stream_kernel(BGeom g) {
     st_base = (unsigned)max(ly, 0) * g.sy4 + (unsigned)max(lx0, 0) * g.sx4 + (unsigned)((lane & 15) << 4);
     if (lx0 < 0) st_base -= (unsigned)(-lx0) * g.sx4;       // (columns left of the image are masked out; the offset stays consistent)
   }
-  char* gbase = reinterpret_cast<char*>(g.grad + img) + (long)it.g0 * (kGC * 4);
+  char* gbase = reinterpret_cast<char*>(g.grad[dir] + img) + (long)it.g0 * (kGC * 4);
 
-  // ---------------------------------------------------------------- main loop: one step = one halo block row of one group
+  // ---------------------------------------------------------------- main loop: one step = one halo block row of one (group, quarter)
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
   const unsigned rd_lane = lds0 + (unsigned)(wx * 1024 + lane * 16);
   const unsigned row = (unsigned)(HC * kGC * 4);
@@ -286,46 +330,62 @@ __global__ __launch_bounds__(kThreads) void corr_bwd_stream_kernel(BGeom g) {
   // does need are reloaded in the first step of every group.
   {
     for (int gi = 0; gi < it.ng; ++gi) {
+      for (int q = 0; q < NSEG; ++q) {
+        // MULTI: quarter q = (qa, qb) of the window holds ny x nx blocks that can be non-zero; the rest is skipped on both sides
+        // of the ring (no step, no DMA).  The band words of the NEXT quarter replace this one's block row by block row, each
+        // right behind the step that consumed it -- five 16-byte loads per step that have the rest of the quarter to land.
+        const int ny = (MULTI && (q & 2)) ? nyl : NBR, nx = (MULTI && (q & 1)) ? nxl : NBR;
+        // (the last quarter of the item requests quarter 0's words once more: in bounds, never used -- no condition on any load)
+        const char* bn = bpu + (long)((q + 1) & 3) * band_qb;
 #pragma unroll
-      for (int qi = 0; qi < NBR; ++qi) {
-        // nothing of this wave's is outstanding at a barrier that the compiler knows of: band loads (first step) and stores
-        // (later groups) were issued long before -- the builtin tells it so, and its own waits stay out of the loop
-        if (qi == 0 && gi == 0) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the band has arrived
-        if (tall && qi == 0 && gi > 0) wg_barrier_b();
-        wg_barrier_b();
-        // (PARTIAL: a quarter of a 9 x 9-block window holds 5 x 5, 5 x 4, 4 x 5 or 4 x 4 blocks that can be non-zero -- 81 of the 100
-        //  the four launches walk; the block rows / columns beyond are skipped, wave-uniformly, the ring and the barriers stay)
-        if (do_mfma && (!PARTIAL || qi < g.ny)) {
-          const unsigned sp = rd_lane + (unsigned)(r_slot * slot_bytes);
-          auto mm = [&](int t, int buf) {
-#pragma unroll
-            for (int qj = 0; qj < NBR; ++qj) {
-              if (PARTIAL && qj >= g.nx) continue;
-              const float a = band[(qi * NBR + qj) * 4 + t];
-              acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[buf][qj][0], acc0, 0, 0, 0);
-              acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[buf][qj][1], acc1, 0, 0, 0);
-              acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[buf][qj][2], acc2, 0, 0, 0);
-              acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[buf][qj][3], acc3, 0, 0, 0);
+        for (int qi = 0; qi < NBR; ++qi) {
+          if (!MULTI || qi < ny) {
+            // nothing of this wave's is outstanding at a barrier that the compiler knows of: band loads (first step) and stores
+            // (later groups) were issued long before -- the builtin tells it so, and its own waits stay out of the loop
+            if (!MULTI && qi == 0 && gi == 0) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the band has arrived
+            if (tall && qi == 0 && (gi | q) != 0) wg_barrier_b();
+            wg_barrier_b();
+            if constexpr (MULTI) {
+              // Row qi's words: (NBR - 1 - qi) rows were requested behind them in the quarter before and qi rows in this one -- 20 loads
+              // may still fly; 16 leaves room for the four stores of a finished group should they retire out of order with the loads.
+              static_assert(NBR == 5, "the counted wait below is written for 5 x 5 quarters");
+              asm volatile("s_waitcnt vmcnt(16)" : "+v"(band[qi * NBR]), "+v"(band[qi * NBR + 1]), "+v"(band[qi * NBR + 2]),
+                                                   "+v"(band[qi * NBR + 3]), "+v"(band[qi * NBR + 4]));
             }
-          };
-          // one burst of NBR ds_read_b128 per halo row t (4 MFMAs per read), issued one row ahead of the MFMAs that consume it
-          __builtin_amdgcn_sched_barrier(0);
-          rd(sp, 0); rd(sp + row, 1);
-          DTT_LANDED(0, NBR); mm(0, 0);
-          __builtin_amdgcn_sched_barrier(0);
-          rd(sp + 2 * row, 0);
-          DTT_LANDED(1, NBR); mm(1, 1);
-          __builtin_amdgcn_sched_barrier(0);
-          rd(sp + 3 * row, 1);
-          DTT_LANDED(0, NBR); mm(2, 0);
-          __builtin_amdgcn_sched_barrier(0);
-          DTT_LANDED(1, 0); mm(3, 1);
-          __builtin_amdgcn_sched_barrier(0);
+            if (do_mfma) {
+              const unsigned sp = rd_lane + (unsigned)(r_slot * slot_bytes);
+              auto mm = [&](int t, int buf) {
+#pragma unroll
+                for (int qj = 0; qj < NBR; ++qj) {
+                  if (MULTI && qj >= nx) continue;
+                  const float a = band[qi * NBR + qj][t];
+                  acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[buf][qj][0], acc0, 0, 0, 0);
+                  acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[buf][qj][1], acc1, 0, 0, 0);
+                  acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[buf][qj][2], acc2, 0, 0, 0);
+                  acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[buf][qj][3], acc3, 0, 0, 0);
+                }
+              };
+              // one burst of NBR ds_read_b128 per halo row t (4 MFMAs per read), issued one row ahead of the MFMAs that consume it
+              __builtin_amdgcn_sched_barrier(0);
+              rd(sp, 0); rd(sp + row, 1);
+              DTT_LANDED(0, NBR); mm(0, 0);
+              __builtin_amdgcn_sched_barrier(0);
+              rd(sp + 2 * row, 0);
+              DTT_LANDED(1, NBR); mm(1, 1);
+              __builtin_amdgcn_sched_barrier(0);
+              rd(sp + 3 * row, 1);
+              DTT_LANDED(0, NBR); mm(2, 0);
+              __builtin_amdgcn_sched_barrier(0);
+              DTT_LANDED(1, 0); mm(3, 1);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+            if (++r_slot == S) r_slot = 0;
+          }
+          if constexpr (MULTI) band_row(bn, qi);
         }
-        if (++r_slot == S) r_slot = 0;
+        r_slot += th - 1;                               // the next segment starts th block rows further on
+        if (r_slot >= S) r_slot -= S;
       }
-      r_slot += th - 1;                                 // the next group starts th block rows further on
-      if (r_slot >= S) r_slot -= S;
       // the group is complete: D[m = 4 * (lane / 16) + r][n = lane % 16] of accumulator s is channel 4 n + s of target pixel m
       char* dst = gbase + (long)gi * (kGC * 4) + st_base;
 #pragma unroll
@@ -333,7 +393,6 @@ __global__ __launch_bounds__(kThreads) void corr_bwd_stream_kernel(BGeom g) {
         if (st_mask & (1u << r)) {
           f32x4 o = {acc0[r] * g.inv, acc1[r] * g.inv, acc2[r] * g.inv, acc3[r] * g.inv};
           char* px = dst + (unsigned)r * g.sx4;
-          if (g.accumulate) o = *reinterpret_cast<const f32x4*>(px) + o;   // (window radius > 8: a later quarter of the window, fixed order)
           *reinterpret_cast<f32x4*>(px) = o;
           if (g.cell_fill) {   // strided lattice (conv3): the image pixels between the lattice points have no gradient
             const int ly = it.Y0 + 4 * wy + (lane >> 4) + g.origin, lx = it.X0 + 4 * wx + r + g.origin;
@@ -350,33 +409,38 @@ __global__ __launch_bounds__(kThreads) void corr_bwd_stream_kernel(BGeom g) {
 #undef DTT_LANDED
 
 // ------------------------------------------------------------------------------------------------ the band, once per op
-// band[dir][n][by][bx][(qi * NBR + qj) * 4 + t][lane]: what lane (m = lane % 16: target pixel (m / 4, m % 4) of block (by, bx);
+// band[quarter][dir][n][by][bx][qi * NBR + qj][lane][t]: what lane (m = lane % 16: target pixel (m / 4, m % 4) of block (by, bx);
 // k = lane / 16) of the wave that owns the block feeds the MFMA of window block (qi, qj), step t as its A operand = the gradient
 // that couples target m with the other frame's halo pixel (4 qi + t, 4 qj + k) of the block's halo -- zero where the pair lies
-// outside the window, the output range or the image.  One workgroup per (direction, image, block): the block's 16 x D*D pairs are
-// staged through LDS with loads that follow gradOut's contiguous axis (the first version gathered straight from memory: 25 loads
-// per thread each touching 64 cache lines in the planes layout, 16.6 us per conv5 op).
+// outside the window, the output range or the image.  The four steps of a block are one 16-byte piece per lane: the wave that owns the
+// block fetches a window block's words with ONE global_load_dwordx4.  One workgroup per (quarter, direction, image, block): the block's
+// 16 x D*D pairs are staged through LDS with loads that follow gradOut's contiguous axis (the first version gathered straight from
+// memory: 25 loads per thread each touching 64 cache lines in the planes layout, 16.6 us per conv5 op).
 struct BandGeom {
   const float* gout; long g_sb, g_sc, g_sp;
   float* band;
   int oh, ow, origin, H, W, R, D;
   unsigned d_magic, d2_magic;          // 65536 / D + 1 (exact for n < 4096), 2^32 / (D * D) + 1
-  int qoff_y, qoff_x;                  // window radius > 8: the launch's NBR x NBR window blocks start at block (qoff_y, qoff_x)
+  int nq, blocks_q;                    // window radius > 8: nq x nq quarters of NBR x NBR window blocks, blocks_q workgroups each,
+  long band_q;                         // band_q floats of band words each
   int ablate;                          // developer timing experiments (DTT_CORR_BWD_ABLATE): 32 no gradOut loads, 64 no band stores
   int lo_y[2], lo_x[2], gh[2], gw[2];
-  long dir_off[2];                     // floats from `band` to a direction's words
+  long dir_off[2];                     // floats from a quarter's first word to a direction's words
   int batch;
 };
 
 template <int NBR, bool SUB>
 __global__ __launch_bounds__(256) void corr_bwd_band_kernel(BandGeom g) {
-  constexpr int NB4 = NBR * NBR * 4;
-  // the displacements one launch can touch per axis: the whole window (2 R + 1 <= 4 (NBR - 1) + 1), or -- SUB: window radius > 8,
+  constexpr int NB2 = NBR * NBR;
+  // the displacements one workgroup can touch per axis: the whole window (2 R + 1 <= 4 (NBR - 1) + 1), or -- SUB: window radius > 8,
   // the window covered in quarters of NBR x NBR blocks -- the 4 NBR + 3 rows a quarter's halo spans around a 4 x 4 block
   constexpr int WIN = SUB ? 4 * NBR + 3 : 4 * (NBR - 1) + 1, WIN2 = WIN * WIN;
   constexpr int NIT = (16 * WIN2 + 255) / 256;
   __shared__ float G[16 * (WIN2 + 1)];                                // G[m * ldg + w]: gradOut of the pair (target m, displacement w)
   int blk = blockIdx.x;
+  const int quarter = SUB ? blk / g.blocks_q : 0;
+  blk -= quarter * g.blocks_q;
+  const int qoff_y = SUB ? NBR * (quarter / g.nq) : 0, qoff_x = SUB ? NBR * (quarter % g.nq) : 0;
   const int n0 = g.batch * g.gh[0] * g.gw[0];
   const int dir = blk >= n0 ? 1 : 0;
   blk -= dir ? n0 : 0;
@@ -385,8 +449,8 @@ __global__ __launch_bounds__(256) void corr_bwd_band_kernel(BandGeom g) {
   const int tid = threadIdx.x;
   // staged displacement indices: tj in [tj0, tj0 + W), ti in [ti0, ti0 + W)
   const int W = SUB ? WIN : g.D, W2 = W * W, ldg = W2 + 1;
-  const int tj0 = !SUB ? 0 : (dir ? 2 * g.R - 4 * g.qoff_y - 4 * NBR + 1 : 4 * g.qoff_y - 3);
-  const int ti0 = !SUB ? 0 : (dir ? 2 * g.R - 4 * g.qoff_x - 4 * NBR + 1 : 4 * g.qoff_x - 3);
+  const int tj0 = !SUB ? 0 : (dir ? 2 * g.R - 4 * qoff_y - 4 * NBR + 1 : 4 * qoff_y - 3);
+  const int ti0 = !SUB ? 0 : (dir ? 2 * g.R - 4 * qoff_x - 4 * NBR + 1 : 4 * qoff_x - 3);
   const unsigned w_magic = SUB ? 65536u / (unsigned)WIN + 1u : g.d_magic, w2_magic = SUB ? 0xffffffffu / (unsigned)WIN2 + 1u : g.d2_magic;
   const float* go = g.gout + (long)n * g.g_sb;
   const unsigned sc32 = (unsigned)g.g_sc, sp32 = (unsigned)g.g_sp;
@@ -421,26 +485,33 @@ __global__ __launch_bounds__(256) void corr_bwd_band_kernel(BandGeom g) {
   for (int i = 0; i < NIT; ++i)
     if (idx[i] >= 0) G[idx[i]] = v[i];
   __syncthreads();
-  // ---- the band words in register order: thread = (lane, step t); the NBR^2 window blocks unrolled
-  const int lane = tid & 63, t = tid >> 6;
+  // ---- the band words in register order: thread = (lane, window blocks j, j + 4, ...), the four steps of a block as one float4
+  const int lane = tid & 63, j = tid >> 6;
   const int m = lane & 15, k = lane >> 4, tyi = m >> 2, txi = m & 3;
-  float* out = g.band + g.dir_off[dir] + (((long)n * gh + by) * gw + bx) * NB4 * 64 + t * 64 + lane;
+  f32x4* out = reinterpret_cast<f32x4*>(g.band + (long)quarter * g.band_q + g.dir_off[dir]) + (((long)n * gh + by) * gw + bx) * NB2 * 64 + lane;
   const float* Gm = G + m * ldg;
 #pragma unroll
-  for (int qi = 0; qi < NBR; ++qi)
+  for (int i = 0; i < (NB2 + 3) / 4; ++i) {
+    const int e = j + 4 * i;
+    if (e >= NB2) break;
+    const int qi = e / NBR, qj = e - qi * NBR;
+    const int hx = 4 * (qj + qoff_x) + k - txi;                     // halo pixel - target pixel + R
+    const int ti = dir ? 2 * g.R - hx : hx;                         // displacement index of the pair
+    f32x4 bw;
 #pragma unroll
-    for (int qj = 0; qj < NBR; ++qj) {
-      const int hy = 4 * (qi + g.qoff_y) + t - tyi, hx = 4 * (qj + g.qoff_x) + k - txi;   // halo pixel - target pixel + R
-      const int tj = dir ? 2 * g.R - hy : hy, ti = dir ? 2 * g.R - hx : hx;               // displacement index of the pair
+    for (int t = 0; t < 4; ++t) {
+      const int hy = 4 * (qi + qoff_y) + t - tyi;
+      const int tj = dir ? 2 * g.R - hy : hy;
       const bool in = tj >= 0 && tj < g.D && ti >= 0 && ti < g.D;
-      const float bw = in ? Gm[(tj - tj0) * W + (ti - ti0)] : 0.f;
-      if (!(g.ablate & 64) || bw == 12345.f) out[(qi * NBR + qj) * 4 * 64] = bw;
+      bw[t] = in ? Gm[(tj - tj0) * W + (ti - ti0)] : 0.f;
     }
+    if (!(g.ablate & 64) || bw[0] == 12345.f) out[e * 64] = bw;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ host side: the plan
 struct BPlan {
-  int nseg, tiles_per_image, tiles_total, chunk, ngroups, items, ahead, use_table;
+  int nseg, tiles_per_image, tiles_total, chunk, rem, nchunks, ngroups, items, ahead, use_table;   // chunk, rem: as BGeom
   size_t lds_bytes;
   BSeg seg[kMaxSeg];
   std::vector<unsigned short> table;
@@ -488,7 +559,8 @@ double makespan(const std::vector<double>& dur, int ncu) {
   return *std::max_element(heap.begin(), heap.end());
 }
 
-bool plan_bwd(int batch, int eh, int ew, int nbr, int ngroups, int ncu, BPlan* out) {
+// gscale: matrix-pipe time of one channel group relative to NBR x NBR window blocks (window radius > 8: the four quarters of a group)
+bool plan_bwd(int batch, int eh, int ew, int nbr, int ngroups, int ncu, double gscale, BPlan* out) {
   const int GH = (eh + 3) / 4, GW = (ew + 3) / 4;
   BPlan p;
   p.nseg = bw_segments(GH, GW, p.seg);
@@ -506,35 +578,36 @@ bool plan_bwd(int batch, int eh, int ew, int nbr, int ngroups, int ncu, BPlan* o
   p.tiles_total = p.tiles_per_image * batch;
   p.ngroups = ngroups;
   // cost of one (tile, group) unit in matrix-pipe time: the waves of a tile sit ceil(waves / 4) deep on a SIMD; a workgroup pays
-  // a set-up (ring fill, band fetch) worth about a third of a two-deep unit
+  // a set-up (ring fill, band fetch, the drain of the workgroup before it) worth about three quarters of a two-deep unit
   std::vector<double> tile_cost;
   for (int s = 0; s < p.nseg; ++s)
-    for (int i = 0; i < p.seg[s].nty * p.seg[s].ntx; ++i) tile_cost.push_back((p.seg[s].th * p.seg[s].tw + 3) / 4);
-  const double setup = 0.6;
+    for (int i = 0; i < p.seg[s].nty * p.seg[s].ntx; ++i) tile_cost.push_back(gscale * ((p.seg[s].th * p.seg[s].tw + 3) / 4));
+  const double setup = 1.5;   // (fitted to forced-chunk sweeps of conv5 / conv4 at radius 8 and 16 on MI355X: measured time / simulated makespan within 2 %)
   double best = 1e30;
-  int best_chunk = ngroups;
+  int best_n = 1;
   std::vector<double> dur;
-  for (int chunk = ngroups; chunk >= 1; --chunk) {
-    const int nchunks = (ngroups + chunk - 1) / chunk;
+  for (int nchunks = 1; nchunks <= ngroups; ++nchunks) {
     if ((long)nchunks * p.tiles_total > 65535) break;                          // (16-bit item numbers; more items than that never pay)
-    if (nchunks > 1 && (ngroups + nchunks - 1) / nchunks != chunk) continue;   // (the same chunk count with a smaller chunk is more even)
+    if ((long)nchunks * p.tiles_total > kTable && best < 1e30) break;          // (... nor does losing the dispatch order that rides in the arguments)
+    const int base = ngroups / nchunks, rem = ngroups % nchunks;               // the groups are dealt evenly: chunk lengths differ by one at most
     dur.clear();
     for (int ci = 0; ci < nchunks; ++ci) {
-      const int len = std::min(chunk, ngroups - ci * chunk);
+      const int len = base + (ci < rem ? 1 : 0);
       for (int b = 0; b < batch; ++b)
         for (double c : tile_cost) dur.push_back(setup + len * c);
     }
     std::sort(dur.begin(), dur.end(), [](double a, double b) { return a > b; });
     const double ms = makespan(dur, ncu);
-    if (ms < best - 1e-9) { best = ms; best_chunk = chunk; }
+    if (ms < best - 1e-9) { best = ms; best_n = nchunks; }
   }
-  p.chunk = best_chunk;
-  if (const char* e = getenv("DTT_CORR_BWD_CHUNK")) {   // developer / test switch: force the channel groups per work item
+  p.nchunks = best_n;
+  if (const char* e = getenv("DTT_CORR_BWD_CHUNK")) {   // developer / test switch: force the channel groups per work item (at most)
     const int c = atoi(e);
-    if (c >= 1) p.chunk = std::min(c, ngroups);
-    while ((long)((ngroups + p.chunk - 1) / p.chunk) * p.tiles_total > 65535) ++p.chunk;
+    if (c >= 1) p.nchunks = (ngroups + std::min(c, ngroups) - 1) / std::min(c, ngroups);
+    while ((long)p.nchunks * p.tiles_total > 65535) --p.nchunks;
   }
-  const int nchunks = (ngroups + p.chunk - 1) / p.chunk;
+  const int nchunks = p.nchunks;
+  p.chunk = ngroups / nchunks; p.rem = ngroups % nchunks;
   p.items = nchunks * p.tiles_total;
   // ---- dispatch order.  Block b runs on XCD b % 8 and the blocks of an XCD start in order: every XCD's queue gets its share
   // of each duration class, longest first; within a class an XCD's share is a contiguous run of (chunk, tile) = neighbouring
@@ -544,7 +617,7 @@ bool plan_bwd(int batch, int eh, int ew, int nbr, int ngroups, int ncu, BPlan* o
     struct It { double dur; int id; };
     std::vector<It> its(p.items);
     for (int ci = 0; ci < nchunks; ++ci) {
-      const int len = std::min(p.chunk, ngroups - ci * p.chunk);
+      const int len = p.chunk + (ci < p.rem ? 1 : 0);
       for (int t = 0; t < p.tiles_total; ++t) its[ci * p.tiles_total + t] = It{setup + len * tile_cost[t % p.tiles_per_image], ci * p.tiles_total + t};
     }
     std::stable_sort(its.begin(), its.end(), [](const It& a, const It& b) { return a.dur > b.dur; });
@@ -577,7 +650,7 @@ bool plan_bwd(int batch, int eh, int ew, int nbr, int ngroups, int ncu, BPlan* o
   return true;
 }
 
-struct PlanKey { int batch, eh, ew, nbr, ngroups, ncu, forced_chunk; };
+struct PlanKey { int batch, eh, ew, nbr, ngroups, ncu, forced_chunk, gscale_pct; };
 bool operator==(const PlanKey& a, const PlanKey& b) { return memcmp(&a, &b, sizeof(PlanKey)) == 0; }
 
 const BPlan* cached_plan(const PlanKey& k) {
@@ -587,22 +660,22 @@ const BPlan* cached_plan(const PlanKey& k) {
   for (auto& e : cache)
     if (e.first == k) return e.second;
   BPlan* p = new BPlan();
-  if (!plan_bwd(k.batch, k.eh, k.ew, k.nbr, k.ngroups, k.ncu, p)) { delete p; p = nullptr; }
+  if (!plan_bwd(k.batch, k.eh, k.ew, k.nbr, k.ngroups, k.ncu, k.gscale_pct / 100.0, p)) { delete p; p = nullptr; }
   cache.emplace_back(k, p);
   return p;
 }
 
-template <int NBR, bool PARTIAL = false>
+template <int NBR, bool MULTI = false>
 int launch_stream(const BGeom& g, int items, size_t lds_bytes, hipStream_t stream) {
   static DttDeviceOnce once;
   bool& done = once.here();
   if (!done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(corr_bwd_stream_kernel<NBR, PARTIAL>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(corr_bwd_stream_kernel<NBR, MULTI>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMax);
     DTT_REQUIRE(e == hipSuccess, "correlation backward (streamed): cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
     done = true;
   }
-  hipLaunchKernelGGL((corr_bwd_stream_kernel<NBR, PARTIAL>), dim3(items), dim3(kThreads), lds_bytes, stream, g);
+  hipLaunchKernelGGL((corr_bwd_stream_kernel<NBR, MULTI>), dim3(items), dim3(kThreads), lds_bytes, stream, g);
   DTT_CHECK_LAUNCH("corr_bwd_stream_kernel");
   return 1;
 }
@@ -638,13 +711,14 @@ extern "C" size_t dtt_correlation_backward_workspace_bytes(int batch, int ic, in
   if (!dtt_correlation_output_shape(ic, ih, iw, pad_size, kernel_size, max_displacement, stride1, stride2, &oc, &oh, &ow)) return 0;
   const int s = stride1, R = max_displacement / s, nbr = R <= 4 ? 3 : 5;
   const int H = (ih + s - 1) / s, W = (iw + s - 1) / s, origin = (max_displacement - pad_size) / s;
+  const int nbr_full = 1 + (R + 1) / 2, nq = (nbr_full + nbr - 1) / nbr;   // window radius > 8: nq x nq quarters, all resident (one launch walks them)
   size_t total = 0;
   for (int dir = 0; dir < 2; ++dir) {
     int lo, hy, hx;
     if (!target_range(dir == 1, oh, ow, H, W, origin, R, &lo, &hy, &hx)) continue;
     total += (size_t)batch * ((hy - lo + 4) / 4) * ((hx - lo + 4) / 4) * nbr * nbr * 4 * 64 * sizeof(float);
   }
-  return total;
+  return total * nq * nq;
 }
 
 // Both gradients, channels-last inputs and gradients; gradOut[n, d, p] at gradOutput[n * g_sb + d * g_sc + p * g_sp].
@@ -679,7 +753,9 @@ int dtt_corr_bwd_stream(const float* gradOutput, long g_sb, long g_sc, long g_sp
   const int nbr = R <= 4 ? 3 : 5;
   const int ncu = dtt_device_cus();
 
-  // ---- the band words of both directions: one small launch
+  // ---- the band words of both directions (and, window radius > 8, of all four window quarters): one small launch
+  const int nbr_full = 1 + (R + 1) / 2, nq = (nbr_full + nbr - 1) / nbr;
+  DTT_REQUIRE(nq == 1 || (nq == 2 && nbr == 5), "correlation backward (streamed): window radius %d not covered", R);
   BandGeom bg;
   memset(&bg, 0, sizeof(bg));
   bg.gout = gradOutput; bg.g_sb = g_sb; bg.g_sc = g_sc; bg.g_sp = g_sp;
@@ -700,6 +776,7 @@ int dtt_corr_bwd_stream(const float* gradOutput, long g_sb, long g_sc, long g_sp
     off += (long)gob * bg.gh[dir] * bg.gw[dir] * nbr * nbr * 4 * 64;
     band_blocks += gob * bg.gh[dir] * bg.gw[dir];
   }
+  bg.nq = nq; bg.blocks_q = band_blocks; bg.band_q = off;
   const size_t bytes = (size_t)gob * ic * ih * iw * sizeof(float);
   // pixels that no lattice point maps to (stride > 1, pad != displacement) keep a zero gradient; on the dense lattice of conv4 /
   // conv5 (stride 1, pad == displacement) both kernels write every element themselves
@@ -710,48 +787,48 @@ int dtt_corr_bwd_stream(const float* gradOutput, long g_sb, long g_sc, long g_sp
   for (int dir = 0; dir < 2; ++dir)
     if ((which & (dir ? 2 : 1)) && !dense && !lattice_dense)
       DTT_REQUIRE(hipMemsetAsync(dir ? gradInput2 : gradInput1, 0, bytes, stream) == hipSuccess, "correlation backward: memset failed");
+  if (band_blocks > 0) {
+    if (nbr == 3) hipLaunchKernelGGL((corr_bwd_band_kernel<3, false>), dim3(band_blocks), dim3(256), 0, stream, bg);
+    else if (nq == 1) hipLaunchKernelGGL((corr_bwd_band_kernel<5, false>), dim3(band_blocks), dim3(256), 0, stream, bg);
+    else hipLaunchKernelGGL((corr_bwd_band_kernel<5, true>), dim3(band_blocks * nq * nq), dim3(256), 0, stream, bg);
+    DTT_CHECK_LAUNCH("corr_bwd_band_kernel");
+  }
   // Window radius > 8 (BASELINE configs[4]: d = 16, 33 x 33 displacements = 9 x 9 window blocks, 324 band words per lane): the window
-  // is covered in quarters of NBR x NBR = 5 x 5 blocks -- per quarter one band launch and one launch per direction whose halo starts
-  // 20 pixels further on; the quarters after the first ADD to the gradient (read-modify-write of the same workgroup's own
-  // elements, in a fixed order: deterministic, still no atomics).
-  const int nbr_full = 1 + (R + 1) / 2, nq = (nbr_full + nbr - 1) / nbr;
-  for (int qa = 0; qa < nq; ++qa)
-    for (int qb = 0; qb < nq; ++qb) {
-      const bool first = qa == 0 && qb == 0;
-      bg.qoff_y = qa * nbr; bg.qoff_x = qb * nbr;
-      if (band_blocks > 0) {
-        if (nbr == 3) hipLaunchKernelGGL((corr_bwd_band_kernel<3, false>), dim3(band_blocks), dim3(256), 0, stream, bg);
-        else if (nq == 1) hipLaunchKernelGGL((corr_bwd_band_kernel<5, false>), dim3(band_blocks), dim3(256), 0, stream, bg);
-        else hipLaunchKernelGGL((corr_bwd_band_kernel<5, true>), dim3(band_blocks), dim3(256), 0, stream, bg);
-        DTT_CHECK_LAUNCH("corr_bwd_band_kernel");
-      }
-      g.hoff_y = 4 * bg.qoff_y; g.hoff_x = 4 * bg.qoff_x;
-      g.ny = std::min(nbr, nbr_full - bg.qoff_y); g.nx = std::min(nbr, nbr_full - bg.qoff_x);
-      static const bool skip_off = getenv("DTT_CORR_BWD_NO_SKIP") != nullptr;     // developer A/B switch
-      const bool partial = nq > 1 && (g.ny < nbr || g.nx < nbr) && !skip_off;
-      g.accumulate = first ? 0 : 1;
-      g.cell_fill = (lattice_dense && first) ? 1 : 0;
-      for (int dir = 0; dir < 2; ++dir) {
-        const bool wrt2 = dir == 1;
-        if (!(which & (wrt2 ? 2 : 1)) || !live[dir]) continue;
-        g.lo_y = g.lo_x = lo[dir]; g.hi_y = hy[dir]; g.hi_x = hx[dir];
-        g.gh = bg.gh[dir]; g.gw = bg.gw[dir];
-        g.band = bg.band + bg.dir_off[dir];
-        const PlanKey key{gob, g.hi_y - g.lo_y + 1, g.hi_x - g.lo_x + 1, nbr, ic / kGC, ncu, getenv("DTT_CORR_BWD_CHUNK") ? atoi(getenv("DTT_CORR_BWD_CHUNK")) : 0};
-        const BPlan* p = cached_plan(key);
-        DTT_REQUIRE(p != nullptr, "correlation backward (streamed): no plan for %d x %d targets, radius %d", key.eh, key.ew, R);
-        g.other = wrt2 ? input1 : input2;
-        g.grad = wrt2 ? gradInput2 : gradInput1;
-        g.nseg = p->nseg; g.tiles_per_image = p->tiles_per_image; g.tiles_total = p->tiles_total;
-        for (int i = 0; i < kMaxSeg; ++i) g.seg[i] = i < p->nseg ? p->seg[i] : BSeg{0x7fffffff, 0, 0, 1, 1, 1, 1, 1};
-        g.chunk = p->chunk; g.ngroups = p->ngroups; g.use_table = p->use_table;
-        if (p->use_table) memcpy(g.table, p->table.data(), sizeof(unsigned short) * p->items);
-        // (one kernel for both directions: which gradient a launch computes is a matter of its band words and of `other`)
-        const int ok = nbr == 3 ? launch_stream<3>(g, p->items, p->lds_bytes, stream)
-                                : partial ? launch_stream<5, true>(g, p->items, p->lds_bytes, stream) : launch_stream<5>(g, p->items, p->lds_bytes, stream);
-        if (!ok) return 0;
-      }
-    }
+  // is covered in quarters of NBR x NBR = 5 x 5 blocks INSIDE the launch -- per channel group the four quarters' halos stream through
+  // the ring one after the other into the same accumulators, the band registers follow (corr_bwd_stream_kernel<5, true>): every gradient
+  // element is still written exactly once, no read-modify-write, in a fixed order.
+  g.nyl = nq > 1 ? nbr_full - nbr : nbr; g.nxl = g.nyl;
+  g.band_q = off;
+  g.cell_fill = lattice_dense ? 1 : 0;
+  g.nimg = gob;
+  // matrix-pipe time of a channel group in units of NBR x NBR window blocks (what the plan's set-up cost is priced against)
+  const int gscale_pct = nq > 1 ? (int)(100.0 * nbr_full * nbr_full / (nbr * nbr)) : 100;
+  static const bool no_merge = getenv("DTT_CORR_BWD_NO_MERGE") != nullptr;      // developer A/B switch: one launch per direction
+  // both directions as ONE grid where their target ranges coincide (pad == displacement: every lattice pixel is a target of both):
+  // the plan sees 2 x batch images, image n >= batch is direction 1's image n - batch -- one dispatch tail instead of two
+  const bool merged = which == 3 && live[0] && live[1] && lo[0] == lo[1] && hy[0] == hy[1] && hx[0] == hx[1] && !no_merge;
+  for (int dir = 0; dir < 2; ++dir) {
+    const bool wrt2 = dir == 1;
+    if (merged && dir == 1) break;
+    if (!merged && (!(which & (wrt2 ? 2 : 1)) || !live[dir])) continue;
+    g.lo_y = g.lo_x = lo[dir]; g.hi_y = hy[dir]; g.hi_x = hx[dir];
+    g.gh = bg.gh[dir]; g.gw = bg.gw[dir];
+    g.band = bg.band + bg.dir_off[dir];
+    const PlanKey key{merged ? 2 * gob : gob, g.hi_y - g.lo_y + 1, g.hi_x - g.lo_x + 1, nbr, ic / kGC, ncu,
+                      getenv("DTT_CORR_BWD_CHUNK") ? atoi(getenv("DTT_CORR_BWD_CHUNK")) : 0, gscale_pct};
+    const BPlan* p = cached_plan(key);
+    DTT_REQUIRE(p != nullptr, "correlation backward (streamed): no plan for %d x %d targets, radius %d", key.eh, key.ew, R);
+    g.other[0] = wrt2 ? input1 : input2; g.grad[0] = wrt2 ? gradInput2 : gradInput1;
+    g.other[1] = input1; g.grad[1] = gradInput2;            // (read by a merged launch only)
+    g.nseg = p->nseg; g.tiles_per_image = p->tiles_per_image; g.tiles_total = p->tiles_total;
+    for (int i = 0; i < kMaxSeg; ++i) g.seg[i] = i < p->nseg ? p->seg[i] : BSeg{0x7fffffff, 0, 0, 1, 1, 1, 1, 1};
+    g.chunk = p->chunk; g.rem = p->rem; g.ngroups = p->ngroups; g.use_table = p->use_table;
+    if (p->use_table) memcpy(g.table, p->table.data(), sizeof(unsigned short) * p->items);
+    // (one kernel for both directions: which gradient a work item computes is a matter of its band words and of `other`)
+    const int ok = nbr == 3 ? launch_stream<3>(g, p->items, p->lds_bytes, stream)
+                            : nq > 1 ? launch_stream<5, true>(g, p->items, p->lds_bytes, stream) : launch_stream<5>(g, p->items, p->lds_bytes, stream);
+    if (!ok) return 0;
+  }
   return 1;
 }
 
@@ -762,13 +839,15 @@ extern "C" int dtt_correlation_backward_plan_check(int batch, int target_h, int 
                                                    int compute_units) {
   if (window_radius < 1 || window_radius > 16 || channels % kGC != 0 || batch < 1 || target_h < 1 || target_w < 1) return 0;
   const int R = window_radius, nbr = R <= 4 ? 3 : 5;
+  const int nbr_full = 1 + (R + 1) / 2;
   BPlan p;
-  if (!plan_bwd(batch, target_h, target_w, nbr, channels / kGC, compute_units > 0 ? compute_units : 256, &p)) return 0;
+  if (!plan_bwd(batch, target_h, target_w, nbr, channels / kGC, compute_units > 0 ? compute_units : 256,
+                R > 8 ? (int)(100.0 * nbr_full * nbr_full / (nbr * nbr)) / 100.0 : 1.0, &p)) return 0;
   BGeom g;
   memset(&g, 0, sizeof(g));
   g.nseg = p.nseg; g.tiles_per_image = p.tiles_per_image; g.tiles_total = p.tiles_total;
   for (int i = 0; i < kMaxSeg; ++i) g.seg[i] = i < p.nseg ? p.seg[i] : BSeg{0x7fffffff, 0, 0, 1, 1, 1, 1, 1};
-  g.chunk = p.chunk; g.ngroups = p.ngroups;
+  g.chunk = p.chunk; g.rem = p.rem; g.ngroups = p.ngroups;
   const int GH = (target_h + 3) / 4, GW = (target_w + 3) / 4, NG = channels / kGC;
   std::vector<unsigned char> owned((size_t)batch * GH * GW * NG, 0);
   std::vector<unsigned char> seen(p.items, 0);
@@ -801,10 +880,12 @@ extern "C" int dtt_correlation_backward_plan(int batch, int target_h, int target
                                              int* items, int* chunk, int* lds_bytes, int* table) {
   if (window_radius < 1 || window_radius > 16 || channels % kGC != 0) return 0;
   const int R = window_radius, nbr = R <= 4 ? 3 : 5;
+  const int nbr_full = 1 + (R + 1) / 2;
   BPlan p;
-  if (!plan_bwd(batch, target_h, target_w, nbr, channels / kGC, compute_units > 0 ? compute_units : 256, &p)) return 0;
+  if (!plan_bwd(batch, target_h, target_w, nbr, channels / kGC, compute_units > 0 ? compute_units : 256,
+                R > 8 ? (int)(100.0 * nbr_full * nbr_full / (nbr * nbr)) / 100.0 : 1.0, &p)) return 0;
   if (items) *items = p.items;
-  if (chunk) *chunk = p.chunk;
+  if (chunk) *chunk = p.chunk + (p.rem ? 1 : 0);   // (the longest work item's channel groups)
   if (lds_bytes) *lds_bytes = (int)p.lds_bytes;
   if (table) *table = p.use_table;
   return 1;

@@ -128,11 +128,15 @@ def test_correlation_streamed_backward_plans_without_gpu():
         return tuple(x.value for x in v)
     # the 600 px training step, B = 2: 2 x (20 tiles of 2 x 4 blocks + the 17th block column as two 4 x 1 and one 2 x 1) = 46 tiles
     items, chunk, lds, table = plan(2, 38, 67, 8, 2048, 256)
-    assert items % 46 == 0 and items == 46 * -(-32 // chunk) and lds <= 144 * 1024 and table == 1
+    # (the channel groups are dealt evenly over items / 46 chunks; `chunk` = the longest chunk)
+    assert items % 46 == 0 and chunk == -(-32 // (items // 46)) and lds <= 144 * 1024 and table == 1
     # one round of workgroups (longest first) must beat the naive one-workgroup-per-tile plan by far: <= 7 two-deep units of a CU
-    assert 4 <= chunk <= 8, chunk
+    assert 3 <= chunk <= 8, chunk
     items4, chunk4, _, _ = plan(2, 38, 67, 8, 1024, 256)
-    assert items4 == 46 * -(-16 // chunk4) and 2 <= chunk4 <= 4
+    assert items4 % 46 == 0 and chunk4 == -(-16 // (items4 // 46)) and 2 <= chunk4 <= 4
+    # both directions as one grid (pad == displacement): the plan sees 2 x batch images
+    itemsm, chunkm, _, tablem = plan(4, 38, 67, 8, 2048, 256)
+    assert itemsm % 92 == 0 and chunkm == -(-32 // (itemsm // 92)) and tablem == 1
     assert plan(2, 38, 67, 4, 512, 256)[0] >= 46                 # conv3 (radius 4 on the stride-2 lattice)
     cases = [(2, 38, 67, 8, 2048, 256), (2, 38, 67, 8, 1024, 256), (2, 38, 67, 4, 512, 256), (8, 38, 67, 8, 2048, 256), (1, 36, 63, 8, 1024, 256),
              (1, 1, 1, 1, 64, 256), (3, 9, 11, 4, 64, 7), (1, 4, 33, 8, 128, 1), (1, 20, 4, 8, 64, 256), (2, 5, 4, 8, 64, 304), (16, 38, 67, 8, 2048, 256),
@@ -143,13 +147,14 @@ def test_correlation_streamed_backward_plans_without_gpu():
                       64 * int(rs.randint(1, 33)), int(rs.choice([1, 8, 64, 104, 240, 256, 304]))))
     for c in cases:
         assert L.dtt_correlation_backward_plan_check(*c) == 1, c
-    assert L.dtt_correlation_backward_plan_check(1, 8, 8, 12, 64, 256) == 1     # radius 9 .. 16: the same launches, once per window quarter
+    assert L.dtt_correlation_backward_plan_check(1, 8, 8, 12, 64, 256) == 1     # radius 9 .. 16: the window's four quarters inside the launch
+    assert L.dtt_correlation_backward_plan_check(2, 36, 63, 16, 2048, 256) == 1 and L.dtt_correlation_backward_plan_check(1, 36, 63, 16, 1024, 256) == 1
     assert L.dtt_correlation_backward_plan_check(1, 8, 8, 17, 64, 256) == 0     # radius > 16: not these kernels
     assert L.dtt_correlation_backward_plan_check(1, 8, 8, 4, 48, 256) == 0      # channels % 64 != 0: round 1's kernels
     assert L.dtt_correlation_backward_stream_supported(2048, 1, 8, 1, 1) == 1 and L.dtt_correlation_backward_stream_supported(512, 1, 8, 2, 2) == 1
     assert L.dtt_correlation_backward_stream_supported(80, 1, 8, 1, 1) == 0 and L.dtt_correlation_backward_stream_supported(64, 3, 8, 1, 1) == 0
     assert L.dtt_correlation_backward_stream_supported(64, 1, 16, 1, 1) == 1 and L.dtt_correlation_backward_stream_supported(64, 1, 17, 1, 1) == 0
-    assert L.dtt_correlation_backward_workspace_bytes(1, 1024, 36, 63, 16, 1, 16, 1, 1) == 2 * 9 * 16 * 100 * 64 * 4   # d = 16: one quarter at a time
+    assert L.dtt_correlation_backward_workspace_bytes(1, 1024, 36, 63, 16, 1, 16, 1, 1) == 4 * 2 * 9 * 16 * 100 * 64 * 4   # d = 16: four window quarters, all resident
     # workspace: the band words of both directions, NBR^2 * 4 * 64 floats per 4 x 4 target block
     assert L.dtt_correlation_backward_workspace_bytes(2, 2048, 38, 67, 8, 1, 8, 1, 1) == 2 * 2 * 10 * 17 * 100 * 64 * 4
     assert L.dtt_correlation_backward_workspace_bytes(2, 80, 38, 67, 8, 1, 8, 1, 1) == 0

@@ -14,6 +14,9 @@ dev = torch.device("cuda:0")
 B = int(os.environ.get("B", 2))
 ITERS = int(os.environ.get("ITERS", 30))
 D = int(os.environ.get("D", 8))
+SHAPE = os.environ.get("SHAPE", "600")   # "600": 600x1067 frames (38x67 / 75x134 maps); "563": 563x1000 (36x63 / 71x125, BASELINE configs[4])
+H5, W5, H3, W3 = (38, 67, 75, 134) if SHAPE == "600" else (36, 63, 71, 125)
+OLD = not os.environ.get("NO_OLD")
 L = _lib.lib()
 
 
@@ -32,7 +35,7 @@ def timeit(name, fn, flops):
 
 g = torch.Generator().manual_seed(3)
 ONLY = os.environ.get("ONLY", "")      # e.g. ONLY=conv5: one map (per-kernel counter averages of a --pmc pass then belong to it)
-for name, C, H, W, s in (("conv5", 2048, 38, 67, 1), ("conv4", 1024, 38, 67, 1), ("conv3", 512, 75, 134, 2)):
+for name, C, H, W, s in (("conv5", 2048, H5, W5, 1), ("conv4", 1024, H5, W5, 1), ("conv3", 512, H3, W3, 2)):
     if ONLY and name != ONLY:
         continue
     f1 = torch.relu(torch.randn(B, C, H, W, generator=g)).to(dev).contiguous(memory_format=torch.channels_last)
@@ -47,6 +50,8 @@ for name, C, H, W, s in (("conv5", 2048, 38, 67, 1), ("conv4", 1024, 38, 67, 1),
         check(L.dtt_correlation_backward_nhwc(ptr(gout), B, oc, oh, ow, ptr(f1), C, H, W, ptr(f2), ptr(b1), ptr(b2), D, 1, D, s, s,
                                               stream_ptr(dev)), "round-1 backward")
     timeit("%s gradients, streamed (band + 2 launches)" % name, lambda: correlation_backward_nhwc(gout, f1, f2, a1, a2, D, 1, D, s, s), flops)
+    if not OLD:
+        continue
     timeit("%s gradients, round 1 (2 launches)" % name, old, flops)
     if not os.environ.get("DTT_CORR_BWD_ABLATE"):
         print("   max |diff| between the two: %.2e / %.2e (max |g| %.2e)" % (float((a1 - b1).abs().max()), float((a2 - b2).abs().max()),
