@@ -582,7 +582,9 @@ bool plan_bwd(int batch, int eh, int ew, int nbr, int ngroups, int ncu, double g
   std::vector<double> tile_cost;
   for (int s = 0; s < p.nseg; ++s)
     for (int i = 0; i < p.seg[s].nty * p.seg[s].ntx; ++i) tile_cost.push_back(gscale * ((p.seg[s].th * p.seg[s].tw + 3) / 4));
-  const double setup = 1.5;   // (fitted to forced-chunk sweeps of conv5 / conv4 at radius 8 and 16 on MI355X: measured time / simulated makespan within 2 %)
+  // (fitted to forced-chunk sweeps on MI355X, measured time / simulated makespan within 2 - 6 %: conv5 / conv4 at radius 8 price a work
+  //  item's set-up at 1.5 units; the quarter-walking kernel's steps are slower per unit and its sweeps rank as if the set-up were free)
+  const double setup = gscale > 1.0 ? 0.3 : 1.5;
   double best = 1e30;
   int best_n = 1;
   std::vector<double> dur;
@@ -622,7 +624,35 @@ bool plan_bwd(int batch, int eh, int ew, int nbr, int ngroups, int ncu, double g
     }
     std::stable_sort(its.begin(), its.end(), [](const It& a, const It& b) { return a.dur > b.dur; });
     std::vector<std::vector<int>> q(8);
-    for (size_t lo = 0; lo < its.size();) {
+    // (measured on MI355X, profiles/r06_corr_bwd_order.txt: tile-major queues win where every chunk has the same length -- conv5 at
+    //  radius 8: 195 -> 175 us for both gradients -- and for the quarter-walking kernel, whose band words are re-read per group and
+    //  quarter: d = 16 conv5 265 -> 254 us with a quarter of the fetch traffic; with uneven chunks (conv4 at radius 8) they break the
+    //  longest-first order and lose 6 %)
+    const int gang = getenv("DTT_CORR_BWD_GANG") ? atoi(getenv("DTT_CORR_BWD_GANG")) : (gscale > 1.0 || p.rem == 0) ? 4 : 0;   // env: developer A/B switch
+    size_t lo0 = 0;
+    if (gang > 0) {
+      // TILE-major queues for the costliest tile class (the 2 x 4 body tiles): an XCD owns a run of neighbouring tiles and walks them
+      // `gang` tiles at a time through all channel chunks -- the work items that are resident together share their tiles' band words
+      // in that XCD's L2 (and neighbouring tiles of a gang part of their halos).  The smaller classes are dealt item by item below.
+      std::vector<int> tl;
+      double cmax = 0;
+      for (double c : tile_cost) cmax = std::max(cmax, c);
+      for (int t = 0; t < p.tiles_total; ++t)
+        if (tile_cost[t % p.tiles_per_image] == cmax) tl.push_back(t);
+      const size_t n = tl.size();
+      for (int x = 0; x < 8; ++x) {
+        const size_t a = n * x / 8, b = n * (x + 1) / 8;
+        for (size_t g0 = a; g0 < b; g0 += gang)
+          for (int ci = 0; ci < nchunks; ++ci)
+            for (size_t i = g0; i < std::min(b, g0 + gang); ++i) q[x].push_back(ci * p.tiles_total + tl[i]);
+      }
+      // (the items of that class lead `its`, whatever their chunk length: skip them)
+      std::vector<It> rest;
+      for (const It& e : its)
+        if (tile_cost[(e.id % p.tiles_total) % p.tiles_per_image] != cmax) rest.push_back(e);
+      its.swap(rest);
+    }
+    for (size_t lo = lo0; lo < its.size();) {
       size_t hi = lo;
       while (hi < its.size() && its[hi].dur == its[lo].dur) ++hi;
       const size_t n = hi - lo;
