@@ -362,9 +362,9 @@ def main():
     # DTT_BENCH_BACKEND=gloo: developer switch to exercise the multi-rank control flow on a box with fewer GPUs than ranks
     # (ranks then share devices; inference mode only -- the training path all-reduces device buffers over RCCL)
     backend = os.environ.get("DTT_BENCH_BACKEND", "nccl")
-    local = local if backend == "nccl" else local % torch.cuda.device_count()
     from dtt.dist import isolate_library_caches
-    isolate_library_caches(local, world)   # every rank its own MIOpen find-db / kernel cache: N processes search on the first step
+    isolate_library_caches(local, world)   # every rank its own MIOpen find-db / kernel cache (keyed on the launcher's LOCAL_RANK: ranks that share a device below still get their own)
+    local = local if backend == "nccl" else local % torch.cuda.device_count()
     torch.cuda.set_device(local)  # before the process group exists: RCCL binds its communicator to the current device
     dev = torch.device("cuda", local)
     if world > 1:

@@ -496,7 +496,28 @@ int dtt_rpn_head_gemm(const float* x, long ldx, int batch, int hw, int K, const 
  * gradient, columns [bg_0, fg_0, ..., bg_{A-1}, fg_{A-1}, box deltas 0 .. 4A-1, zeros up to ld], with the adjoint of the pairwise
  * softmax applied (cls_prob: the forward's probabilities).  dX and dW then are dtt_head_gemm / dtt_head_gemm_dw over these rows. */
 int dtt_rpn_head_grad_rows(const float* grad_cls_prob, const float* grad_bbox_pred, const float* cls_prob, int batch, int hw,
-                           int num_anchors, float* rows, long ld, void* stream);
+                           int num_anchors, float* rows, long ld, int cls_grad_is_logits, void* stream);
+/* (cls_grad_is_logits = 1: grad_cls_prob already is the gradient with respect to the score LOGITS -- dtt_rpn_loss_backward's --
+ *  and is copied into its columns as it is; 0: the gradient with respect to the probabilities, softmax adjoint applied.) */
+
+/* The two RPN losses of rpn/rpn.py:86-105 for `legs` legs (frames of a pair) of batch / legs images each, one launch:
+ * loss[leg] = cross-entropy over the anchors the anchor-target layer labelled 0 / 1 (labels: (batch, 1, A*h, w) floats, -1 = not
+ * sampled; rpn.py:90-97 gathers them with nonzero() + index_select -- the mean over the labelled anchors is the same number) read
+ * as -log cls_prob[label] of the pairwise-softmaxed scores (dtt_rpn_head_gemm's cls_prob); loss[legs + leg] = _smooth_l1_loss(
+ * bbox_pred, bbox_targets, inside, outside, sigma, dim = [1, 2, 3]) (net_utils.py:73-87, rpn.py:104-105).  count[leg]: the leg's
+ * labelled anchors.  Deterministic (per-workgroup partials added in index order by the last workgroup).  workspace:
+ * dtt_rpn_loss_workspace_bytes(batch, hw) bytes, caller-owned. */
+size_t dtt_rpn_loss_workspace_bytes(int batch, int hw);
+int dtt_rpn_loss_forward(const float* cls_prob, const float* bbox_pred, const float* labels, const float* bbox_targets,
+                         const float* inside_weights, const float* outside_weights, int batch, int legs, int num_anchors, int hw,
+                         float sigma, float* loss, float* count, void* workspace, size_t workspace_bytes, void* stream);
+/* Gradient of sum_leg grad_loss[leg] * class loss + grad_loss[legs + leg] * box loss (grad_loss, count: device arrays):
+ * grad_logits (batch, 2A, h, w) with respect to the score LOGITS, (p - y) * g / count -- what cross_entropy on the logits gives
+ * (rpn.py:97), alive where a probability underflows -- and grad_bbox (batch, 4A, h, w) with respect to bbox_pred; every element
+ * is written.  Feed both to dtt_rpn_head_grad_rows with cls_grad_is_logits = 1. */
+int dtt_rpn_loss_backward(const float* cls_prob, const float* bbox_pred, const float* labels, const float* bbox_targets,
+                          const float* inside_weights, const float* outside_weights, const float* grad_loss, const float* count,
+                          int batch, int legs, int num_anchors, int hw, float sigma, float* grad_logits, float* grad_bbox, void* stream);
 
 /* Weight gradient of the packed 1x1 heads (training graph, rfcn.py:49-53): dw[n][k] = sum_m gout[m][n] * x[m][k] for n < N,
  * k < K over the M pixel rows of the position-major maps -- gout (M, g_cols >= N columns readable, row stride ldg floats; the

@@ -12,6 +12,7 @@
 //                 (anchor_target_layer.py:168-189)
 // IoU / encode arithmetic is binary32 in the reference's operation order, FP contraction off; log is
 // correctly rounded via double (declared semantics, see oracle/rpn_oracle.py).
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -203,15 +204,118 @@ __global__ __launch_bounds__(kThreads) void at_finish(const float* __restrict__ 
 // that image's counts (anchor_target_layer.py:143-154): weights[0] positive, [1] negative.
 constexpr int kSubThreads = 1024;
 constexpr int kBatch = 16;   // label / key pairs in flight per thread
+// The fast path (images of up to kCache * 1024 = 32 768 anchors: 30 552 at 600 x 1067): ONE pass over memory.  A thread keeps its
+// kCache label / key pairs in registers; a 4096-bin histogram of the keys' top 12 bits per class finds the bin that holds the
+// quota-th smallest key (a parallel scan over the bins, not a serial walk), the handful of candidates of that bin (n / 4096 on
+// average) go to a list in LDS where each is ranked against the others by (key, index), and the labels beyond the threshold pair
+// are cleared from the registers.  A bin with more than kList candidates (keys that are not random) falls back to the radix
+// select below -- the same subset either way: the quota smallest (key, index) pairs.
+constexpr int kCache = 32, kBins = 4096, kList = 1024;
+
+struct SubShared {
+  int hist[2][kBins];
+  unsigned list_key[2][kList];
+  int list_idx[2][kList];
+  int wsum[2][8];
+  int ctl[2][3];       // the bin, how many of its candidates stay, how many it holds
+  int lcount[2];
+  unsigned thr_key[2];
+  int thr_idx[2];
+};
+
+__device__ bool at_subsample_fast(SubShared& S, int* __restrict__ lab, const unsigned* __restrict__ key, int n, bool sel0, bool sel1,
+                                  bool cut0, bool cut1, int quota0, int quota1) {
+  const int tid = threadIdx.x;
+  auto sel = [&](int c) { return c ? sel1 : sel0; };
+  auto cut = [&](int c) { return c ? cut1 : cut0; };
+  int cs[kCache];
+  unsigned ks[kCache];
+#pragma unroll
+  for (int u = 0; u < kCache; ++u) {
+    const int i = tid + u * kSubThreads;
+    cs[u] = i < n ? lab[i] : -1;
+    ks[u] = i < n ? key[i] : 0u;
+  }
+  for (int i = tid; i < 2 * kBins; i += kSubThreads) (&S.hist[0][0])[i] = 0;
+  if (tid < 2) S.lcount[tid] = 0;
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < kCache; ++u)
+    if (cs[u] >= 0 && sel(cs[u])) atomicAdd(&S.hist[cs[u]][ks[u] >> 20], 1);
+  __syncthreads();
+  {
+    // class c = tid / 512 scans its 4096 bins, 8 per thread
+    const int c = tid >> 9, t = tid & 511, lane = tid & 63, wv = t >> 6;
+    int own = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) own += S.hist[c][t * 8 + j];
+    int incl = own;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int v = __shfl_up(incl, o);
+      if (lane >= o) incl += v;
+    }
+    if (lane == 63) S.wsum[c][wv] = incl;
+    __syncthreads();
+    int before = incl - own;
+    for (int w = 0; w < wv; ++w) before += S.wsum[c][w];
+    const int rem = c ? quota1 : quota0;
+    if (sel(c) && before < rem && before + own >= rem) {
+      int cum = before, d = t * 8;
+      for (; d < t * 8 + 7; ++d) {
+        if (cum + S.hist[c][d] >= rem) break;
+        cum += S.hist[c][d];
+      }
+      S.ctl[c][0] = d; S.ctl[c][1] = rem - cum; S.ctl[c][2] = S.hist[c][d];
+    }
+  }
+  __syncthreads();
+  if ((sel0 && S.ctl[0][2] > kList) || (sel1 && S.ctl[1][2] > kList)) return false;   // (uniform: read from LDS)
+#pragma unroll
+  for (int u = 0; u < kCache; ++u) {
+    const int c = cs[u];
+    if (c >= 0 && sel(c) && (int)(ks[u] >> 20) == S.ctl[c][0]) {
+      const int pos = atomicAdd(&S.lcount[c], 1);
+      S.list_key[c][pos] = ks[u]; S.list_idx[c][pos] = tid + u * kSubThreads;
+    }
+  }
+  __syncthreads();
+  {
+    const int c = tid >> 9;
+    if (sel(c)) {
+      const int m = S.ctl[c][2], want = S.ctl[c][1] - 1;
+      for (int e = tid & 511; e < m; e += 512) {
+        const unsigned k = S.list_key[c][e];
+        const int i = S.list_idx[c][e];
+        int rank = 0;
+        for (int o = 0; o < m; ++o) {
+          const unsigned ko = S.list_key[c][o];
+          rank += (ko < k || (ko == k && S.list_idx[c][o] < i)) ? 1 : 0;
+        }
+        if (rank == want) { S.thr_key[c] = k; S.thr_idx[c] = i; }
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < kCache; ++u) {
+    const int i = tid + u * kSubThreads, c = cs[u];
+    if (i >= n || c < 0 || !cut(c)) continue;
+    const bool keep = sel(c) && (ks[u] < S.thr_key[c] || (ks[u] == S.thr_key[c] && i <= S.thr_idx[c]));
+    if (!keep) lab[i] = -1;
+  }
+  return true;
+}
 
 __global__ __launch_bounds__(kSubThreads) void at_subsample(int* __restrict__ labels, const unsigned* __restrict__ keys, int n,
                                                             int batch, const int* __restrict__ counts, int rpn_batchsize,
                                                             int num_fg, float positive_weight, int* __restrict__ after,
-                                                            float* __restrict__ weights) {
+                                                            float* __restrict__ weights, int no_fast) {
   // per class c (0 background, 1 foreground): hist[c][256]; ctl[c] = {digit, remaining, equal}
-  __shared__ int hist[2][256];
-  __shared__ int ctl[2][3];
-  __shared__ int wave_cnt[kSubThreads / 64];
+  __shared__ SubShared S;
+  int (*hist)[256] = reinterpret_cast<int (*)[256]>(&S.hist[0][0]);      // (the radix select's 2 x 256 bins alias the fast path's histogram)
+  int (*ctl)[3] = S.ctl;
+  int* wave_cnt = &S.list_idx[0][0];
   const int b = blockIdx.x, tid = threadIdx.x;
   int* lab = labels + (long)b * n;
   const unsigned* key = keys + (long)b * n;
@@ -224,6 +328,11 @@ __global__ __launch_bounds__(kSubThreads) void at_subsample(int* __restrict__ la
   unsigned prefix[2] = {0u, 0u};
   int rem[2] = {quota[0], quota[1]}, equal[2] = {0, 0};
   unsigned mask = 0;
+  static_assert(kSubThreads == 1024 && kBins == 8 * 512, "at_subsample_fast: two classes x 512 threads x 8 bins");
+  const bool fast = (cut[0] || cut[1]) && n <= kCache * kSubThreads && !no_fast && at_subsample_fast(S, lab, key, n, sel[0], sel[1], cut[0], cut[1], quota[0], quota[1]);
+  if (fast) {
+    // (labels cleared; the counts below are all that is left)
+  } else {
   if (sel[0] || sel[1]) {
     // radix select, both classes in the same four passes over the image's labels / keys
     for (int shift = 24; shift >= 0; shift -= 8) {
@@ -302,6 +411,7 @@ __global__ __launch_bounds__(kSubThreads) void at_subsample(int* __restrict__ la
       if (eq && rank >= rem[c]) lab[i] = -1;
       running += total;
     }
+  }
   }
   if (tid == 0) {
     const int fg_left = cut[1] ? max(num_fg, 0) : sum_fg, bg_left = cut[0] ? max(num_bg, 0) : sum_bg;
@@ -398,8 +508,9 @@ extern "C" int dtt_anchor_target_device(const float* gt_boxes, const float* im_i
   hipLaunchKernelGGL(at_gt_max, grid, dim3(kThreads), 0, stream, gt_boxes, anchors, g, gt_max_scratch);
   hipLaunchKernelGGL(at_assign, grid, dim3(kThreads), 0, stream, gt_boxes, anchors, g, gt_max_scratch, negative_overlap,
                      positive_overlap, clobber_positives, labels, argmax_gt, counts);
+  const int no_fast = getenv("DTT_AT_SUBSAMPLE_SLOW") ? 1 : 0;             // developer / test switch: the radix select only
   hipLaunchKernelGGL(at_subsample, dim3(batch), dim3(kSubThreads), 0, stream, labels, keys, g.n, batch, counts, rpn_batchsize,
-                     num_fg, positive_weight, counts + 2 * batch, weights);
+                     num_fg, positive_weight, counts + 2 * batch, weights, no_fast);
   hipLaunchKernelGGL(at_finish, grid, dim3(kThreads), 0, stream, gt_boxes, anchors, g, labels, argmax_gt, inside_weight, 0.f, 0.f,
                      weights, labels_out, bbox_targets, bbox_inside_weights, bbox_outside_weights);
   DTT_CHECK_LAUNCH("anchor_target (device)");

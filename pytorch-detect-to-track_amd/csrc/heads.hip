@@ -831,7 +831,7 @@ extern "C" int dtt_rpn_head_gemm(const float* x, long ldx, int batch, int hw, in
 namespace {
 __global__ __launch_bounds__(256) void rpn_head_grad_rows_kernel(const float* __restrict__ g_prob, const float* __restrict__ g_bbox,
                                                                  const float* __restrict__ prob, int batch, int hw, int A,
-                                                                 float* __restrict__ rows, long ld) {
+                                                                 float* __restrict__ rows, long ld, int logits) {
   const long m = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= (long)batch * hw) return;
   const int b = (int)(m / hw), p = (int)(m - (long)b * hw);
@@ -847,8 +847,8 @@ __global__ __launch_bounds__(256) void rpn_head_grad_rows_kernel(const float* __
       const float pb = pp[(long)(a + u) * hw], pf = pp[(long)(A + a + u) * hw];
       const float g0 = gp ? gp[(long)(a + u) * hw] : 0.f, g1 = gp ? gp[(long)(A + a + u) * hw] : 0.f;
       const float dot = g0 * pb + g1 * pf;
-      ov[2 * u] = pb * (g0 - dot);
-      ov[2 * u + 1] = pf * (g1 - dot);
+      ov[2 * u] = logits ? g0 : pb * (g0 - dot);          // (logits: g is the gradient with respect to the scores already)
+      ov[2 * u + 1] = logits ? g1 : pf * (g1 - dot);
     }
     *reinterpret_cast<float4*>(out + 2 * a) = o;
   }
@@ -863,14 +863,14 @@ __global__ __launch_bounds__(256) void rpn_head_grad_rows_kernel(const float* __
 }  // namespace
 
 extern "C" int dtt_rpn_head_grad_rows(const float* grad_cls_prob, const float* grad_bbox_pred, const float* cls_prob, int batch, int hw,
-                                      int num_anchors, float* rows, long ld, void* stream_) {
+                                      int num_anchors, float* rows, long ld, int cls_grad_is_logits, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   DTT_REQUIRE(cls_prob && rows && batch > 0 && hw > 0 && num_anchors > 0 && num_anchors % 2 == 0, "rpn_head_grad_rows: bad arguments");
   DTT_REQUIRE(ld >= 6 * num_anchors && ld % 4 == 0 && (reinterpret_cast<uintptr_t>(rows) & 15) == 0,
               "rpn_head_grad_rows: rows need a 16-byte aligned base and a row length (%ld) that is a multiple of 4 >= %d", ld, 6 * num_anchors);
   const long M = (long)batch * hw;
   hipLaunchKernelGGL(rpn_head_grad_rows_kernel, dim3(dtt_cdiv(M, 256)), dim3(256), 0, stream, grad_cls_prob, grad_bbox_pred, cls_prob, batch,
-                     hw, num_anchors, rows, ld);
+                     hw, num_anchors, rows, ld, cls_grad_is_logits);
   DTT_CHECK_LAUNCH("rpn_head_grad_rows");
   return 1;
 }

@@ -79,7 +79,10 @@ SIGNATURES = {
     "dtt_head_gemm": (_I, [_P, _L, _I, _I, _P, _P, _I, _P, _L, _I, _I, _P]),
     "dtt_psroi_pm_backward": (_I, [_P, _P, _I, _I, _I, _I, _I, _F, _I, _I, _L, _P, _P, _P]),
     "dtt_rpn_head_gemm": (_I, [_P, _L, _I, _I, _I, _P, _P, _I, _I, _P, _P, _P]),
-    "dtt_rpn_head_grad_rows": (_I, [_P, _P, _P, _I, _I, _I, _P, _L, _P]),
+    "dtt_rpn_head_grad_rows": (_I, [_P, _P, _P, _I, _I, _I, _P, _L, _I, _P]),
+    "dtt_rpn_loss_workspace_bytes": (_Z, [_I, _I]),
+    "dtt_rpn_loss_forward": (_I, [_P] * 6 + [_I, _I, _I, _I, _F, _P, _P, _P, _Z, _P]),
+    "dtt_rpn_loss_backward": (_I, [_P] * 8 + [_I, _I, _I, _I, _F, _P, _P, _P]),
     "dtt_head_gemm_dw_workspace_bytes": (_Z, [_I, _I, _I]),
     "dtt_head_gemm_dw": (_I, [_P, _L, _I, _P, _L, _I, _I, _I, _P, _P, _Z, _P]),
     "dtt_psroi_pm_forward": (_I, [_P, _L, _I, _I, _I, _I, _I, _I, _P, _F, _I, _P, _P, _P]),

@@ -194,18 +194,37 @@ def isolate_library_caches(local_rank, world, env=None):
     the whole warm-up (or read a half-written entry).  Give every rank its own MIOPEN_USER_DB_PATH / MIOPEN_CUSTOM_CACHE_DIR --
     must run before the first convolution of the process (the library reads the variables when its handle is created).  A user's
     own setting wins.  (hipBLASLt candidate timing, dtt_gemm_tune, keeps its picks in process memory: nothing is shared.)
+
+    The directory holds code objects the library will LOAD, so it lives under the user's own cache directory
+    ($DTT_CACHE_ROOT, else $XDG_CACHE_HOME/dtt, else ~/.cache/dtt -- not a world-writable /tmp), is created with mode 0700 and is
+    refused when it (or its root) belongs to somebody else or is writable by group / others.  Its name carries the job
+    (MASTER_PORT / TORCHELASTIC_RUN_ID: two jobs of one user on a node do not meet) and the rank the LAUNCHER gave -- pass
+    LOCAL_RANK as it came, before any modulo onto shared devices.
     Returns the directory used, or None when nothing was changed (one rank, or both variables already set)."""
     import os
-    import tempfile
+    import stat
     env = os.environ if env is None else env
     if world <= 1 or ("MIOPEN_USER_DB_PATH" in env and "MIOPEN_CUSTOM_CACHE_DIR" in env):
         return None
-    base = os.path.join(env.get("DTT_CACHE_ROOT", tempfile.gettempdir()), "dtt_miopen_uid%d_rank%d" % (os.getuid(), local_rank))
+    root = env.get("DTT_CACHE_ROOT") or os.path.join(env.get("XDG_CACHE_HOME") or os.path.join(os.path.expanduser("~"), ".cache"), "dtt")
+    job = "".join(ch for ch in str(env.get("TORCHELASTIC_RUN_ID") or env.get("MASTER_PORT") or "job") if ch.isalnum() or ch in "-_")[:48] or "job"
+    base = os.path.join(root, "miopen_%s_rank%d" % (job, local_rank))
+
+    def private_dir(d):
+        os.makedirs(d, mode=0o700, exist_ok=True)
+        st = os.stat(d)
+        if st.st_uid != os.getuid() or not stat.S_ISDIR(st.st_mode):
+            raise PermissionError("isolate_library_caches: %s is not a directory owned by uid %d" % (d, os.getuid()))
+        if st.st_mode & 0o022:
+            os.chmod(d, st.st_mode & ~0o077 & 0o7777)      # ours, but left open by an earlier umask: close it
+            if os.stat(d).st_mode & 0o022:
+                raise PermissionError("isolate_library_caches: %s is writable by group / others" % d)
+        return d
+    private_dir(root)
+    private_dir(base)
     for key, sub in (("MIOPEN_USER_DB_PATH", "db"), ("MIOPEN_CUSTOM_CACHE_DIR", "cache")):
         if key not in env:
-            d = os.path.join(base, sub)
-            os.makedirs(d, exist_ok=True)
-            env[key] = d
+            env[key] = private_dir(os.path.join(base, sub))
     return base
 
 

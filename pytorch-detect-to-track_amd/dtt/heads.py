@@ -421,7 +421,9 @@ class RpnHeadFn(torch.autograd.Function):
     GEMM over those rows with the transposed weights, dW `dtt_head_gemm_dw`, dBias a column sum."""
 
     @staticmethod
-    def forward(ctx, x_rows, w, bias, A, batch, height, width):
+    def forward(ctx, x_rows, w, bias, A, batch, height, width, logit_grads=False):
+        """logit_grads: the gradient that comes back for cls_prob is the gradient with respect to the score LOGITS (RpnLossFn's:
+        cls_prob's only differentiable consumer in the training graph), not with respect to the probabilities."""
         require_gpu(x_rows)
         x_rows = x_rows.contiguous()
         M, K = x_rows.shape
@@ -433,14 +435,14 @@ class RpnHeadFn(torch.autograd.Function):
             check(_lib.lib().dtt_rpn_head_gemm(ptr(x_rows), K, batch, height * width, K, ptr(w), ptr(bias), w.shape[0], A, ptr(prob),
                                                ptr(bbox), stream_ptr(x_rows.device)), "rpn_head_gemm")
         ctx.save_for_backward(x_rows, w, prob)
-        ctx.cfg = (A, batch, height * width)
+        ctx.cfg = (A, batch, height * width, bool(logit_grads))
         return prob, bbox
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, g_prob, g_bbox):
         x_rows, w, prob = ctx.saved_tensors
-        A, batch, hw = ctx.cfg
+        A, batch, hw, logit_grads = ctx.cfg
         M, K = x_rows.shape
         N16 = w.shape[0]
         dev = x_rows.device
@@ -452,7 +454,7 @@ class RpnHeadFn(torch.autograd.Function):
         with torch.cuda.device(dev):
             grows = torch.empty((M, LG), dtype=torch.float32, device=dev)   # (columns >= 6 A are written as zeros)
             check(L.dtt_rpn_head_grad_rows(ptr(g_prob) if g_prob is not None else None, ptr(g_bbox) if g_bbox is not None else None,
-                                           ptr(prob), batch, hw, A, ptr(grows), LG, stream_ptr(dev)), "rpn_head_grad_rows")
+                                           ptr(prob), batch, hw, A, ptr(grows), LG, 1 if logit_grads else 0, stream_ptr(dev)), "rpn_head_grad_rows")
             if ctx.needs_input_grad[0]:
                 wt = torch.zeros((K, LG), dtype=torch.float32, device=dev)    # dX (M, K) = grows (M, LG) @ wt.T
                 wt[:, :N16] = w.t()
@@ -468,7 +470,52 @@ class RpnHeadFn(torch.autograd.Function):
                       "rpn head dW")
             if ctx.needs_input_grad[2]:
                 gb = grows[:, :N16].sum(0)
-        return gx, gw, gb, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None
+
+
+class RpnLossFn(torch.autograd.Function):
+    """The two RPN losses of rpn/rpn.py:86-105 for `legs` legs in one launch (`dtt_rpn_loss_forward`): cls_prob (legs*B, 2A, H, W)
+    and bbox_pred (legs*B, 4A, H, W) from `RpnHeadFn(..., logit_grads=True)`, the anchor-target layer's four outputs for the same
+    images -> losses (2*legs,): [leg] = class loss (cross-entropy over the labelled anchors), [legs + leg] = box loss.
+    THE GRADIENT RETURNED FOR cls_prob IS THE GRADIENT WITH RESPECT TO THE SCORE LOGITS, (p - y) * g / count
+    (`dtt_rpn_loss_backward`): it bypasses the softmax adjoint, which multiplies by p and vanishes where p underflows -- the
+    reference's cross_entropy on the logits keeps -g / count there.  Only `RpnHeadFn` with logit_grads=True may produce cls_prob."""
+
+    @staticmethod
+    def forward(ctx, cls_prob, bbox_pred, labels, targets, w_in, w_out, legs, sigma):
+        require_gpu(cls_prob)
+        dev = cls_prob.device
+        B2, A2, H, W = cls_prob.shape
+        A = A2 // 2
+        ts = [t.contiguous() for t in (cls_prob, bbox_pred, labels, targets, w_in, w_out)]
+        if ts[1].shape != (B2, 4 * A, H, W) or ts[2].numel() != B2 * A * H * W or any(t.shape != ts[1].shape for t in ts[3:]):
+            raise ValueError("RpnLossFn: shapes %s do not belong to one RPN head" % [tuple(t.shape) for t in ts])
+        if any(t.dtype != torch.float32 for t in ts) or B2 % legs:
+            raise ValueError("RpnLossFn: float32 tensors and a batch that is a multiple of the legs are required")
+        L = _lib.lib()
+        loss = torch.empty((2 * legs,), dtype=torch.float32, device=dev)
+        count = torch.empty((legs,), dtype=torch.float32, device=dev)
+        nb = int(L.dtt_rpn_loss_workspace_bytes(B2, H * W))
+        ws = torch.empty((nb // 4,), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            check(L.dtt_rpn_loss_forward(*[ptr(t) for t in ts], B2, legs, A, H * W, float(sigma), ptr(loss), ptr(count), ptr(ws), nb,
+                                         stream_ptr(dev)), "rpn_loss")
+        ctx.save_for_backward(*ts, count)
+        ctx.cfg = (B2, legs, A, H * W, float(sigma))
+        return loss
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_loss):
+        *ts, count = ctx.saved_tensors
+        B2, legs, A, hw, sigma = ctx.cfg
+        dev = ts[0].device
+        g_loss = g_loss.contiguous().float()
+        g_logits, g_bbox = torch.empty_like(ts[0]), torch.empty_like(ts[1])
+        with torch.cuda.device(dev):
+            check(_lib.lib().dtt_rpn_loss_backward(*[ptr(t) for t in ts], ptr(g_loss), ptr(count), B2, legs, A, hw, sigma, ptr(g_logits),
+                                                   ptr(g_bbox), stream_ptr(dev)), "rpn_loss backward")
+        return g_logits, g_bbox, None, None, None, None, None, None
 
 
 def pm_to_nchw(pm_map, head, batch, height, width):

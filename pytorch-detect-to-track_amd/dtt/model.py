@@ -158,22 +158,6 @@ class _RPN(nn.Module):
             self.rpn_loss_box = _smooth_l1_loss(bbox_pred, tgt, w_in, w_out, sigma=3, dim=[1, 2, 3])
         return rois, self.rpn_loss_cls, self.rpn_loss_box
 
-    def losses_from_probabilities(self, cls_prob, bbox_pred, gt_boxes, im_info, num_boxes):
-        """rpn.py:74-107 for one leg when the heads come out of the one-launch GEMM, whose epilogue has already applied the
-        pairwise softmax (dtt.heads.RpnHeadFn): the cross-entropy of rpn.py:97 over the sampled anchors is -log of the label's
-        probability (the same number to rounding; the softmax's adjoint is applied in RpnHeadFn.backward).
-        Known difference, diverging runs only: when the label's probability underflows to 0 in fp32 (a logit gap above ~87) the loss
-        reads 85.2 (= -log 1e-37) and that anchor's gradient is 0, where the reference's cross_entropy on the logits keeps growing
-        with a gradient of p - y = -1.  Nothing below that gap differs."""
-        B = cls_prob.size(0)
-        labels, tgt, w_in, w_out = self.RPN_anchor_target((cls_prob.detach(), gt_boxes, im_info, num_boxes))
-        prob = self.reshape(cls_prob, 2).permute(0, 2, 3, 1).contiguous().view(-1, 2)
-        # (mean over the anchors whose label is not -1: ignore_index instead of the reference's nonzero() + index_select, which reads
-        #  the number of sampled anchors back to the host in the middle of the forward)
-        self.rpn_loss_cls = F.nll_loss(torch.log(prob.clamp_min(1e-37)), labels.view(-1).long(), ignore_index=-1)
-        self.rpn_loss_box = _smooth_l1_loss(bbox_pred, tgt, w_in, w_out, sigma=3, dim=[1, 2, 3])
-        return self.rpn_loss_cls, self.rpn_loss_box
-
 
 # ------------------------------------------------------------------------------------------ RFCN
 class _RFCN(nn.Module):
@@ -549,7 +533,7 @@ class _RFCN(nn.Module):
         concat, no NCHW copies; the correlation gradient kernels read their columns of the rows' gradient).  The proposal layer
         runs once for both legs; anchor-target and RoI sampling keep the reference's per-leg order (they draw from numpy's RNG);
         PSRoI pooling of both legs is one position-major launch pair with a map-stationary backward (PsroiPmFn)."""
-        from .heads import (HeadGemmFn, PsroiPmFn, RpnHeadFn, TrackingRowsFn, pack_heads_differentiable,
+        from .heads import (HeadGemmFn, PsroiPmFn, RpnHeadFn, RpnLossFn, TrackingRowsFn, pack_heads_differentiable,
                             pack_rpn_heads_differentiable)
         rpn = self.RFCN_rpn
         H, W = top.size(2), top.size(3)
@@ -562,7 +546,8 @@ class _RFCN(nn.Module):
         if not (conv1.is_contiguous(memory_format=torch.channels_last) and not conv1.is_contiguous()):
             conv1 = conv1.contiguous(memory_format=torch.channels_last)
         w_rpn, b_rpn, A = pack_rpn_heads_differentiable(rpn.RPN_cls_score, rpn.RPN_bbox_pred)
-        rpn_prob, rpn_bbox = RpnHeadFn.apply(conv1.permute(0, 2, 3, 1).reshape(-1, conv1.size(1)), w_rpn, b_rpn, A, n_legs * B, H, W)
+        # (the class loss's gradient comes back with respect to the score logits: RpnLossFn below is cls_prob's only differentiable consumer)
+        rpn_prob, rpn_bbox = RpnHeadFn.apply(conv1.permute(0, 2, 3, 1).reshape(-1, conv1.size(1)), w_rpn, b_rpn, A, n_legs * B, H, W, True)
         if os.environ.get("DTT_TRAIN_PROPOSALS_MERGED", "1") != "0":   # (env: developer A/B switch)
             all_rois = rpn.proposals(rpn_prob, rpn_bbox, im_info.view(n_legs * B, -1))   # (n_legs * B, post, 5), image index in column 0
         else:
@@ -571,9 +556,13 @@ class _RFCN(nn.Module):
                 all_rois[i * B:(i + 1) * B, :, 0] += i * B
         out = self._new_out()
         sampled = []
+        # the anchor-target layer's outputs of all legs in four tensors (each leg's call writes its slice: the reference's per-leg order
+        # of RNG draws stays), read by ONE launch of the hand-written RPN losses behind the loop
+        f32 = dict(dtype=torch.float32, device=dev)
+        at_all = [torch.empty((n_legs * B, 1, A * H, W), **f32)] + [torch.empty((n_legs * B, 4 * A, H, W), **f32) for _ in range(3)]
         for i in range(n_legs):
             sl = slice(i * B, (i + 1) * B)
-            l_cls, l_box = rpn.losses_from_probabilities(rpn_prob[sl], rpn_bbox[sl], gt_boxes[i][:, :, :5], im_info[i], num_boxes[i])
+            rpn.RPN_anchor_target((rpn_prob[sl].detach(), gt_boxes[i][:, :, :5], im_info[i], num_boxes[i]), out=[t[sl] for t in at_all])
             leg_rois = all_rois[sl].clone()
             leg_rois[:, :, 0] -= i * B                                    # batch index within the leg, as the reference's per-leg RPN
             leg_rois, label, target, w_in, w_out = self.RFCN_proposal_target(leg_rois, gt_boxes[i][:, :, :5], num_boxes[i])
@@ -581,10 +570,13 @@ class _RFCN(nn.Module):
             sampled.append((label, target.view(-1, target.size(2)), w_in.view(-1, w_in.size(2)), w_out.view(-1, w_out.size(2))))
             out["rois_label"].append(label)
             out["rois"].append(leg_rois)
-            out["rpn_loss_cls"].append(l_cls.view(1)); out["rpn_loss_bbox"].append(l_box.view(1))
             if getattr(self._cfg, "RFCN_ROI_FEATURES", ""):
                 feats = (feats if i else []) + [self._roi_features(top[sl].detach(), leg_rois.view(-1, 5))]
                 self.roi_feat = feats
+        rpn_losses = RpnLossFn.apply(rpn_prob, rpn_bbox, *at_all, n_legs, 3.0)      # rpn.py:86-105 (sigma = 3)
+        for i in range(n_legs):
+            out["rpn_loss_cls"].append(rpn_losses[i:i + 1]); out["rpn_loss_bbox"].append(rpn_losses[n_legs + i:n_legs + i + 1])
+        rpn.rpn_loss_cls, rpn.rpn_loss_box = rpn_losses[n_legs - 1], rpn_losses[2 * n_legs - 1]   # (the module attributes: the last leg's, as the reference's)
         # ---- PSRoI pooling + vote of both legs over the one position-major map (one gradient map comes back)
         rois_all = torch.cat([r.detach().reshape(-1, 5) for r in out["rois"]], 0).clone()
         n_per = out["rois"][0].size(0) * out["rois"][0].size(1)

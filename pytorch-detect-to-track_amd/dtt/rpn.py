@@ -167,7 +167,7 @@ class _AnchorTargetLayer(nn.Module):
         self._num_anchors = anchors.size(0)
         self._allowed_border = 0
 
-    def forward(self, input):
+    def forward(self, input, out=None):
         rpn_cls_score, gt_boxes, im_info, _num_boxes = input
         T = self._cfg.TRAIN
         if T.RPN_POSITIVE_WEIGHT >= 0 and not (0 < T.RPN_POSITIVE_WEIGHT < 1):
@@ -176,17 +176,18 @@ class _AnchorTargetLayer(nn.Module):
                                      self._feat_stride, T.RPN_BATCHSIZE, T.RPN_FG_FRACTION, T.RPN_NEGATIVE_OVERLAP,
                                      T.RPN_POSITIVE_OVERLAP, T.RPN_CLOBBER_POSITIVES,
                                      T.RPN_BBOX_INSIDE_WEIGHTS[0], positive_weight=T.RPN_POSITIVE_WEIGHT,
-                                     mode=getattr(T, "SAMPLER_RNG", "device"))
+                                     mode=getattr(T, "SAMPLER_RNG", "device"), out=out)
 
 
 def anchor_target_forward(gt_boxes, im_info, anchors, height, width, feat_stride, rpn_batchsize=256,
                           fg_fraction=0.5, negative_overlap=0.3, positive_overlap=0.7, clobber_positives=False,
-                          inside_weight=1.0, rng=np.random, positive_weight=-1.0, mode="reference", keys=None):
+                          inside_weight=1.0, rng=np.random, positive_weight=-1.0, mode="reference", keys=None, out=None):
     """positive_weight < 0: every sampled anchor weighs 1 / num_examples (anchor_target_layer.py:143-147).  In (0, 1): the
     branch the reference asserts on but never finishes (:148-150 leave positive_weights / negative_weights undefined, a
     NameError at :152) is completed the way the py-faster-rcnn layer it was ported from defines it: positives share
     `positive_weight`, negatives 1 - positive_weight, i.e. p / num_positives and (1 - p) / num_negatives -- counted, like
-    num_examples, on the LAST image of the batch (:144 `labels[i]`)."""
+    num_examples, on the LAST image of the batch (:144 `labels[i]`).
+    out: the four result tensors to write into (contiguous float32, e.g. one leg's slices of the buffers `RpnLossFn` reads)."""
     require_gpu(gt_boxes)
     dev = gt_boxes.device
     gt = gt_boxes.detach()[:, :, :5].float().contiguous()
@@ -196,7 +197,7 @@ def anchor_target_forward(gt_boxes, im_info, anchors, height, width, feat_stride
     n = A * height * width
     if mode == "device":
         return _anchor_target_device(gt, im_info, anchors, B, G, A, height, width, feat_stride, rpn_batchsize, fg_fraction,
-                                     negative_overlap, positive_overlap, clobber_positives, inside_weight, positive_weight, rng, keys)
+                                     negative_overlap, positive_overlap, clobber_positives, inside_weight, positive_weight, rng, keys, out)
     info0 = im_info[0].detach().cpu()
     im_h0, im_w0 = int(info0[0]), int(info0[1])  # long(im_info[0][0]) (anchor_target_layer.py:85-86)
     L = _lib.lib()
@@ -230,10 +231,7 @@ def anchor_target_forward(gt_boxes, im_info, anchors, height, width, feat_stride
             n_pos, n_neg = after[B - 1]
             w_pos = float(np.float32(positive_weight) / np.float32(n_pos)) if n_pos > 0 else math.inf
             w_neg = float(np.float32(1.0 - positive_weight) / np.float32(n_neg)) if n_neg > 0 else math.inf
-        labels_out = torch.empty((B, 1, A * height, width), dtype=torch.float32, device=dev)
-        targets = torch.empty((B, 4 * A, height, width), dtype=torch.float32, device=dev)
-        inside = torch.empty_like(targets)
-        outside = torch.empty_like(targets)
+        labels_out, targets, inside, outside = _anchor_target_outputs(out, B, A, height, width, dev)
         check(L.dtt_anchor_target_finish(ptr(gt), im_h0, im_w0, ptr(anchors), ptr(labels), ptr(argmax), B, G, A,
                                          height, width, int(feat_stride), float(inside_weight), w_pos, w_neg,
                                          ptr(labels_out), ptr(targets), ptr(inside), ptr(outside), stream_ptr(dev)),
@@ -241,8 +239,20 @@ def anchor_target_forward(gt_boxes, im_info, anchors, height, width, feat_stride
     return [labels_out, targets, inside, outside]
 
 
+def _anchor_target_outputs(out, B, A, height, width, dev):
+    """The layer's four outputs: fresh tensors, or the caller's (checked)."""
+    shapes = [(B, 1, A * height, width)] + [(B, 4 * A, height, width)] * 3
+    if out is None:
+        return [torch.empty(s, dtype=torch.float32, device=dev) for s in shapes]
+    out = list(out)
+    for t, s in zip(out, shapes):
+        if tuple(t.shape) != s or t.dtype != torch.float32 or t.device != dev or not t.is_contiguous():
+            raise ValueError("anchor_target: out tensors must be contiguous float32 %s on %s" % (shapes, dev))
+    return out
+
+
 def _anchor_target_device(gt, im_info, anchors, B, G, A, height, width, feat_stride, rpn_batchsize, fg_fraction, negative_overlap,
-                          positive_overlap, clobber_positives, inside_weight, positive_weight, rng, keys):
+                          positive_overlap, clobber_positives, inside_weight, positive_weight, rng, keys, out=None):
     """mode == "device" (cfg.TRAIN.SAMPLER_RNG, the RoI sampler's counterpart): `dtt_anchor_target_device` -- no host read, no
     upload that waits for the stream.  The reference's numpy permutations (anchor_target_layer.py:124-141) become one 32-bit
     random key per anchor, drawn without looking at the labels: of a class over its quota the candidates with the smallest
@@ -261,9 +271,7 @@ def _anchor_target_device(gt, im_info, anchors, B, G, A, height, width, feat_str
     f32 = dict(dtype=torch.float32, device=dev)
     labels, argmax = torch.empty((B, n), **i32), torch.empty((B, n), **i32)
     counts, scratch, weights = torch.empty((B, 4), **i32), torch.empty((B * G,), **i32), torch.empty((2,), **f32)
-    labels_out = torch.empty((B, 1, A * height, width), **f32)
-    targets = torch.empty((B, 4 * A, height, width), **f32)
-    inside, outside = torch.empty_like(targets), torch.empty_like(targets)
+    labels_out, targets, inside, outside = _anchor_target_outputs(out, B, A, height, width, dev)
     with torch.cuda.device(dev):
         check(_lib.lib().dtt_anchor_target_device(ptr(gt), ptr(im_info), ptr(anchors), ptr(keys), B, G, A, height, width,
                                                   int(feat_stride), int(rpn_batchsize), int(fg_fraction * rpn_batchsize),

@@ -193,6 +193,17 @@ def test_isolate_library_caches_gives_every_rank_its_own_miopen_paths(tmp_path):
         assert base and os.path.isdir(e["MIOPEN_USER_DB_PATH"]) and os.path.isdir(e["MIOPEN_CUSTOM_CACHE_DIR"])
         envs.append(e)
     assert len({e["MIOPEN_USER_DB_PATH"] for e in envs}) == 3 and len({e["MIOPEN_CUSTOM_CACHE_DIR"] for e in envs}) == 3
+    # private (0700, ours), per job: another MASTER_PORT gets other directories; a directory that is open to others is closed or refused
+    import stat
+    assert all(stat.S_IMODE(os.stat(e[k]).st_mode) & 0o077 == 0 for e in envs for k in ("MIOPEN_USER_DB_PATH", "MIOPEN_CUSTOM_CACHE_DIR"))
+    other = {"DTT_CACHE_ROOT": str(tmp_path), "MASTER_PORT": "29511"}
+    isolate_library_caches(0, 3, env=other)
+    assert other["MIOPEN_USER_DB_PATH"] not in {e["MIOPEN_USER_DB_PATH"] for e in envs} and "29511" in other["MIOPEN_USER_DB_PATH"]
+    loose = tmp_path / "loose"
+    loose.mkdir()
+    os.chmod(loose, 0o777)
+    isolate_library_caches(0, 2, env={"DTT_CACHE_ROOT": str(loose)})
+    assert stat.S_IMODE(os.stat(loose).st_mode) & 0o022 == 0                                  # our own directory, left open: closed
     assert isolate_library_caches(0, 1, env={}) is None                                     # one rank: nothing to isolate
     mine = {"MIOPEN_USER_DB_PATH": "/x", "MIOPEN_CUSTOM_CACHE_DIR": "/y"}
     assert isolate_library_caches(1, 8, env=mine) is None and mine["MIOPEN_USER_DB_PATH"] == "/x"   # the user's setting wins

@@ -321,6 +321,100 @@ def test_rpn_head_autograd_matches_conv2d_softmax_in_float64(dev, B, H, W, K, A)
     assert rel(rows2.grad.view(B, H, W, K).permute(0, 3, 1, 2), x64b.grad) < 1e-4
 
 
+@pytest.mark.parametrize("B,legs,H,W,K,A", [(4, 2, 38, 67, 512, 12), (2, 1, 13, 17, 64, 2), (6, 3, 9, 11, 96, 6)])
+def test_rpn_losses_autograd_match_cross_entropy_and_smooth_l1_in_float64(dev, B, legs, H, W, K, A):
+    """RpnHeadFn(logit_grads=True) + RpnLossFn (rpn.py:63-71, 86-105: the two RPN losses of all legs in one launch, the class loss's
+    gradient taken with respect to the score logits) against the reference's graph in float64 -- conv2d -> view(B, 2, A*H, W) ->
+    permute -> F.cross_entropy over the labelled anchors (nonzero() + index_select, rpn.py:90-97) and _smooth_l1_loss(sigma = 3,
+    dim = [1, 2, 3]) -- per leg: loss values to 1e-5, the gradients with respect to the input rows, both weights and both biases
+    to 1e-4 of each tensor's largest entry.  Run twice: bit-identical losses (deterministic reduction)."""
+    from dtt.heads import RpnHeadFn, RpnLossFn, pack_rpn_heads_differentiable
+    g = torch.Generator().manual_seed(B * 100 + A)
+    cls, box = torch.nn.Conv2d(K, 2 * A, 1), torch.nn.Conv2d(K, 4 * A, 1)
+    for c, sc in ((cls, 0.08), (box, 0.03)):
+        c.weight.data = torch.randn(c.weight.shape, generator=g) * sc
+        c.bias.data = torch.randn(c.bias.shape, generator=g) * 0.1
+    cls, box = cls.to(dev), box.to(dev)
+    x = torch.relu(torch.randn(B, K, H, W, generator=g)).to(dev)
+    # anchor-target outputs: ~2 % labelled anchors, targets / weights as the layer lays them out
+    labels = torch.full((B, 1, A * H, W), -1.0)
+    r = torch.rand(labels.shape, generator=g)
+    labels[r < 0.015] = 0.0
+    labels[r < 0.005] = 1.0
+    tgt = torch.randn(B, 4 * A, H, W, generator=g) * 0.5
+    fg = (labels.view(B, A, H, W) == 1).repeat_interleave(4, dim=1)
+    lab_any = (labels.view(B, A, H, W) >= 0).repeat_interleave(4, dim=1)
+    w_in = fg.float()
+    w_out = lab_any.float() / 256.0
+    labels, tgt, w_in, w_out = (t.to(dev) for t in (labels, tgt, w_in, w_out))
+    wsum = torch.tensor([1.0 + 0.5 * i for i in range(2 * legs)], device=dev)        # a different weight on every loss scalar
+
+    def ours():
+        for p in (cls.weight, cls.bias, box.weight, box.bias):
+            p.grad = None
+        rows = x.permute(0, 2, 3, 1).reshape(B * H * W, K).contiguous().requires_grad_(True)
+        w, b, _ = pack_rpn_heads_differentiable(cls, box)
+        prob, bbox = RpnHeadFn.apply(rows, w, b, A, B, H, W, True)
+        losses = RpnLossFn.apply(prob, bbox, labels, tgt, w_in, w_out, legs, 3.0)
+        (losses * wsum).sum().backward()
+        return losses.detach().clone(), rows.grad.clone(), [p.grad.clone() for p in (cls.weight, cls.bias, box.weight, box.bias)]
+    losses, gx, gp = ours()
+    losses_b, gx_b, _ = ours()
+    assert torch.equal(losses, losses_b) and torch.equal(gx, gx_b), "the reduction is not deterministic"
+    x64 = x.double().requires_grad_(True)
+    ref = [t.detach().double().requires_grad_(True) for t in (cls.weight, cls.bias, box.weight, box.bias)]
+    per = B // legs
+    total = 0.0
+    want = torch.zeros(2 * legs, dtype=torch.float64)
+    for leg in range(legs):
+        sl = slice(leg * per, (leg + 1) * per)
+        score = F.conv2d(x64[sl], ref[0], ref[1])
+        score_r = score.view(per, 2, A * H, W).permute(0, 2, 3, 1).contiguous().view(-1, 2)
+        lab = labels[sl].view(-1)
+        keep = (lab != -1).nonzero().view(-1)
+        l_cls = F.cross_entropy(score_r.index_select(0, keep), lab.index_select(0, keep).long())
+        pred = F.conv2d(x64[sl], ref[2], ref[3])
+        d = w_in[sl].double() * (pred - tgt[sl].double())
+        ad = d.abs()
+        quad = (ad < 1.0 / 9.0).double()
+        l_box = (w_out[sl].double() * (d * d * 4.5 * quad + (ad - 0.5 / 9.0) * (1.0 - quad))).sum((1, 2, 3)).mean()
+        want[leg], want[legs + leg] = float(l_cls), float(l_box)
+        total = total + float(wsum[leg]) * l_cls + float(wsum[legs + leg]) * l_box
+    total.backward()
+    assert np.allclose(losses.cpu().double().numpy(), want.numpy(), rtol=1e-5, atol=1e-7), (losses, want)
+    rel = lambda a, r: float((a.double() - r).abs().max() / r.abs().max().clamp_min(1e-30))
+    assert rel(gx.view(B, H, W, K).permute(0, 3, 1, 2), x64.grad) < 1e-4, "dX"
+    for name, a, r in zip(("cls dW", "cls dBias", "box dW", "box dBias"), gp, ref):
+        assert rel(a, r.grad) < 1e-4, name
+
+
+def test_rpn_class_loss_gradient_survives_an_underflowing_probability(dev):
+    """Where the label's probability underflows in fp32 (a logit gap above ~88) the reference's cross_entropy on the logits still has
+    the gradient p - y = -1 / count for that anchor (rpn.py:97); a loss taken as -log(p) through the softmax's adjoint multiplies by p
+    and returns 0.  dtt_rpn_loss_backward writes the logit gradient itself: -1 / count on the label's score, +1 / count on the other."""
+    from dtt import _lib
+    from dtt._lib import check, ptr, stream_ptr
+    L = _lib.lib()
+    A, H, W = 2, 1, 4
+    prob = torch.zeros(1, 2 * A, H, W, device=dev)
+    prob[0, :A] = 1.0                                   # background certain, foreground probability exactly 0
+    labels = torch.full((1, 1, A * H, W), -1.0, device=dev)
+    labels.view(1, A, H, W)[0, 0, 0, 1] = 1.0           # a foreground label on an anchor whose p_fg = 0
+    labels.view(1, A, H, W)[0, 1, 0, 2] = 0.0           # and an easy background anchor
+    z = torch.zeros(1, 4 * A, H, W, device=dev)
+    g_loss = torch.tensor([1.0, 0.0], device=dev)
+    count = torch.tensor([2.0], device=dev)
+    g_logits, g_bbox = torch.full_like(prob, float("nan")), torch.full_like(z, float("nan"))
+    with torch.cuda.device(dev):
+        check(L.dtt_rpn_loss_backward(ptr(prob), ptr(z), ptr(labels), ptr(z), ptr(z), ptr(z), ptr(g_loss), ptr(count), 1, 1, A, H * W, 3.0,
+                                      ptr(g_logits), ptr(g_bbox), stream_ptr(dev)), "rpn_loss backward")
+    gl = g_logits.cpu().view(2, A, H, W)
+    assert float(gl[1, 0, 0, 1]) == -0.5 and float(gl[0, 0, 0, 1]) == 0.5          # (p - y) / count with p_fg = 0, p_bg = 1
+    assert float(gl[0, 1, 0, 2]) == 0.0 and float(gl[1, 1, 0, 2]) == 0.0            # the easy anchor: p - y = 0
+    gl[1, 0, 0, 1] = gl[0, 0, 0, 1] = 0.0
+    assert float(gl.abs().max()) == 0.0 and float(g_bbox.abs().max()) == 0.0       # everything else written as zero
+
+
 @pytest.mark.parametrize("B,H,W,C345", [(2, 38, 67, (128, 192, 256)), (1, 20, 31, (64, 64, 128))])
 def test_tracking_rows_autograd_matches_the_reference_concat(dev, B, H, W, C345):
     """TrackingRowsFn + HeadGemmFn over it = corr_bbox_net(torch.cat([bbox_t, bbox_t+tau, corr3, corr4, corr5], 1)) of

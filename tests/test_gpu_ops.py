@@ -880,15 +880,22 @@ def test_anchor_target_positive_weight(dev):
 
 @pytest.mark.parametrize("case,batchsize,fg_fraction,tie", [("b2_38x67", 256, 0.5, False), ("b3_12x20", 256, 0.5, False),
                                                           ("b2_38x67", 16, 0.25, False), ("b2_19x32", 2, 1.0, False),
-                                                          ("b2_38x67", 256, 0.5, True)])
-def test_anchor_target_device_mode_follows_its_selection_rule(dev, case, batchsize, fg_fraction, tie):
+                                                          ("b2_38x67", 256, 0.5, True), ("b2_38x67", 256, 0.5, "coarse"),
+                                                          ("b2_38x67", 64, 0.5, "coarse")])
+@pytest.mark.parametrize("slow", [False, True])
+def test_anchor_target_device_mode_follows_its_selection_rule(dev, monkeypatch, case, batchsize, fg_fraction, tie, slow):
     """cfg.TRAIN.SAMPLER_RNG = "device" (`dtt_anchor_target_device`: no host read anywhere in the layer): of a class over its quota
     the anchors with the smallest (key, anchor index) stay -- restated in numpy on the labels BEFORE subsampling (the reference-mode
     kernels with a quota nothing exceeds; they are pinned bit-exact to the reference above).  Labels exact, quotas as
     anchor_target_layer.py:118-141 (num_fg foreground, batch - foreground-before-subsampling background, every background anchor
     when that is <= 0), targets untouched by the subsampling, outside weights 1 / num_examples of the LAST image.  `tie`: all keys
-    equal -- the k-th smallest key is shared by every candidate and the anchor index decides."""
+    equal -- the k-th smallest key is shared by every candidate and the anchor index decides (more candidates in one histogram bin
+    than the one-pass selection lists: it hands over to the radix select); "coarse": only the keys' top 12 bits vary -- a dozen
+    candidates per bin, all ties, ranked by anchor index inside the one-pass selection.  `slow`: DTT_AT_SUBSAMPLE_SLOW, the radix
+    select alone -- both paths must give the rule's subset."""
     from dtt.rpn import anchor_target_forward, generate_anchors
+    if slow:
+        monkeypatch.setenv("DTT_AT_SUBSAMPLE_SLOW", "1")
     g = np.load(os.path.join(G, "anchor_target.npz"))
     base = torch.from_numpy(generate_anchors(scales=g["scales"], ratios=g["ratios"])).float()
     H, W = (int(v) for v in g[case + "/hw"])
@@ -897,7 +904,9 @@ def test_anchor_target_device_mode_follows_its_selection_rule(dev, case, batchsi
     n = A * K
     pre = anchor_target_forward(gt, info, base, H, W, 16, rpn_batchsize=10 ** 7)            # nothing over quota: labels before subsampling
     rs = np.random.RandomState(B * 1000 + batchsize)
-    keys = np.zeros((B, n), np.int32) + 12345 if tie else rs.randint(0, 2 ** 31 - 1, size=(B, n)).astype(np.int32)
+    keys = np.zeros((B, n), np.int32) + 12345 if tie is True else rs.randint(0, 2 ** 31 - 1, size=(B, n)).astype(np.int32)
+    if tie == "coarse":
+        keys &= ~np.int32((1 << 20) - 1)
     if not tie:
         m = keys[:, 3::7].shape[1]
         keys[:, 0:7 * m:7] = keys[:, 3::7]                                                 # plenty of equal keys among the candidates
