@@ -251,6 +251,57 @@ def corr_bwd_secondary(op_us, args, model):
                            "channels-last, band-stationary / halo-streamed: dtt_correlation_backward_nhwc_strided; event tag corr_bwd_op)")
 
 
+def rank_zero():
+    return int(os.environ.get("RANK", "0")) == 0
+
+
+def train_hot_path_secondary(step, args, dev, n=5):
+    """secondary.train_step.hot_path: the hand-written NON-MFMA ops of the training step, each timed by the
+    library's event hook over `n` more (untimed) steps -- one tag at a time, events on the launch stream -- with the algorithmic bytes
+    of SURVEY 8(d) per step and the fraction of the 8 TB/s HBM peak they amount to.  All are far from it: these are latency- and
+    dependency-bound ops on small data (the proposal layer's sort and greedy sweep are serial by construction); the figure says how
+    far, the time says what it costs."""
+    legs, B = args.frames, args.batch
+    imgs = legs * B
+    H16, W16 = -(-args.height // 16), -(-args.width // 16)
+    K, A = H16 * W16, 12
+    n_anchor = K * A
+    N = 12000                                        # TRAIN.RPN_PRE_NMS_TOP_N (cfgs/res101.yml)
+    mask = N * (-(-N // 64)) * 8
+    od_cls, od_loc = 31, 4
+    pm_floats = 49 * 32 + 49 * 4                      # position-major map floats per pixel: class bins (padded to 32) + box bins
+    rois = 128 * imgs                                 # TRAIN.BATCH_SIZE RoIs per image
+    specs = [
+        # tag, algorithmic bytes per step, what they are
+        ("proposal_op", imgs * ((24 + 48) * K * 4 + n_anchor * 5 * 4 + N * 16 + 2 * mask),
+         "scores + deltas read, decoded boxes written (SURVEY 8d: 0.73 + 0.61 MB per image) + the NMS below"),
+        ("nms_op", imgs * (N * 16 + 2 * mask), "N = 12000 boxes read, the 18.05 MB bit matrix written and read once per image (SURVEY 8d)"),
+        ("anchor_target_op", imgs * (14 * n_anchor * 4), "keys read; labels, targets and the two weight maps written (13 floats per anchor)"),
+        ("rpn_loss", imgs * (19 * n_anchor * 4), "cls_prob, labels, bbox_pred, targets and both weight maps read once"),
+        ("psroi_pm_bwd", imgs * K * pm_floats * 4 + (B * K * 49 * 4 * 4 if legs == 2 else 0) + rois * (od_cls + od_loc) * 4,
+         "the position-major gradient maps written once (class + box bins of every pixel of both legs; the tracking head's box bins) + "
+         "the vote gradients read"),
+    ]
+    out = {}
+    for tag, nbytes, what in specs:
+        k = KernelTimer(tag, 64 * n, dev)
+        k.attach()
+        for _ in range(n):
+            step()
+        torch.cuda.synchronize(dev)
+        d = k.durations_us(k.detach())
+        if not d or len(d) % n:
+            continue
+        per = len(d) // n
+        us = sorted(sum(d[i * per:(i + 1) * per]) for i in range(n))[n // 2]      # median step
+        out[tag] = {"us_per_step": round(us, 2), "ops_per_step": round(len(d) / n, 2), "algorithmic_bytes_per_step": int(nbytes),
+                    "bound": "hbm", "achieved": round(nbytes / (us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "bytes": what}
+    out["note"] = ("event tags of libdtt_hip.so (dtt_profile_attach), %d untimed steps each; nms_op is part of proposal_op; psroi_pm_bwd sums the "
+                   "detection and tracking heads' calls" % n)
+    return out
+
+
 def measure_train_step(args, cfg, dev, world, im, info, gt, nb):
     """BASELINE configs[3]'s per-rank workload beside the inference figure: `--train-steps` timed training steps (forward, five
     losses, backward, bucketed gradient all-reduce, SGD; trainval_net.py:310-368) of a second, identically built model on the same
@@ -318,6 +369,8 @@ def measure_train_step(args, cfg, dev, world, im, info, gt, nb):
     durs = kt.durations_us(used)
     if n_ops and used == n_ops * n:
         res["corr_bwd"] = corr_bwd_secondary([sum(durs[i + pos] for i in range(0, len(durs), n_ops)) / n for pos in range(n_ops)], args, model)
+    if world == 1 and rank_zero():
+        res["hot_path"] = train_hot_path_secondary(step, args, dev)
     if one_rank_group:
         dist.destroy_process_group()
     return res
@@ -627,10 +680,29 @@ def main():
                                 "bound": "hbm", "achieved": round(ps_bytes / (psroi_us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS,
                                 "unit": "GB/s", "frac": round(ps_bytes / (psroi_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                                 "launch_us": round(psroi_us, 2), "algorithmic_bytes_per_launch": ps_bytes}
+        if args.mode == "infer":
+            # the proposal layer of the inference step (one call for every image of the batch) and the NMS inside it
+            n_img = args.frames * args.batch
+            N = cfg.TEST.RPN_PRE_NMS_TOP_N
+            mask = N * (-(-N // 64)) * 8
+            for tag, name, nbytes, what in (
+                    ("proposal_op", "proposal", n_img * ((24 + 48) * H16 * W16 * 4 + 12 * H16 * W16 * 5 * 4 + N * 16 + 2 * mask),
+                     "dtt_proposal_forward: ranking of 12 x %d x %d scores per image, decode + clip of the top %d, NMS (0.7), RoI tensor; "
+                     "bytes = scores + deltas in, decoded boxes out (SURVEY 8d: 0.73 + 0.61 MB per image) + the NMS's" % (H16, W16, N)),
+                    ("nms_op", "nms_test", n_img * (N * 16 + 2 * mask),
+                     "the layer's NMS, both phases (nms_mask_kernel + nms_sweep_kernel): N = %d boxes read, the %.2f MB bit matrix written and "
+                     "read once per image (SURVEY 8d); the two-phase split computes only the tiles the sweep visits" % (N, mask / 1e6))):
+                us = extra(tag, 1, lambda d: d[0], n=4)
+                if us:
+                    sec[name] = {"kernel": what, "bound": "hbm", "achieved": round(nbytes / (us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                                 "unit": "GB/s", "frac": round(nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "op_us": round(us, 2),
+                                 "algorithmic_bytes_per_op": int(nbytes)}
         if args.mode == "train" and world == 1 and args.frames == 2:
             bw_us = [extra("corr_bwd_op", 3, lambda d, pos=pos: d[pos]) for pos in range(3)]
             if all(v for v in bw_us):
                 sec["corr_bwd"] = corr_bwd_secondary(bw_us, args, model)
+        if args.mode == "train" and world == 1:
+            sec["hot_path"] = train_hot_path_secondary(step, args, dev)
         if args.frames == 1:
             # no correlation in the single-frame graph: the dominant hand-written kernel of the step is the class + box head GEMM
             h = sec.get("heads")

@@ -503,6 +503,7 @@ extern "C" int dtt_anchor_target_device(const float* gt_boxes, const float* im_i
   g.B = batch; g.G = num_gt; g.A = num_anchors; g.H = height; g.W = width; g.K = height * width;
   g.n = g.K * g.A; g.stride = feat_stride; g.im_h = 0; g.im_w = 0; g.im_info = im_info;
   const int ninit = batch * num_gt > batch * 2 ? batch * num_gt : batch * 2;
+  dtt_prof_begin("anchor_target_op", stream);   // (event tag: the whole layer in device mode, five launches)
   hipLaunchKernelGGL(at_init, dim3(dtt_cdiv(ninit, 256)), dim3(256), 0, stream, gt_max_scratch, batch * num_gt, counts, batch * 2);
   dim3 grid(dtt_cdiv(g.n, kThreads), batch);
   hipLaunchKernelGGL(at_gt_max, grid, dim3(kThreads), 0, stream, gt_boxes, anchors, g, gt_max_scratch);
@@ -513,6 +514,7 @@ extern "C" int dtt_anchor_target_device(const float* gt_boxes, const float* im_i
                      num_fg, positive_weight, counts + 2 * batch, weights, no_fast);
   hipLaunchKernelGGL(at_finish, grid, dim3(kThreads), 0, stream, gt_boxes, anchors, g, labels, argmax_gt, inside_weight, 0.f, 0.f,
                      weights, labels_out, bbox_targets, bbox_inside_weights, bbox_outside_weights);
+  dtt_prof_end("anchor_target_op", stream);
   DTT_CHECK_LAUNCH("anchor_target (device)");
   return 1;
 }

@@ -63,10 +63,13 @@ struct WGeom {
 };
 
 __device__ __forceinline__ void dma16w(const char* sbase, unsigned voff, unsigned lds_addr) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
-               :
+  // m0 (the DMA's LDS base) is put back inside the statement: it is a reserved register the compiler neither allocates nor saves
+  // around inline asm -- a statement that merely listed it as clobbered would rely on hipcc never keeping a value of its own there
+  unsigned keep_m0;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep_m0)
                : "s"(lds_addr), "v"(voff), "s"(sbase)
-               : "memory", "m0");
+               : "memory");
 }
 __device__ __forceinline__ const char* uptrw(const char* p) {
   const unsigned long long v = (unsigned long long)p;

@@ -70,10 +70,13 @@ struct HeadGeom {
 // address lds_addr + lane * 16.  Written as asm so that the loader's instruction stream is SALU + VMEM only: a VALU
 // address add would queue behind the MFMAs of the compute wave that shares the SIMD (see head_gemm_kernel).
 __device__ __forceinline__ void dma16(const char* sbase, unsigned voff, unsigned lds_addr) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
-               :
+  // m0 (the DMA's LDS base) is put back inside the statement: it is a reserved register the compiler neither allocates nor saves
+  // around inline asm -- a statement that merely listed it as clobbered would rely on hipcc never keeping a value of its own there
+  unsigned keep_m0;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep_m0)
                : "s"(lds_addr), "v"(voff), "s"(sbase)
-               : "memory", "m0");
+               : "memory");
 }
 __device__ __forceinline__ const char* uniform_ptr(const char* p) {
   const unsigned long long v = (unsigned long long)p;
@@ -892,6 +895,7 @@ extern "C" int dtt_psroi_pm_backward(const float* grad_vote, const float* rois, 
   // per-image RoI runs behind the bin edges: 2 words per image, zeroed here, filled by the edges kernel
   unsigned* range = reinterpret_cast<unsigned*>(edges + (long)(num_rois > 0 ? num_rois : 0) * (4 * pooled + 1));
   DTT_REQUIRE(hipMemsetAsync(range, 0, sizeof(unsigned) * 2 * batch_size, stream) == hipSuccess, "psroi_pm backward: memset failed");
+  dtt_prof_begin("psroi_pm_bwd", stream);   // (event tag: edges + the map-stationary gradient kernel)
   if (num_rois > 0) {
     hipLaunchKernelGGL(psroi_pm_edges_kernel, dim3(dtt_cdiv(num_rois, 256)), dim3(256), 0, stream, rois, num_rois, spatial_scale, pooled,
                        height, width, batch_size, edges, range, grad_vote, output_dim);
@@ -904,6 +908,7 @@ extern "C" int dtt_psroi_pm_backward(const float* grad_vote, const float* rois, 
   if (cp == 32) { if (pooled == 7) DTT_PMB_LAUNCH(32, 7); else DTT_PMB_LAUNCH(32, 0); }
   else { if (pooled == 7) DTT_PMB_LAUNCH(4, 7); else DTT_PMB_LAUNCH(4, 0); }
 #undef DTT_PMB_LAUNCH
+  dtt_prof_end("psroi_pm_bwd", stream);
   DTT_CHECK_LAUNCH("psroi_pm_bwd");
   return 1;
 }

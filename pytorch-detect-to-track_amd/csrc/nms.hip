@@ -583,11 +583,14 @@ int dtt_nms_batched_launch(const float* boxes, int boxes_dim, long box_batch_str
                            long mask_batch_stride, int* keep_out, long keep_batch_stride, int* num_out,
                            float* rois_out, int rois_rows, hipStream_t stream) {
   const int split = dtt_nms_split(n_max, max_keep, keep_out != nullptr);
+  dtt_prof_begin("nms_op", stream);   // (event tag: the whole NMS, both phases)
   if (!dtt_nms_phase1(boxes, boxes_dim, box_batch_stride, n_per_image, n_max, batch, thresh, max_keep, mask, mask_batch_stride,
                       keep_out, keep_batch_stride, num_out, rois_out, rois_rows, split, stream))
     return 0;
-  return dtt_nms_phase2(boxes, boxes_dim, box_batch_stride, n_per_image, n_max, batch, thresh, max_keep, mask, mask_batch_stride,
-                        keep_out, keep_batch_stride, num_out, rois_out, rois_rows, split, stream);
+  const int ok = dtt_nms_phase2(boxes, boxes_dim, box_batch_stride, n_per_image, n_max, batch, thresh, max_keep, mask, mask_batch_stride,
+                                keep_out, keep_batch_stride, num_out, rois_out, rois_rows, split, stream);
+  dtt_prof_end("nms_op", stream);
+  return ok;
 }
 
 extern "C" size_t dtt_nms_workspace_bytes(int boxes_num) { return dtt_nms_mask_bytes(boxes_num); }

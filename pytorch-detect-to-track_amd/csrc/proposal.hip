@@ -624,18 +624,22 @@ static int decode_nms(const float* bbox_pred, const float* im_info, const float*
     DTT_CHECK_LAUNCH("proposal_decode");
   }
   int* nout = num_out ? num_out : num_ws;
+  // (event tag nms_op: the layer's whole NMS -- both phases' mask and sweep launches and the decode of the second half between them)
+  dtt_prof_begin("nms_op", stream);
   if (!dtt_nms_phase1(boxes, 4, (long)g.topn * 4, nullptr, g.topn, batch, nms_thresh, post_nms_topN, mask, mask_stride, keep, g.topn,
                       nout, rois_out, post_nms_topN, split, stream))
     return 0;
-  if (!split) return 1;
+  if (!split) { dtt_prof_end("nms_op", stream); return 1; }
   if (g.topn > first && !boxes_ready) {
     const long cbw = (g.topn + 63) / 64;
     hipLaunchKernelGGL(proposal_decode, dim3((g.topn - first + 255) / 256, batch), dim3(256), 0, stream, order, bbox_pred, im_info,
                        anchors, g, boxes, first, g.topn, mask + (long)g.topn * cbw, mask_stride);
     DTT_CHECK_LAUNCH("proposal_decode (second half)");
   }
-  return dtt_nms_phase2(boxes, 4, (long)g.topn * 4, nullptr, g.topn, batch, nms_thresh, post_nms_topN, mask, mask_stride, keep, g.topn,
-                        nout, rois_out, post_nms_topN, split, stream);
+  const int ok = dtt_nms_phase2(boxes, 4, (long)g.topn * 4, nullptr, g.topn, batch, nms_thresh, post_nms_topN, mask, mask_stride, keep, g.topn,
+                                nout, rois_out, post_nms_topN, split, stream);
+  dtt_prof_end("nms_op", stream);
+  return ok;
 }
 
 extern "C" int dtt_proposal_decode_nms(const float* bbox_pred, const float* im_info, const float* anchors, int batch,
@@ -655,18 +659,23 @@ extern "C" int dtt_proposal_forward(const float* cls_prob, const float* bbox_pre
   DTT_REQUIRE(post_nms_topN > 0, "proposal: post_nms_topN must be > 0");
   DTT_REQUIRE(batch > 0 && num_anchors > 0 && height > 0 && width > 0 && feat_stride > 0, "proposal: bad shape");
   const PropPlan p = plan_proposal(batch, num_anchors, height, width, feat_stride, pre_nms_topN);
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  int ok;
+  dtt_prof_begin("proposal_op", stream);   // (event tag: the whole layer -- ranking, decode, NMS, RoI tensor)
   if (p.nruns) {
     // scores and box deltas both at hand: the ranking kernel decodes the boxes it selects (no decode launches)
     DTT_REQUIRE(workspace && workspace_bytes >= p.total, "proposal: workspace too small (%zu < %zu)", workspace_bytes, p.total);
     DTT_REQUIRE(batch <= 65535, "proposal: more than 65535 images in one call");
-    if (!select_runs(p, cls_prob, bbox_pred, im_info, anchors, batch, static_cast<unsigned char*>(workspace),
-                     static_cast<hipStream_t>(stream_)))
+    if (!select_runs(p, cls_prob, bbox_pred, im_info, anchors, batch, static_cast<unsigned char*>(workspace), stream))
       return 0;
-    return decode_nms(bbox_pred, im_info, anchors, batch, num_anchors, height, width, feat_stride, pre_nms_topN, post_nms_topN,
-                      nms_thresh, rois_out, num_out, workspace, workspace_bytes, stream_, true);
-  }
-  if (!dtt_proposal_select_sort(cls_prob, batch, num_anchors, height, width, pre_nms_topN, workspace, workspace_bytes, stream_))
-    return 0;
-  return dtt_proposal_decode_nms(bbox_pred, im_info, anchors, batch, num_anchors, height, width, feat_stride, pre_nms_topN,
+    ok = decode_nms(bbox_pred, im_info, anchors, batch, num_anchors, height, width, feat_stride, pre_nms_topN, post_nms_topN,
+                    nms_thresh, rois_out, num_out, workspace, workspace_bytes, stream_, true);
+  } else {
+    if (!dtt_proposal_select_sort(cls_prob, batch, num_anchors, height, width, pre_nms_topN, workspace, workspace_bytes, stream_))
+      return 0;
+    ok = dtt_proposal_decode_nms(bbox_pred, im_info, anchors, batch, num_anchors, height, width, feat_stride, pre_nms_topN,
                                  post_nms_topN, nms_thresh, rois_out, num_out, workspace, workspace_bytes, stream_);
+  }
+  dtt_prof_end("proposal_op", stream);
+  return ok;
 }

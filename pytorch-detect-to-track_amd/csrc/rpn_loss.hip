@@ -70,17 +70,34 @@ __global__ __launch_bounds__(kLossThreads) void rpn_loss_fwd_kernel(LossGeom g, 
   __syncthreads();
   if (!last) return;
   __threadfence();
-  // the last workgroup: leg by leg, partials in index order (one lane per leg; a few hundred adds)
-  if ((int)threadIdx.x < g.legs) {
-    const int leg = threadIdx.x, per = g.batch / g.legs;
+  // the last workgroup: leg by leg, every thread adds its fixed share of the leg's partials (index t, t + 256, ...) in double, then a
+  // fixed-shape tree over the 256 shares -- the same order of additions whichever workgroup comes last.  (The partials are read with
+  // agent-scope loads: past this CU's L1, nothing serialised -- a volatile walk by one lane waited for every load in turn.)
+  __shared__ double tree[3][kLossThreads];
+  const int per = g.batch / g.legs;
+  const long per_leg = (long)per * kLossZ * nblk;
+  for (int leg = 0; leg < g.legs; ++leg) {
     double sc = 0.0, sn = 0.0, sb = 0.0;
-    const volatile float* pv = partial;
-    for (long i = (long)leg * per * kLossZ * nblk; i < (long)(leg + 1) * per * kLossZ * nblk; ++i) {
-      sc += (double)pv[i * 4]; sn += (double)pv[i * 4 + 1]; sb += (double)pv[i * 4 + 2];
+    for (long i = (long)leg * per_leg + threadIdx.x; i < (long)(leg + 1) * per_leg; i += kLossThreads) {
+      sc += (double)__hip_atomic_load(partial + i * 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      sn += (double)__hip_atomic_load(partial + i * 4 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      sb += (double)__hip_atomic_load(partial + i * 4 + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    loss[leg] = (float)(sc / sn);                 // (no labelled anchor: 0 / 0 = nan, as F.cross_entropy's mean over nothing)
-    loss[g.legs + leg] = (float)(sb / (double)per);
-    count[leg] = (float)sn;
+    __syncthreads();
+    tree[0][threadIdx.x] = sc; tree[1][threadIdx.x] = sn; tree[2][threadIdx.x] = sb;
+    __syncthreads();
+    for (int o = kLossThreads / 2; o >= 1; o >>= 1) {
+      if ((int)threadIdx.x < o) {
+        tree[0][threadIdx.x] += tree[0][threadIdx.x + o]; tree[1][threadIdx.x] += tree[1][threadIdx.x + o];
+        tree[2][threadIdx.x] += tree[2][threadIdx.x + o];
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      loss[leg] = (float)(tree[0][0] / tree[1][0]);             // (no labelled anchor: 0 / 0 = nan, as F.cross_entropy's mean over nothing)
+      loss[g.legs + leg] = (float)(tree[2][0] / (double)per);
+      count[leg] = (float)tree[1][0];
+    }
   }
   if (threadIdx.x == 0) *ticket = 0u;
 }

@@ -180,18 +180,23 @@ def correlation_backward_nhwc(grad_output, input1, input2, g1, g2, pad_size, ker
     streamed = bool(L.dtt_correlation_backward_stream_supported(C, kernel_size, max_displacement, stride1, stride2)) and corr_bwd_stream_enabled()
     with torch.cuda.device(dev):
         if not streamed:
-            # round 1's kernels: a contiguous (B, D*D, oh, ow) gradOutput and both gradient outputs.  A rows-form gradient is
-            # gathered into that tensor first, a gradient the caller does not want goes to a scratch map, a sliced destination is
-            # filled through a contiguous-in-channels-last temporary (this path is the developer switch's and the fallback of
-            # channel counts that are not a multiple of 64: correctness first)
+            # round 1's kernels: a contiguous (B, D*D, oh, ow) gradOutput and both gradient outputs, dense channels-last.  A rows-form
+            # gradient is gathered into that tensor first, a gradient the caller does not want goes to a scratch map (this path is the
+            # developer switch's and the fallback of channel counts that are not a multiple of 64: correctness first)
             if max_displacement // max(stride2, 1) > 8:
                 raise ValueError("correlation backward (channels-last): window radius %d needs the streamed kernels (channels %% 64 == 0, "
                                  "DTT_CORR_BWD_STREAM not 0)" % (max_displacement // max(stride2, 1)))
             if rows is not None:
+                if rows.dim() != 2 or rows.dtype != torch.float32 or rows.shape[0] != B * oh * ow or col < 0 or col + oc > rows.shape[1]:
+                    raise ValueError("correlation backward: rows must be float32 (%d, >= %d)" % (B * oh * ow, col + oc))
                 grad_output = rows[:, col:col + oc].reshape(B, oh, ow, oc).permute(0, 3, 1, 2)
             grad_output = grad_output.contiguous()
             t1 = g1 if g1 is not None else torch.empty_like(input1)
             t2 = g2 if g2 is not None else torch.empty_like(input2)
+            for t in (t1, t2):   # the kernel writes dense NHWC: a channel- or spatially-sliced destination would be overrun
+                if t.shape != input1.shape or t.dtype != torch.float32 or not t.is_contiguous(memory_format=torch.channels_last):
+                    raise ValueError("correlation backward (channels-last): the gradient maps must be dense channels-last float32 %s "
+                                     "(batch slices are; channel or spatial slices are not)" % (tuple(input1.shape),))
             check(L.dtt_correlation_backward_nhwc(ptr(grad_output), B, oc, oh, ow, ptr(input1), C, H, W, ptr(input2), ptr(t1), ptr(t2),
                                                   pad_size, kernel_size, max_displacement, stride1, stride2, stream_ptr(dev)),
                   "correlation backward (channels-last)")

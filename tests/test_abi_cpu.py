@@ -158,3 +158,22 @@ def test_correlation_streamed_backward_plans_without_gpu():
     # workspace: the band words of both directions, NBR^2 * 4 * 64 floats per 4 x 4 target block
     assert L.dtt_correlation_backward_workspace_bytes(2, 2048, 38, 67, 8, 1, 8, 1, 1) == 2 * 2 * 10 * 17 * 100 * 64 * 4
     assert L.dtt_correlation_backward_workspace_bytes(2, 80, 38, 67, 8, 1, 8, 1, 1) == 0
+
+
+def test_no_inline_asm_statement_clobbers_m0():
+    """The LDS-DMA statements (csrc/correlation_wsplit.hip, correlation_bwd.hip, heads.hip) set m0 and put it back inside the statement:
+    m0 is a reserved register hipcc neither allocates nor saves around inline asm, so a statement that merely LISTS it as clobbered
+    (-Winline-asm: "clobber list contains reserved registers ... undefined behaviour") relies on the compiler never keeping a value
+    of its own there.  No source may name it in a clobber list, and every statement that writes it must also restore it."""
+    import glob
+    import re
+    src = os.path.join(ROOT, "pytorch-detect-to-track_amd", "csrc")
+    hits = 0
+    for f in sorted(glob.glob(os.path.join(src, "*.hip")) + glob.glob(os.path.join(src, "*.h"))):
+        text = open(f).read()
+        assert not re.search(r':[^;]*"m0"\s*\)', text), f + ": m0 in a clobber list"
+        for stmt in re.findall(r'asm volatile\((?:[^;]|\n)*?\);', text):
+            if "s_mov_b32 m0" in stmt:
+                hits += 1
+                assert "s_mov_b32 %0, m0" in stmt and stmt.count("s_mov_b32 m0") == 2, f + ": m0 written but not saved and restored"
+    assert hits == 3

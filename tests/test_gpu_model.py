@@ -285,11 +285,14 @@ def test_drivers_on_an_ilsvrc_devkit(tmp_path):
         cfg.DATA_DIR = saved
 
 
-def test_fused_training_trunk_matches_reference_graph():
+def test_fused_training_trunk_matches_reference_graph(monkeypatch):
     """dtt.fuse.FusedTrainTrunk (frozen BatchNorm folded out of the activation path, fused bias/residual/ReLU with a
     one-pass backward) against the module graph.  Block by block (same input, same upstream gradient) outputs, input
     gradients and weight gradients agree to fp32 rounding; through the whole random-init trunk the two graphs drift
-    apart by ReLU-mask flips, so that comparison is a loose sanity bound."""
+    apart by ReLU-mask flips, so that comparison is a loose sanity bound.  Runs with torch.backends.cudnn.deterministic:
+    which convolution kernels MIOpen picks otherwise varies from box to box, and with it the backward kernels' rounding
+    (tests/test_gpu_train_fullsize.py does the same)."""
+    monkeypatch.setattr(torch.backends.cudnn, "deterministic", True)
     from dtt.config import cfg
     from dtt.fuse import FusedTrainTrunk, fuse_for_training, unfuse
     from dtt.synth import build_model, calibrate_batchnorm_, make_batch
@@ -326,19 +329,19 @@ def test_fused_training_trunk_matches_reference_graph():
                 (y * probe).sum().backward()
                 outs.append((y.detach().clone(), xi.grad.clone(), [c.weight.grad.clone() for c in ft.convs[k:k + n]]))
             (y0, gx0, gw0), (y1, gx1, gw1), (y2, gx2, gw2) = outs
-            assert float((y0 - y2).norm()) <= 2e-5 * float(y0.norm()) and float((gx0 - gx2).norm()) <= 1e-2 * float(gx0.norm())
+            assert float((y0 - y2).norm()) <= 2e-5 * float(y0.norm()) and float((gx0 - gx2).norm()) <= 5e-3 * float(gx0.norm())
             for a, b in zip(gw0, gw2):
-                assert float((a - b).norm()) <= 1e-2 * max(1e-12, float(a.norm())), k
-            # forward to fp32 rounding; gradients to the accuracy of MIOpen's Winograd backward kernels (the two graphs
-            # hand them differently scaled weights; which kernels a box picks varies: 5.3e-3 seen on one of three boxes in round 5),
-            # far below what a wrong mask / missing residual term would give (O(1))
+                assert float((a - b).norm()) <= 5e-3 * max(1e-12, float(a.norm())), k
+            # forward to fp32 rounding; gradients to the accuracy of MIOpen's backward kernels (the two graphs hand them differently
+            # scaled weights), far below what a wrong mask / missing residual term would give (O(1))
             close = lambda a, b, tol: float((a - b).norm()) <= tol * max(1e-12, float(a.norm()))
-            assert close(y0, y1, 2e-5) and close(gx0, gx1, 1e-2), (k, float((y0 - y1).norm() / y0.norm()), float((gx0 - gx1).norm() / gx0.norm()))
+            assert close(y0, y1, 2e-5) and close(gx0, gx1, 5e-3), (k, float((y0 - y1).norm() / y0.norm()), float((gx0 - gx1).norm() / gx0.norm()))
             for a, b in zip(gw0, gw1):
-                assert close(a, b, 1e-2), (k, float((a - b).norm() / a.norm()))
+                assert close(a, b, 5e-3), (k, float((a - b).norm() / a.norm()))
             k += n
             checked += 1
     assert checked == 13  # layer2..layer4 of ResNet-50
+    monkeypatch.undo()     # (the whole-trunk comparison below runs on the library's default kernel choice, as the training step does)
 
     probes = None
 
