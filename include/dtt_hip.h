@@ -543,10 +543,22 @@ int dtt_psroi_pm_det_forward(const float* map, long pixel_stride, int loc_offset
  * grad_vote[roi][c] / pooled^2 / bin_area, added in RoI order -- map-stationary, no atomics (the reference scatters with
  * atomicAdd), deterministic.  Every pixel's floats [0, pooled^2 * cp) are WRITTEN (zeros where no RoI reaches): no pre-zeroing.
  * edges: caller-owned scratch, num_rois * (4 * pooled + 1) + 2 * batch_size ints (the bin edges of every RoI, then the run of RoI
- * indices of every image: a pixel's workgroup only walks the RoIs of its own image).  cp in {4, 32} as in the forward. */
+ * indices of every image: a pixel's wave only walks the RoIs of its own image).  cp in {4, 32} as in the forward. */
 int dtt_psroi_pm_backward(const float* grad_vote, const float* rois, int num_rois, int batch_size, int height, int width,
                           int pooled, float spatial_scale, int output_dim, int cp, long pixel_stride, float* grad_map,
                           int* edges, void* stream);
+/* The same gradient for up to TWO heads pooled from one map with the same RoIs (the class and box heads of rfcn.py:133-150: the
+ * reference runs PSROIPoolBackward once per head), in ONE launch: one wave per pixel lists the (RoI, bin) pairs that cover it once
+ * and serves both heads.  Head 0's bins start at column 0 of a pixel's row (cp0 columns per bin), head 1's at pooled^2 * cp0
+ * (cp1 per bin; grad_vote1 NULL = one head); cp0 + cp1 <= 64.  Columns [0, row_floats) of EVERY pixel are written -- the sums,
+ * zeros where no RoI reaches and in the padding columns behind the heads -- so row_floats = pixel_stride hands the head GEMM's
+ * backward a whole gradient map.  add_cols (pixels, add_count) or NULL: a compact gradient added into columns [add_first,
+ * add_first + add_count) behind the pooling sums (the map's second consumer under autograd: the box deltas the tracking branch
+ * concatenates, rfcn.py:166-169).  pooled = 7.  No scratch: the bin edges are computed inside the launch. */
+int dtt_psroi_pm_backward_heads(const float* grad_vote0, int output_dim0, int cp0, const float* grad_vote1, int output_dim1, int cp1,
+                                const float* rois, int num_rois, int batch_size, int height, int width, int pooled, float spatial_scale,
+                                long pixel_stride, int row_floats, const float* add_cols, int add_first, int add_count,
+                                float* grad_map, void* stream);
 
 /* ---------------------------------------------------------------- zero-jump Viterbi tube linking
  * Replaces VideoPostProcessor._make_tubes / _zero_jump_link / _score_of_edge (lib/model/utils/tracking_utils.py:

@@ -881,10 +881,11 @@ extern "C" int dtt_rpn_head_grad_rows(const float* grad_cls_prob, const float* g
 // Backward of dtt_psroi_pm_forward's vote: grad_map (batch*height*width pixels, pixel_stride floats apart; this call writes
 // floats [bin*cp + c] for bin < pooled^2, c < cp of EVERY pixel -- zeros where no RoI reaches, so no pre-zeroing) from
 // grad_vote (num_rois, output_dim).  edges: caller-owned scratch of num_rois * (4 * pooled + 1) + 2 * batch_size ints.
-extern "C" int dtt_psroi_pm_backward(const float* grad_vote, const float* rois, int num_rois, int batch_size, int height, int width,
-                                     int pooled, float spatial_scale, int output_dim, int cp, long pixel_stride, float* grad_map,
-                                     int* edges, void* stream_) {
-  hipStream_t stream = static_cast<hipStream_t>(stream_);
+// (round 6: the exported dtt_psroi_pm_backward lives in psroi_bwd.hip -- one wave per pixel, all heads in one launch; this is the
+//  one-workgroup-per-pixel kernel of rounds 4 - 5, reached with DTT_PSROI_BWD_OLD=1 for the A/B and for pooled sizes other than 7)
+__attribute__((visibility("hidden"))) int dtt_psroi_pm_backward_old(const float* grad_vote, const float* rois, int num_rois, int batch_size,
+                                                                    int height, int width, int pooled, float spatial_scale, int output_dim,
+                                                                    int cp, long pixel_stride, float* grad_map, int* edges, hipStream_t stream) {
   DTT_REQUIRE(batch_size > 0 && height > 0 && width > 0 && pooled > 0 && output_dim > 0 && num_rois >= 0, "psroi_pm backward: bad shape");
   DTT_REQUIRE(cp >= output_dim && (long)pooled * pooled * cp <= pixel_stride, "psroi_pm backward: %d bins x %d do not fit the pixel stride %ld",
               pooled * pooled, cp, pixel_stride);

@@ -1,0 +1,514 @@
+// Gradient of the position-major PSRoI pooling + vote (heads.hip: psroi_pm_kernel) with respect to the map, for ALL the heads
+// pooled from one map in one launch (gfx950).
+//
+// Reference: PSROIPoolBackward (psroi_pooling_kernel.cu:109-170) composed with the AvgPool2d vote (rfcn.py:62-64):
+//     d map[b, h, w, bin, c] = sum over the RoIs r of image b whose bin `bin` contains (h, w) of  gvote[r, c] / (P*P) / area(r, bin)
+// The reference scatters with atomicAdd, one launch per head.  Here the map is stationary and one WAVE owns a pixel:
+//
+//   prologue (once per workgroup, the only __syncthreads): the run of RoI rows that holds the image's RoIs is found, their
+//             vote-gradient rows (all heads side by side, 36 floats per RoI for the class + box heads) are staged in LDS, their bin
+//             edges computed with the forward's arithmetic (psroi_bin.h) and packed start | end << 16 -- no edges kernel, no
+//             scratch, no memset in front of the launch;
+//   phase 1   lanes = RoIs: the bins of lane's RoI that contain the pixel are a rectangle [ph_lo, ph_hi] x [pw_lo, pw_hi]
+//             (edges are non-decreasing: the count of starts <= h and of ends <= h give the range with 14 compares); the row range
+//             is recomputed only when the wave's pixel run enters a new map row, the column edges stay in registers;
+//             an in-wave prefix sum (DPP) places every lane's (RoI, bin, weight) entries in RoI order in the wave's LDS list;
+//   phase 2   lanes = columns (classes of head 0, then the box deltas of head 1): the list is walked in order, each entry one
+//             read-modify-write of the wave's accumulator row in LDS (batches of 4 whose bins differ are issued together);
+//   write-out the pixel's whole row (all bins of all heads, the padding columns as zeros, optionally plus a compact gradient that
+//             autograd would otherwise add in a further pass) leaves as 16-byte stores and the accumulator is zeroed behind them.
+//
+// No atomics, no pre-zeroed output, summation in RoI order: run-to-run bit-identical.  The one-workgroup-per-pixel kernel this
+// replaces (heads.hip: psroi_pm_bwd_kernel, kept behind DTT_PSROI_BWD_OLD=1 for the A/B) re-read the edges and the gradient rows
+// from L2 for every pixel and took three workgroup barriers per pixel: 68.6 us for the class head + 12 us for the box head of the
+// training step's 10184 pixels (profiles/r05_train_steady_state.txt).
+#include <stdlib.h>
+#include <algorithm>
+#include "common.h"
+#include "psroi_bin.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kListCap = 128;     // (RoI, bin, weight) entries of one wave between two walks
+constexpr int kMaxRounds = 4;     // RoIs staged per chunk <= 64 * kMaxRounds
+constexpr int kWOut = 4;          // 16-byte pieces of the accumulator row a lane has in flight in the write-out
+constexpr int kWTab = 256;        // 1 / (P*P) / area for bin areas below this from a table (a bin is about 1/P of the map per side)
+
+#ifdef DTT_PSROI_BWD_STAMP   // developer timeline (tools/psroi_bwd_timeline.py): shader-clock stamps of waves 0 and NW-1 of two workgroups
+__device__ unsigned long long dtt_psroi_bwd_stamps[2 * 2 * 64];
+__device__ unsigned long long dtt_psroi_bwd_wg[1024 * 3];      // per workgroup: entry, end (100 MHz clock), HW_ID
+#define PB_STAMP(idx) do { const int sb_ = blockIdx.x == 0 ? 0 : blockIdx.x == gridDim.x / 2 ? 1 : -1; \
+    if (sb_ >= 0 && (threadIdx.x & 63) == 0 && ((threadIdx.x >> 6) == 0 || (threadIdx.x >> 6) == NW - 1) && (idx) < 64) \
+      dtt_psroi_bwd_stamps[(sb_ * 2 + ((threadIdx.x >> 6) != 0)) * 64 + (idx)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define PB_STAMP(idx) do {} while (0)
+#endif
+
+struct PmBwd {
+  const float* gv0; const float* gv1;     // (num_rois, od0) / (num_rois, od1) or NULL
+  int od0, cp0, od1, cp1;
+  const float* rois; int num_rois; float spatial_scale; int batch_size;
+  int height, width; long pixel_stride; int row_floats;   // columns written per pixel: [0, row_floats)
+  const float* add; int add_first, add_count;             // optional (pixels, add_count) rows added into columns [add_first, +add_count)
+  float* gmap;
+  int cap;                                 // RoIs staged per chunk (multiple of 64, <= 64 * kMaxRounds)
+  int per_image;                           // ceil(num_rois / batch_size): where image b's RoIs start when every image lists as many
+  int ppw;                                 // pixels per wave
+  int wgs_per_image;
+  int ablate;                              // developer timing experiments (DTT_PSROI_BWD_ABLATE): 1 no listing, 2 no list walk, 4 no stores, 8 prologue only
+};
+
+// inclusive prefix sum over the 64 lanes (all active): row_shr 1 2 4 8 inside the rows of 16, then row_bcast 15 / 31
+__device__ __forceinline__ int wave_incl_scan(int x) {
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);
+  return x;
+}
+__device__ __forceinline__ int sgpr(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float sgprf(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+
+template <int P, int NW, int NR>
+__global__ __launch_bounds__(NW * 64) void psroi_pm_bwd_rows_kernel(PmBwd a) {
+  static_assert(P <= 15, "bin counts are packed in 4 bits");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  PB_STAMP(0);
+#ifdef DTT_PSROI_BWD_STAMP
+  if (threadIdx.x == 0 && blockIdx.x < 1024) {
+    dtt_psroi_bwd_wg[blockIdx.x * 3] = __builtin_amdgcn_s_memrealtime();
+    dtt_psroi_bwd_wg[blockIdx.x * 3 + 2] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 11) | (0 << 6) | 4) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
+  }
+  if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2)) dtt_psroi_bwd_stamps[(blockIdx.x == 0 ? 0 : 2) * 64 + 62] = __builtin_amdgcn_s_memrealtime();
+#endif
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int gvw = a.cp0 + a.cp1;
+  const int cap = a.cap;
+  // LDS: [per wave: accumulator row | list] [gradient rows cap x gvw] [row edges P x cap] [column edges P x cap] [non-zero flags cap] [own-image flags cap] [weights] [run]
+  const int acc_floats = (a.row_floats + 3) & ~3;
+  float* acc = smem + (long)wave * (acc_floats + 2 * kListCap);
+  int* list_rb = reinterpret_cast<int*>(acc + acc_floats);
+  float* list_w = acc + acc_floats + kListCap;
+  float* gvs = smem + (long)NW * (acc_floats + 2 * kListCap);
+  int* erow = reinterpret_cast<int*>(gvs + (long)cap * gvw);
+  int* ecol = erow + P * cap;
+  int* eimg = ecol + P * cap;
+  int* eown = eimg + cap;                                 // [cap]: the RoI row belongs to this workgroup's image
+  float* wtab = reinterpret_cast<float*>(eown + cap);
+  int* run = reinterpret_cast<int*>(wtab + kWTab);       // [2]: the image's run of RoI rows
+
+  const int b = blockIdx.x / a.wgs_per_image;
+  const int hw = a.height * a.width;
+  const int p_first = (blockIdx.x - b * a.wgs_per_image) * (NW * a.ppw) + wave * a.ppw;   // this wave's pixel run in image b
+  const float inv_bins = 1.f / (float)(P * P);
+  const bool col_on = lane < gvw;
+
+  // stage RoI rows [c0, c0 + n): gradient rows (all heads side by side), a flag per RoI whose rows are not all zeros (pre-zeroed), whether
+  // the row belongs to this image, bin edges by the forward's arithmetic
+  auto stage = [&](int c0, int n) {
+    // a wave per RoI row, lane = column: the loads of a wave's rows are all in flight together (no index arithmetic per element)
+    for (int r0 = wave; r0 < n; r0 += 4 * NW) {
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int r = min(r0 + u * NW, n - 1);
+        v[u] = 0.f;
+        if (lane < a.cp0) { if (lane < a.od0) v[u] = a.gv0[(long)(c0 + r) * a.od0 + lane]; }
+        else if (lane - a.cp0 < a.od1) v[u] = a.gv1[(long)(c0 + r) * a.od1 + (lane - a.cp0)];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int r = r0 + u * NW;
+        if (r < n && col_on) gvs[r * gvw + lane] = v[u];
+        if (r < n && v[u] != 0.f) eimg[r] = 1;       // (benign race: every writer stores 1)
+      }
+    }
+    // a wave per (bin index k, 64 RoIs)
+    const int nrd = (n + 63) >> 6;
+    for (int t = wave, k = 0, rd = wave; t < P * nrd; t += NW, rd += NW) {
+      while (rd >= nrd) { rd -= nrd; ++k; }
+      const int r = rd * 64 + lane;
+      if (r < n) {
+        float roi[5];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) roi[q] = a.rois[(long)(c0 + r) * 5 + q];
+        const Bin bn = psroi_bin(roi, a.spatial_scale, k, k, P, P, a.height, a.width);   // rows depend on ph only, columns on pw only
+        erow[k * cap + r] = bn.hstart | (bn.hend << 16);
+        ecol[k * cap + r] = bn.wstart | (bn.wend << 16);
+        if (k == 0) eown[r] = min(max((int)roi[0], 0), a.batch_size - 1) == b ? 1 : 0;      // (the forward's clamp)
+      }
+    }
+  };
+  // ---- the run [r_first, r_end) of RoI rows that holds this image's RoIs (callers list their RoIs image by image: the run is the
+  //      image's own RoIs; rows of other images inside it are masked), the weight table, the zeroed accumulator.  Callers that list
+  //      the same number of RoIs per image (training) have image b's run at b * per_image: that chunk is staged WHILE the run is
+  //      being looked for (one global-memory round trip less in front of the first pixel) and kept when the run lies inside it.
+  if (tid < 2) run[tid] = tid == 0 ? a.num_rois : 0;
+  for (int i = tid; i < kWTab; i += NW * 64) wtab[i] = inv_bins / (float)i;
+  for (int i = tid; i < cap; i += NW * 64) eimg[i] = 0;
+  for (int i = lane; i < acc_floats / 4; i += 64) reinterpret_cast<f32x4*>(acc)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+  PB_STAMP(1);
+  const int guess_c0 = min(b * a.per_image, a.num_rois), guess_n = min(cap, a.num_rois - guess_c0);
+  {
+    int lo = a.num_rois, hi = 0;
+    for (int r = tid; r < a.num_rois; r += NW * 64)
+      if (min(max((int)a.rois[(long)r * 5], 0), a.batch_size - 1) == b) { lo = min(lo, r); hi = r + 1; }   // (the forward's clamp)
+    if (guess_n > 0) stage(guess_c0, guess_n);
+    if (hi > 0) { atomicMin(&run[0], lo); atomicMax(&run[1], hi); }
+  }
+  PB_STAMP(2);
+  __syncthreads();
+  PB_STAMP(3);
+  int r_first = run[0], r_end = run[1];
+  const bool guessed = r_end > r_first && guess_n > 0 && r_first >= guess_c0 && r_end <= guess_c0 + guess_n;
+  if (guessed) { r_first = guess_c0; r_end = guess_c0 + guess_n; }     // (the staged chunk, one chunk)
+  const int nchunks = guessed ? 1 : r_end > r_first ? (r_end - r_first + cap - 1) / cap : 0;
+
+  // lane = column of the accumulator row in phase 2
+  char* const acc_lane = reinterpret_cast<char*>(acc + (lane < a.cp0 ? lane : P * P * a.cp0 + (lane - a.cp0)));
+  const unsigned col_mul4 = 4u * (lane < a.cp0 ? a.cp0 : a.cp1);
+  const float* const gv_lane = gvs + (col_on ? lane : 0);
+
+  int cw[NR][P];                  // column edges of lane's RoIs (packed), per round of 64 RoIs
+  int prow[NR];                   // row range of lane's RoIs at the current map row: lo | hi1 << 4 (hi1 = hi + 1; lo >= hi1: none)
+  int cur_h = -1;
+
+  // one entry: accumulator[bin][lane's column] += gradient row[lane's column] * weight (the entry is wave-uniform: unpacked on the scalar unit)
+  auto apply1 = [&](int rb, float w) {
+    const int s = sgpr(rb);
+    const float sw = sgprf(w);
+    if (col_on) {
+      float* ap = reinterpret_cast<float*>(acc_lane + __umul24((unsigned)(s >> 8), col_mul4));
+      *ap += gv_lane[(s & 0xff) * gvw] * sw;
+    }
+  };
+
+  // the list in order (= RoI order), four entries at a time: the NEXT four entries and their gradient values are fetched while the
+  // accumulator words of the current four make their round trip through LDS (a walk that waits for entry, gradient and accumulator
+  // one after the other was 20 of the launch's 49 us); entries of a batch whose bins differ are read and written together
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  auto walk = [&](int nl) {
+    int i = 0;
+    if (nl >= 4) {
+      i32x4 e = *reinterpret_cast<const i32x4*>(list_rb);
+      f32x4 wv = *reinterpret_cast<const f32x4*>(list_w);
+      int s0 = sgpr(e[0]), s1 = sgpr(e[1]), s2 = sgpr(e[2]), s3 = sgpr(e[3]);
+      float w0 = sgprf(wv[0]), w1 = sgprf(wv[1]), w2 = sgprf(wv[2]), w3 = sgprf(wv[3]);
+      float g0 = gv_lane[(s0 & 0xff) * gvw], g1 = gv_lane[(s1 & 0xff) * gvw], g2 = gv_lane[(s2 & 0xff) * gvw], g3 = gv_lane[(s3 & 0xff) * gvw];
+      for (;;) {
+        const int in = i + 4;
+        const bool more = in + 4 <= nl;
+        const int ic = more ? in : i;                    // (clamped: the last batch re-reads itself)
+        e = *reinterpret_cast<const i32x4*>(list_rb + ic);
+        wv = *reinterpret_cast<const f32x4*>(list_w + ic);
+        const int b0 = s0 >> 8, b1 = s1 >> 8, b2 = s2 >> 8, b3 = s3 >> 8;
+        const bool distinct = b0 != b1 && b0 != b2 && b0 != b3 && b1 != b2 && b1 != b3 && b2 != b3;   // scalar unit
+        if (col_on) {
+          float* a0 = reinterpret_cast<float*>(acc_lane + __umul24((unsigned)b0, col_mul4));
+          float* a1 = reinterpret_cast<float*>(acc_lane + __umul24((unsigned)b1, col_mul4));
+          float* a2 = reinterpret_cast<float*>(acc_lane + __umul24((unsigned)b2, col_mul4));
+          float* a3 = reinterpret_cast<float*>(acc_lane + __umul24((unsigned)b3, col_mul4));
+          if (distinct) {
+            const float v0 = *a0, v1 = *a1, v2 = *a2, v3 = *a3;
+            *a0 = v0 + g0 * w0; *a1 = v1 + g1 * w1; *a2 = v2 + g2 * w2; *a3 = v3 + g3 * w3;
+          } else {
+            *a0 += g0 * w0; *a1 += g1 * w1; *a2 += g2 * w2; *a3 += g3 * w3;
+          }
+        }
+        i = in;
+        if (!more) break;
+        s0 = sgpr(e[0]); s1 = sgpr(e[1]); s2 = sgpr(e[2]); s3 = sgpr(e[3]);
+        w0 = sgprf(wv[0]); w1 = sgprf(wv[1]); w2 = sgprf(wv[2]); w3 = sgprf(wv[3]);
+        g0 = gv_lane[(s0 & 0xff) * gvw]; g1 = gv_lane[(s1 & 0xff) * gvw]; g2 = gv_lane[(s2 & 0xff) * gvw]; g3 = gv_lane[(s3 & 0xff) * gvw];
+      }
+    }
+    for (; i < nl; ++i) apply1(list_rb[i], list_w[i]);
+  };
+
+  int h = p_first / a.width, w = p_first - h * a.width - 1;      // (the wave's pixels are consecutive: one division per wave)
+  for (int it = 0; it < a.ppw; ++it) {
+    const int p = p_first + it;
+    const bool valid = p < hw;
+    if (++w == a.width) { w = 0; ++h; }
+    int nlist = 0;
+    // the compact gradient of the pixel is requested now and added in front of the write-out (it sat on the critical path of every
+    // pixel as a dependent global load: 1.8 k of a pixel's 6 k cycles)
+    float addv[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool add_pre = a.add && a.add_count <= 256 && valid;
+    if (add_pre) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (lane + 64 * u < a.add_count) addv[u] = a.add[((long)b * hw + p) * a.add_count + lane + 64 * u];
+    }
+    for (int ch = 0; ch < nchunks; ++ch) {
+      const int c0 = r_first + ch * cap;
+      const int n = min(cap, r_end - c0);
+      if (nchunks > 1 || it == 0) {
+        if (nchunks > 1 || !guessed) {
+          __syncthreads();
+          for (int i = tid; i < cap; i += NW * 64) eimg[i] = 0;
+          __syncthreads();
+          stage(c0, n);
+          __syncthreads();
+        }
+        // A RoI whose gradient rows are all zeros adds nothing anywhere (background RoIs in the box head; the zero-padded ground-truth
+        // rows of the tracking RoIs -- (0,0,0,0) boxes whose 49 bins ALL cover pixel (0, 0)): it belongs to no image
+#pragma unroll
+        for (int rd = 0; rd < NR; ++rd) {
+          const int rl = min(rd * 64 + lane, cap - 1);
+          const bool on = rd * 64 + lane < n && eimg[rl] != 0 && eown[rl] != 0;
+#pragma unroll
+          for (int k = 0; k < P; ++k) cw[rd][k] = on ? ecol[k * cap + rl] : 0;   // (start = end = 0: contains no pixel)
+        }
+        cur_h = -1;
+        PB_STAMP(4);
+      }
+      if (!valid || (a.ablate & 8)) continue;
+      if (h != cur_h) {
+        cur_h = h;
+#pragma unroll
+        for (int rd = 0; rd < NR; ++rd) {
+          const int rl = min(rd * 64 + lane, cap - 1);
+          int lo = 0, hi1 = 0;
+          if (rd * 64 < n) {
+#pragma unroll
+            for (int k = 0; k < P; ++k) {
+              const int e = erow[k * cap + rl];
+              hi1 += (e & 0xffff) <= h ? 1 : 0;     // starts <= h: a prefix of the bins
+              lo += (e >> 16) <= h ? 1 : 0;         // ends <= h: the bins before the first one that still contains h
+            }
+          }
+          prow[rd] = lo | (hi1 << 4);
+        }
+      }
+      // ---- phase 1: lane's RoI rd*64 + lane -> the rectangle of its bins that contains (h, w): plo | phi1 << 4 | qlo << 8 | qhi1 << 12
+      int rect[NR];
+#pragma unroll
+      for (int rd = 0; rd < NR; ++rd) {
+        int qlo = 0, qhi1 = 0;
+        if (rd * 64 < n) {
+#pragma unroll
+          for (int k = 0; k < P; ++k) {
+            qhi1 += (cw[rd][k] & 0xffff) <= w ? 1 : 0;
+            qlo += (cw[rd][k] >> 16) <= w ? 1 : 0;
+          }
+        }
+        rect[rd] = prow[rd] | (qlo << 8) | (qhi1 << 12);
+      }
+      PB_STAMP(5 + 6 * it);
+#pragma unroll 1
+      for (int rd = 0; rd * 64 < n; ++rd) {
+        int rc = rect[0];
+#pragma unroll
+        for (int q = 1; q < NR; ++q) rc = rd == q ? rect[q] : rc;
+        const int plo = rc & 15, phi1 = (rc >> 4) & 15, qlo = (rc >> 8) & 15, qhi1 = rc >> 12;
+        const int nh = (phi1 > plo && qhi1 > qlo) ? (phi1 - plo) * (qhi1 - qlo) : 0;   // (masked RoIs: zero column edges, nh = 0)
+        const int incl = wave_incl_scan(nh);
+        const int total = __builtin_amdgcn_readlane(incl, 63);
+        if (total == 0 || (a.ablate & 1)) continue;
+        if (nlist + total > kListCap) {
+          // walk what is listed, then take this round on its own (or serially when one round alone overflows the list)
+          walk(nlist);
+          nlist = 0;
+        }
+        const int rl = rd * 64 + lane;
+        if (total <= kListCap) {
+          int pos = nlist + incl - nh;
+          if (nh > 0) {
+            for (int ph = plo; ph < phi1; ++ph) {
+              const int er = erow[ph * cap + rl];
+              const unsigned hgt = (unsigned)((er >> 16) - (er & 0xffff));
+              for (int pw = qlo; pw < qhi1; ++pw) {
+                const int ec = ecol[pw * cap + rl];
+                const unsigned area = __umul24(hgt, (unsigned)((ec >> 16) - (ec & 0xffff)));
+                list_rb[pos] = rl | ((ph * P + pw) << 8);
+                list_w[pos] = area < (unsigned)kWTab ? wtab[area] : inv_bins / (float)area;
+                ++pos;
+              }
+            }
+          }
+          nlist += total;
+        } else {
+          // (degenerate RoIs: more than two bins each on average -- RoI by RoI in order, every lane walking the same rectangle)
+          unsigned long long m = __ballot(nh > 0);
+          while (m) {
+            const int src = __builtin_ctzll(m);
+            m &= m - 1;
+            const int s_rl = rd * 64 + src;
+            const int s_plo = __builtin_amdgcn_readlane(plo, src), s_phi1 = __builtin_amdgcn_readlane(phi1, src);
+            const int s_qlo = __builtin_amdgcn_readlane(qlo, src), s_qhi1 = __builtin_amdgcn_readlane(qhi1, src);
+            const float g = gv_lane[s_rl * gvw];
+            for (int ph = s_plo; ph < s_phi1; ++ph) {
+              const int er = erow[ph * cap + s_rl];
+              const int hgt = (er >> 16) - (er & 0xffff);
+              for (int pw = s_qlo; pw < s_qhi1; ++pw) {
+                const int ec = ecol[pw * cap + s_rl];
+                const int area = hgt * ((ec >> 16) - (ec & 0xffff));
+                if (col_on) *reinterpret_cast<float*>(acc_lane + (unsigned)(ph * P + pw) * col_mul4) += g * (inv_bins / (float)area);
+              }
+            }
+          }
+        }
+      }
+      // ---- phase 2 for this chunk: the list in order (= RoI order); four entries whose bins differ go together
+      PB_STAMP(6 + 6 * it);
+      if (a.ablate & 2) nlist = 0;
+#ifdef DTT_PSROI_BWD_STAMP
+      if (blockIdx.x == 0 && tid == 0 && it < 4) dtt_psroi_bwd_stamps[56 + it] = (unsigned long long)nlist;   // (entries walked)
+#endif
+      walk(nlist);
+      nlist = 0;
+      PB_STAMP(7 + 6 * it);
+    }
+    if (!valid || (a.ablate & 4)) continue;
+    // ---- write-out: the whole row of the pixel, the accumulator zeroed behind the reads
+    const long px = (long)b * hw + p;
+    if (add_pre) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (lane + 64 * u < a.add_count) acc[a.add_first + lane + 64 * u] += addv[u];
+    } else if (a.add) {
+      for (int c = lane; c < a.add_count; c += 64) acc[a.add_first + c] += a.add[px * a.add_count + c];
+    }
+    PB_STAMP(8 + 6 * it);
+    float* dst = a.gmap + px * a.pixel_stride;
+    if (((a.pixel_stride | a.row_floats) & 3) == 0 && (reinterpret_cast<uintptr_t>(a.gmap) & 15) == 0) {
+      const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+      const int n4 = a.row_floats / 4;
+#pragma unroll 1
+      for (int j0 = lane; j0 < n4; j0 += 64 * kWOut) {      // kWOut 16-byte pieces per lane in flight
+        f32x4 v[kWOut];
+#pragma unroll
+        for (int u = 0; u < kWOut; ++u) v[u] = reinterpret_cast<f32x4*>(acc)[min(j0 + 64 * u, n4 - 1)];
+#pragma unroll
+        for (int u = 0; u < kWOut; ++u)
+          if (j0 + 64 * u < n4) {
+            __builtin_nontemporal_store(v[u], reinterpret_cast<f32x4*>(dst) + j0 + 64 * u);
+            reinterpret_cast<f32x4*>(acc)[j0 + 64 * u] = zero;
+          }
+      }
+    } else {
+      for (int j = lane; j < a.row_floats; j += 64) { dst[j] = acc[j]; acc[j] = 0.f; }
+    }
+    PB_STAMP(9 + 6 * it);
+  }
+  PB_STAMP(50);
+#ifdef DTT_PSROI_BWD_STAMP
+  if (threadIdx.x == 0 && blockIdx.x < 1024) dtt_psroi_bwd_wg[blockIdx.x * 3 + 1] = __builtin_amdgcn_s_memrealtime();
+  if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2)) dtt_psroi_bwd_stamps[(blockIdx.x == 0 ? 0 : 2) * 64 + 63] = __builtin_amdgcn_s_memrealtime();
+#endif
+}
+
+template <int P, int NW, int NR>
+int launch_rows(const PmBwd& a, int batch_size, size_t lds, hipStream_t stream) {
+  static DttDeviceOnce attr_once;
+  bool& attr = attr_once.here();
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(psroi_pm_bwd_rows_kernel<P, NW, NR>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    DTT_REQUIRE(e == hipSuccess, "psroi_pm backward: cannot raise dynamic LDS limit");
+    attr = true;
+  }
+  hipLaunchKernelGGL((psroi_pm_bwd_rows_kernel<P, NW, NR>), dim3(batch_size * a.wgs_per_image), dim3(NW * 64), lds, stream, a);
+  return 1;
+}
+
+}  // namespace
+
+#ifdef DTT_PSROI_BWD_STAMP
+extern "C" int dtt_psroi_bwd_stamps_read(unsigned long long* host, int n) {
+  (void)hipDeviceSynchronize();
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(dtt_psroi_bwd_stamps), sizeof(unsigned long long) * n) == hipSuccess;
+}
+extern "C" int dtt_psroi_bwd_wg_read(unsigned long long* host, int n) {
+  (void)hipDeviceSynchronize();
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(dtt_psroi_bwd_wg), sizeof(unsigned long long) * n) == hipSuccess;
+}
+#endif
+
+__attribute__((visibility("hidden"))) int dtt_psroi_pm_backward_old(const float* grad_vote, const float* rois, int num_rois, int batch_size,
+                                                                    int height, int width, int pooled, float spatial_scale, int output_dim,
+                                                                    int cp, long pixel_stride, float* grad_map, int* edges, hipStream_t stream);
+
+// Backward of the votes of up to two heads pooled from one position-major map (dtt_psroi_pm_forward / dtt_psroi_pm_det_forward):
+// head h has output_dim_h columns padded to cp_h per bin; head 0's bins start at column 0 of a pixel's row, head 1's at
+// pooled^2 * cp0.  Writes columns [0, row_floats) of EVERY pixel (zeros where no RoI reaches and in the padding columns past
+// the heads): no pre-zeroing, no scratch, ONE launch.  add_cols (pixels, add_count) or NULL: a compact gradient added into columns
+// [add_first, add_first + add_count) after the pooling sums (the second consumer of the map under autograd).
+extern "C" int dtt_psroi_pm_backward_heads(const float* grad_vote0, int output_dim0, int cp0, const float* grad_vote1, int output_dim1,
+                                           int cp1, const float* rois, int num_rois, int batch_size, int height, int width, int pooled,
+                                           float spatial_scale, long pixel_stride, int row_floats, const float* add_cols, int add_first,
+                                           int add_count, float* grad_map, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  DTT_REQUIRE(batch_size > 0 && height > 0 && width > 0 && pooled > 0 && output_dim0 > 0 && num_rois >= 0, "psroi_pm backward: bad shape");
+  DTT_REQUIRE(height < 32768 && width < 32768, "psroi_pm backward: map side above 32767");
+  if (!grad_vote1) { output_dim1 = 0; cp1 = 0; }
+  DTT_REQUIRE(cp0 >= output_dim0 && cp1 >= output_dim1 && cp0 + cp1 <= 64, "psroi_pm backward: %d + %d columns per bin (at most 64 together)", cp0, cp1);
+  DTT_REQUIRE((long)pooled * pooled * (cp0 + cp1) <= row_floats && row_floats <= pixel_stride,
+              "psroi_pm backward: %d bins x %d do not fit the row of %d (stride %ld)", pooled * pooled, cp0 + cp1, row_floats, pixel_stride);
+  DTT_REQUIRE(grad_map && (num_rois == 0 || (grad_vote0 && rois)), "psroi_pm backward: null pointer");
+  DTT_REQUIRE(!add_cols || (add_first >= 0 && add_count > 0 && add_first + add_count <= row_floats), "psroi_pm backward: added columns outside the row");
+  DTT_REQUIRE(pooled == 7, "psroi_pm backward: pooled size %d not instantiated (7)", pooled);
+  PmBwd a;
+  a.gv0 = grad_vote0; a.gv1 = grad_vote1; a.od0 = output_dim0; a.cp0 = cp0; a.od1 = output_dim1; a.cp1 = cp1;
+  a.rois = rois; a.num_rois = num_rois; a.spatial_scale = spatial_scale; a.batch_size = batch_size;
+  a.height = height; a.width = width; a.pixel_stride = pixel_stride;
+  a.row_floats = row_floats; a.add = add_cols; a.add_first = add_first; a.add_count = add_count; a.gmap = grad_map;
+  // RoIs staged per chunk: the per-image share when callers list the same number per image (training: 128), more chunks otherwise
+  const int per_image = dtt_cdiv(num_rois > 0 ? num_rois : 1, batch_size);
+  a.cap = std::min(64 * kMaxRounds, dtt_cdiv(per_image, 64) * 64);
+  a.per_image = per_image;
+  static const int env_nw = getenv("DTT_PSROI_BWD_WAVES") ? atoi(getenv("DTT_PSROI_BWD_WAVES")) : 0;   // developer sweeps
+  const int acc_floats = (row_floats + 3) & ~3;
+  const size_t shared = ((size_t)a.cap * (cp0 + cp1) + (size_t)(2 * pooled + 2) * a.cap + kWTab + 2) * 4;
+  auto lds_of = [&](int nw) { return (size_t)nw * (acc_floats + 2 * kListCap) * 4 + shared; };
+  // (16 waves share one staged chunk; a call with a handful of RoIs -- the tracking head -- has nothing to share and starts sooner as
+  //  small workgroups: 14.3 -> 9.8 us for its 5092 pixels)
+  int nw = env_nw ? env_nw : (num_rois <= 64 ? 4 : 16);
+  DTT_REQUIRE(nw == 4 || nw == 8 || nw == 16, "psroi_pm backward: DTT_PSROI_BWD_WAVES must be 4, 8 or 16");
+  if (a.cap > 128 && nw == 16) nw = 8;   // (four rounds of RoIs in registers: more than what 16 waves leave each lane)
+  while (nw > 4 && lds_of(nw) > 160 * 1024) nw >>= 1;
+  DTT_REQUIRE(lds_of(nw) <= 160 * 1024, "psroi_pm backward: row of %d floats does not fit LDS", row_floats);
+  // pixels per wave: one round of workgroups over the CUs (what fits a CU at once), so the prologue is paid once
+  const int hw = height * width;
+  const int cus = dtt_device_cus();
+  const int wg_per_cu = (int)std::max((size_t)1, std::min((size_t)(2048 / (nw * 64)), (size_t)(160 * 1024) / lds_of(nw)));
+  static const int env_ppw = getenv("DTT_PSROI_BWD_PPW") ? atoi(getenv("DTT_PSROI_BWD_PPW")) : 0;
+  const long slots = (long)cus * wg_per_cu * nw;
+  a.ppw = env_ppw > 0 ? env_ppw : std::max(1, dtt_cdiv((long)batch_size * hw, slots));
+  a.wgs_per_image = dtt_cdiv(hw, nw * a.ppw);
+  static const int env_ablate = getenv("DTT_PSROI_BWD_ABLATE") ? atoi(getenv("DTT_PSROI_BWD_ABLATE")) : 0;
+  a.ablate = env_ablate;
+  dtt_prof_begin("psroi_pm_bwd", stream);   // (event tag: the one launch)
+  int ok;
+  const int nr = a.cap / 64;   // 1, 2, 3 (run as 4) or 4 rounds of 64 RoIs per chunk
+#define DTT_PMB_ROWS(NWV)                                                                              \
+  (nr == 1 ? launch_rows<7, NWV, 1>(a, batch_size, lds_of(nw), stream)                                  \
+           : nr == 2 ? launch_rows<7, NWV, 2>(a, batch_size, lds_of(nw), stream) : launch_rows<7, NWV, 4>(a, batch_size, lds_of(nw), stream))
+  if (nw == 16) ok = DTT_PMB_ROWS(16);
+  else if (nw == 8) ok = DTT_PMB_ROWS(8);
+  else ok = DTT_PMB_ROWS(4);
+#undef DTT_PMB_ROWS
+  if (!ok) return 0;
+  dtt_prof_end("psroi_pm_bwd", stream);
+  DTT_CHECK_LAUNCH("psroi_pm_bwd");
+  return 1;
+}
+
+// One head (the ABI of rounds 4 - 5): columns [0, pooled^2 * cp) of every pixel.
+extern "C" int dtt_psroi_pm_backward(const float* grad_vote, const float* rois, int num_rois, int batch_size, int height, int width,
+                                     int pooled, float spatial_scale, int output_dim, int cp, long pixel_stride, float* grad_map,
+                                     int* edges, void* stream_) {
+  const char* env_old = getenv("DTT_PSROI_BWD_OLD");   // (read per call: the A/B test flips it inside one process)
+  const bool old = env_old && atoi(env_old) != 0;
+  if (old || pooled != 7)
+    return dtt_psroi_pm_backward_old(grad_vote, rois, num_rois, batch_size, height, width, pooled, spatial_scale, output_dim, cp, pixel_stride,
+                                     grad_map, edges, static_cast<hipStream_t>(stream_));
+  return dtt_psroi_pm_backward_heads(grad_vote, output_dim, cp, nullptr, 0, 0, rois, num_rois, batch_size, height, width, pooled, spatial_scale,
+                                     pixel_stride, pooled * pooled * cp, nullptr, 0, 0, grad_map, stream_);
+}

@@ -78,6 +78,7 @@ SIGNATURES = {
     "dtt_gemm_batched_tune": (_I, [_P, _P, _P, _I, _L, _I, _I, _P, _Z, _P]),
     "dtt_head_gemm": (_I, [_P, _L, _I, _I, _P, _P, _I, _P, _L, _I, _I, _P]),
     "dtt_psroi_pm_backward": (_I, [_P, _P, _I, _I, _I, _I, _I, _F, _I, _I, _L, _P, _P, _P]),
+    "dtt_psroi_pm_backward_heads": (_I, [_P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _F, _L, _I, _P, _I, _I, _P, _P]),
     "dtt_rpn_head_gemm": (_I, [_P, _L, _I, _I, _I, _P, _P, _I, _I, _P, _P, _P]),
     "dtt_rpn_head_grad_rows": (_I, [_P, _P, _P, _I, _I, _I, _P, _L, _I, _P]),
     "dtt_rpn_loss_workspace_bytes": (_Z, [_I, _I]),

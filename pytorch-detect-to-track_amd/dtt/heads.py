@@ -305,23 +305,41 @@ class PsroiPmFn(torch.autograd.Function):
         batch, height, width, scale, heads, M, stride = ctx.geom
         dev = rois.device
         gmap = torch.empty((M, stride), dtype=torch.float32, device=dev)
-        covered = 0
         R = rois.shape[0]
+        L = _lib.lib()
+        add = gvotes[len(heads)] if ctx.extract is not None else None
+        tiled = all(h["offset"] == sum(g["group"] ** 2 * g["cp"] for g in heads[:i]) for i, h in enumerate(heads))
+        assert tiled, "heads must tile the row from column 0"
+        if len(heads) <= 2 and all(h["group"] == 7 for h in heads) and sum(h["cp"] for h in heads) <= 64:
+            # one launch for the heads of the map (one wave per pixel, the padding columns and the second consumer's gradient in the
+            # same pass): csrc/psroi_bwd.hip
+            gvs = [torch.zeros((R, h["od"]), dtype=torch.float32, device=dev) if gv is None else gv.contiguous()
+                   for h, gv in zip(heads, gvotes[:len(heads)])]
+            h0, h1 = heads[0], heads[1] if len(heads) == 2 else None
+            if add is not None:
+                add = add.contiguous()
+            with torch.cuda.device(dev):
+                check(L.dtt_psroi_pm_backward_heads(ptr(gvs[0]), h0["od"], h0["cp"], ptr(gvs[1]) if h1 else None, h1["od"] if h1 else 0,
+                                                    h1["cp"] if h1 else 0, ptr(rois), R, batch, height, width, 7, scale, stride, stride,
+                                                    ptr(add) if add is not None else None, ctx.extract[0] if add is not None else 0,
+                                                    ctx.extract[1] if add is not None else 0, ptr(gmap), stream_ptr(dev)),
+                      "psroi_pm backward (heads)")
+            return gmap, None, None, None, None, None, None, None
+        covered = 0
         with torch.cuda.device(dev):
             for h, gv in zip(heads, gvotes[:len(heads)]):
                 G, cp, od = h["group"], h["cp"], h["od"]
-                assert h["offset"] == covered, "heads must tile the row from column 0"
                 covered += G * G * cp
                 gv = torch.zeros((R, od), dtype=torch.float32, device=dev) if gv is None else gv.contiguous()
                 edges = torch.empty((max(R, 1) * (4 * G + 1) + 2 * batch,), dtype=torch.int32, device=dev)   # bin edges + per-image RoI runs
-                check(_lib.lib().dtt_psroi_pm_backward(ptr(gv), ptr(rois), R, batch, height, width, G, scale, od, cp, stride,
-                                                       ctypes.c_void_p(gmap.data_ptr() + 4 * h["offset"]), ptr(edges),
-                                                       stream_ptr(dev)), "psroi_pm backward")
+                check(L.dtt_psroi_pm_backward(ptr(gv), ptr(rois), R, batch, height, width, G, scale, od, cp, stride,
+                                              ctypes.c_void_p(gmap.data_ptr() + 4 * h["offset"]), ptr(edges),
+                                              stream_ptr(dev)), "psroi_pm backward")
         if covered < stride:
             gmap[:, covered:].zero_()
-        if ctx.extract is not None and gvotes[len(heads)] is not None:
+        if add is not None:
             c0, nc = ctx.extract
-            gmap[:, c0:c0 + nc] += gvotes[len(heads)]
+            gmap[:, c0:c0 + nc] += add
         return gmap, None, None, None, None, None, None, None
 
 

@@ -1,6 +1,8 @@
 """Hand-written R-FCN heads (exact-fp32 MFMA GEMM, position-major output) and the lanes = classes PSRoI pooling
 (csrc/heads.hip) through the C ABI: head output against F.conv2d in fp32 (1e-4), pooled bins and votes bit-identical
 to the CPU oracle on the same map.  Needs an MI355X."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -247,6 +249,113 @@ def test_psroi_pm_backward_matches_oracle(dev, B, H, W, R):
     votes = PsroiPmFn.apply(pm, rt, B, H, W, 1 / 16.0, heads)
     torch.autograd.backward(votes, [torch.from_numpy(g).to(dev) for g in gv])
     assert torch.equal(pm.grad, gm)
+
+
+def _pm_bwd_heads(dev, gvs, heads, rois, B, H, W, stride, row_floats, add=None, add_first=0):
+    """dtt_psroi_pm_backward_heads through the C ABI into a NaN-filled map (every column it owns must be written)."""
+    import ctypes
+    from dtt import _lib
+    from dtt._lib import check, ptr, stream_ptr
+    L = _lib.lib()
+    R = rois.shape[0]
+    gmap = torch.full((B * H * W, stride), float("nan"), dtype=torch.float32, device=dev)
+    h0, h1 = heads[0], heads[1] if len(heads) == 2 else None
+    with torch.cuda.device(dev):
+        check(L.dtt_psroi_pm_backward_heads(ptr(gvs[0]), h0["od"], h0["cp"], ptr(gvs[1]) if h1 else None, h1["od"] if h1 else 0,
+                                            h1["cp"] if h1 else 0, ptr(rois), R, B, H, W, 7, 1 / 16.0, stride, row_floats,
+                                            ptr(add) if add is not None else None, add_first, add.shape[1] if add is not None else 0,
+                                            ptr(gmap), stream_ptr(dev)), "psroi_pm backward (heads)")
+    return gmap
+
+
+def _pm_bwd_single(dev, gv, head, rois, B, H, W, stride, old):
+    """dtt_psroi_pm_backward for one head; old = the one-workgroup-per-pixel kernel of rounds 4 - 5 (DTT_PSROI_BWD_OLD=1)."""
+    import ctypes
+    from dtt import _lib
+    from dtt._lib import check, ptr, stream_ptr
+    L = _lib.lib()
+    R = rois.shape[0]
+    gmap = torch.full((B * H * W, stride), float("nan"), dtype=torch.float32, device=dev)
+    edges = torch.empty((max(R, 1) * 29 + 2 * B,), dtype=torch.int32, device=dev)
+    prev = os.environ.get("DTT_PSROI_BWD_OLD")
+    os.environ["DTT_PSROI_BWD_OLD"] = "1" if old else "0"
+    try:
+        with torch.cuda.device(dev):
+            check(L.dtt_psroi_pm_backward(ptr(gv), ptr(rois), R, B, H, W, 7, 1 / 16.0, head["od"], head["cp"], stride,
+                                          ctypes.c_void_p(gmap.data_ptr() + 4 * head["offset"]), ptr(edges), stream_ptr(dev)), "psroi_pm backward")
+        torch.cuda.synchronize(dev)
+    finally:
+        if prev is None:
+            del os.environ["DTT_PSROI_BWD_OLD"]
+        else:
+            os.environ["DTT_PSROI_BWD_OLD"] = prev
+    return gmap
+
+
+@pytest.mark.parametrize("B,H,W,R,kind", [
+    (4, 38, 67, 512, "train"),        # the training step: 128 RoIs per image, one staged chunk, two rounds of 64
+    (2, 38, 67, 16, "few"),           # the tracking head's handful of RoIs
+    (1, 38, 67, 700, "chunks"),       # more RoIs per image than one chunk holds (3 chunks of 256): workgroup-synchronised restaging
+    (2, 10, 12, 400, "tiny"),         # tiny RoIs: all 49 bins of each cover the same pixels -> the list overflows, serial walk
+    (3, 12, 9, 200, "unsorted"),      # RoIs of the images interleaved (an image's run contains other images' RoIs)
+    (2, 9, 11, 0, "none"),
+])
+def test_psroi_pm_backward_heads_one_launch(dev, B, H, W, R, kind):
+    """dtt_psroi_pm_backward_heads (csrc/psroi_bwd.hip: one wave per pixel, class + box heads in one launch, padding columns and the
+    added compact gradient in the same pass) against (a) the oracle's PSROIPoolBackward (psroi_pooling_kernel.cu:109-170) fed the
+    AvgPool2d gradient (rfcn.py:62-64) at 1e-5, (b) the one-workgroup-per-pixel kernel of rounds 4 - 5 head by head, BIT for bit (same
+    RoI order of the adds), (c) itself run twice.  Cases: one chunk / several chunks of staged RoIs, list overflow, interleaved images,
+    zero-gradient RoIs (skipped), a row length that is not a multiple of 4 (scalar write-out), no RoIs."""
+    from dtt.heads import pm_to_nchw
+    rng = np.random.RandomState(R + H)
+    heads = [dict(offset=0, cp=32, od=31, group=7), dict(offset=49 * 32, cp=4, od=4, group=7)]
+    stride = 1792
+    if R:
+        rois = _rois(rng, R, B, H, W)
+        if kind == "tiny":
+            cx, cy = rng.randint(0, W * 16 - 8, size=R), rng.randint(0, H * 16 - 8, size=R)
+            rois[:, 1], rois[:, 2] = cx, cy
+            rois[:, 3], rois[:, 4] = cx + rng.randint(0, 3, size=R), cy + rng.randint(0, 3, size=R)
+            rois[: R // 2, 1:] = np.array([33, 17, 34, 18], np.float32)          # 200 RoIs on one pixel: 9800 list entries for it
+        if kind == "unsorted":
+            rois[:, 0] = rng.randint(0, B, size=R)
+        else:
+            rois[:, 0] = np.sort(rois[:, 0])
+    else:
+        rois = np.zeros((0, 5), np.float32)
+    gv = [rng.normal(size=(R, h["od"])).astype(np.float32) for h in heads]
+    if R:
+        gv[1][rng.rand(R) < 0.75] = 0            # background RoIs: no box gradient
+        dead = rng.rand(R) < 0.1
+        gv[0][dead] = 0; gv[1][dead] = 0         # rows that are zero in both heads: given to no image
+    rt = torch.from_numpy(rois).to(dev)
+    gvt = [torch.from_numpy(g).to(dev) for g in gv]
+    add = torch.from_numpy(rng.normal(size=(B * H * W, 196)).astype(np.float32)).to(dev)
+    gm = _pm_bwd_heads(dev, gvt, heads, rt, B, H, W, stride, stride, add, 49 * 32)
+    assert bool((gm[:, 49 * 36:] == 0).all()), "padding columns behind the heads"
+    assert torch.equal(gm, _pm_bwd_heads(dev, gvt, heads, rt, B, H, W, stride, stride, add, 49 * 32)), "run to run"
+    plain = _pm_bwd_heads(dev, gvt, heads, rt, B, H, W, stride, 49 * 36)
+    assert bool(torch.isnan(plain[:, 49 * 36:]).all()), "columns past row_floats must not be written"
+    want_add = plain[:, :49 * 36].clone()
+    want_add[:, 49 * 32:] += add
+    assert torch.equal(gm[:, :49 * 36], want_add), "added compact gradient"
+    for h, g, gt in zip(heads, gv, gvt):
+        od = h["od"]
+        top_diff = np.repeat((g / np.float32(49.0)).reshape(R, od, 1, 1), 49, axis=2).reshape(R, od, 7, 7).astype(np.float32)
+        want = O.psroi_pool_backward(top_diff, rois, (B, od * 49, H, W), 7, 7, 1 / 16.0, 7, od) if R else np.zeros((B, od * 49, H, W), np.float32)
+        got = pm_to_nchw(plain, h, B, H, W).cpu().numpy()
+        np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5 * max(1.0, float(np.abs(want).max())))
+        cols = slice(h["offset"], h["offset"] + 49 * h["cp"])
+        old = _pm_bwd_single(dev, gt, h, rt, B, H, W, stride, old=True)
+        assert torch.equal(plain[:, cols], old[:, cols]), "one-launch kernel vs the per-pixel-workgroup kernel, head od=%d" % od
+        new1 = _pm_bwd_single(dev, gt, h, rt, B, H, W, stride, old=False)
+        assert torch.equal(new1[:, cols], old[:, cols]), "single-head entry on the wave-per-pixel kernel"
+    # a row that is not a multiple of four floats (scalar write-out), one head
+    h = dict(offset=0, cp=4, od=3, group=7)
+    g3 = torch.from_numpy(rng.normal(size=(R, 3)).astype(np.float32)).to(dev)
+    odd = _pm_bwd_heads(dev, [g3], [h], rt, B, H, W, 203, 197)
+    ref = _pm_bwd_single(dev, g3, h, rt, B, H, W, 203, old=True)
+    assert torch.equal(odd[:, :196], ref[:, :196]) and bool((odd[:, 196] == 0).all()) and bool(torch.isnan(odd[:, 197:]).all())
 
 
 @pytest.mark.parametrize("M,N,K,g_cols", [(10184, 1776, 512, 1792), (1000, 100, 36, 128), (33, 17, 4, 20), (4097, 300, 132, 320),

@@ -11,14 +11,17 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def test_rfcn_forward_contract_and_parity():
+@pytest.mark.parametrize("layers,B,H,W", [(50, 2, 224, 320),
+                                          (101, 1, 600, 1067)])   # BASELINE configs[2]'s network and frame size, one pair (the cpu_baseline leg's graph)
+def test_rfcn_forward_contract_and_parity(layers, B, H, W):
+    """The whole inference graph on the GPU against the CPU restatement of the reference graph (oracle/cpu_graph.py: torch CPU
+    convolutions + the oracle's ops) on the same weights and frames -- at a small size and ONCE at Res-101 600 x 1067."""
     from dtt.config import apply_dataset_defaults, cfg
     from dtt.synth import build_model, calibrate_batchnorm_, make_batch
     from oracle import cpu_graph
     apply_dataset_defaults("imagenet_vid")
     dev = torch.device("cuda:0")
-    B, H, W = 2, 224, 320
-    model = build_model(50, cfg=cfg).eval()
+    model = build_model(layers, cfg=cfg).eval()
     im, info, gt, nb = make_batch(B, H, W, seed=5)
     calibrate_batchnorm_(model, im[:, 0])
     ref = cpu_graph.rfcn_forward_test(model, im, info, cfg)
