@@ -57,6 +57,8 @@ struct PmBwd {
   int per_image;                           // ceil(num_rois / batch_size): where image b's RoIs start when every image lists as many
   int ppw;                                 // pixels per wave
   int wgs_per_image;
+  unsigned width_magic, wpi_magic;         // 2^32 / width + 1, 2^32 / wgs_per_image + 1 (0: divide)
+  int rowtab;                              // the row-range table applies (map rows of at least NW pixels) and fits LDS
   int ablate;                              // developer timing experiments (DTT_PSROI_BWD_ABLATE): 1 no listing, 2 no list walk, 4 no stores, 8 prologue only
 };
 
@@ -69,6 +71,10 @@ __device__ __forceinline__ int wave_incl_scan(int x) {
   x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);
   x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);
   return x;
+}
+// n / d through magic = 2^32 / d + 1 (exact while n * d < 2^32: the launcher passes 0 otherwise, and the division is done)
+__device__ __forceinline__ int mdiv(int n, int d, unsigned magic) {
+  return magic ? (int)(((unsigned long long)(unsigned)n * magic) >> 32) : n / d;
 }
 __device__ __forceinline__ int sgpr(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ float sgprf(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
@@ -90,20 +96,27 @@ __global__ __launch_bounds__(NW * 64) void psroi_pm_bwd_rows_kernel(PmBwd a) {
   const int cap = a.cap;
   // LDS: [per wave: accumulator row | list] [gradient rows cap x gvw] [row edges P x cap] [column edges P x cap] [non-zero flags cap] [own-image flags cap] [weights] [run]
   const int acc_floats = (a.row_floats + 3) & ~3;
-  float* acc = smem + (long)wave * (acc_floats + 2 * kListCap);
+  float* acc = smem + (long)wave * (acc_floats + 2 * kListCap + 4);
   int* list_rb = reinterpret_cast<int*>(acc + acc_floats);
   float* list_w = acc + acc_floats + kListCap;
-  float* gvs = smem + (long)NW * (acc_floats + 2 * kListCap);
+  float* gvs = smem + (long)NW * (acc_floats + 2 * kListCap + 4);
   int* erow = reinterpret_cast<int*>(gvs + (long)cap * gvw);
   int* ecol = erow + P * cap;
   int* eimg = ecol + P * cap;
   int* eown = eimg + cap;                                 // [cap]: the RoI row belongs to this workgroup's image
   float* wtab = reinterpret_cast<float*>(eown + cap);
+  // [ppw][2][cap] bytes (a.rowtab): the row range lo | hi1 << 4 of every staged RoI at the (at most two) map rows that hold the
+  // workgroup's NW consecutive pixels of round `it`
+  unsigned char* rowtab = reinterpret_cast<unsigned char*>(wtab + kWTab + 2);
   int* run = reinterpret_cast<int*>(wtab + kWTab);       // [2]: the image's run of RoI rows
 
-  const int b = blockIdx.x / a.wgs_per_image;
+  const int b = mdiv(blockIdx.x, a.wgs_per_image, a.wpi_magic);
   const int hw = a.height * a.width;
-  const int p_first = (blockIdx.x - b * a.wgs_per_image) * (NW * a.ppw) + wave * a.ppw;   // this wave's pixel run in image b
+  // Pixels are dealt to the waves of an image ROUND ROBIN (wave j of the image's wgs_per_image * NW waves takes pixels j, j + waves, ...): the
+  // RoIs crowd the middle of the map, and a wave that owned consecutive pixels there worked 2.3 x as long as one at the border (workgroup
+  // lifetimes 14.7 .. 34.1 us, median 23.8: profiles/r06_psroi_bwd_timeline_before.txt) -- a wave's pixels now lie a third of the map apart.
+  const int p_first = (blockIdx.x - b * a.wgs_per_image) * NW + wave;
+  const int p_step = a.wgs_per_image * NW;
   const float inv_bins = 1.f / (float)(P * P);
   const bool col_on = lane < gvw;
 
@@ -143,6 +156,33 @@ __global__ __launch_bounds__(NW * 64) void psroi_pm_bwd_rows_kernel(PmBwd a) {
       }
     }
   };
+  // Row range of every staged RoI at the rows this workgroup's pixels lie in (a wave's pixels jump from row to row: 14 LDS reads + 60
+  // vector instructions per pixel otherwise): round `it` takes the NW consecutive pixels from wg_p0 + it * p_step on, i.e. the row of
+  // the first one and possibly the next.  Needs the staged edges: call behind a barrier, and put one behind it.
+  const int wg_p0 = (blockIdx.x - b * a.wgs_per_image) * NW;
+  const int wg_h0 = mdiv(wg_p0, a.width, a.width_magic), wg_w0 = wg_p0 - wg_h0 * a.width;
+  const int step_h = mdiv(p_step, a.width, a.width_magic), step_w = p_step - step_h * a.width;
+  auto build_rowtab = [&](int n) {
+    if (!a.rowtab) return;
+#pragma unroll 1
+    for (int slot = wave; slot < 2 * a.ppw; slot += NW) {
+      const int it = slot >> 1;
+      const int hh = wg_h0 + it * step_h + mdiv(wg_w0 + it * step_w, a.width, a.width_magic) + (slot & 1);
+#pragma unroll 1
+      for (int r = lane; r < cap; r += 64) {
+        int lo = 0, hi1 = 0;
+        if (r < n) {
+#pragma unroll
+          for (int k = 0; k < P; ++k) {
+            const int e = erow[k * cap + r];
+            hi1 += (e & 0xffff) <= hh ? 1 : 0;     // starts <= h: a prefix of the bins
+            lo += (e >> 16) <= hh ? 1 : 0;         // ends <= h: the bins before the first one that still contains h
+          }
+        }
+        rowtab[slot * cap + r] = (unsigned char)(lo | (hi1 << 4));
+      }
+    }
+  };
   // ---- the run [r_first, r_end) of RoI rows that holds this image's RoIs (callers list their RoIs image by image: the run is the
   //      image's own RoIs; rows of other images inside it are masked), the weight table, the zeroed accumulator.  Callers that list
   //      the same number of RoIs per image (training) have image b's run at b * per_image: that chunk is staged WHILE the run is
@@ -155,14 +195,20 @@ __global__ __launch_bounds__(NW * 64) void psroi_pm_bwd_rows_kernel(PmBwd a) {
   PB_STAMP(1);
   const int guess_c0 = min(b * a.per_image, a.num_rois), guess_n = min(cap, a.num_rois - guess_c0);
   {
+    // (one LDS atomic pair per WAVE, from the ballot of its lanes' rows: 64 lanes on one address took 10 k cycles in front of barrier 2)
     int lo = a.num_rois, hi = 0;
-    for (int r = tid; r < a.num_rois; r += NW * 64)
-      if (min(max((int)a.rois[(long)r * 5], 0), a.batch_size - 1) == b) { lo = min(lo, r); hi = r + 1; }   // (the forward's clamp)
+    for (int r0 = wave * 64; r0 < a.num_rois; r0 += NW * 64) {
+      const int r = r0 + lane;
+      const bool own = r < a.num_rois && min(max((int)a.rois[(long)min(r, a.num_rois - 1) * 5], 0), a.batch_size - 1) == b;   // (the forward's clamp)
+      const unsigned long long m = __ballot(own);
+      if (m) { lo = min(lo, r0 + (int)__builtin_ctzll(m)); hi = max(hi, r0 + 64 - (int)__builtin_clzll(m)); }
+    }
     if (guess_n > 0) stage(guess_c0, guess_n);
-    if (hi > 0) { atomicMin(&run[0], lo); atomicMax(&run[1], hi); }
+    if (hi > 0 && lane == 0) { atomicMin(&run[0], lo); atomicMax(&run[1], hi); }
   }
   PB_STAMP(2);
   __syncthreads();
+  if (guess_n > 0) build_rowtab(guess_n);
   PB_STAMP(3);
   int r_first = run[0], r_end = run[1];
   const bool guessed = r_end > r_first && guess_n > 0 && r_first >= guess_c0 && r_end <= guess_c0 + guess_n;
@@ -170,71 +216,65 @@ __global__ __launch_bounds__(NW * 64) void psroi_pm_bwd_rows_kernel(PmBwd a) {
   const int nchunks = guessed ? 1 : r_end > r_first ? (r_end - r_first + cap - 1) / cap : 0;
 
   // lane = column of the accumulator row in phase 2
-  char* const acc_lane = reinterpret_cast<char*>(acc + (lane < a.cp0 ? lane : P * P * a.cp0 + (lane - a.cp0)));
-  const unsigned col_mul4 = 4u * (lane < a.cp0 ? a.cp0 : a.cp1);
+  // (lanes past the heads' columns add into a spare word behind the wave's list: straight-line code instead of four exec-mask regions per batch)
+  char* const acc_lane = reinterpret_cast<char*>(!col_on ? acc + acc_floats + 2 * kListCap : acc + (lane < a.cp0 ? lane : P * P * a.cp0 + (lane - a.cp0)));
+  const unsigned col_mul4 = !col_on ? 0u : 4u * (lane < a.cp0 ? a.cp0 : a.cp1);
   const float* const gv_lane = gvs + (col_on ? lane : 0);
 
   int cw[NR][P];                  // column edges of lane's RoIs (packed), per round of 64 RoIs
   int prow[NR];                   // row range of lane's RoIs at the current map row: lo | hi1 << 4 (hi1 = hi + 1; lo >= hi1: none)
   int cur_h = -1;
 
-  // one entry: accumulator[bin][lane's column] += gradient row[lane's column] * weight (the entry is wave-uniform: unpacked on the scalar unit)
-  auto apply1 = [&](int rb, float w) {
-    const int s = sgpr(rb);
-    const float sw = sgprf(w);
-    if (col_on) {
-      float* ap = reinterpret_cast<float*>(acc_lane + __umul24((unsigned)(s >> 8), col_mul4));
-      *ap += gv_lane[(s & 0xff) * gvw] * sw;
-    }
+  // The list in order (= RoI order): each lane takes ONE entry of the next 64 into registers (one LDS read for 64 entries; a broadcast
+  // read per entry cost as many LDS cycles as the accumulation itself) and the entries come back one by one through v_readlane;
+  // accumulator[bin][lane's column] += gradient row[lane's column] * weight, four entries at a time -- read and written together when
+  // their bins differ.  (ds_add_f32 instead of read - add - write keeps the bits and the order and needs no round trip, but the LDS
+  // runs a float atomic at about 1000 cycles per instruction: 48 -> 191 us for the launch.)
+  auto add1 = [&](int s, float sw, float g) {
+    *reinterpret_cast<float*>(acc_lane + __umul24((unsigned)(s >> 8), col_mul4)) += g * sw;
   };
-
-  // the list in order (= RoI order), four entries at a time: the NEXT four entries and their gradient values are fetched while the
-  // accumulator words of the current four make their round trip through LDS (a walk that waits for entry, gradient and accumulator
-  // one after the other was 20 of the launch's 49 us); entries of a batch whose bins differ are read and written together
-  typedef int i32x4 __attribute__((ext_vector_type(4)));
   auto walk = [&](int nl) {
-    int i = 0;
-    if (nl >= 4) {
-      i32x4 e = *reinterpret_cast<const i32x4*>(list_rb);
-      f32x4 wv = *reinterpret_cast<const f32x4*>(list_w);
-      int s0 = sgpr(e[0]), s1 = sgpr(e[1]), s2 = sgpr(e[2]), s3 = sgpr(e[3]);
-      float w0 = sgprf(wv[0]), w1 = sgprf(wv[1]), w2 = sgprf(wv[2]), w3 = sgprf(wv[3]);
-      float g0 = gv_lane[(s0 & 0xff) * gvw], g1 = gv_lane[(s1 & 0xff) * gvw], g2 = gv_lane[(s2 & 0xff) * gvw], g3 = gv_lane[(s3 & 0xff) * gvw];
-      for (;;) {
-        const int in = i + 4;
-        const bool more = in + 4 <= nl;
-        const int ic = more ? in : i;                    // (clamped: the last batch re-reads itself)
-        e = *reinterpret_cast<const i32x4*>(list_rb + ic);
-        wv = *reinterpret_cast<const f32x4*>(list_w + ic);
+#pragma unroll 1
+    for (int base = 0; base < nl; base += 64) {
+      const int mine = min(base + lane, nl - 1);
+      const int e = list_rb[mine];
+      const int ew = __float_as_int(list_w[mine]);
+      const int cnt = min(64, nl - base);
+      int j = 0;
+#pragma unroll 1
+      for (; j + 4 <= cnt; j += 4) {
+        const int s0 = __builtin_amdgcn_readlane(e, j), s1 = __builtin_amdgcn_readlane(e, j + 1);
+        const int s2 = __builtin_amdgcn_readlane(e, j + 2), s3 = __builtin_amdgcn_readlane(e, j + 3);
+        const float g0 = gv_lane[(s0 & 0xff) * gvw], g1 = gv_lane[(s1 & 0xff) * gvw];
+        const float g2 = gv_lane[(s2 & 0xff) * gvw], g3 = gv_lane[(s3 & 0xff) * gvw];
+        const float w0 = __int_as_float(__builtin_amdgcn_readlane(ew, j)), w1 = __int_as_float(__builtin_amdgcn_readlane(ew, j + 1));
+        const float w2 = __int_as_float(__builtin_amdgcn_readlane(ew, j + 2)), w3 = __int_as_float(__builtin_amdgcn_readlane(ew, j + 3));
         const int b0 = s0 >> 8, b1 = s1 >> 8, b2 = s2 >> 8, b3 = s3 >> 8;
         const bool distinct = b0 != b1 && b0 != b2 && b0 != b3 && b1 != b2 && b1 != b3 && b2 != b3;   // scalar unit
-        if (col_on) {
-          float* a0 = reinterpret_cast<float*>(acc_lane + __umul24((unsigned)b0, col_mul4));
-          float* a1 = reinterpret_cast<float*>(acc_lane + __umul24((unsigned)b1, col_mul4));
-          float* a2 = reinterpret_cast<float*>(acc_lane + __umul24((unsigned)b2, col_mul4));
-          float* a3 = reinterpret_cast<float*>(acc_lane + __umul24((unsigned)b3, col_mul4));
-          if (distinct) {
-            const float v0 = *a0, v1 = *a1, v2 = *a2, v3 = *a3;
-            *a0 = v0 + g0 * w0; *a1 = v1 + g1 * w1; *a2 = v2 + g2 * w2; *a3 = v3 + g3 * w3;
-          } else {
-            *a0 += g0 * w0; *a1 += g1 * w1; *a2 += g2 * w2; *a3 += g3 * w3;
-          }
+        float* a0 = reinterpret_cast<float*>(acc_lane + __umul24((unsigned)b0, col_mul4));
+        float* a1 = reinterpret_cast<float*>(acc_lane + __umul24((unsigned)b1, col_mul4));
+        float* a2 = reinterpret_cast<float*>(acc_lane + __umul24((unsigned)b2, col_mul4));
+        float* a3 = reinterpret_cast<float*>(acc_lane + __umul24((unsigned)b3, col_mul4));
+        if (distinct) {
+          const float v0 = *a0, v1 = *a1, v2 = *a2, v3 = *a3;
+          *a0 = v0 + g0 * w0; *a1 = v1 + g1 * w1; *a2 = v2 + g2 * w2; *a3 = v3 + g3 * w3;
+        } else {
+          *a0 += g0 * w0; *a1 += g1 * w1; *a2 += g2 * w2; *a3 += g3 * w3;
         }
-        i = in;
-        if (!more) break;
-        s0 = sgpr(e[0]); s1 = sgpr(e[1]); s2 = sgpr(e[2]); s3 = sgpr(e[3]);
-        w0 = sgprf(wv[0]); w1 = sgprf(wv[1]); w2 = sgprf(wv[2]); w3 = sgprf(wv[3]);
-        g0 = gv_lane[(s0 & 0xff) * gvw]; g1 = gv_lane[(s1 & 0xff) * gvw]; g2 = gv_lane[(s2 & 0xff) * gvw]; g3 = gv_lane[(s3 & 0xff) * gvw];
+      }
+#pragma unroll 1
+      for (; j < cnt; ++j) {
+        const int s0 = __builtin_amdgcn_readlane(e, j);
+        add1(s0, __int_as_float(__builtin_amdgcn_readlane(ew, j)), gv_lane[(s0 & 0xff) * gvw]);
       }
     }
-    for (; i < nl; ++i) apply1(list_rb[i], list_w[i]);
   };
 
-  int h = p_first / a.width, w = p_first - h * a.width - 1;      // (the wave's pixels are consecutive: one division per wave)
+  int h = mdiv(p_first, a.width, a.width_magic), w = p_first - h * a.width;          // (no division per pixel)
   for (int it = 0; it < a.ppw; ++it) {
-    const int p = p_first + it;
+    const int p = p_first + it * p_step;
     const bool valid = p < hw;
-    if (++w == a.width) { w = 0; ++h; }
+    if (it > 0) { h += step_h; w += step_w; if (w >= a.width) { w -= a.width; ++h; } }
     int nlist = 0;
     // the compact gradient of the pixel is requested now and added in front of the write-out (it sat on the critical path of every
     // pixel as a dependent global load: 1.8 k of a pixel's 6 k cycles)
@@ -255,6 +295,10 @@ __global__ __launch_bounds__(NW * 64) void psroi_pm_bwd_rows_kernel(PmBwd a) {
           __syncthreads();
           stage(c0, n);
           __syncthreads();
+          build_rowtab(n);
+          __syncthreads();
+        } else if (a.rowtab) {
+          __syncthreads();          // (the table of the chunk staged in the prologue)
         }
         // A RoI whose gradient rows are all zeros adds nothing anywhere (background RoIs in the box head; the zero-padded ground-truth
         // rows of the tracking RoIs -- (0,0,0,0) boxes whose 49 bins ALL cover pixel (0, 0)): it belongs to no image
@@ -275,6 +319,11 @@ __global__ __launch_bounds__(NW * 64) void psroi_pm_bwd_rows_kernel(PmBwd a) {
         for (int rd = 0; rd < NR; ++rd) {
           const int rl = min(rd * 64 + lane, cap - 1);
           int lo = 0, hi1 = 0;
+          if (a.rowtab) {
+            const int row0 = wg_h0 + it * step_h + mdiv(wg_w0 + it * step_w, a.width, a.width_magic);   // (scalar unit)
+            prow[rd] = rd * 64 < n ? rowtab[(2 * it + (h - row0)) * cap + rl] : 0;
+            continue;
+          }
           if (rd * 64 < n) {
 #pragma unroll
             for (int k = 0; k < P; ++k) {
@@ -349,7 +398,7 @@ __global__ __launch_bounds__(NW * 64) void psroi_pm_bwd_rows_kernel(PmBwd a) {
               for (int pw = s_qlo; pw < s_qhi1; ++pw) {
                 const int ec = ecol[pw * cap + s_rl];
                 const int area = hgt * ((ec >> 16) - (ec & 0xffff));
-                if (col_on) *reinterpret_cast<float*>(acc_lane + (unsigned)(ph * P + pw) * col_mul4) += g * (inv_bins / (float)area);
+                add1((ph * P + pw) << 8, inv_bins / (float)area, g);
               }
             }
           }
@@ -466,10 +515,8 @@ extern "C" int dtt_psroi_pm_backward_heads(const float* grad_vote0, int output_d
   static const int env_nw = getenv("DTT_PSROI_BWD_WAVES") ? atoi(getenv("DTT_PSROI_BWD_WAVES")) : 0;   // developer sweeps
   const int acc_floats = (row_floats + 3) & ~3;
   const size_t shared = ((size_t)a.cap * (cp0 + cp1) + (size_t)(2 * pooled + 2) * a.cap + kWTab + 2) * 4;
-  auto lds_of = [&](int nw) { return (size_t)nw * (acc_floats + 2 * kListCap) * 4 + shared; };
-  // (16 waves share one staged chunk; a call with a handful of RoIs -- the tracking head -- has nothing to share and starts sooner as
-  //  small workgroups: 14.3 -> 9.8 us for its 5092 pixels)
-  int nw = env_nw ? env_nw : (num_rois <= 64 ? 4 : 16);
+  auto lds_of = [&](int nw) { return (size_t)nw * (acc_floats + 2 * kListCap + 4) * 4 + shared; };
+  int nw = env_nw ? env_nw : 16;
   DTT_REQUIRE(nw == 4 || nw == 8 || nw == 16, "psroi_pm backward: DTT_PSROI_BWD_WAVES must be 4, 8 or 16");
   if (a.cap > 128 && nw == 16) nw = 8;   // (four rounds of RoIs in registers: more than what 16 waves leave each lane)
   while (nw > 4 && lds_of(nw) > 160 * 1024) nw >>= 1;
@@ -480,16 +527,26 @@ extern "C" int dtt_psroi_pm_backward_heads(const float* grad_vote0, int output_d
   const int wg_per_cu = (int)std::max((size_t)1, std::min((size_t)(2048 / (nw * 64)), (size_t)(160 * 1024) / lds_of(nw)));
   static const int env_ppw = getenv("DTT_PSROI_BWD_PPW") ? atoi(getenv("DTT_PSROI_BWD_PPW")) : 0;
   const long slots = (long)cus * wg_per_cu * nw;
-  a.ppw = env_ppw > 0 ? env_ppw : std::max(1, dtt_cdiv((long)batch_size * hw, slots));
+  // (at least two pixels per wave: every workgroup pays the same prologue, and a launch whose pixels are cheap -- the tracking head's
+  //  handful of RoIs -- is all prologue: 16.2 us as 1274 four-wave workgroups of one pixel per wave, 12.5 us as 160 of these)
+  a.ppw = env_ppw > 0 ? env_ppw : std::max(2, dtt_cdiv((long)batch_size * hw, slots));
   a.wgs_per_image = dtt_cdiv(hw, nw * a.ppw);
+  a.ppw = dtt_cdiv(hw, nw * a.wgs_per_image);       // (round robin: the rounds that reach a pixel)
   static const int env_ablate = getenv("DTT_PSROI_BWD_ABLATE") ? atoi(getenv("DTT_PSROI_BWD_ABLATE")) : 0;
   a.ablate = env_ablate;
+  const long n_max = std::max((long)hw + (long)nw * a.wgs_per_image, (long)batch_size * a.wgs_per_image);
+  a.width_magic = n_max * width < (1L << 32) && width > 1 ? (unsigned)((1ULL << 32) / (unsigned)width + 1) : 0u;
+  a.wpi_magic = n_max * a.wgs_per_image < (1L << 32) && a.wgs_per_image > 1 ? (unsigned)((1ULL << 32) / (unsigned)a.wgs_per_image + 1) : 0u;
+  // (the row-range table: the workgroup's NW consecutive pixels of a round must lie in at most two map rows)
+  const size_t table_b = (size_t)2 * a.ppw * a.cap;
+  a.rowtab = width >= nw && lds_of(nw) + table_b <= 160 * 1024 ? 1 : 0;
+  const size_t lds_total = lds_of(nw) + (a.rowtab ? table_b : 0);
   dtt_prof_begin("psroi_pm_bwd", stream);   // (event tag: the one launch)
   int ok;
   const int nr = a.cap / 64;   // 1, 2, 3 (run as 4) or 4 rounds of 64 RoIs per chunk
 #define DTT_PMB_ROWS(NWV)                                                                              \
-  (nr == 1 ? launch_rows<7, NWV, 1>(a, batch_size, lds_of(nw), stream)                                  \
-           : nr == 2 ? launch_rows<7, NWV, 2>(a, batch_size, lds_of(nw), stream) : launch_rows<7, NWV, 4>(a, batch_size, lds_of(nw), stream))
+  (nr == 1 ? launch_rows<7, NWV, 1>(a, batch_size, lds_total, stream)                                  \
+           : nr == 2 ? launch_rows<7, NWV, 2>(a, batch_size, lds_total, stream) : launch_rows<7, NWV, 4>(a, batch_size, lds_total, stream))
   if (nw == 16) ok = DTT_PMB_ROWS(16);
   else if (nw == 8) ok = DTT_PMB_ROWS(8);
   else ok = DTT_PMB_ROWS(4);

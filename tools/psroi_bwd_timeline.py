@@ -29,7 +29,7 @@ buf = (ctypes.c_ulonglong * 256)()
 L.dtt_psroi_bwd_stamps_read.argtypes = [ctypes.c_void_p, ctypes.c_int]
 assert L.dtt_psroi_bwd_stamps_read(buf, 256)
 st = np.array(buf, dtype=np.uint64).reshape(4, 64).astype(np.int64)
-names = {0: "entry", 1: "init done (sync 1)", 2: "run scan + staging issued", 3: "sync 2", 4: "column edges in registers", 50: "end"}
+names = {44: "run scan issued", 40: "  gradient rows landed (first batch)", 41: "  gradient rows in LDS", 42: "  RoI floats landed", 43: "  bin edges computed", 45: "barrier 2 passed", 0: "entry", 1: "init done (sync 1)", 2: "run scan + staging issued", 3: "sync 2", 4: "column edges in registers", 50: "end"}
 for it in range(4):
     names[5 + 6 * it] = "px %d tests done" % it
     names[6 + 6 * it] = "px %d listed" % it
@@ -44,7 +44,7 @@ for row, label in enumerate(["workgroup 0 wave 0", "workgroup 0 last wave", "mid
     t0 = st[row, 0]
     print("== %s (shader-clock ticks since entry, step)" % label)
     prev = t0
-    for i in sorted(names):
+    for i in sorted(names, key=lambda i: st[row, i]):
         if st[row, i]:
             print("  %-32s %8d  +%6d" % (names[i], st[row, i] - t0, st[row, i] - prev))
             prev = st[row, i]
