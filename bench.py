@@ -223,7 +223,10 @@ def corr_bwd_secondary(op_us, args, model):
     if not getattr(model, "_train_pm", False):
         ops = ops[::-1]
     pmc, pmc_src = measured_traffic("pmc_corr_bwd")
-    same_shape = (args.batch, args.height, args.width, args.disp) == (2, 600, 1067, 8)
+    shape = (args.batch, args.height, args.width, args.disp)
+    # counters are taken at two shapes (tools/profile_round.sh): BASELINE configs[2] / [3]'s and, with the d16_ prefix, configs[4]'s per rank
+    prefix = "" if shape == (2, 600, 1067, 8) else "d16_" if shape == (1, 563, 1000, 16) else None
+    same_shape = prefix is not None
     bw = {}
     for us, (name, C, R, HWc) in zip(op_us, ops):
         D2 = (2 * R + 1) ** 2
@@ -241,14 +244,16 @@ def corr_bwd_secondary(op_us, args, model):
              "mfma": {"achieved": round(mf, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(mf / FP32_MFMA_PEAK_TFLOPS, 4)},
              "hbm": {"achieved": round(hb, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hb / HBM_PEAK_GBS, 4)},
              "algorithmic_flops_per_op": fl, "algorithmic_bytes_per_op": by, "traffic": None}
-        m = (pmc or {}).get(name[:5].replace("corr", "conv"))
+        m = (pmc or {}).get((prefix or "") + name[:5].replace("corr", "conv"))
         if m and same_shape:
             e["traffic"] = m["traffic_bytes_per_op"]
         bw[name] = e
-    bw["traffic_source"] = (pmc_src + " (same libdtt_hip.so: sha256 checked; FETCH_SIZE x 2 + WRITE_SIZE over the op's three launches)"
-                            if pmc and same_shape else (pmc_src if not pmc else "counters were taken at B=2, 600x1067, d=8: not quoted for this shape"))
-    return dict(bw, kernel="correlation gradient op = corr_bwd_band_kernel + 2 x corr_bwd_stream_kernel (both gradients of one correlation, "
-                           "channels-last, band-stationary / halo-streamed: dtt_correlation_backward_nhwc_strided; event tag corr_bwd_op)")
+    bw["traffic_source"] = (pmc_src + " (same libdtt_hip.so: sha256 checked; FETCH_SIZE x 2 + WRITE_SIZE over the op's launches)"
+                            if pmc and same_shape else (pmc_src if not pmc else
+                                                        "counters were taken at B=2 600x1067 d=8 and B=1 563x1000 d=16: not quoted for this shape"))
+    return dict(bw, kernel="correlation gradient op = corr_bwd_band_kernel + ONE corr_bwd_stream_kernel launch (both gradients of one correlation "
+                           "as one grid, the four window quarters of a radius 9 - 16 window inside it; channels-last, band-stationary / "
+                           "halo-streamed: dtt_correlation_backward_nhwc_strided; event tag corr_bwd_op)")
 
 
 def rank_zero():

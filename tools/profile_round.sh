@@ -51,8 +51,17 @@ if has bwdpmc; then  # counters of the streamed gradient kernels, one map per pa
     done
     ARGS="$ARGS $m:$(firstdb $O/bw_${m}_FETCH_SIZE):$(firstdb $O/bw_${m}_WRITE_SIZE)"
   done
+  for m in conv5 conv4 conv3; do   # BASELINE configs[4]'s per-rank shape: B = 1, 563 x 1000, d = 16 (window radius 16: the quarters inside ONE launch)
+    for c in FETCH_SIZE WRITE_SIZE; do
+      (cd /tmp && ONLY=$m B=1 D=16 SHAPE=563 NO_OLD=1 ITERS=5 timeout 400 rocprofv3 --kernel-trace --pmc $c -d $O/bw16_${m}_$c -o p -- python $OLDPWD/tools/time_corr_bwd.py > $O/tp.log 2>&1)
+      echo "== d16 $m  $c" >> $O/pmc_corr_bwd.txt
+      python tools/rocpd_pmc.py $(firstdb $O/bw16_${m}_$c) 2>&1 | grep "corr_bwd_stream\|corr_bwd_band" >> $O/pmc_corr_bwd.txt
+      rm -f $O/tp.log
+    done
+    ARGS="$ARGS d16_$m:$(firstdb $O/bw16_${m}_FETCH_SIZE):$(firstdb $O/bw16_${m}_WRITE_SIZE)"
+  done
   python tools/pmc_corr_bwd_json.py $O/pmc_corr_bwd.json $ARGS > $O/pmc_corr_bwd.log 2>&1 || { echo "profile_round: pmc_corr_bwd.json not produced"; cat $O/pmc_corr_bwd.log; }
-  rm -rf $O/bw_conv?_*
+  rm -rf $O/bw_conv?_* $O/bw16_conv?_*
 fi
 
 if has cfg; then     # the other BASELINE configurations; configs[4] with its per-rank TRAINING step riding along (secondary.train_step)
@@ -64,7 +73,7 @@ fi
 
 if has traintrace; then
   timeout 600 rocprofv3 --kernel-trace -d $O/trace -o tr -- python bench.py --mode train --steps 5 --warmup 3 > $O/prof_train_stdout.log 2>&1
-  python tools/rocpd_steady.py $(firstdb $O/trace) 3 "psroi_pm_bwd_kernel<32" 400 > $O/train_steady_state.txt 2>&1 || echo "profile_round: training window REFUSED"
+  python tools/rocpd_steady.py $(firstdb $O/trace) 3 "psroi_pm_bwd_rows_kernel<7, 16, 2>" 400 > $O/train_steady_state.txt 2>&1 || echo "profile_round: training window REFUSED"
   python tools/rocpd_stats.py $(firstdb $O/trace) > $O/train_kernel_stats.txt 2>&1
   rm -rf $O/trace
 fi
