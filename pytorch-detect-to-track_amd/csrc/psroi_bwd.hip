@@ -24,6 +24,7 @@
 // training step's 10184 pixels (profiles/r05_train_steady_state.txt).
 #include <stdlib.h>
 #include <algorithm>
+#include <type_traits>
 #include "common.h"
 #include "psroi_bin.h"
 
@@ -39,6 +40,7 @@ constexpr int kWTab = 256;        // 1 / (P*P) / area for bin areas below this f
 #ifdef DTT_PSROI_BWD_STAMP   // developer timeline (tools/psroi_bwd_timeline.py): shader-clock stamps of waves 0 and NW-1 of two workgroups
 __device__ unsigned long long dtt_psroi_bwd_stamps[2 * 2 * 64];
 __device__ unsigned long long dtt_psroi_bwd_wg[1024 * 3];      // per workgroup: entry, end (100 MHz clock), HW_ID
+__device__ unsigned int dtt_psroi_bwd_cnt[1024 * 4];           // per workgroup: list entries walked, serial rounds, flushes, chunks
 #define PB_STAMP(idx) do { const int sb_ = blockIdx.x == 0 ? 0 : blockIdx.x == gridDim.x / 2 ? 1 : -1; \
     if (sb_ >= 0 && (threadIdx.x & 63) == 0 && ((threadIdx.x >> 6) == 0 || (threadIdx.x >> 6) == NW - 1) && (idx) < 64) \
       dtt_psroi_bwd_stamps[(sb_ * 2 + ((threadIdx.x >> 6) != 0)) * 64 + (idx)] = __builtin_readcyclecounter(); } while (0)
@@ -58,7 +60,6 @@ struct PmBwd {
   int ppw;                                 // pixels per wave
   int wgs_per_image;
   unsigned width_magic, wpi_magic;         // 2^32 / width + 1, 2^32 / wgs_per_image + 1 (0: divide)
-  int rowtab;                              // the row-range table applies (map rows of at least NW pixels) and fits LDS
   int ablate;                              // developer timing experiments (DTT_PSROI_BWD_ABLATE): 1 no listing, 2 no list walk, 4 no stores, 8 prologue only
 };
 
@@ -81,10 +82,11 @@ __device__ __forceinline__ float sgprf(float v) { return __int_as_float(__builti
 
 template <int P, int NW, int NR>
 __global__ __launch_bounds__(NW * 64) void psroi_pm_bwd_rows_kernel(PmBwd a) {
-  static_assert(P <= 15, "bin counts are packed in 4 bits");
+  static_assert(P <= 15 && P * P <= kListCap, "bin counts are packed in 4 bits; a lane's entries fit the list");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   PB_STAMP(0);
 #ifdef DTT_PSROI_BWD_STAMP
+  if (threadIdx.x < 4 && blockIdx.x < 1024) dtt_psroi_bwd_cnt[blockIdx.x * 4 + threadIdx.x] = 0;
   if (threadIdx.x == 0 && blockIdx.x < 1024) {
     dtt_psroi_bwd_wg[blockIdx.x * 3] = __builtin_amdgcn_s_memrealtime();
     dtt_psroi_bwd_wg[blockIdx.x * 3 + 2] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 11) | (0 << 6) | 4) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
@@ -105,17 +107,16 @@ __global__ __launch_bounds__(NW * 64) void psroi_pm_bwd_rows_kernel(PmBwd a) {
   int* eimg = ecol + P * cap;
   int* eown = eimg + cap;                                 // [cap]: the RoI row belongs to this workgroup's image
   float* wtab = reinterpret_cast<float*>(eown + cap);
-  // [ppw][2][cap] bytes (a.rowtab): the row range lo | hi1 << 4 of every staged RoI at the (at most two) map rows that hold the
-  // workgroup's NW consecutive pixels of round `it`
-  unsigned char* rowtab = reinterpret_cast<unsigned char*>(wtab + kWTab + 2);
   int* run = reinterpret_cast<int*>(wtab + kWTab);       // [2]: the image's run of RoI rows
 
   const int b = mdiv(blockIdx.x, a.wgs_per_image, a.wpi_magic);
   const int hw = a.height * a.width;
-  // Pixels are dealt to the waves of an image ROUND ROBIN (wave j of the image's wgs_per_image * NW waves takes pixels j, j + waves, ...): the
-  // RoIs crowd the middle of the map, and a wave that owned consecutive pixels there worked 2.3 x as long as one at the border (workgroup
-  // lifetimes 14.7 .. 34.1 us, median 23.8: profiles/r06_psroi_bwd_timeline_before.txt) -- a wave's pixels now lie a third of the map apart.
-  const int p_first = (blockIdx.x - b * a.wgs_per_image) * NW + wave;
+  // Pixels are dealt ROUND ROBIN, consecutive pixels to DIFFERENT workgroups: pixel p of an image goes to workgroup p mod G, wave
+  // (p / G) mod NW, round p / (G NW)  (G = wgs_per_image).  The RoIs crowd parts of the map: with a run of consecutive pixels per wave,
+  // workgroup lifetimes were 14.7 .. 34.1 us (median 23.8); with 16 consecutive pixels per workgroup and round, the training step's
+  // sampled RoIs (foreground around the ground truth) still left 1248 (median) .. 4393 list entries per workgroup.  Every workgroup now
+  // samples the whole map.
+  const int p_first = (blockIdx.x - b * a.wgs_per_image) + a.wgs_per_image * wave;
   const int p_step = a.wgs_per_image * NW;
   const float inv_bins = 1.f / (float)(P * P);
   const bool col_on = lane < gvw;
@@ -156,33 +157,7 @@ __global__ __launch_bounds__(NW * 64) void psroi_pm_bwd_rows_kernel(PmBwd a) {
       }
     }
   };
-  // Row range of every staged RoI at the rows this workgroup's pixels lie in (a wave's pixels jump from row to row: 14 LDS reads + 60
-  // vector instructions per pixel otherwise): round `it` takes the NW consecutive pixels from wg_p0 + it * p_step on, i.e. the row of
-  // the first one and possibly the next.  Needs the staged edges: call behind a barrier, and put one behind it.
-  const int wg_p0 = (blockIdx.x - b * a.wgs_per_image) * NW;
-  const int wg_h0 = mdiv(wg_p0, a.width, a.width_magic), wg_w0 = wg_p0 - wg_h0 * a.width;
   const int step_h = mdiv(p_step, a.width, a.width_magic), step_w = p_step - step_h * a.width;
-  auto build_rowtab = [&](int n) {
-    if (!a.rowtab) return;
-#pragma unroll 1
-    for (int slot = wave; slot < 2 * a.ppw; slot += NW) {
-      const int it = slot >> 1;
-      const int hh = wg_h0 + it * step_h + mdiv(wg_w0 + it * step_w, a.width, a.width_magic) + (slot & 1);
-#pragma unroll 1
-      for (int r = lane; r < cap; r += 64) {
-        int lo = 0, hi1 = 0;
-        if (r < n) {
-#pragma unroll
-          for (int k = 0; k < P; ++k) {
-            const int e = erow[k * cap + r];
-            hi1 += (e & 0xffff) <= hh ? 1 : 0;     // starts <= h: a prefix of the bins
-            lo += (e >> 16) <= hh ? 1 : 0;         // ends <= h: the bins before the first one that still contains h
-          }
-        }
-        rowtab[slot * cap + r] = (unsigned char)(lo | (hi1 << 4));
-      }
-    }
-  };
   // ---- the run [r_first, r_end) of RoI rows that holds this image's RoIs (callers list their RoIs image by image: the run is the
   //      image's own RoIs; rows of other images inside it are masked), the weight table, the zeroed accumulator.  Callers that list
   //      the same number of RoIs per image (training) have image b's run at b * per_image: that chunk is staged WHILE the run is
@@ -208,7 +183,6 @@ __global__ __launch_bounds__(NW * 64) void psroi_pm_bwd_rows_kernel(PmBwd a) {
   }
   PB_STAMP(2);
   __syncthreads();
-  if (guess_n > 0) build_rowtab(guess_n);
   PB_STAMP(3);
   int r_first = run[0], r_end = run[1];
   const bool guessed = r_end > r_first && guess_n > 0 && r_first >= guess_c0 && r_end <= guess_c0 + guess_n;
@@ -234,6 +208,9 @@ __global__ __launch_bounds__(NW * 64) void psroi_pm_bwd_rows_kernel(PmBwd a) {
     *reinterpret_cast<float*>(acc_lane + __umul24((unsigned)(s >> 8), col_mul4)) += g * sw;
   };
   auto walk = [&](int nl) {
+#ifdef DTT_PSROI_BWD_STAMP
+    if (lane == 0 && blockIdx.x < 1024) { atomicAdd(&dtt_psroi_bwd_cnt[blockIdx.x * 4], (unsigned)nl); atomicAdd(&dtt_psroi_bwd_cnt[blockIdx.x * 4 + 2], 1u); }
+#endif
 #pragma unroll 1
     for (int base = 0; base < nl; base += 64) {
       const int mine = min(base + lane, nl - 1);
@@ -270,6 +247,30 @@ __global__ __launch_bounds__(NW * 64) void psroi_pm_bwd_rows_kernel(PmBwd a) {
     }
   };
 
+  // staged chunk -> this lane's column edges (registers); restage: the chunk is not the one the prologue staged
+  auto enter_chunk = [&](int c0, int n, bool restage) {
+    if (restage) {
+      __syncthreads();
+      for (int i = tid; i < cap; i += NW * 64) eimg[i] = 0;
+      __syncthreads();
+      stage(c0, n);
+      __syncthreads();
+    }
+    // A RoI whose gradient rows are all zeros adds nothing anywhere (background RoIs in the box head; the zero-padded ground-truth
+    // rows of the tracking RoIs -- (0,0,0,0) boxes whose 49 bins ALL cover pixel (0, 0)): it belongs to no image
+#pragma unroll
+    for (int rd = 0; rd < NR; ++rd) {
+      const int rl = min(rd * 64 + lane, cap - 1);
+      const bool on = rd * 64 + lane < n && eimg[rl] != 0 && eown[rl] != 0;
+#pragma unroll
+      for (int k = 0; k < P; ++k) cw[rd][k] = on ? ecol[k * cap + rl] : 0;   // (start = end = 0: contains no pixel)
+    }
+    cur_h = -1;
+    PB_STAMP(4);
+  };
+  // The pixel loop, instantiated twice: `single` = the image's RoIs are ONE staged chunk (staged before the loop: no staging code, no
+  // barrier and none of its registers inside the loop -- the common case); otherwise every pixel walks the chunks, restaging each.
+  auto pixels = [&](auto single) {
   int h = mdiv(p_first, a.width, a.width_magic), w = p_first - h * a.width;          // (no division per pixel)
   for (int it = 0; it < a.ppw; ++it) {
     const int p = p_first + it * p_step;
@@ -288,30 +289,7 @@ __global__ __launch_bounds__(NW * 64) void psroi_pm_bwd_rows_kernel(PmBwd a) {
     for (int ch = 0; ch < nchunks; ++ch) {
       const int c0 = r_first + ch * cap;
       const int n = min(cap, r_end - c0);
-      if (nchunks > 1 || it == 0) {
-        if (nchunks > 1 || !guessed) {
-          __syncthreads();
-          for (int i = tid; i < cap; i += NW * 64) eimg[i] = 0;
-          __syncthreads();
-          stage(c0, n);
-          __syncthreads();
-          build_rowtab(n);
-          __syncthreads();
-        } else if (a.rowtab) {
-          __syncthreads();          // (the table of the chunk staged in the prologue)
-        }
-        // A RoI whose gradient rows are all zeros adds nothing anywhere (background RoIs in the box head; the zero-padded ground-truth
-        // rows of the tracking RoIs -- (0,0,0,0) boxes whose 49 bins ALL cover pixel (0, 0)): it belongs to no image
-#pragma unroll
-        for (int rd = 0; rd < NR; ++rd) {
-          const int rl = min(rd * 64 + lane, cap - 1);
-          const bool on = rd * 64 + lane < n && eimg[rl] != 0 && eown[rl] != 0;
-#pragma unroll
-          for (int k = 0; k < P; ++k) cw[rd][k] = on ? ecol[k * cap + rl] : 0;   // (start = end = 0: contains no pixel)
-        }
-        cur_h = -1;
-        PB_STAMP(4);
-      }
+      if constexpr (!decltype(single)::value) enter_chunk(c0, n, true);
       if (!valid || (a.ablate & 8)) continue;
       if (h != cur_h) {
         cur_h = h;
@@ -319,11 +297,6 @@ __global__ __launch_bounds__(NW * 64) void psroi_pm_bwd_rows_kernel(PmBwd a) {
         for (int rd = 0; rd < NR; ++rd) {
           const int rl = min(rd * 64 + lane, cap - 1);
           int lo = 0, hi1 = 0;
-          if (a.rowtab) {
-            const int row0 = wg_h0 + it * step_h + mdiv(wg_w0 + it * step_w, a.width, a.width_magic);   // (scalar unit)
-            prow[rd] = rd * 64 < n ? rowtab[(2 * it + (h - row0)) * cap + rl] : 0;
-            continue;
-          }
           if (rd * 64 < n) {
 #pragma unroll
             for (int k = 0; k < P; ++k) {
@@ -360,51 +333,35 @@ __global__ __launch_bounds__(NW * 64) void psroi_pm_bwd_rows_kernel(PmBwd a) {
         const int incl = wave_incl_scan(nh);
         const int total = __builtin_amdgcn_readlane(incl, 63);
         if (total == 0 || (a.ablate & 1)) continue;
-        if (nlist + total > kListCap) {
-          // walk what is listed, then take this round on its own (or serially when one round alone overflows the list)
-          walk(nlist);
-          nlist = 0;
-        }
+        // the round's entries go to the list in lane (= RoI) order, as many whole lanes as fit; a full list is walked and refilled
+        // (a pixel under a stack of small RoIs -- all 49 bins of each on it -- lists thousands of entries; walking them RoI by RoI,
+        // every lane on the same rectangle, made the workgroups that owned such pixels the launch's stragglers: 69 against 26 us)
         const int rl = rd * 64 + lane;
-        if (total <= kListCap) {
-          int pos = nlist + incl - nh;
-          if (nh > 0) {
+        auto weight = [&](unsigned area) { return area < (unsigned)kWTab ? wtab[area] : inv_bins / (float)area; };
+        int done = 0;
+#pragma unroll 1
+        while (done < total) {
+          const bool take = nh > 0 && incl - nh >= done && incl - done <= kListCap - nlist;
+          const unsigned long long tm = __ballot(take);
+          if (tm == 0ULL) { walk(nlist); nlist = 0; continue; }     // (a lane lists at most P * P = 49 <= kListCap entries: it fits an empty list)
+          const int upto = __builtin_amdgcn_readlane(incl, 63 - (int)__builtin_clzll(tm));
+          if (take) {
+            int pos = nlist + incl - nh - done;
             for (int ph = plo; ph < phi1; ++ph) {
               const int er = erow[ph * cap + rl];
               const unsigned hgt = (unsigned)((er >> 16) - (er & 0xffff));
               for (int pw = qlo; pw < qhi1; ++pw) {
                 const int ec = ecol[pw * cap + rl];
-                const unsigned area = __umul24(hgt, (unsigned)((ec >> 16) - (ec & 0xffff)));
                 list_rb[pos] = rl | ((ph * P + pw) << 8);
-                list_w[pos] = area < (unsigned)kWTab ? wtab[area] : inv_bins / (float)area;
+                list_w[pos] = weight(__umul24(hgt, (unsigned)((ec >> 16) - (ec & 0xffff))));
                 ++pos;
               }
             }
           }
-          nlist += total;
-        } else {
-          // (degenerate RoIs: more than two bins each on average -- RoI by RoI in order, every lane walking the same rectangle)
-          unsigned long long m = __ballot(nh > 0);
-          while (m) {
-            const int src = __builtin_ctzll(m);
-            m &= m - 1;
-            const int s_rl = rd * 64 + src;
-            const int s_plo = __builtin_amdgcn_readlane(plo, src), s_phi1 = __builtin_amdgcn_readlane(phi1, src);
-            const int s_qlo = __builtin_amdgcn_readlane(qlo, src), s_qhi1 = __builtin_amdgcn_readlane(qhi1, src);
-            const float g = gv_lane[s_rl * gvw];
-            for (int ph = s_plo; ph < s_phi1; ++ph) {
-              const int er = erow[ph * cap + s_rl];
-              const int hgt = (er >> 16) - (er & 0xffff);
-              for (int pw = s_qlo; pw < s_qhi1; ++pw) {
-                const int ec = ecol[pw * cap + s_rl];
-                const int area = hgt * ((ec >> 16) - (ec & 0xffff));
-                add1((ph * P + pw) << 8, inv_bins / (float)area, g);
-              }
-            }
-          }
+          nlist += upto - done;
+          done = upto;
         }
       }
-      // ---- phase 2 for this chunk: the list in order (= RoI order); four entries whose bins differ go together
       PB_STAMP(6 + 6 * it);
       if (a.ablate & 2) nlist = 0;
 #ifdef DTT_PSROI_BWD_STAMP
@@ -446,6 +403,16 @@ __global__ __launch_bounds__(NW * 64) void psroi_pm_bwd_rows_kernel(PmBwd a) {
     }
     PB_STAMP(9 + 6 * it);
   }
+  };
+#ifdef DTT_PSROI_BWD_STAMP
+  if (tid == 0 && blockIdx.x < 1024) dtt_psroi_bwd_cnt[blockIdx.x * 4 + 3] = (unsigned)nchunks | (guessed ? 0x100u : 0u) | ((unsigned)(r_end - r_first) << 16);
+#endif
+  if (nchunks <= 1) {
+    if (nchunks == 1) enter_chunk(r_first, min(cap, r_end - r_first), !guessed);
+    pixels(std::true_type{});
+  } else {
+    pixels(std::false_type{});
+  }
   PB_STAMP(50);
 #ifdef DTT_PSROI_BWD_STAMP
   if (threadIdx.x == 0 && blockIdx.x < 1024) dtt_psroi_bwd_wg[blockIdx.x * 3 + 1] = __builtin_amdgcn_s_memrealtime();
@@ -473,6 +440,10 @@ int launch_rows(const PmBwd& a, int batch_size, size_t lds, hipStream_t stream) 
 extern "C" int dtt_psroi_bwd_stamps_read(unsigned long long* host, int n) {
   (void)hipDeviceSynchronize();
   return hipMemcpyFromSymbol(host, HIP_SYMBOL(dtt_psroi_bwd_stamps), sizeof(unsigned long long) * n) == hipSuccess;
+}
+extern "C" int dtt_psroi_bwd_cnt_read(unsigned int* host, int n) {
+  (void)hipDeviceSynchronize();
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(dtt_psroi_bwd_cnt), sizeof(unsigned int) * n) == hipSuccess;
 }
 extern "C" int dtt_psroi_bwd_wg_read(unsigned long long* host, int n) {
   (void)hipDeviceSynchronize();
@@ -537,17 +508,14 @@ extern "C" int dtt_psroi_pm_backward_heads(const float* grad_vote0, int output_d
   const long n_max = std::max((long)hw + (long)nw * a.wgs_per_image, (long)batch_size * a.wgs_per_image);
   a.width_magic = n_max * width < (1L << 32) && width > 1 ? (unsigned)((1ULL << 32) / (unsigned)width + 1) : 0u;
   a.wpi_magic = n_max * a.wgs_per_image < (1L << 32) && a.wgs_per_image > 1 ? (unsigned)((1ULL << 32) / (unsigned)a.wgs_per_image + 1) : 0u;
-  // (the row-range table: the workgroup's NW consecutive pixels of a round must lie in at most two map rows)
-  const size_t table_b = (size_t)2 * a.ppw * a.cap;
-  a.rowtab = width >= nw && lds_of(nw) + table_b <= 160 * 1024 ? 1 : 0;
-  const size_t lds_total = lds_of(nw) + (a.rowtab ? table_b : 0);
+  const size_t lds_total = lds_of(nw);
   dtt_prof_begin("psroi_pm_bwd", stream);   // (event tag: the one launch)
   int ok;
   const int nr = a.cap / 64;   // 1, 2, 3 (run as 4) or 4 rounds of 64 RoIs per chunk
 #define DTT_PMB_ROWS(NWV)                                                                              \
-  (nr == 1 ? launch_rows<7, NWV, 1>(a, batch_size, lds_total, stream)                                  \
-           : nr == 2 ? launch_rows<7, NWV, 2>(a, batch_size, lds_total, stream) : launch_rows<7, NWV, 4>(a, batch_size, lds_total, stream))
-  if (nw == 16) ok = DTT_PMB_ROWS(16);
+  (nr == 1 ? launch_rows<7, NWV, 1>(a, batch_size, lds_total, stream) : launch_rows<7, NWV, 2>(a, batch_size, lds_total, stream))
+  if (nr > 2) ok = nw == 8 ? launch_rows<7, 8, 4>(a, batch_size, lds_total, stream) : launch_rows<7, 4, 4>(a, batch_size, lds_total, stream);
+  else if (nw == 16) ok = DTT_PMB_ROWS(16);
   else if (nw == 8) ok = DTT_PMB_ROWS(8);
   else ok = DTT_PMB_ROWS(4);
 #undef DTT_PMB_ROWS
