@@ -107,7 +107,7 @@ __global__ __launch_bounds__(NW * 64) void psroi_pm_bwd_rows_kernel(PmBwd a) {
   int* eimg = ecol + P * cap;
   int* eown = eimg + cap;                                 // [cap]: the RoI row belongs to this workgroup's image
   float* wtab = reinterpret_cast<float*>(eown + cap);
-  int* run = reinterpret_cast<int*>(wtab + kWTab);       // [2]: the image's run of RoI rows
+  int* run = reinterpret_cast<int*>(wtab + kWTab);       // [0 .. 1]: the image's run of RoI rows; [2]: the workgroup's pixel ticket
 
   const int b = mdiv(blockIdx.x, a.wgs_per_image, a.wpi_magic);
   const int hw = a.height * a.width;
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(NW * 64) void psroi_pm_bwd_rows_kernel(PmBwd a) {
   //      image's own RoIs; rows of other images inside it are masked), the weight table, the zeroed accumulator.  Callers that list
   //      the same number of RoIs per image (training) have image b's run at b * per_image: that chunk is staged WHILE the run is
   //      being looked for (one global-memory round trip less in front of the first pixel) and kept when the run lies inside it.
-  if (tid < 2) run[tid] = tid == 0 ? a.num_rois : 0;
+  if (tid < 3) run[tid] = tid == 0 ? a.num_rois : tid == 1 ? 0 : NW;      // (tickets 0 .. NW - 1: every wave's first pixel)
   for (int i = tid; i < kWTab; i += NW * 64) wtab[i] = inv_bins / (float)i;
   for (int i = tid; i < cap; i += NW * 64) eimg[i] = 0;
   for (int i = lane; i < acc_floats / 4; i += 64) reinterpret_cast<f32x4*>(acc)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -271,11 +271,25 @@ __global__ __launch_bounds__(NW * 64) void psroi_pm_bwd_rows_kernel(PmBwd a) {
   // The pixel loop, instantiated twice: `single` = the image's RoIs are ONE staged chunk (staged before the loop: no staging code, no
   // barrier and none of its registers inside the loop -- the common case); otherwise every pixel walks the chunks, restaging each.
   auto pixels = [&](auto single) {
+  constexpr bool kTickets = decltype(single)::value;
+  // One staged chunk: the workgroup's NW * ppw pixels (g + G * k, k = 0 .. NW * ppw - 1) are taken by TICKET -- a wave that owns a
+  // pixel under a stack of RoIs (thousands of list entries, walked by that one wave) leaves the others to the rest of the workgroup:
+  // with a fixed three pixels per wave such workgroups ran 41 - 44 us against a median of 27 with the same number of entries.  With
+  // several chunks every wave must pass the same barriers: pixel k = wave + NW * it.
   int h = mdiv(p_first, a.width, a.width_magic), w = p_first - h * a.width;          // (no division per pixel)
-  for (int it = 0; it < a.ppw; ++it) {
-    const int p = p_first + it * p_step;
+  int ticket = wave;
+  for (int it = 0; kTickets ? ticket < NW * a.ppw : it < a.ppw; ++it) {
+    int p = p_first + it * p_step;
+    if constexpr (kTickets) {
+      p = p_first - a.wgs_per_image * wave + a.wgs_per_image * ticket;
+      h = mdiv(p, a.width, a.width_magic); w = p - h * a.width;
+      int next = 0;
+      if (lane == 0) next = atomicAdd(&run[2], 1);
+      ticket = __builtin_amdgcn_readfirstlane(next);         // (the NEXT pixel's ticket, on its way while this pixel is worked on)
+    } else {
+      if (it > 0) { h += step_h; w += step_w; if (w >= a.width) { w -= a.width; ++h; } }
+    }
     const bool valid = p < hw;
-    if (it > 0) { h += step_h; w += step_w; if (w >= a.width) { w -= a.width; ++h; } }
     int nlist = 0;
     // the compact gradient of the pixel is requested now and added in front of the write-out (it sat on the critical path of every
     // pixel as a dependent global load: 1.8 k of a pixel's 6 k cycles)
@@ -485,7 +499,7 @@ extern "C" int dtt_psroi_pm_backward_heads(const float* grad_vote0, int output_d
   a.per_image = per_image;
   static const int env_nw = getenv("DTT_PSROI_BWD_WAVES") ? atoi(getenv("DTT_PSROI_BWD_WAVES")) : 0;   // developer sweeps
   const int acc_floats = (row_floats + 3) & ~3;
-  const size_t shared = ((size_t)a.cap * (cp0 + cp1) + (size_t)(2 * pooled + 2) * a.cap + kWTab + 2) * 4;
+  const size_t shared = ((size_t)a.cap * (cp0 + cp1) + (size_t)(2 * pooled + 2) * a.cap + kWTab + 4) * 4;
   auto lds_of = [&](int nw) { return (size_t)nw * (acc_floats + 2 * kListCap + 4) * 4 + shared; };
   int nw = env_nw ? env_nw : 16;
   DTT_REQUIRE(nw == 4 || nw == 8 || nw == 16, "psroi_pm backward: DTT_PSROI_BWD_WAVES must be 4, 8 or 16");
