@@ -253,7 +253,8 @@ def corr_bwd_secondary(op_us, args, model):
                                                         "counters were taken at B=2 600x1067 d=8 and B=1 563x1000 d=16: not quoted for this shape"))
     return dict(bw, kernel="correlation gradient op = corr_bwd_band_kernel + ONE corr_bwd_stream_kernel launch (both gradients of one correlation "
                            "as one grid, the four window quarters of a radius 9 - 16 window inside it; channels-last, band-stationary / "
-                           "halo-streamed: dtt_correlation_backward_nhwc_strided; event tag corr_bwd_op)")
+                           "halo-streamed: dtt_correlation_backward_nhwc_phase; event tag corr_bwd_op; DTT_CORR_BWD_OVERLAP=1 lays the bands of "
+                           "the later ops out on a second stream: shorter ops, a longer step -- off)")
 
 
 def rank_zero():

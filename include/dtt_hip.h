@@ -139,6 +139,16 @@ int dtt_correlation_backward_nhwc_strided(const float* gradOutput, long g_batch_
                                           int goc, int goh, int gow, const float* input1, int ic, int ih, int iw, const float* input2,
                                           float* gradInput1, float* gradInput2, int pad_size, int kernel_size, int max_displacement,
                                           int stride1, int stride2, int which, void* workspace, size_t workspace_bytes, void* stream);
+/* The same op in two phases (round 6): phase 1 = lay out the band words in the workspace (reads gradOutput only; event tag
+ * "corr_bwd_band"), phase 2 = the gradients from a workspace that a phase-1 call with the same arguments filled ("corr_bwd_op"),
+ * 3 = both (= dtt_correlation_backward_nhwc_strided).  The phases may be issued on different streams, ordered by the caller
+ * (dtt.heads.TrackingRowsFn with DTT_CORR_BWD_OVERLAP=1: the bands of conv4 / conv5 beside conv3's gradient op -- measured: the ops
+ * get shorter, the step longer; off by default). */
+int dtt_correlation_backward_nhwc_phase(const float* gradOutput, long g_batch_stride, long g_ch_stride, long g_px_stride, int gob,
+                                        int goc, int goh, int gow, const float* input1, int ic, int ih, int iw, const float* input2,
+                                        float* gradInput1, float* gradInput2, int pad_size, int kernel_size, int max_displacement,
+                                        int stride1, int stride2, int which, int phase, void* workspace, size_t workspace_bytes,
+                                        void* stream);
 size_t dtt_correlation_backward_workspace_bytes(int batch, int ic, int ih, int iw, int pad_size, int kernel_size,
                                                 int max_displacement, int stride1, int stride2);
 /* 1 if the streamed gradient kernels cover the geometry (kernel_size 1, stride1 == stride2 | max_displacement, radius <= 8,

@@ -1397,7 +1397,7 @@ extern "C" int dtt_correlation_backward(const float* gradOutput, int gob, int go
 // Band-stationary, halo-streamed gradient kernels for channels-last maps (correlation_bwd.hip)
 int dtt_corr_bwd_stream(const float* gradOutput, long g_sb, long g_sc, long g_sp, int gob, int goh, int gow, const float* input1, int ic,
                         int ih, int iw, const float* input2, float* gradInput1, float* gradInput2, int pad_size, int max_displacement,
-                        int stride, int which, void* workspace, size_t workspace_bytes, hipStream_t stream);
+                        int stride, int which, int phase, void* workspace, size_t workspace_bytes, hipStream_t stream);
 extern "C" int dtt_correlation_backward_stream_supported(int ic, int kernel_size, int max_displacement, int stride1, int stride2);
 
 static int backward_nhwc_checks(const float* gradOutput, int gob, int goc, int goh, int gow, const float* input1, int ic, int ih, int iw,
@@ -1422,25 +1422,41 @@ static int backward_nhwc_checks(const float* gradOutput, int gob, int goc, int g
 // p * g_px_stride] (p = oy * ow + ox): the reference's (n, D*D, oh, ow) planes (strides D*D*oh*ow, oh*ow, 1) or columns of
 // position-major rows (g_ch_stride = 1, g_px_stride = the row length).  which: 1 = gradInput1 only, 2 = gradInput2 only, 3 = both.
 // workspace: dtt_correlation_backward_workspace_bytes(...) bytes, caller-owned, overwritten.
-extern "C" int dtt_correlation_backward_nhwc_strided(const float* gradOutput, long g_batch_stride, long g_ch_stride, long g_px_stride,
-                                                     int gob, int goc, int goh, int gow, const float* input1, int ic, int ih, int iw,
-                                                     const float* input2, float* gradInput1, float* gradInput2, int pad_size,
-                                                     int kernel_size, int max_displacement, int stride1, int stride2, int which,
-                                                     void* workspace, size_t workspace_bytes, void* stream_) {
+// phase: 1 = lay out the band words in the workspace only (reads gradOutput; event tag corr_bwd_band), 2 = the gradients from a
+// workspace that a phase-1 call with the same arguments filled (event tag corr_bwd_op), 3 = both.  The two phases may run on
+// different streams (the caller orders them): the band launches of several correlations then run beside another op.
+extern "C" int dtt_correlation_backward_nhwc_phase(const float* gradOutput, long g_batch_stride, long g_ch_stride, long g_px_stride,
+                                                   int gob, int goc, int goh, int gow, const float* input1, int ic, int ih, int iw,
+                                                   const float* input2, float* gradInput1, float* gradInput2, int pad_size,
+                                                   int kernel_size, int max_displacement, int stride1, int stride2, int which, int phase,
+                                                   void* workspace, size_t workspace_bytes, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  DTT_REQUIRE(which >= 1 && which <= 3 && ((which & 1) == 0 || gradInput1) && ((which & 2) == 0 || gradInput2),
-              "correlation backward: null gradient pointer / bad selector");
+  DTT_REQUIRE(phase >= 1 && phase <= 3, "correlation backward: phase %d (1 band words, 2 gradients, 3 both)", phase);
+  DTT_REQUIRE(which >= 1 && which <= 3 && (phase == 1 || (((which & 1) == 0 || gradInput1) && ((which & 2) == 0 || gradInput2))),
+              "correlation backward: null gradient pointer / bad selector");      // (phase 1 writes no gradient)
   int nbr = 0;
   if (!backward_nhwc_checks(gradOutput, gob, goc, goh, gow, input1, ic, ih, iw, input2, gradInput1, gradInput2, pad_size, kernel_size,
                             max_displacement, stride1, stride2, &nbr, 9))
     return 0;
   DTT_REQUIRE(dtt_correlation_backward_stream_supported(ic, kernel_size, max_displacement, stride1, stride2),
               "correlation backward (channels-last, streamed): needs channels %% 64 == 0 (got %d); use dtt_correlation_backward_nhwc", ic);
-  dtt_prof_begin("corr_bwd_op", stream);
+  const char* tag = phase == 1 ? "corr_bwd_band" : "corr_bwd_op";
+  dtt_prof_begin(tag, stream);
   const int ok = dtt_corr_bwd_stream(gradOutput, g_batch_stride, g_ch_stride, g_px_stride, gob, goh, gow, input1, ic, ih, iw, input2,
-                                     gradInput1, gradInput2, pad_size, max_displacement, stride1, which, workspace, workspace_bytes, stream);
-  dtt_prof_end("corr_bwd_op", stream);
+                                     gradInput1, gradInput2, pad_size, max_displacement, stride1, which, phase, workspace, workspace_bytes,
+                                     stream);
+  dtt_prof_end(tag, stream);
   return ok;
+}
+
+extern "C" int dtt_correlation_backward_nhwc_strided(const float* gradOutput, long g_batch_stride, long g_ch_stride, long g_px_stride,
+                                                     int gob, int goc, int goh, int gow, const float* input1, int ic, int ih, int iw,
+                                                     const float* input2, float* gradInput1, float* gradInput2, int pad_size,
+                                                     int kernel_size, int max_displacement, int stride1, int stride2, int which,
+                                                     void* workspace, size_t workspace_bytes, void* stream_) {
+  return dtt_correlation_backward_nhwc_phase(gradOutput, g_batch_stride, g_ch_stride, g_px_stride, gob, goc, goh, gow, input1, ic, ih, iw,
+                                             input2, gradInput1, gradInput2, pad_size, kernel_size, max_displacement, stride1, stride2, which,
+                                             3, workspace, workspace_bytes, stream_);
 }
 
 // Round 1's channels-last gradient kernels (corr_bwd_mfma<.., NHWC = true>): gradOutput the reference's contiguous (n, D*D, oh, ow),

@@ -755,10 +755,11 @@ extern "C" size_t dtt_correlation_backward_workspace_bytes(int batch, int ic, in
 }
 
 // Both gradients, channels-last inputs and gradients; gradOut[n, d, p] at gradOutput[n * g_sb + d * g_sc + p * g_sp].
-// which: 1 = gradInput1 only, 2 = gradInput2 only, 3 = both.
+// which: 1 = gradInput1 only, 2 = gradInput2 only, 3 = both.  phase: 1 = lay out the band words in the workspace (reads gradOutput only),
+// 2 = the gradients from a workspace that phase 1 filled (reads the maps and the workspace), 3 = both, one after the other.
 int dtt_corr_bwd_stream(const float* gradOutput, long g_sb, long g_sc, long g_sp, int gob, int goh, int gow, const float* input1, int ic,
                         int ih, int iw, const float* input2, float* gradInput1, float* gradInput2, int pad_size, int max_displacement,
-                        int stride, int which, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+                        int stride, int which, int phase, void* workspace, size_t workspace_bytes, hipStream_t stream) {
   const int s = stride, R = max_displacement / s;
   DTT_REQUIRE((max_displacement - pad_size) % s == 0, "correlation backward (channels-last): displacement - padding must be a multiple of the stride");
   DTT_REQUIRE((long)ih * iw * ic * 4 < 0xffffffffl, "correlation backward (channels-last): one image exceeds the 32-bit offset range");
@@ -818,14 +819,15 @@ int dtt_corr_bwd_stream(const float* gradOutput, long g_sb, long g_sc, long g_sp
   // both directions and zeroes the stride x stride cell of image pixels behind it -- again every element is written here
   const bool lattice_dense = s > 1 && s <= 4 && g.origin == 0 && goh == g.H && gow == g.W;
   for (int dir = 0; dir < 2; ++dir)
-    if ((which & (dir ? 2 : 1)) && !dense && !lattice_dense)
+    if ((phase & 2) && (which & (dir ? 2 : 1)) && !dense && !lattice_dense)
       DTT_REQUIRE(hipMemsetAsync(dir ? gradInput2 : gradInput1, 0, bytes, stream) == hipSuccess, "correlation backward: memset failed");
-  if (band_blocks > 0) {
+  if (band_blocks > 0 && (phase & 1)) {
     if (nbr == 3) hipLaunchKernelGGL((corr_bwd_band_kernel<3, false>), dim3(band_blocks), dim3(256), 0, stream, bg);
     else if (nq == 1) hipLaunchKernelGGL((corr_bwd_band_kernel<5, false>), dim3(band_blocks), dim3(256), 0, stream, bg);
     else hipLaunchKernelGGL((corr_bwd_band_kernel<5, true>), dim3(band_blocks * nq * nq), dim3(256), 0, stream, bg);
     DTT_CHECK_LAUNCH("corr_bwd_band_kernel");
   }
+  if (!(phase & 2)) return 1;
   // Window radius > 8 (BASELINE configs[4]: d = 16, 33 x 33 displacements = 9 x 9 window blocks, 324 band words per lane): the window
   // is covered in quarters of NBR x NBR = 5 x 5 blocks INSIDE the launch -- per channel group the four quarters' halos stream through
   // the ring one after the other into the same accumulators, the band registers follow (corr_bwd_stream_kernel<5, true>): every gradient

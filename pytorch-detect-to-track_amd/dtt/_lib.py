@@ -36,6 +36,8 @@ SIGNATURES = {
     "dtt_correlation_backward_nhwc": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "dtt_correlation_backward_nhwc_strided": (_I, [_P, _L, _L, _L, _I, _I, _I, _I, _P, _I, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I,
                                                    _P, _Z, _P]),
+    "dtt_correlation_backward_nhwc_phase": (_I, [_P, _L, _L, _L, _I, _I, _I, _I, _P, _I, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I,
+                                                 _P, _Z, _P]),
     "dtt_correlation_backward_workspace_bytes": (_Z, [_I] * 9),
     "dtt_correlation_backward_stream_supported": (_I, [_I] * 5),
     "dtt_correlation_backward_plan_check": (_I, [_I] * 6),

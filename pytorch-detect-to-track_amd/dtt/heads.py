@@ -385,16 +385,54 @@ class TrackingRowsFn(torch.autograd.Function):
         g_loc = None
         if ctx.needs_input_grad[0]:
             g_loc = torch.cat([grows[:, :n_box], grows[:, n_box:2 * n_box]], 0)
-        gmaps = []
-        for i, (m, g, c0) in enumerate(zip(maps, geoms, cols)):
-            if not ctx.needs_input_grad[1 + i]:
-                gmaps.append(None)
-                continue
+        # The three gradient ops run one after the other; each starts with a small launch that lays out its band words (18 us for
+        # conv4 / conv5: 680 workgroups that leave most of the chip idle).  The bands of the LATER ops only read `grows`: with
+        # DTT_CORR_BWD_OVERLAP=1 they are laid out on a second stream beside the first op (round 6).  MEASURED AND LEFT OFF: the two
+        # ops get 17 us shorter each (conv4 111.8 -> 94.1, conv5 183.5 -> 167.2 us, conv3 beside the bands 45.6 -> 55.2) but the training
+        # step gets 0.85 ms LONGER (37.94 -> 38.80 ms, two runs each way): the second stream's fork / join costs more elsewhere in
+        # the step than the 25 us it hides.
+        import os
+        from .ops import corr_bwd_stream_enabled
+        todo = [(i, m, g, c0) for i, (m, g, c0) in enumerate(zip(maps, geoms, cols)) if ctx.needs_input_grad[1 + i]]
+        gmaps = [None] * len(maps)
+        dev = grows.device
+        split = (len(todo) >= 2 and os.environ.get("DTT_CORR_BWD_OVERLAP", "0") == "1" and corr_bwd_stream_enabled()
+                 and all(m.size(1) % 64 == 0 for _, m, _, _ in todo))
+        wss = {}
+        if split:
+            main, side = torch.cuda.current_stream(dev), _side_stream(dev)
+            ready = torch.cuda.Event()
+            ready.record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(ready)                       # (the rows' gradient is the main stream's work)
+                grows.record_stream(side)
+                for i, m, g, c0 in todo[1:]:
+                    wss[i] = correlation_backward_nhwc(None, m[:B], m[B:2 * B], None, None, *g, rows=grows, col=c0, phase=1)
+                    wss[i].record_stream(main)
+                laid = torch.cuda.Event()
+                laid.record(side)
+        for k, (i, m, g, c0) in enumerate(todo):
             # (two legs: every image's gradient is written by one of the two kernels, which zero-fill where they have to)
             gm = torch.empty_like(m) if m.size(0) == 2 * B else torch.zeros_like(m)
-            correlation_backward_nhwc(None, m[:B], m[B:2 * B], gm[:B], gm[B:2 * B], *g, rows=grows, col=c0)
-            gmaps.append(gm)
+            if split and k == 1:
+                torch.cuda.current_stream(dev).wait_event(laid)
+            if i in wss:
+                correlation_backward_nhwc(None, m[:B], m[B:2 * B], gm[:B], gm[B:2 * B], *g, rows=grows, col=c0, phase=2, workspace=wss[i])
+            else:
+                correlation_backward_nhwc(None, m[:B], m[B:2 * B], gm[:B], gm[B:2 * B], *g, rows=grows, col=c0)
+            gmaps[i] = gm
         return (g_loc, *gmaps, None, None, None)
+
+
+_SIDE_STREAMS = {}
+
+
+def _side_stream(dev):
+    """One extra stream per device for work that only has to meet the main stream again later (the band words of the correlation gradients)."""
+    key = str(dev)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return _SIDE_STREAMS[key]
 
 
 _DEVICE_CONSTANTS = {}

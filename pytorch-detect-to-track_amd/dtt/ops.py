@@ -167,17 +167,21 @@ def corr_bwd_stream_enabled():
 
 
 def correlation_backward_nhwc(grad_output, input1, input2, g1, g2, pad_size, kernel_size, max_displacement, stride1, stride2,
-                              rows=None, col=0):
+                              rows=None, col=0, phase=3, workspace=None):
     """Both correlation gradients on channels-last maps, written into the channels-last tensors g1 / g2 (either may be None).
     grad_output: the reference's (B, D*D, oh, ow) tensor -- or, with `rows`, columns [col, col + D*D) of a position-major
     (B*oh*ow, ld) matrix (the gradient of the tracking head's input rows: read where it lies).  Channels % 64 == 0: the
-    band-stationary streamed kernels (`dtt_correlation_backward_nhwc_strided`, workspace from the caching allocator); other
-    channel counts: round 1's kernels (`dtt_correlation_backward_nhwc`; contiguous grad_output, both gradients)."""
+    band-stationary streamed kernels (`dtt_correlation_backward_nhwc_phase`, workspace from the caching allocator); other
+    channel counts: round 1's kernels (`dtt_correlation_backward_nhwc`; contiguous grad_output, both gradients).
+    phase (streamed kernels only): 1 = lay out the band words and RETURN the workspace tensor (issued on the current stream: the
+    caller may run it on a second stream), 2 = the gradients from `workspace`, 3 = both."""
     L = _lib.lib()
     B, C, H, W = input1.shape
     oc, oh, ow = correlation_output_shape(C, H, W, pad_size, kernel_size, max_displacement, stride1, stride2)
     dev = input1.device
     streamed = bool(L.dtt_correlation_backward_stream_supported(C, kernel_size, max_displacement, stride1, stride2)) and corr_bwd_stream_enabled()
+    if phase != 3 and not streamed:
+        raise ValueError("correlation backward: phases are a feature of the streamed kernels (channels % 64 == 0)")
     with torch.cuda.device(dev):
         if not streamed:
             # round 1's kernels: a contiguous (B, D*D, oh, ow) gradOutput and both gradient outputs, dense channels-last.  A rows-form
@@ -211,13 +215,16 @@ def correlation_backward_nhwc(grad_output, input1, input2, g1, g2, pad_size, ker
             ld = rows.stride(0)
             gptr, sb, sc, sp = ctypes.c_void_p(rows.data_ptr() + 4 * col), oh * ow * ld, 1, ld
         nbytes = int(L.dtt_correlation_backward_workspace_bytes(B, C, H, W, pad_size, kernel_size, max_displacement, stride1, stride2))
-        ws = torch.empty((max(nbytes, 4) + 3) // 4, dtype=torch.float32, device=dev)
-        which = (1 if g1 is not None else 0) | (2 if g2 is not None else 0)
-        check(L.dtt_correlation_backward_nhwc_strided(gptr, sb, sc, sp, B, oc, oh, ow, ptr(input1), C, H, W, ptr(input2),
-                                                      ptr(g1) if g1 is not None else None, ptr(g2) if g2 is not None else None,
-                                                      pad_size, kernel_size, max_displacement, stride1, stride2, which,
-                                                      ptr(ws), ws.numel() * 4, stream_ptr(dev)),
+        ws = workspace if phase == 2 else torch.empty((max(nbytes, 4) + 3) // 4, dtype=torch.float32, device=dev)
+        if ws is None or ws.numel() * 4 < nbytes:
+            raise ValueError("correlation backward: phase 2 needs the workspace phase 1 returned")
+        which = 3 if phase == 1 else (1 if g1 is not None else 0) | (2 if g2 is not None else 0)
+        check(L.dtt_correlation_backward_nhwc_phase(gptr, sb, sc, sp, B, oc, oh, ow, ptr(input1), C, H, W, ptr(input2),
+                                                    ptr(g1) if g1 is not None else None, ptr(g2) if g2 is not None else None,
+                                                    pad_size, kernel_size, max_displacement, stride1, stride2, which, phase,
+                                                    ptr(ws), ws.numel() * 4, stream_ptr(dev)),
               "correlation backward (channels-last, streamed)")
+        return ws if phase == 1 else None
 
 
 class CorrelationNHWCFunction(Function):

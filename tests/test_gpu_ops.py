@@ -90,6 +90,57 @@ def test_nms_training_size_sweep_pipeline(dev, n, clusters, mk):
     np.testing.assert_array_equal(got, again)
 
 
+def test_nms_largest_box_count_and_the_error_beyond_it(dev):
+    """include/dtt_hip.h: boxes_num <= 65408 (the pipelined sweep keeps its removal words beside 156 KB of staging area in one CU's
+    LDS).  At the bound the keep list still equals the oracle's (well separated boxes + a cluster: the oracle's O(n * kept)
+    loop stays cheap); one more box is a clean error through the C ABI, not a launch failure."""
+    from dtt.ops import nms
+    n = 65408
+    rng = np.random.RandomState(7)
+    gx, gy = np.meshgrid(np.arange(256), np.arange(256))
+    ctr = np.stack([gx.ravel(), gy.ravel()], 1)[:n].astype(np.float64) * 40.0          # 40 px apart, 30 px boxes: no overlap
+    boxes = np.concatenate([ctr, ctr + 30.0], 1)
+    boxes[1000:1400] = boxes[1000] + rng.normal(0, 1.0, size=(400, 4))                  # one cluster of 400 heavily overlapping boxes
+    dets = np.concatenate([boxes, np.sort(rng.uniform(0, 1, n))[::-1][:, None]], 1).astype(np.float32)
+    keep = nms(cu(dets, dev), 0.7, max_keep=300).cpu().numpy().ravel()
+    ref = O.nms(dets[:4000], 0.7)          # (the first 300 survivors lie among the first 4000 boxes: everything outside the cluster survives)
+    np.testing.assert_array_equal(keep, ref[:300])
+    more = np.concatenate([dets, dets[:1]], 0)
+    with pytest.raises(RuntimeError, match="65408|boxes"):
+        nms(cu(more, dev), 0.7, max_keep=300)
+
+
+@pytest.mark.parametrize("C,H,W,d,s", [(1024, 38, 67, 8, 1), (512, 75, 134, 8, 2), (128, 36, 63, 16, 1)])
+def test_correlation_backward_in_two_phases_on_two_streams(dev, C, H, W, d, s):
+    """dtt_correlation_backward_nhwc_phase (round 6): the band words laid out on a SECOND stream (phase 1, reads the rows' gradient
+    only), the gradients from that workspace on the main stream behind an event (phase 2) -- bit-identical to the one-call op
+    (phase 3), planes and rows layouts, radius 8 and 16; this is how dtt.heads.TrackingRowsFn.backward overlaps the bands of conv4 /
+    conv5 with conv3's gradient op."""
+    from dtt.ops import correlation_backward_nhwc, correlation_output_shape
+    rng = np.random.RandomState(C + d)
+    B = 2
+    x1 = torch.from_numpy(rng.normal(size=(B, C, H, W)).astype(np.float32)).to(dev).contiguous(memory_format=torch.channels_last)
+    x2 = torch.from_numpy(rng.normal(size=(B, C, H, W)).astype(np.float32)).to(dev).contiguous(memory_format=torch.channels_last)
+    oc, oh, ow = correlation_output_shape(C, H, W, d, 1, d, s, s)
+    ld, col = oc + 40, 16
+    rows = torch.from_numpy(rng.normal(size=(B * oh * ow, ld)).astype(np.float32)).to(dev)
+    a1, a2 = torch.full_like(x1, float("nan")), torch.full_like(x2, float("nan"))
+    correlation_backward_nhwc(None, x1, x2, a1, a2, d, 1, d, s, s, rows=rows, col=col)
+    b1, b2 = torch.full_like(x1, float("nan")), torch.full_like(x2, float("nan"))
+    main, side = torch.cuda.current_stream(dev), torch.cuda.Stream(device=dev)
+    ready = torch.cuda.Event(); ready.record(main)
+    with torch.cuda.stream(side):
+        side.wait_event(ready)
+        ws = correlation_backward_nhwc(None, x1, x2, None, None, d, 1, d, s, s, rows=rows, col=col, phase=1)
+        laid = torch.cuda.Event(); laid.record(side)
+    main.wait_event(laid)
+    assert correlation_backward_nhwc(None, x1, x2, b1, b2, d, 1, d, s, s, rows=rows, col=col, phase=2, workspace=ws) is None
+    torch.cuda.synchronize(dev)
+    assert torch.equal(a1, b1) and torch.equal(a2, b2) and not bool(torch.isnan(a1).any())
+    with pytest.raises(ValueError):
+        correlation_backward_nhwc(None, x1, x2, b1, b2, d, 1, d, s, s, rows=rows, col=col, phase=2)      # no workspace
+
+
 def test_nms_empty_and_max_keep(dev):
     from dtt.ops import nms
     assert nms(torch.zeros((0, 5), device=dev), 0.7) == []

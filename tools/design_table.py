@@ -62,7 +62,7 @@ def avg(pat):      # all grids of a kernel name together: launches per step x th
             mm = re.search(r"([\d.]+) calls/step\s+([\d.]+) us/step", l)
             calls += float(mm.group(1)); us += float(mm.group(2))
     return "%g × %.1f µs" % (calls, us / calls) if calls else "n/a"
-add("training step under rocprofv3 (%s launches per step)" % m2.group(1), "`nms_sweep_kernel` %s (round 4: 2 × 136), `nms_mask_kernel` %s, `corr_bwd_stream_kernel<5>` %s, `head_dw_kernel` %s, `psroi_pm_bwd_kernel<32,7>` %s" % (
-    avg("nms_sweep_kernel"), avg("nms_mask_kernel"), avg("corr_bwd_stream_kernel<5"), avg("head_dw_kernel"), avg("psroi_pm_bwd_kernel<32")), "train_steady_state.txt")
+add("training step under rocprofv3 (%s launches per step)" % m2.group(1), "`nms_sweep_kernel` %s (round 4: 2 × 136), `nms_mask_kernel` %s, `corr_bwd_stream_kernel<5>` %s, `head_dw_kernel` %s, `psroi_pm_bwd_rows_kernel` (detection / tracking) %s" % (
+    avg("nms_sweep_kernel"), avg("nms_mask_kernel"), avg("corr_bwd_stream_kernel<5"), avg("head_dw_kernel"), avg("psroi_pm_bwd_rows_kernel")), "train_steady_state.txt")
 print("| what | figure | file(s) under `profiles/` |\n|---|---|---|")
 print("\n".join(rows))

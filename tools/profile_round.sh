@@ -62,6 +62,14 @@ if has bwdpmc; then  # counters of the streamed gradient kernels, one map per pa
   done
   python tools/pmc_corr_bwd_json.py $O/pmc_corr_bwd.json $ARGS > $O/pmc_corr_bwd.log 2>&1 || { echo "profile_round: pmc_corr_bwd.json not produced"; cat $O/pmc_corr_bwd.log; }
   rm -rf $O/bw_conv?_* $O/bw16_conv?_*
+  # the PSRoI backward launch (class + box heads of the training step's 10184 pixels; the tracking head's): bytes fetched / written per launch
+  rm -f $O/pmc_psroi_bwd.txt
+  for c in FETCH_SIZE WRITE_SIZE; do
+    (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $c -d $O/pb_$c -o p -- python $OLDPWD/tools/time_psroi_bwd.py --iters 20 > $O/tp.log 2>&1)
+    python tools/rocpd_pmc.py $(firstdb $O/pb_$c) 2>&1 | grep "psroi_pm_bwd" >> $O/pmc_psroi_bwd.txt
+    rm -rf $O/pb_$c $O/tp.log
+  done
+  timeout 300 python tools/time_psroi_bwd.py > $O/psroi_bwd_microbench.txt 2>&1
 fi
 
 if has cfg; then     # the other BASELINE configurations; configs[4] with its per-rank TRAINING step riding along (secondary.train_step)

@@ -165,6 +165,17 @@ t = read("pmc_corr_bwd.txt")
 if t:
     row("pmc_corr_bwd.txt", "one `--pmc` pass per counter and map over `tools/time_corr_bwd.py`", "%d counter rows (FETCH / WRITE / MFMA busy / LDS conflicts / active / wave cycles x conv5, conv4, conv3)" % len(
         [l for l in t.splitlines() if "dispatches" in l]))
+t = read("pmc_psroi_bwd.txt")
+if t:
+    fig = []
+    for l in t.splitlines():
+        m = re.search(r"(\[grid \d+\])?\s+(FETCH_SIZE|WRITE_SIZE)\s+dispatches\s+\d+\s+avg\s+([\d.]+)", l)
+        if m:
+            fig.append("%s %s %.1f MB raw" % (m.group(1) or "", m.group(2), float(m.group(3)) * 1024 / 1e6))
+    row("pmc_psroi_bwd.txt", "`rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE` (separate passes) over `tools/time_psroi_bwd.py`; `tools/rocpd_pmc.py`", "; ".join(fig))
+t = read("psroi_bwd_microbench.txt")
+if t:
+    row("psroi_bwd_microbench.txt", "`python tools/time_psroi_bwd.py`", " / ".join(l.split(":", 1)[1].split("  ")[0].strip() for l in t.splitlines() if l.startswith(("detection", "tracking"))))
 for name, cmd in (("bench_config4_stdout.log", "`python bench.py --no-cpu-baseline --pooling align --disp 16 --height 563 --width 1000 --batch 1` (BASELINE configs[4], its training step rides along)"),
                   ("bench_frames1_stdout.log", "`python bench.py --frames 1 --no-train-step` (BASELINE configs[1])"),
                   ("bench_train_stdout.log", "`python bench.py --mode train --steps 8 --warmup 4` (BASELINE configs[3] per rank)"),
@@ -177,7 +188,7 @@ if t:
         m = re.match(r"\S*?(\w+_kernel(?:<[^>]*>)?).*?\s([\d.]+) calls/step\s+([\d.]+) us/step.*avg\s+([\d.]+)", l)
         if m and any(k in l for k in ("corr_bwd", "nms_", "head_dw", "psroi_pm_bwd", "at_subsample")):
             own.append("`%s` %s x %s us" % (m.group(1), m.group(2), m.group(4)))
-    row("train_steady_state.txt", "`rocprofv3 --kernel-trace -- python bench.py --mode train --steps 5 --warmup 3`; `tools/rocpd_steady.py <db> 3 \"psroi_pm_bwd_kernel<32\" 400`",
+    row("train_steady_state.txt", "`rocprofv3 --kernel-trace -- python bench.py --mode train --steps 5 --warmup 3`; `tools/rocpd_steady.py <db> 3 \"psroi_pm_bwd_rows_kernel<7, 16, 2>\" 400`",
         t.splitlines()[0] + ("; " + "; ".join(own[:12]) if own else ""))
 row("train_kernel_stats.txt", "same trace; `tools/rocpd_stats.py`", "whole run incl. warm-up")
 for name, cmd in (("fetch_calib.txt", "`rocprofv3 --pmc FETCH_SIZE` over `tools/probes/fetch_calib.hip`"), ("write_calib.txt", "`rocprofv3 --pmc WRITE_SIZE` over `tools/probes/write_calib.hip`")):
