@@ -43,13 +43,13 @@ add("training step, configs[3] per rank (600×1067, bs = 2)", "**%.2f ms** (`--m
     tr["ms_per_step"], ts["ms_per_step"], ts["gradient_buckets"]["count"], ts["gradient_buckets"]["bytes"] / 1e6, ts["gradient_buckets"]["allreduce_ms"]), "bench_train_stdout.log`, `%s_bench_stdout.log" % R)
 bj = json.load(open(f("pmc_corr_bwd.json")))
 cb = tr["secondary"]["corr_bwd"]
-add("correlation gradient ops, radius 8 (band kernel + 2 launches)", "; ".join("%s %.1f µs = %.3f of %s, traffic %.1f MB = %.2f×" % (
+add("correlation gradient ops, radius 8 (band kernel + ONE launch for both directions)", "; ".join("%s %.1f µs = %.3f of %s, traffic %.1f MB = %.2f×" % (
     k[:5], cb[k]["op_us"], cb[k]["frac"], cb[k]["bound"].upper(), bj["conv" + k[4]]["traffic_bytes_per_op"] / 1e6, bj["conv" + k[4]]["ratio"]) for k in ("corr5_bwd", "corr4_bwd", "corr3_bwd")),
     "bench_train_stdout.log`, `%s_pmc_corr_bwd.json" % R)
 c4 = line("bench_config4_stdout.log"); c4t = line("bench_train_config4_stdout.log")
 add("configs[4] per rank (563×1000, d = 16, RoI-Align, bs = 1): inference", "**%.1f frame-pairs/s** (%.3f ms); conv5 op (33 × 33 window, one launch) %.1f µs = %.3f" % (c4["value"], c4["ms_per_step"], c4["roofline"]["op_us"], c4["roofline"]["frac"]), "bench_config4_stdout.log")
 cb4 = c4t["secondary"]["corr_bwd"]
-add("configs[4] per rank: training step", "**%.2f ms**; gradient ops at radius 16 (four quarters): conv5 %.1f µs = %.3f, conv4 %.1f µs = %.3f, conv3 (radius 8) %.1f µs" % (
+add("configs[4] per rank: training step", "**%.2f ms**; gradient ops at radius 16 (the four window quarters inside ONE launch; counter traffic: `r06_pmc_corr_bwd.json` `d16_*`): conv5 %.1f µs = %.3f, conv4 %.1f µs = %.3f, conv3 (radius 8) %.1f µs" % (
     c4t["ms_per_step"], cb4["corr5_bwd"]["op_us"], cb4["corr5_bwd"]["frac"], cb4["corr4_bwd"]["op_us"], cb4["corr4_bwd"]["frac"], cb4["corr3_bwd"]["op_us"]), "bench_train_config4_stdout.log")
 f1 = line("bench_frames1_stdout.log")
 add("configs[1] (single-frame R-FCN, bs = 2)", "**%.1f frames/s** (%.3f ms); head GEMM over 2 images %.1f µs = %.3f" % (f1["value"], f1["ms_per_step"], f1["roofline"]["launch_us"], f1["roofline"]["frac"]), "bench_frames1_stdout.log")

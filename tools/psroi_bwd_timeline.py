@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Timeline of two workgroups of psroi_pm_bwd_rows_kernel from the shader-clock stamps of the DTT_PSROI_BWD_STAMP build (developer tool):
-    SRCS="common.hip psroi_bwd.hip heads.hip" tools/build_variant.sh pbstamp "-DDTT_PSROI_BWD_STAMP -L/opt/rocm/lib -lhipblaslt"
-    DTT_HIP_LIBRARY=tools/_variants/pbstamp.so python tools/psroi_bwd_timeline.py"""
+the whole library with psroi_bwd.hip compiled -DDTT_PSROI_BWD_STAMP into tools/_variants/pbstamp.so (the Makefile's flags, the other
+objects from csrc/build/), then   DTT_HIP_LIBRARY=tools/_variants/pbstamp.so python tools/psroi_bwd_timeline.py
+(tools/probes/psroi_bwd_instep_clock.py reads the same stamps behind a `bench.py --mode train` run: the launch inside the step.)"""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "pytorch-detect-to-track_amd"), os.path.join(ROOT, "tools")]
