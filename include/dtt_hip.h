@@ -35,7 +35,10 @@ const char* dtt_last_error(void);
 /* Measurement hook (no reference counterpart): bracket every launch (or whole op) named `tag` with
  * hipEventRecord(begin_events[i]) / hipEventRecord(end_events[i]) on the launch stream, for the first n launches.
  * Tags -- ops: "corr_fwd_op" (one forward correlation, whatever kernels it takes), "corr_bwd_op" (both gradients of one
- * correlation: band kernel + two streamed launches); kernels: "corr_nhwc" (corr_wsplit_kernel), "corr_fwd_mfma" /
+ * correlation: band kernel + the streamed launch; phase 2 alone when the op is issued in phases, whose phase 1 is "corr_bwd_band"),
+ * "proposal_op" (the proposal layer of all images of a call, "nms_op" inside it: both NMS phases), "anchor_target_op",
+ * "rpn_loss" (forward of both RPN losses), "psroi_pm_bwd" (the one-launch PSRoI backward of a map's heads);
+ * kernels: "corr_nhwc" (corr_wsplit_kernel), "corr_fwd_mfma" /
  * "corr_fwd_reduce" (the NCHW pair), "head_gemm", "rpn_head_gemm", "psroi_pm" (position-major poolings), "psroi_fwd_plane",
  * "nms_mask", "nms_sweep", "proposal_select_sort".  tag = NULL detaches.  Events are hipEvent_t handles owned
  * by the caller.  dtt_profile_count() = launches recorded so far. */
