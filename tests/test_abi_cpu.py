@@ -177,3 +177,31 @@ def test_no_inline_asm_statement_clobbers_m0():
                 hits += 1
                 assert "s_mov_b32 %0, m0" in stmt and stmt.count("s_mov_b32 m0") == 2, f + ": m0 written but not saved and restored"
     assert hits == 3
+
+
+def test_round6_entry_points_validate_their_arguments_without_a_gpu():
+    """dtt_psroi_pm_backward_heads / dtt_correlation_backward_nhwc_phase / dtt_rpn_loss_forward: bad shapes, null pointers and
+    unsupported geometries come back as status 0 + an error string before anything touches a device (the reference's launchers print
+    and return 0: correlation_cuda_kernel.cu:362-368)."""
+    from dtt import _lib
+    L = _lib.lib()
+    buf = (ctypes.c_float * 64)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    heads = lambda **kw: L.dtt_psroi_pm_backward_heads(*[kw.get(k, d) for k, d in (
+        ("gv0", p), ("od0", 31), ("cp0", 32), ("gv1", p), ("od1", 4), ("cp1", 4), ("rois", p), ("R", 1), ("B", 1), ("H", 4), ("W", 4),
+        ("pooled", 7), ("scale", 0.0625), ("stride", 1792), ("row", 1792), ("add", None), ("a0", 0), ("an", 0), ("gmap", p), ("stream", None))])
+    assert heads(pooled=3) == 0 and "not instantiated" in _lib.last_error()
+    assert heads(cp0=48, cp1=32) == 0 and "at most 64" in _lib.last_error()
+    assert heads(row=1000) == 0 and "do not fit" in _lib.last_error()
+    assert heads(gmap=None) == 0 and "null pointer" in _lib.last_error()
+    assert heads(add=p, a0=1700, an=196) == 0 and "outside the row" in _lib.last_error()
+    assert heads(H=40000) == 0 and "32767" in _lib.last_error()
+    # correlation gradients in phases: the phase selector and the streamed kernels' geometry
+    phase = lambda ph, ic=64: L.dtt_correlation_backward_nhwc_phase(p, 81 * 16, 16, 1, 1, 81, 4, 4, p, ic, 4, 4, p, p, p, 4, 1, 4, 1, 1, 3, ph, p, 1 << 20, None)
+    assert phase(0) == 0 and "phase" in _lib.last_error()
+    assert phase(4) == 0 and "phase" in _lib.last_error()
+    assert phase(3, ic=48) == 0 and "channels" in _lib.last_error()
+    # RPN losses: the workspace query runs anywhere; a workspace that is too small is refused
+    nb = L.dtt_rpn_loss_workspace_bytes(4, 38 * 67)
+    assert nb > 0
+    assert L.dtt_rpn_loss_forward(p, p, p, p, p, p, 4, 2, 12, 38 * 67, 3.0, p, p, p, 8, None) == 0 and _lib.last_error()
