@@ -310,7 +310,9 @@ class PsroiPmFn(torch.autograd.Function):
         add = gvotes[len(heads)] if ctx.extract is not None else None
         tiled = all(h["offset"] == sum(g["group"] ** 2 * g["cp"] for g in heads[:i]) for i, h in enumerate(heads))
         assert tiled, "heads must tile the row from column 0"
-        if len(heads) <= 2 and all(h["group"] == 7 for h in heads) and sum(h["cp"] for h in heads) <= 64:
+        import os
+        per_head = os.environ.get("DTT_PSROI_BWD_OLD", "0") not in ("", "0")      # developer A/B: round 5's launches (one per head + zero_ + add)
+        if not per_head and len(heads) <= 2 and all(h["group"] == 7 for h in heads) and sum(h["cp"] for h in heads) <= 64:
             # one launch for the heads of the map (one wave per pixel, the padding columns and the second consumer's gradient in the
             # same pass): csrc/psroi_bwd.hip
             gvs = [torch.zeros((R, h["od"]), dtype=torch.float32, device=dev) if gv is None else gv.contiguous()
